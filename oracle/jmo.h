@@ -1,0 +1,228 @@
+/*
+ * jmo.h -- ORACLE: plain-C restatement of the JM lencod per-macroblock hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY. Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may call it, and only as the checker
+ * (or as the timed CPU baseline), never as the thing shipped. The product path (h.264_amd/)
+ * neither links nor imports this library.
+ *
+ * Parity status: PINNED. Each function follows the reference file:line cited at its definition;
+ * the restatement is validated (container only) by swapping it INTO the real JM built from
+ * /root/reference (oracle/tap/swap_oracle.c): bitstreams must stay byte-identical, including the
+ * reference's own known-answer pair bin/test.264 + bin/test_rec.yuv.
+ *
+ * Conventions: pels are JM's `imgpel` (unsigned short, lencod/inc/global.h:46-52); all arithmetic
+ * is int32 like JM's `int`. Pure functions over explicit arguments: no globals, re-entrant.
+ */
+#ifndef JMO_H
+#define JMO_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef unsigned short jmo_pel;
+
+#define JMO_PAD        20        /* IMG_PAD_SIZE, lencod/inc/defines.h:107 */
+#define JMO_PAD4       80        /* IMG_PAD_SIZE_TIMES4 */
+#define JMO_MAX_VALUE  999999    /* MAX_VALUE, defines.h:111 */
+#define JMO_INT_MAX    2147483647
+
+enum { JMO_YUV400 = 0, JMO_YUV420 = 1, JMO_YUV422 = 2, JMO_YUV444 = 3 };
+enum { JMO_F_PEL = 0, JMO_H_PEL = 1, JMO_Q_PEL = 2 };
+enum { JMO_ERR_SAD = 0, JMO_ERR_SSE = 1, JMO_ERR_SATD = 2 };
+
+/* ------------------------------------------------------------------ sub-pel reference planes */
+
+/* Chroma plane geometry for a format (lencod.c:2851-2884 chroma_mc_setup; image.c:1624-1632). */
+typedef struct {
+  int sub_x, sub_y;       /* number of fractional planes in x / y (8x8, 8x4, 4x4)            */
+  int pad_x, pad_y;       /* img_pad_size_uv_x/y                                              */
+  int shift_x, shift_y;   /* chroma_shift_x/y                                                 */
+  int mask_x, mask_y;     /* chroma_mask_mv_x/y                                               */
+  int mul_x, mul_y;       /* weight step per plane (img_chroma.c:390-405)                     */
+  int mb_cr_size_x, mb_cr_size_y;
+} jmo_chroma_geom;
+
+void jmo_chroma_geometry(int yuv_format, jmo_chroma_geom *g);
+
+/* getSubImagesLuma (img_luma.c:45): img is H rows of W pels (stride in pels); out is
+ * [4][4][H+40][W+40] contiguous, plane index (y&3)*4 + (x&3). max_val = img->max_imgpel_value. */
+void jmo_interp_luma(const jmo_pel *img, int W, int H, int stride, int max_val, jmo_pel *out);
+
+/* getSubImagesChroma (img_chroma.c:374) for ONE component: img is Hc x Wc; out is
+ * [sub_y][sub_x][Hc+2*pad_y][Wc+2*pad_x] contiguous and MUST be zero-initialised by the caller
+ * exactly like JM's calloc (memalloc.c:142): JM never writes the last row and column. */
+void jmo_interp_chroma(const jmo_pel *img, int Wc, int Hc, int stride, int yuv_format, jmo_pel *out);
+
+/* A stored reference picture as the ME functions see it (StorablePicture, mbuffer.h:20-95). */
+typedef struct {
+  int W, H;                 /* size_x, size_y                                   */
+  int Wp, Hp;               /* size_x_padded, size_y_padded                     */
+  int width_pad, height_pad;/* size_x_pad, size_y_pad (mbuffer.c:421-422)       */
+  const jmo_pel *luma[16];  /* plane (y&3)*4+(x&3), each Hp x Wp contiguous     */
+  int yuv_format;
+  jmo_chroma_geom cg;
+  int Wc, Hc, Wcp, Hcp;     /* chroma size and padded size                      */
+  int width_pad_cr, height_pad_cr; /* size_x_cr_pad, size_y_cr_pad (mbuffer.c:425-426) */
+  const jmo_pel *cr[2][64]; /* plane suby*sub_x+subx, each Hcp x Wcp, may be NULL */
+} jmo_ref;
+
+/* luma/cb/cr: contiguous plane stacks as jmo_interp_* write them (cb/cr may be NULL); callers with
+ * separately allocated planes (JM: memalloc.c:116-127) fill r->luma[] / r->cr[][] themselves. */
+void jmo_ref_init(jmo_ref *r, int W, int H, int yuv_format, const jmo_pel *luma,
+                  const jmo_pel *cb, const jmo_pel *cr);
+
+/* ------------------------------------------------------------------ distortion */
+
+/* Everything the me_distortion.c kernels read from JM globals (me_distortion.c:35-56). */
+typedef struct {
+  const jmo_ref *ref;
+  int umv;                  /* ref_access_method: 0 FAST_ACCESS, 1 UMV_ACCESS                 */
+  int chroma_me;            /* ChromaMEEnable                                                 */
+  int chroma_me_weight;     /* input->ChromaMEWeight                                          */
+  int test8x8;              /* test8x8transform (mv-search.c:640)                             */
+  int max_val, max_val_uv;  /* img->max_imgpel_value, img->max_imgpel_value_comp[1]           */
+  /* weighted prediction (only read by the *WP kernels) */
+  int weight_luma, offset_luma, wp_luma_round, luma_log_weight_denom;
+  int weight_cr[2], offset_cr[2], wp_chroma_round, chroma_log_weight_denom;
+} jmo_dist;
+
+int jmo_sad   (const jmo_dist *d, const jmo_pel *src, int bsy, int bsx, int min_mcost, int cand_x, int cand_y);
+int jmo_sad_wp(const jmo_dist *d, const jmo_pel *src, int bsy, int bsx, int min_mcost, int cand_x, int cand_y);
+int jmo_satd   (const jmo_dist *d, const jmo_pel *src, int bsy, int bsx, int min_mcost, int cand_x, int cand_y);
+int jmo_satd_wp(const jmo_dist *d, const jmo_pel *src, int bsy, int bsx, int min_mcost, int cand_x, int cand_y);
+int jmo_sse    (const jmo_dist *d, const jmo_pel *src, int bsy, int bsx, int min_mcost, int cand_x, int cand_y);
+int jmo_hadamard_sad4x4(const int *diff);   /* HadamardSAD4x4, me_distortion.c:182 */
+int jmo_hadamard_sad8x8(const int *diff);   /* HadamardSAD8x8, me_distortion.c:272 */
+
+/* ------------------------------------------------------------------ search */
+
+/* mvbits / spiral tables (mv-search.c:333-393) */
+int  jmo_mvbits(int d);
+void jmo_spiral(int search_range, short *sx, short *sy, int max_points);
+int  jmo_mv_cost(int lambda_factor, int cx, int cy, int px, int py); /* MV_COST_SMP, defines.h:128 */
+void jmo_block_size(int blocktype, int *bsx, int *bsy);              /* blc_size, configfile.c:805-841 */
+
+/* Frame/slice-level inputs of the search functions (JM: input->, img->, active_pps->). */
+typedef struct {
+  int rdopt;                /* input->rdopt                                                   */
+  int is_b_slice;           /* img->type == B_SLICE                                           */
+  int chroma_me;            /* input->ChromaMEEnable: 0, 1 = ME_YUV_FP, 2 = ME_YUV_FP_SP       */
+  int chroma_me_weight;
+  int transform8x8_mode;    /* input->Transform8x8Mode                                        */
+  int metric[3];            /* input->MEErrorMetric[F/H/Q]                                    */
+  int apply_weights;        /* weighted ME active for this call                               */
+  int max_val, max_val_uv;
+  int level_mv_min, level_mv_max; /* LEVELMVLIMIT[img->LevelIndex][0..1] (mv-search.h:35-54)   */
+  int weight_luma, offset_luma, wp_luma_round, luma_log_weight_denom;
+  int weight_cr[2], offset_cr[2], wp_chroma_round, chroma_log_weight_denom;
+} jmo_me_params;
+
+/* Search centre for SearchMode=-1 (mv-search.c:752-762) */
+void jmo_search_center(const jmo_me_params *p, int pred_mv_x, int pred_mv_y, int search_range,
+                       short *mv_x, short *mv_y);
+
+/* FullPelBlockMotionSearch (me_fullsearch.c:47). ref_is_0 = (ref == 0). */
+int jmo_fullpel_search(const jmo_me_params *p, const jmo_ref *ref, const jmo_pel *orig_pic, int ref_is_0,
+                       int pic_pix_x, int pic_pix_y, int blocktype, int pred_mv_x, int pred_mv_y,
+                       short *mv_x, short *mv_y, int search_range, int min_mcost, int lambda_factor);
+
+/* SubPelBlockMotionSearch (me_fullsearch.c:341). lambda[3]. */
+int jmo_subpel_search(const jmo_me_params *p, const jmo_ref *ref, const jmo_pel *orig_pic, int ref_is_0,
+                      int pic_pix_x, int pic_pix_y, int blocktype, int pred_mv_x, int pred_mv_y,
+                      short *mv_x, short *mv_y, int search_pos2, int search_pos4, int min_mcost,
+                      const int *lambda);
+
+/* The integer+sub-pel chain of BlockMotionSearch for SearchMode=-1 (mv-search.c:751-826) given the
+ * predictor: copies nothing, orig_pic is the packed source block (mv-search.c:607-626). */
+int jmo_block_search_full(const jmo_me_params *p, const jmo_ref *ref, const jmo_pel *orig_pic, int ref_is_0,
+                          int pic_pix_x, int pic_pix_y, int blocktype, int pred_mv_x, int pred_mv_y,
+                          int search_range, const int *lambda, short *mv_out /*[2] qpel*/,
+                          short *mv_int /*[2] pel, may be NULL*/, int *cost_int /*may be NULL*/);
+
+/* SetupFastFullPelSearch + SetupLargerBlocks (me_fullfast.c:491,210): block_sad is
+ * [8][16][max_pos] ints (types 1..7 used), orig_mb the packed 16x16 (+chroma at 256/512). */
+typedef struct {
+  int search_range, max_pos;
+  int center_x, center_y;   /* search_center_x/y (absolute pel)  */
+  int pos_00;
+  int *block_sad;           /* [8][16][max_pos] */
+} jmo_fastfull;
+void jmo_fastfull_setup(const jmo_me_params *p, const jmo_ref *ref, const jmo_pel *orig_mb,
+                        int opix_x, int opix_y, int pmv_x, int pmv_y, int search_range, jmo_fastfull *ff);
+int  jmo_fastfull_search(const jmo_me_params *p, const jmo_fastfull *ff, int opix_x, int opix_y,
+                         int pic_pix_x, int pic_pix_y, int blocktype, int pred_mv_x, int pred_mv_y,
+                         short *mv_x, short *mv_y, int min_mcost, int lambda_factor);
+
+/* ------------------------------------------------------------------ transform / quant */
+
+void jmo_forward4x4 (int (*block)[16], int (*tblock)[16], int pos_y, int pos_x);   /* transform.c:31  */
+void jmo_inverse4x4 (int (*tblock)[16], int (*block)[16], int pos_y, int pos_x);   /* transform.c:81  */
+void jmo_hadamard4x4 (int (*block)[4], int (*tblock)[4]);                          /* transform.c:131 */
+void jmo_ihadamard4x4(int (*tblock)[4], int (*block)[4]);                          /* transform.c:180 */
+void jmo_forward8x8 (int (*block)[16], int (*tblock)[16], int pos_y, int pos_x);   /* transform.c:229 */
+void jmo_inverse8x8 (int (*tblock)[16], int (*block)[16], int pos_y, int pos_x);   /* transform.c:325 */
+
+extern const int jmo_quant_coef[6][4][4];      /* block.c:39  */
+extern const int jmo_dequant_coef[6][4][4];    /* block.c:48  */
+int jmo_quant_coef8(int qp_rem, int j, int i);   /* quant_coef8,   transform8x8.c:39  */
+int jmo_dequant_coef8(int qp_rem, int j, int i); /* dequant_coef8, transform8x8.c:104 */
+extern const unsigned char jmo_qp_scale_cr[52];/* block.c:64 */
+extern const unsigned char jmo_sngl_scan[16][2], jmo_field_scan[16][2];         /* block.h:26-41 */
+extern const unsigned char jmo_sngl_scan8x8[64][2], jmo_field_scan8x8[64][2];   /* transform8x8.c:171-193 */
+extern const unsigned char jmo_coeff_cost4x4[2][16];                            /* block.h:45 */
+extern const unsigned char jmo_coeff_cost8x8[2][64];                            /* transform8x8.c:197 */
+
+/* Flat (no scaling matrix) tables as CalculateQuantParam/CalculateQuant8Param build them
+ * (q_matrix.c:451-738) and default offsets as CalculateOffsetParam builds them (q_offsets.c:491-744):
+ * levelscale = quant_coef[qp%6], invlevelscale = dequant_coef[qp%6] << 4,
+ * leveloffset = offset << (Q_BITS + qp/6 - 11), offset 682 (intra in I/P-intra) or 342. */
+void jmo_flat_tables4x4(int qp, int offset11, int *levelscale, int *invlevelscale, int *leveloffset);
+void jmo_flat_tables8x8(int qp, int offset11, int *levelscale, int *invlevelscale, int *leveloffset);
+
+/* Quantiser inputs of one dct_* call (block.c:867-879). Tables are row-major [j][i]. */
+typedef struct {
+  int qp;                   /* currMB->qp_scaled[pl] (luma) or qpc+scale (chroma)             */
+  const int *levelscale;    /* [16] or [64]                                                    */
+  const int *invlevelscale;
+  const int *leveloffset;
+  int adaptive_rounding;    /* img->AdaptiveRounding                                           */
+  int adapt_rnd_weight;     /* AdaptRndWeight / AdaptRndCrWeight                               */
+  int field_scan;           /* currMB->is_field_mode                                           */
+  int disthres;             /* input->disthres                                                 */
+  int max_val;              /* img->max_imgpel_value(_uv)                                      */
+  int cavlc;                /* input->symbol_mode == CAVLC                                     */
+  int img_qp;               /* img->qp (CAVLC_LEVEL_LIMIT guard, block.c:647,1147)             */
+  int transform8x8_flag;    /* currMB->luma_transform_size_8x8_flag (dct_8x8 CAVLC interleave) */
+} jmo_quant;
+
+/* dct_4x4 (block.c:843). m7/mpr are the MB-sized tiles; levels/runs (>= 17 ints each) receive the
+ * (level,run) list 0-terminated in level; recon is the 16x16 destination tile (stride 16) written at (block_y..+3,
+ * block_x..+3); fadjust may be NULL when !adaptive_rounding. Returns nonzero. */
+int jmo_dct_4x4(const jmo_quant *q, int (*m7)[16], const jmo_pel (*mpr)[16], int block_x, int block_y,
+                int *coeff_cost, int *levels, int *runs, jmo_pel (*recon)[16], int (*fadjust)[16]);
+
+/* dct_8x8 (transform8x8.c:1452). levels/runs are [4][65] (cofAC[b8][0..3][0|1]); for CABAC or
+ * !transform8x8_flag only row 0 is used. */
+int jmo_dct_8x8(const jmo_quant *q, int (*m7)[16], const jmo_pel (*mpr)[16], int b8, int *coeff_cost,
+                int (*levels)[65], int (*runs)[65], jmo_pel (*recon)[16], int (*fadjust)[16]);
+
+/* dct_16x16 (block.c:564). cur/pred are 16x16 source and prediction tiles; dc_levels/runs [17];
+ * ac_levels/runs [16][16] indexed b8*4+b4. Returns ac_coef (0 or 15). */
+int jmo_dct_16x16(const jmo_quant *q, const jmo_pel (*cur)[16], const jmo_pel (*pred)[16],
+                  int *dc_levels, int *dc_runs, int (*ac_levels)[16], int (*ac_runs)[16],
+                  jmo_pel (*recon)[16], int (*fadjust)[16]);
+
+/* dct_chroma (block.c:1051) for one component. q = AC/DC(4:2:0) quantiser; qdc = the qp+3 DC
+ * quantiser of 4:2:2 (ignored otherwise). m7 is the full 16x16 tile (the 4:2:2 row/col-swap quirk of
+ * block.c:1120 reads columns 8..15). cbp_blk is in/out (64-bit). Returns the new cr_cbp. */
+int jmo_dct_chroma(const jmo_quant *q, const jmo_quant *qdc, int yuv_format, int uv, int cr_cbp,
+                   int (*m7)[16], const jmo_pel (*mpr)[16], int *dc_levels, int *dc_runs,
+                   int (*ac_levels)[16], int (*ac_runs)[16] /* [8][16] indexed b8*4+b4 within comp */,
+                   jmo_pel (*recon)[16], int (*fadjust)[16], long long *cbp_blk);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

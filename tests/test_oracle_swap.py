@@ -1,0 +1,96 @@
+"""Pins the oracle: the C restatement (oracle/jmo_*.c) is swapped INTO the real JM encoder built from
+/root/reference (oracle/tap/swap_oracle.c, symbol interposition) and the bitstream + reconstruction JM
+writes must stay byte-identical to the unmodified encoder's, for every shipped cfg x SearchMode and a set
+of option variants. The first case is the reference's own known-answer pair bin/test.264 + bin/test_rec.yuv.
+
+Container only: needs /root/reference (sources + bin/ fixtures) and `make -C oracle ref`.
+Skipped on the GPU box, where neither exists.
+"""
+import hashlib
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+RDIR = os.path.join(ROOT, "oracle", "_ref")
+
+pytestmark = [
+    pytest.mark.reference,
+    pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "bin")), reason="/root/reference not present"),
+]
+
+
+@pytest.fixture(scope="module")
+def rundir(tmp_path_factory):
+    if not (os.path.exists(os.path.join(RDIR, "jm_swap")) and os.path.exists(os.path.join(RDIR, "jm_plain"))):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-j8", "all", "ref"], check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    d = tmp_path_factory.mktemp("jmrun")
+    for f in os.listdir(os.path.join(REF, "bin")):
+        if f.endswith(".cfg") or f.endswith(".yuv"):
+            shutil.copy(os.path.join(REF, "bin", f), d / f)
+    for f in ("test.264", "test_rec.yuv"):
+        os.remove(d / f) if os.path.exists(d / f) else None
+    return d
+
+
+def _run(exe, rundir, args, env=None):
+    for f in ("test.264", "test_rec.yuv"):
+        if os.path.exists(rundir / f):
+            os.remove(rundir / f)
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run([os.path.join(RDIR, exe)] + args, cwd=rundir, env=e,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-500:]
+    out = []
+    for f in ("test.264", "test_rec.yuv"):
+        with open(rundir / f, "rb") as fh:
+            out.append(hashlib.md5(fh.read()).hexdigest())
+    return out
+
+
+def test_known_answer_with_oracle_swapped_in(rundir):
+    """default encoder.cfg: the reference ships the expected bitstream and reconstruction."""
+    _run("jm_swap", rundir, [])
+    for f in ("test.264", "test_rec.yuv"):
+        with open(rundir / f, "rb") as a, open(os.path.join(REF, "bin", f), "rb") as b:
+            assert a.read() == b.read(), f
+
+
+CFGS = ["encoder.cfg", "encoder_baseline.cfg", "encoder_main.cfg", "encoder_extended.cfg", "encoder_yuv422.cfg"]
+MATRIX = [(c, ["-d", c, "-p", "SearchMode=%d" % sm]) for c in CFGS for sm in (-1, 0, 1, 2, 3)]
+VARIANTS = {
+    "baseline FS R16": "-d encoder_baseline.cfg -p SearchMode=-1 -p SearchRange=16",
+    "baseline FS rdopt0": "-d encoder_baseline.cfg -p SearchMode=-1 -p RDOptimization=0",
+    "baseline FFS rdopt0": "-d encoder_baseline.cfg -p SearchMode=0 -p RDOptimization=0",
+    "main FS rdopt0": "-d encoder_main.cfg -p SearchMode=-1 -p RDOptimization=0",
+    "main FFS ChromaME1": "-d encoder_main.cfg -p SearchMode=0 -p ChromaMEEnable=1",
+    "main FS ChromaME1": "-d encoder_main.cfg -p SearchMode=-1 -p ChromaMEEnable=1",
+    "main FS ChromaME2": "-d encoder_main.cfg -p SearchMode=-1 -p ChromaMEEnable=2",
+    "422 FS ChromaME2": "-d encoder_yuv422.cfg -p SearchMode=-1 -p ChromaMEEnable=2",
+    "422 FFS ChromaME1": "-d encoder_yuv422.cfg -p SearchMode=0 -p ChromaMEEnable=1",
+    "main FS WP": "-d encoder_main.cfg -p SearchMode=-1 -p WeightedPrediction=1 -p WeightedBiprediction=1 -p UseWeightedReferenceME=1",
+    "main FFS WP": "-d encoder_main.cfg -p SearchMode=0 -p WeightedPrediction=1 -p WeightedBiprediction=1 -p UseWeightedReferenceME=1",
+    "main EPZS WP": "-d encoder_main.cfg -p SearchMode=3 -p WeightedPrediction=1 -p UseWeightedReferenceME=1",
+    "main FS SATD-fpel": "-d encoder_main.cfg -p SearchMode=-1 -p MEDistortionFPel=2",
+    "main FS SAD-all": "-d encoder_main.cfg -p SearchMode=-1 -p MEDistortionHPel=0 -p MEDistortionQPel=0",
+    "high 8x8 FS": "-d encoder.cfg -p SearchMode=-1 -p Transform8x8Mode=2",
+    "high CAVLC 8x8": "-d encoder.cfg -p SymbolMode=0 -p Transform8x8Mode=1",
+    "main qp8": "-d encoder_main.cfg -p QPISlice=8 -p QPPSlice=8 -p QPBSlice=9",
+    "main qp45": "-d encoder_main.cfg -p QPISlice=45 -p QPPSlice=45 -p QPBSlice=46",
+    "main field": "-d encoder_main.cfg -p PicInterlace=1 -p ReferenceReorder=0 -p PocMemoryManagement=0",
+    "main mbaff": "-d encoder_main.cfg -p MbInterlace=1 -p ReferenceReorder=0 -p PocMemoryManagement=0",
+    "444": "-d encoder_yuv422.cfg -p YUVFormat=3 -p ProfileIDC=244 -p InputFile=foreman_part_qcif_444.yuv",
+}
+
+
+@pytest.mark.parametrize("name,args", [("%s sm%s" % (c, a[-1].split("=")[1]), a) for c, a in MATRIX]
+                         + [(k, v.split()) for k, v in VARIANTS.items()])
+def test_bitstream_identical_with_oracle_swapped_in(rundir, name, args):
+    plain = _run("jm_plain", rundir, args)
+    swapped = _run("jm_swap", rundir, args)
+    assert plain == swapped, name
