@@ -1,0 +1,12 @@
+"""h.264_amd -- MI355X (gfx950) implementation of the JM lencod per-macroblock hot path.
+
+The product is the C-ABI shared library `libjmhip.so` (include/jmhip.h, hand-written HIP under csrc/).
+This package is the thin Python binding over that ABI used by the tests and bench.py. It never computes
+anything itself and has no CPU fallback: if the library is missing or no GPU is present the calls raise.
+
+The directory name contains a dot, so load it by path (tests/conftest.py::load_pkg, __graft_entry__.py).
+"""
+from .jmhip import (  # noqa: F401
+    JmhipError, Context, MeParams, load_library, library_path, declared_symbols, partition_table,
+    build_library, NPART, PAD, STAGES,
+)

@@ -1,0 +1,312 @@
+// jmhip_ctx.hip -- context, device pictures, upload/download, stage timing (C ABI entry points)
+#include "jmhip_internal.h"
+
+static void chroma_geometry(int yuv, ChromaGeom *g)   // lencod/src/lencod.c:2851-2884, img_chroma.c:390-405
+{
+  memset(g, 0, sizeof(*g));
+  if (yuv == JMHIP_YUV420)      *g = {8, 8, 10, 10, 3, 3, 7, 7, 1, 1, 8, 8};
+  else if (yuv == JMHIP_YUV422) *g = {8, 4, 10, 20, 3, 2, 7, 3, 1, 2, 8, 16};
+  else if (yuv == JMHIP_YUV444) *g = {4, 4, 20, 20, 2, 2, 3, 3, 2, 2, 16, 16};
+}
+
+extern "C" int jmhip_abi_version(void) { return JMHIP_ABI_VERSION; }
+
+extern "C" const char *jmhip_strerror(int code)
+{
+  switch (code) {
+  case JMHIP_OK: return "ok";
+  case JMHIP_ERR_ARG: return "bad argument";
+  case JMHIP_ERR_DEVICE: return "HIP device error";
+  case JMHIP_ERR_UNSUPPORTED: return "configuration not supported by this version";
+  case JMHIP_ERR_NOMEM: return "out of device memory";
+  default: return "unknown error";
+  }
+}
+
+extern "C" const char *jmhip_last_error(jmhip_ctx *ctx) { return ctx ? ctx->err.c_str() : "no context"; }
+
+extern "C" int jmhip_ctx_create(const jmhip_config *cfg, jmhip_ctx **out)
+{
+  if (!cfg || !out) return JMHIP_ERR_ARG;
+  *out = nullptr;
+  if (cfg->width <= 0 || cfg->height <= 0 || (cfg->width & 15) || (cfg->height & 15)) return JMHIP_ERR_ARG;
+  if (cfg->yuv_format < JMHIP_YUV400 || cfg->yuv_format > JMHIP_YUV444) return JMHIP_ERR_ARG;
+  if (cfg->bit_depth != 8) return JMHIP_ERR_UNSUPPORTED;
+  if (cfg->max_refs < 1 || cfg->max_refs > 32 || cfg->search_range < 0 || cfg->search_range > 64) return JMHIP_ERR_ARG;
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return JMHIP_ERR_DEVICE;
+  if (cfg->device < 0 || cfg->device >= ndev) return JMHIP_ERR_ARG;
+  if (hipSetDevice(cfg->device) != hipSuccess) return JMHIP_ERR_DEVICE;
+
+  jmhip_ctx *c = new jmhip_ctx();
+  c->cfg = *cfg;
+  c->W = cfg->width; c->H = cfg->height;
+  c->Wp = c->W + 2 * JMHIP_PAD; c->Hp = c->H + 2 * JMHIP_PAD;
+  c->mbw = c->W / 16; c->mbh = c->H / 16;
+  chroma_geometry(cfg->yuv_format, &c->cg);
+  if (cfg->yuv_format != JMHIP_YUV400) {
+    c->Wc = (cfg->yuv_format == JMHIP_YUV444) ? c->W : c->W / 2;
+    c->Hc = (cfg->yuv_format == JMHIP_YUV420) ? c->H / 2 : c->H;
+    c->Wcp = c->Wc + 2 * c->cg.pad_x; c->Hcp = c->Hc + 2 * c->cg.pad_y;
+  }
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return JMHIP_ERR_DEVICE; }
+  c->refs.resize(cfg->max_refs);
+
+  auto alloc = [&](uint8_t **p, size_t bytes) -> bool {
+    if (hipMalloc((void **)p, bytes) != hipSuccess) return false;
+    return hipMemsetAsync(*p, 0, bytes, c->stream) == hipSuccess;
+  };
+  bool ok = true;
+  const size_t ysz = (size_t)c->W * c->H, csz = (size_t)c->Wc * c->Hc;
+  for (auto &r : c->refs) {
+    ok = ok && alloc(&r.y, ysz);
+    ok = ok && alloc(&r.luma_sub, 16 * (size_t)c->Wp * c->Hp);
+    if (csz) {
+      ok = ok && alloc(&r.u, csz) && alloc(&r.v, csz);
+      // zero-initialised like JM's calloc (memalloc.c:142): the last row/column are never written
+      for (int k = 0; k < 2; k++) ok = ok && alloc(&r.cr_sub[k], (size_t)c->cg.sub_x * c->cg.sub_y * c->Wcp * c->Hcp);
+    }
+  }
+  ok = ok && alloc(&c->cur_y, ysz);
+  if (csz) ok = ok && alloc(&c->cur_u, csz) && alloc(&c->cur_v, csz);
+  if (!ok) { jmhip_ctx_destroy(c); return JMHIP_ERR_NOMEM; }
+  if (hipStreamSynchronize(c->stream) != hipSuccess) { jmhip_ctx_destroy(c); return JMHIP_ERR_DEVICE; }
+  *out = c;
+  return JMHIP_OK;
+}
+
+extern "C" void jmhip_ctx_destroy(jmhip_ctx *c)
+{
+  if (!c) return;
+  (void)hipSetDevice(c->cfg.device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (auto &r : c->refs) {
+    (void)hipFree(r.y); (void)hipFree(r.u); (void)hipFree(r.v); (void)hipFree(r.luma_sub);
+    (void)hipFree(r.cr_sub[0]); (void)hipFree(r.cr_sub[1]);
+  }
+  (void)hipFree(c->cur_y); (void)hipFree(c->cur_u); (void)hipFree(c->cur_v);
+  (void)hipFree(c->stage_dev); (void)hipFree(c->me_jobs_dev); (void)hipFree(c->me_res_dev);
+  (void)hipFree(c->tq_jobs_dev); (void)hipFree(c->tq_res_dev); (void)hipFree(c->tq_quant_dev);
+  for (auto &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+  for (auto e : c->evt_pool) (void)hipEventDestroy(e);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+// ---------------------------------------------------------------------------------------- timing
+
+static int drain_timing(jmhip_ctx *c)
+{
+  for (auto &p : c->pending) {
+    float ms = 0.f;
+    JM_HIP_CHECK(c, hipEventSynchronize(p.b));
+    JM_HIP_CHECK(c, hipEventElapsedTime(&ms, p.a, p.b));
+    c->stage_ms[p.stage] += ms;
+    c->stage_launches[p.stage] += 1;
+    c->evt_pool.push_back(p.a); c->evt_pool.push_back(p.b);
+  }
+  c->pending.clear();
+  return JMHIP_OK;
+}
+
+static hipEvent_t get_evt(jmhip_ctx *c)
+{
+  if (!c->evt_pool.empty()) { hipEvent_t e = c->evt_pool.back(); c->evt_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+void jm_stage_begin(jmhip_ctx *c, int stage)
+{
+  if (!c->timing) return;
+  jmhip_ctx::PendingEvt p{stage, get_evt(c), get_evt(c)};
+  (void)hipEventRecord(p.a, c->stream);
+  c->pending.push_back(p);
+}
+
+void jm_stage_end(jmhip_ctx *c, int stage)
+{
+  if (!c->timing || c->pending.empty()) return;
+  (void)stage;
+  (void)hipEventRecord(c->pending.back().b, c->stream);
+}
+
+extern "C" int jmhip_sync(jmhip_ctx *c)
+{
+  if (!c) return JMHIP_ERR_ARG;
+  JM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_timing_enable(jmhip_ctx *c, int on)
+{
+  if (!c) return JMHIP_ERR_ARG;
+  c->timing = on != 0;
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_timing_read(jmhip_ctx *c, double ms[JMHIP_STAGE_COUNT], int launches[JMHIP_STAGE_COUNT])
+{
+  if (!c || !ms || !launches) return JMHIP_ERR_ARG;
+  int rc = drain_timing(c);
+  if (rc) return rc;
+  for (int i = 0; i < JMHIP_STAGE_COUNT; i++) {
+    ms[i] = c->stage_ms[i]; launches[i] = c->stage_launches[i];
+    c->stage_ms[i] = 0; c->stage_launches[i] = 0;
+  }
+  return JMHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------- pictures
+
+__global__ void narrow_u16_kernel(const uint16_t *__restrict__ src, uint8_t *__restrict__ dst, int w, int h, int sstride)
+{
+  int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x < w && y < h) dst[(size_t)y * w + x] = (uint8_t)src[(size_t)y * sstride + x];
+}
+
+__global__ void widen_u8_kernel(const uint8_t *__restrict__ src, uint16_t *__restrict__ dst, size_t n)
+{
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
+static int ensure_stage(jmhip_ctx *c, size_t bytes)
+{
+  if (c->stage_bytes >= bytes) return JMHIP_OK;
+  if (c->stage_dev) JM_HIP_CHECK(c, hipFree(c->stage_dev));
+  c->stage_dev = nullptr; c->stage_bytes = 0;
+  if (hipMalloc(&c->stage_dev, bytes) != hipSuccess) return jm_fail(c, JMHIP_ERR_NOMEM, "staging buffer");
+  c->stage_bytes = bytes;
+  return JMHIP_OK;
+}
+
+// copy one plane (w x h samples) into a tightly packed 8-bit device plane
+static int upload_plane(jmhip_ctx *c, uint8_t *dst, const void *src, int w, int h, int pel_bytes, int stride, int device_ptrs)
+{
+  if (!src) return jm_fail(c, JMHIP_ERR_ARG, "NULL plane");
+  if (stride < w) return jm_fail(c, JMHIP_ERR_ARG, "stride < width");
+  if (pel_bytes == 1) {
+    JM_HIP_CHECK(c, hipMemcpy2DAsync(dst, w, src, stride, w, h, device_ptrs ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    return JMHIP_OK;
+  }
+  if (pel_bytes != 2 || device_ptrs) return jm_fail(c, JMHIP_ERR_ARG, "pel_bytes must be 1 (or 2 for host pointers)");
+  size_t bytes = (size_t)stride * h * 2;
+  int rc = ensure_stage(c, bytes);
+  if (rc) return rc;
+  JM_HIP_CHECK(c, hipMemcpyAsync(c->stage_dev, src, bytes, hipMemcpyHostToDevice, c->stream));
+  dim3 grid((w + 255) / 256, h);
+  narrow_u16_kernel<<<grid, 256, 0, c->stream>>>((const uint16_t *)c->stage_dev, dst, w, h, stride);
+  JM_HIP_CHECK(c, hipGetLastError());
+  // the staging buffer is reused by the next plane: order is kept by the stream
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_ref_upload(jmhip_ctx *c, int ref, const void *Y, const void *U, const void *V,
+                                int pel_bytes, int stride_y, int stride_c, int device_ptrs)
+{
+  if (!c) return JMHIP_ERR_ARG;
+  if (ref < 0 || ref >= (int)c->refs.size()) return jm_fail(c, JMHIP_ERR_ARG, "ref slot out of range");
+  JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
+  RefSlot &r = c->refs[ref];
+  int rc = upload_plane(c, r.y, Y, c->W, c->H, pel_bytes, stride_y, device_ptrs);
+  if (rc) return rc;
+  if (c->Wc) {
+    if ((rc = upload_plane(c, r.u, U, c->Wc, c->Hc, pel_bytes, stride_c, device_ptrs))) return rc;
+    if ((rc = upload_plane(c, r.v, V, c->Wc, c->Hc, pel_bytes, stride_c, device_ptrs))) return rc;
+  }
+  r.has_pic = true; r.has_luma_sub = false; r.has_cr_sub = false;
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_cur_upload(jmhip_ctx *c, const void *Y, const void *U, const void *V,
+                                int pel_bytes, int stride_y, int stride_c, int device_ptrs)
+{
+  if (!c) return JMHIP_ERR_ARG;
+  JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
+  int rc = upload_plane(c, c->cur_y, Y, c->W, c->H, pel_bytes, stride_y, device_ptrs);
+  if (rc) return rc;
+  if (c->Wc && U && V) {
+    if ((rc = upload_plane(c, c->cur_u, U, c->Wc, c->Hc, pel_bytes, stride_c, device_ptrs))) return rc;
+    if ((rc = upload_plane(c, c->cur_v, V, c->Wc, c->Hc, pel_bytes, stride_c, device_ptrs))) return rc;
+  }
+  c->has_cur = true;
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_ref_device_planes(jmhip_ctx *c, int ref, void **Y, void **U, void **V, int *pitch_y, int *pitch_c)
+{
+  if (!c) return JMHIP_ERR_ARG;
+  if (ref < 0 || ref >= (int)c->refs.size()) return jm_fail(c, JMHIP_ERR_ARG, "ref slot out of range");
+  RefSlot &r = c->refs[ref];
+  if (Y) *Y = r.y;
+  if (U) *U = r.u;
+  if (V) *V = r.v;
+  if (pitch_y) *pitch_y = c->W;
+  if (pitch_c) *pitch_c = c->Wc;
+  r.has_pic = true;          // the caller writes the planes itself (device-to-device exchange)
+  r.has_luma_sub = false; r.has_cr_sub = false;
+  return JMHIP_OK;
+}
+
+static int download_planes(jmhip_ctx *c, const uint8_t *src, size_t n, void *out, int pel_bytes)
+{
+  if (!out) return jm_fail(c, JMHIP_ERR_ARG, "NULL output");
+  if (pel_bytes == 1) {
+    JM_HIP_CHECK(c, hipMemcpyAsync(out, src, n, hipMemcpyDeviceToHost, c->stream));
+  } else if (pel_bytes == 2) {
+    int rc = ensure_stage(c, n * 2);
+    if (rc) return rc;
+    widen_u8_kernel<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(src, (uint16_t *)c->stage_dev, n);
+    JM_HIP_CHECK(c, hipGetLastError());
+    JM_HIP_CHECK(c, hipMemcpyAsync(out, c->stage_dev, n * 2, hipMemcpyDeviceToHost, c->stream));
+  } else return jm_fail(c, JMHIP_ERR_ARG, "pel_bytes must be 1 or 2");
+  JM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_ref_download_luma(jmhip_ctx *c, int ref, void *out, int pel_bytes)
+{
+  if (!c) return JMHIP_ERR_ARG;
+  if (ref < 0 || ref >= (int)c->refs.size()) return jm_fail(c, JMHIP_ERR_ARG, "ref slot out of range");
+  if (!c->refs[ref].has_luma_sub) return jm_fail(c, JMHIP_ERR_ARG, "luma sub-pel planes not built (call jmhip_interp_luma)");
+  return download_planes(c, c->refs[ref].luma_sub, 16 * (size_t)c->Wp * c->Hp, out, pel_bytes);
+}
+
+extern "C" int jmhip_ref_download_chroma(jmhip_ctx *c, int ref, int uv, void *out, int pel_bytes)
+{
+  if (!c) return JMHIP_ERR_ARG;
+  if (ref < 0 || ref >= (int)c->refs.size() || uv < 0 || uv > 1) return jm_fail(c, JMHIP_ERR_ARG, "ref/uv out of range");
+  if (!c->Wc) return jm_fail(c, JMHIP_ERR_ARG, "4:0:0 has no chroma");
+  if (!c->refs[ref].has_cr_sub) return jm_fail(c, JMHIP_ERR_ARG, "chroma sub-pel planes not built (call jmhip_interp_chroma)");
+  return download_planes(c, c->refs[ref].cr_sub[uv], (size_t)c->cg.sub_x * c->cg.sub_y * c->Wcp * c->Hcp, out, pel_bytes);
+}
+
+extern "C" int jmhip_interp_luma(jmhip_ctx *c, int ref)
+{
+  if (!c) return JMHIP_ERR_ARG;
+  if (ref < 0 || ref >= (int)c->refs.size()) return jm_fail(c, JMHIP_ERR_ARG, "ref slot out of range");
+  if (!c->refs[ref].has_pic) return jm_fail(c, JMHIP_ERR_ARG, "reference picture not uploaded");
+  JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
+  jm_stage_begin(c, JMHIP_STAGE_INTERP_LUMA);
+  int rc = jm_launch_interp_luma(c, ref);
+  jm_stage_end(c, JMHIP_STAGE_INTERP_LUMA);
+  if (rc == JMHIP_OK) c->refs[ref].has_luma_sub = true;
+  return rc;
+}
+
+extern "C" int jmhip_interp_chroma(jmhip_ctx *c, int ref)
+{
+  if (!c) return JMHIP_ERR_ARG;
+  if (ref < 0 || ref >= (int)c->refs.size()) return jm_fail(c, JMHIP_ERR_ARG, "ref slot out of range");
+  if (!c->Wc) return jm_fail(c, JMHIP_ERR_ARG, "4:0:0 has no chroma");
+  if (!c->refs[ref].has_pic) return jm_fail(c, JMHIP_ERR_ARG, "reference picture not uploaded");
+  JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
+  jm_stage_begin(c, JMHIP_STAGE_INTERP_CHROMA);
+  int rc = jm_launch_interp_chroma(c, ref);
+  jm_stage_end(c, JMHIP_STAGE_INTERP_CHROMA);
+  if (rc == JMHIP_OK) c->refs[ref].has_cr_sub = true;
+  return rc;
+}

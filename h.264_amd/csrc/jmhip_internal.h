@@ -1,0 +1,70 @@
+// jmhip_internal.h -- shared declarations of libjmhip.so (C++/HIP side; the public ABI is include/jmhip.h)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "jmhip.h"
+
+struct ChromaGeom {           // chroma_mc_setup, lencod/src/lencod.c:2851-2884
+  int sub_x, sub_y, pad_x, pad_y, shift_x, shift_y, mask_x, mask_y, mul_x, mul_y, mb_w, mb_h;
+};
+
+struct RefSlot {
+  uint8_t *y = nullptr, *u = nullptr, *v = nullptr;   // integer-pel recon, pitch = W / Wc
+  uint8_t *luma_sub = nullptr;                        // [16][Hp][Wp]
+  uint8_t *cr_sub[2] = {nullptr, nullptr};            // [sub_y*sub_x][Hcp][Wcp]
+  bool has_pic = false, has_luma_sub = false, has_cr_sub = false;
+};
+
+struct jmhip_ctx {
+  jmhip_config cfg{};
+  hipStream_t stream = nullptr;
+  int W = 0, H = 0, Wp = 0, Hp = 0;                   // luma and padded luma size
+  int Wc = 0, Hc = 0, Wcp = 0, Hcp = 0;               // chroma and padded chroma size
+  int mbw = 0, mbh = 0;
+  ChromaGeom cg{};
+  std::vector<RefSlot> refs;
+  uint8_t *cur_y = nullptr, *cur_u = nullptr, *cur_v = nullptr;
+  bool has_cur = false;
+  // staging for 16-bit sample conversion
+  void *stage_dev = nullptr; size_t stage_bytes = 0;
+  // ME job/result arrays
+  void *me_jobs_dev = nullptr; void *me_res_dev = nullptr; int me_capacity = 0; int me_n = 0;
+  // TQ arrays
+  void *tq_jobs_dev = nullptr, *tq_res_dev = nullptr, *tq_quant_dev = nullptr; int tq_capacity = 0, tq_qcap = 0;
+  // timing
+  bool timing = false;
+  double stage_ms[JMHIP_STAGE_COUNT] = {0};
+  int stage_launches[JMHIP_STAGE_COUNT] = {0};
+  struct PendingEvt { int stage; hipEvent_t a, b; };
+  std::vector<PendingEvt> pending;
+  std::vector<hipEvent_t> evt_pool;
+  std::string err;
+};
+
+#define JM_HIP_CHECK(ctx, call)                                                              \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                        \
+      return JMHIP_ERR_DEVICE;                                                               \
+    }                                                                                        \
+  } while (0)
+
+static inline int jm_fail(jmhip_ctx *ctx, int code, const char *msg)
+{
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+// RAII-less stage timer: call begin before the launches of a stage and end after them.
+void jm_stage_begin(jmhip_ctx *ctx, int stage);
+void jm_stage_end(jmhip_ctx *ctx, int stage);
+
+// kernels (one translation unit each)
+int jm_launch_interp_luma(jmhip_ctx *ctx, int ref);
+int jm_launch_interp_chroma(jmhip_ctx *ctx, int ref);

@@ -1,0 +1,239 @@
+"""ctypes binding of include/jmhip.h (the C ABI of libjmhip.so). Plumbing only."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+NPART = 41
+PAD = 20
+STAGES = ("interp_luma", "interp_chroma", "me_int", "me_sub", "mc", "tq")
+
+_lib = None
+
+
+class JmhipError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(HERE, "libjmhip.so")
+
+
+def build_library(verbose=False):
+    """hipcc --offload-arch=gfx950 build of csrc/*.hip into libjmhip.so (cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", os.path.join(HERE, "csrc"), "-j4"], capture_output=not verbose, text=True)
+    if r.returncode != 0:
+        raise JmhipError("building libjmhip.so failed:\n" + (r.stderr or "")[-4000:])
+    return library_path()
+
+
+def declared_symbols():
+    """Entry points declared in include/jmhip.h."""
+    with open(os.path.join(ROOT, "include", "jmhip.h")) as f:
+        txt = f.read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(jmhip_[a-z0-9_]+)\s*\(", txt)))
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int), ("width", C.c_int), ("height", C.c_int), ("yuv_format", C.c_int),
+                ("bit_depth", C.c_int), ("max_refs", C.c_int), ("search_range", C.c_int)]
+
+
+class MeParams(C.Structure):
+    _fields_ = [("search_mode", C.c_int), ("search_range", C.c_int), ("rdopt", C.c_int), ("is_b_slice", C.c_int),
+                ("level_mv_min", C.c_int), ("level_mv_max", C.c_int), ("lambda_", C.c_int * 3),
+                ("transform8x8_mode", C.c_int), ("subpel", C.c_int), ("partition_mask", C.c_uint64)]
+
+
+ME_MB_DTYPE = np.dtype([("mb_x", "<i2"), ("mb_y", "<i2"), ("ref", "<i2"), ("ref_is_0", "<i2"),
+                        ("pred_mv", "<i2", (NPART, 2))])
+ME_RESULT_DTYPE = np.dtype([("mv", "<i2", (NPART, 2)), ("cost", "<i4", (NPART,)),
+                            ("mv_int", "<i2", (NPART, 2)), ("cost_int", "<i4", (NPART,))])
+DIST_JOB_DTYPE = np.dtype([("pic_x", "<i2"), ("pic_y", "<i2"), ("bsx", "<i2"), ("bsy", "<i2"),
+                           ("cand_x", "<i4"), ("cand_y", "<i4"), ("ref", "<i2"), ("use_satd", "<i2")])
+
+
+def load_library():
+    """Loads libjmhip.so. Raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise JmhipError("libjmhip.so is not built (%s): run __graft_entry__.build() or make -C h.264_amd/csrc" % path)
+    lib = C.CDLL(path)
+    vp, ip = C.c_void_p, C.c_int
+    lib.jmhip_ctx_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    lib.jmhip_ctx_destroy.argtypes = [vp]
+    lib.jmhip_ctx_destroy.restype = None
+    lib.jmhip_sync.argtypes = [vp]
+    lib.jmhip_last_error.argtypes = [vp]
+    lib.jmhip_last_error.restype = C.c_char_p
+    lib.jmhip_strerror.argtypes = [ip]
+    lib.jmhip_strerror.restype = C.c_char_p
+    lib.jmhip_timing_enable.argtypes = [vp, ip]
+    lib.jmhip_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(ip)]
+    lib.jmhip_ref_upload.argtypes = [vp, ip, vp, vp, vp, ip, ip, ip, ip]
+    lib.jmhip_cur_upload.argtypes = [vp, vp, vp, vp, ip, ip, ip, ip]
+    lib.jmhip_interp_luma.argtypes = [vp, ip]
+    lib.jmhip_interp_chroma.argtypes = [vp, ip]
+    lib.jmhip_ref_download_luma.argtypes = [vp, ip, vp, ip]
+    lib.jmhip_ref_download_chroma.argtypes = [vp, ip, ip, vp, ip]
+    lib.jmhip_ref_device_planes.argtypes = [vp, ip, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(ip), C.POINTER(ip)]
+    lib.jmhip_partition_info.argtypes = [ip] + [C.POINTER(ip)] * 5
+    lib.jmhip_partition_info.restype = None
+    lib.jmhip_me_frame.argtypes = [vp, C.POINTER(MeParams), vp, ip, vp]
+    lib.jmhip_me_frame_async.argtypes = [vp, C.POINTER(MeParams), vp, ip]
+    lib.jmhip_me_results_download.argtypes = [vp, vp, ip]
+    lib.jmhip_distortion_batch.argtypes = [vp, vp, ip, vp]
+    _lib = lib
+    return lib
+
+
+def partition_table():
+    """[(blocktype, x4, y4, w4, h4)] for partition 0..40 (jmhip_partition_info)."""
+    lib = load_library()
+    out = []
+    for p in range(NPART):
+        v = [C.c_int() for _ in range(5)]
+        lib.jmhip_partition_info(p, *[C.byref(x) for x in v])
+        out.append(tuple(x.value for x in v))
+    return out
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Context:
+    """One jmhip_ctx: device-resident reference slots + current picture on one GPU."""
+
+    def __init__(self, width, height, yuv_format=1, max_refs=1, search_range=32, device=0, bit_depth=8):
+        self.lib = load_library()
+        self.cfg = Config(device, width, height, yuv_format, bit_depth, max_refs, search_range)
+        self.h = C.c_void_p()
+        rc = self.lib.jmhip_ctx_create(C.byref(self.cfg), C.byref(self.h))
+        if rc != 0:
+            raise JmhipError("jmhip_ctx_create: " + self.lib.jmhip_strerror(rc).decode())
+        self.W, self.H = width, height
+        self.Wp, self.Hp = width + 2 * PAD, height + 2 * PAD
+        self.yuv_format = yuv_format
+        if yuv_format == 1:
+            self.sub, self.cpad = (8, 8), (10, 10)
+            self.Wc, self.Hc = width // 2, height // 2
+        elif yuv_format == 2:
+            self.sub, self.cpad = (8, 4), (10, 20)
+            self.Wc, self.Hc = width // 2, height
+        elif yuv_format == 3:
+            self.sub, self.cpad = (4, 4), (20, 20)
+            self.Wc, self.Hc = width, height
+        else:
+            self.sub, self.cpad, self.Wc, self.Hc = (0, 0), (0, 0), 0, 0
+        self.Wcp, self.Hcp = self.Wc + 2 * self.cpad[0], self.Hc + 2 * self.cpad[1]
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise JmhipError("%s: %s (%s)" % (what, self.lib.jmhip_strerror(rc).decode(),
+                                              self.lib.jmhip_last_error(self.h).decode()))
+
+    def close(self):
+        if self.h:
+            self.lib.jmhip_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        self._chk(self.lib.jmhip_sync(self.h), "jmhip_sync")
+
+    # ---- pictures
+    @staticmethod
+    def _planes(Y, U, V):
+        Y = np.ascontiguousarray(Y)
+        pel = Y.dtype.itemsize
+        if Y.dtype not in (np.uint8, np.uint16):
+            raise JmhipError("samples must be uint8 or uint16 (imgpel)")
+        U = np.ascontiguousarray(U, dtype=Y.dtype) if U is not None else None
+        V = np.ascontiguousarray(V, dtype=Y.dtype) if V is not None else None
+        return Y, U, V, pel
+
+    def ref_upload(self, ref, Y, U=None, V=None):
+        Y, U, V, pel = self._planes(Y, U, V)
+        self._chk(self.lib.jmhip_ref_upload(self.h, ref, _ptr(Y), _ptr(U), _ptr(V), pel, Y.shape[1],
+                                            U.shape[1] if U is not None else 0, 0), "jmhip_ref_upload")
+
+    def ref_upload_device(self, ref, y_ptr, u_ptr, v_ptr, stride_y, stride_c):
+        self._chk(self.lib.jmhip_ref_upload(self.h, ref, y_ptr, u_ptr, v_ptr, 1, stride_y, stride_c, 1), "jmhip_ref_upload(device)")
+
+    def cur_upload(self, Y, U=None, V=None):
+        Y, U, V, pel = self._planes(Y, U, V)
+        self._chk(self.lib.jmhip_cur_upload(self.h, _ptr(Y), _ptr(U), _ptr(V), pel, Y.shape[1],
+                                            U.shape[1] if U is not None else 0, 0), "jmhip_cur_upload")
+
+    def cur_upload_device(self, y_ptr, u_ptr, v_ptr, stride_y, stride_c):
+        self._chk(self.lib.jmhip_cur_upload(self.h, y_ptr, u_ptr, v_ptr, 1, stride_y, stride_c, 1), "jmhip_cur_upload(device)")
+
+    def ref_device_planes(self, ref):
+        y, u, v = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        py, pc = C.c_int(), C.c_int()
+        self._chk(self.lib.jmhip_ref_device_planes(self.h, ref, C.byref(y), C.byref(u), C.byref(v), C.byref(py), C.byref(pc)),
+                  "jmhip_ref_device_planes")
+        return y.value, u.value, v.value, py.value, pc.value
+
+    # ---- getSubImagesLuma / getSubImagesChroma
+    def interp_luma(self, ref):
+        self._chk(self.lib.jmhip_interp_luma(self.h, ref), "jmhip_interp_luma")
+
+    def interp_chroma(self, ref):
+        self._chk(self.lib.jmhip_interp_chroma(self.h, ref), "jmhip_interp_chroma")
+
+    def download_luma_planes(self, ref, dtype=np.uint8):
+        out = np.empty((4, 4, self.Hp, self.Wp), dtype=dtype)
+        self._chk(self.lib.jmhip_ref_download_luma(self.h, ref, _ptr(out), out.dtype.itemsize), "jmhip_ref_download_luma")
+        return out
+
+    def download_chroma_planes(self, ref, uv, dtype=np.uint8):
+        out = np.empty((self.sub[1], self.sub[0], self.Hcp, self.Wcp), dtype=dtype)
+        self._chk(self.lib.jmhip_ref_download_chroma(self.h, ref, uv, _ptr(out), out.dtype.itemsize), "jmhip_ref_download_chroma")
+        return out
+
+    # ---- motion estimation
+    def me_frame(self, prm, mbs):
+        mbs = np.ascontiguousarray(mbs, dtype=ME_MB_DTYPE)
+        res = np.zeros(len(mbs), dtype=ME_RESULT_DTYPE)
+        self._chk(self.lib.jmhip_me_frame(self.h, C.byref(prm), _ptr(mbs), len(mbs), _ptr(res)), "jmhip_me_frame")
+        return res
+
+    def me_frame_async(self, prm, mbs):
+        mbs = np.ascontiguousarray(mbs, dtype=ME_MB_DTYPE)
+        self._chk(self.lib.jmhip_me_frame_async(self.h, C.byref(prm), _ptr(mbs), len(mbs)), "jmhip_me_frame_async")
+
+    def me_results(self, n):
+        res = np.zeros(n, dtype=ME_RESULT_DTYPE)
+        self._chk(self.lib.jmhip_me_results_download(self.h, _ptr(res), n), "jmhip_me_results_download")
+        return res
+
+    def distortion_batch(self, jobs):
+        jobs = np.ascontiguousarray(jobs, dtype=DIST_JOB_DTYPE)
+        out = np.zeros(len(jobs), dtype=np.int32)
+        self._chk(self.lib.jmhip_distortion_batch(self.h, _ptr(jobs), len(jobs), _ptr(out)), "jmhip_distortion_batch")
+        return out
+
+    # ---- timing
+    def timing_enable(self, on=True):
+        self._chk(self.lib.jmhip_timing_enable(self.h, 1 if on else 0), "jmhip_timing_enable")
+
+    def timing_read(self):
+        ms = (C.c_double * len(STAGES))()
+        n = (C.c_int * len(STAGES))()
+        self._chk(self.lib.jmhip_timing_read(self.h, ms, n), "jmhip_timing_read")
+        return {s: (ms[i], n[i]) for i, s in enumerate(STAGES)}

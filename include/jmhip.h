@@ -1,0 +1,221 @@
+/*
+ * jmhip.h -- C ABI of libjmhip.so: the JM lencod per-macroblock hot path on MI355X (gfx950).
+ *
+ * Boundary: plain C, pointers and sizes only. Every entry point names the reference interface it
+ * replaces (paths relative to the reference repo's lencod/). The library is HIP-only: there is no CPU
+ * fallback, a missing device or a failed launch is an error code (never different numerics).
+ *
+ * Model. JM runs the path one call per block under a serial macroblock loop; the device runs it one
+ * launch per FRAME stage. A context owns device-resident pictures:
+ *   reference slots  -- integer-pel recon + the 16 quarter-pel luma planes + the 8x8 (4:2:0) / 4x8 (4:2:2)
+ *                       / 4x4 (4:4:4) eighth-pel chroma planes, exactly the arrays JM's StorablePicture
+ *                       holds after UnifiedOneForthPix (src/image.c:1601), as 8-bit samples;
+ *   the current picture (source samples);
+ *   per-macroblock job/result arrays of the stage calls below.
+ * Calls enqueue on the context's HIP stream and return; jmhip_sync() (or any download) completes them.
+ * From JM's single thread every exported function is therefore synchronous once followed by a download.
+ *
+ * Sample type at the boundary: JM's `imgpel` is unsigned short even for 8-bit video
+ * (inc/global.h:46-52). Upload/download take either 1- or 2-byte samples (pel_bytes); on the device
+ * 8-bit video is stored packed (BitDepth > 8 is rejected with JMHIP_ERR_UNSUPPORTED in this version).
+ */
+#ifndef JMHIP_H
+#define JMHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JMHIP_ABI_VERSION 1
+
+typedef struct jmhip_ctx jmhip_ctx;
+
+enum {
+  JMHIP_OK = 0,
+  JMHIP_ERR_ARG = 1,          /* bad argument (NULL, size mismatch, out of range)            */
+  JMHIP_ERR_DEVICE = 2,       /* HIP call failed / no gfx950 device                           */
+  JMHIP_ERR_UNSUPPORTED = 3,  /* valid JM configuration this version does not implement       */
+  JMHIP_ERR_NOMEM = 4
+};
+
+enum { JMHIP_YUV400 = 0, JMHIP_YUV420 = 1, JMHIP_YUV422 = 2, JMHIP_YUV444 = 3 };   /* img->yuv_format */
+
+#define JMHIP_PAD 20                      /* IMG_PAD_SIZE, inc/defines.h:107                            */
+#define JMHIP_NPART 41                    /* partitions of one MB over block types 1..7                 */
+
+/* ------------------------------------------------------------------ context */
+
+typedef struct {
+  int device;              /* HIP device ordinal                                                     */
+  int width, height;       /* coded luma size (multiples of 16; JM pads 1080 -> 1088, configfile.c:997) */
+  int yuv_format;          /* JMHIP_YUV4xx                                                           */
+  int bit_depth;           /* 8                                                                      */
+  int max_refs;            /* number of reference slots                                              */
+  int search_range;        /* input->search_range: sizes the per-MB search window                    */
+} jmhip_config;
+
+int  jmhip_ctx_create(const jmhip_config *cfg, jmhip_ctx **out);
+void jmhip_ctx_destroy(jmhip_ctx *ctx);
+int  jmhip_sync(jmhip_ctx *ctx);
+const char *jmhip_last_error(jmhip_ctx *ctx);      /* text of the last failure on this context */
+const char *jmhip_strerror(int code);
+int  jmhip_abi_version(void);
+
+/* Kernel timing on the context's stream (hipEvents recorded around each stage launch).
+ * jmhip_timing_enable(ctx,1) makes every stage call record start/stop events; jmhip_timing_read returns
+ * the accumulated milliseconds and launch count per stage since the last reset and resets them. */
+enum { JMHIP_STAGE_INTERP_LUMA = 0, JMHIP_STAGE_INTERP_CHROMA, JMHIP_STAGE_ME_INT, JMHIP_STAGE_ME_SUB,
+       JMHIP_STAGE_MC, JMHIP_STAGE_TQ, JMHIP_STAGE_COUNT };
+int jmhip_timing_enable(jmhip_ctx *ctx, int on);
+int jmhip_timing_read(jmhip_ctx *ctx, double ms[JMHIP_STAGE_COUNT], int launches[JMHIP_STAGE_COUNT]);
+
+/* ------------------------------------------------------------------ pictures */
+
+/* Upload the reconstructed integer-pel picture of a reference into slot `ref` (what JM holds in
+ * StorablePicture.imgY / imgUV[2], inc/mbuffer.h:20-95). Strides in samples. U/V may be NULL for 4:0:0.
+ * `device_ptrs` != 0: Y/U/V are device pointers (8-bit packed only), copied device-to-device. */
+int jmhip_ref_upload(jmhip_ctx *ctx, int ref, const void *Y, const void *U, const void *V,
+                     int pel_bytes, int stride_y, int stride_c, int device_ptrs);
+
+/* getSubImagesLuma (src/img_luma.c:45, proto inc/img_luma.h:20): builds the 16 quarter-pel planes of slot
+ * `ref` from its uploaded integer picture. Layout on device: plane (y&3)*4+(x&3), each
+ * (height+40) x (width+40) samples, JM's imgY_sub[4][4][H+40][W+40]. */
+int jmhip_interp_luma(jmhip_ctx *ctx, int ref);
+
+/* getSubImagesChroma (src/img_chroma.c:374, proto inc/img_chroma.h:20): imgUV_sub[2][sy][sx][..][..]. */
+int jmhip_interp_chroma(jmhip_ctx *ctx, int ref);
+
+/* Test/diagnostic: copy sub-pel planes back. `out` holds 16 (luma) or sub_y*sub_x (chroma, one component
+ * uv = 0/1) planes of padded size, contiguous, pel_bytes per sample. */
+int jmhip_ref_download_luma(jmhip_ctx *ctx, int ref, void *out, int pel_bytes);
+int jmhip_ref_download_chroma(jmhip_ctx *ctx, int ref, int uv, void *out, int pel_bytes);
+
+/* Device addresses of a slot's integer-pel picture (for device-to-device exchange, e.g. the RCCL
+ * all-gather of reconstructed slice bands): pitch in bytes. */
+int jmhip_ref_device_planes(jmhip_ctx *ctx, int ref, void **Y, void **U, void **V, int *pitch_y, int *pitch_c);
+
+/* Upload the current (source) picture: pCurImg / imgUV_org (inc/global.h). */
+int jmhip_cur_upload(jmhip_ctx *ctx, const void *Y, const void *U, const void *V,
+                     int pel_bytes, int stride_y, int stride_c, int device_ptrs);
+
+/* ------------------------------------------------------------------ motion estimation */
+
+/* Partition order inside a macroblock (index 0..40), JM's PartitionMotionSearch order
+ * (src/mv-search.c:1378): type 1: 16x16; 2: 16x8 top,bottom; 3: 8x16 left,right; 4: 8x8 b8=0..3;
+ * 5: 8x4 per b8 (top,bottom); 6: 4x8 per b8 (left,right); 7: 4x4 per b8 (raster in the 8x8).
+ * jmhip_partition_info() returns blocktype and the 4x4-unit rectangle of partition p. */
+void jmhip_partition_info(int p, int *blocktype, int *x4, int *y4, int *w4, int *h4);
+
+enum { JMHIP_SEARCH_FULL = -1, JMHIP_SEARCH_FASTFULL = 0 };   /* input->SearchMode */
+
+/* Slice/frame-level inputs of the search (JM: input->, img->, active_pps->). */
+typedef struct {
+  int search_mode;         /* JMHIP_SEARCH_FULL: FullPelBlockMotionSearch (src/me_fullsearch.c:47), centre per
+                              partition from its own predictor (src/mv-search.c:752-762);
+                              JMHIP_SEARCH_FASTFULL: FastFullPelBlockMotionSearch (src/me_fullfast.c:833), one
+                              centre per MB from the 16x16 predictor (:550-566)                        */
+  int search_range;        /* <= cfg.search_range                                                    */
+  int rdopt;               /* input->rdopt                                                           */
+  int is_b_slice;          /* img->type == B_SLICE                                                   */
+  int level_mv_min, level_mv_max;   /* LEVELMVLIMIT[img->LevelIndex][0..1], inc/mv-search.h:35-54    */
+  int lambda[3];           /* lambda_factor[F_PEL,H_PEL,Q_PEL] (src/slice.c:1329-1358)                */
+  int transform8x8_mode;   /* input->Transform8x8Mode: SATD uses the 8x8 Hadamard for block types <= 4 */
+  int subpel;              /* !input->DisableSubpelME                                                 */
+  uint64_t partition_mask; /* bit p set: partition p is searched (all 41: (1<<41)-1)                  */
+} jmhip_me_params;
+
+/* Per-macroblock inputs. pred_mv: motion-vector predictor per partition in quarter-pel units, what
+ * SetMotionVectorPredictor (src/mv-search.c:87) yields for that partition. ref: reference slot. */
+typedef struct {
+  int16_t mb_x, mb_y;                    /* macroblock position in MB units                          */
+  int16_t ref;                           /* reference slot; ref_is_0 = (JM ref index == 0)            */
+  int16_t ref_is_0;
+  int16_t pred_mv[JMHIP_NPART][2];
+} jmhip_me_mb;
+
+typedef struct {
+  int16_t mv[JMHIP_NPART][2];            /* final MV, quarter-pel (img->all_mv value)                 */
+  int32_t cost[JMHIP_NPART];             /* min_mcost returned by BlockMotionSearch's search chain     */
+  int16_t mv_int[JMHIP_NPART][2];        /* integer-search result in pel units (before << 2)          */
+  int32_t cost_int[JMHIP_NPART];         /* min_mcost after the integer search                         */
+} jmhip_me_result;
+
+/* One frame stage: for every MB in `mbs` runs, per partition, the chain of BlockMotionSearch
+ * (src/mv-search.c:560) from the predictor on: search centre, integer full search over
+ * (2R+1)^2 candidates with SAD + MV_COST_SMP (inc/defines.h:128) and lowest-spiral-index tie-break,
+ * then half- and quarter-pel refinement with SATD (src/me_fullsearch.c:341). Uses the current picture
+ * and the reference slots. mbs/results are host arrays of n entries. */
+int jmhip_me_frame(jmhip_ctx *ctx, const jmhip_me_params *prm, const jmhip_me_mb *mbs, int n,
+                   jmhip_me_result *results);
+
+/* Same, split for device-resident pipelines: enqueue with host job upload, leave results on device. */
+int jmhip_me_frame_async(jmhip_ctx *ctx, const jmhip_me_params *prm, const jmhip_me_mb *mbs, int n);
+int jmhip_me_results_download(jmhip_ctx *ctx, jmhip_me_result *results, int n);
+
+/* Single distortion evaluations with JM's signatures' meaning, batched (tests, EPZS/UMHex host loops):
+ * computeSAD / computeSATD (src/me_distortion.c:351,657; protos inc/me_distortion.h:43-54) with
+ * min_mcost = INT_MAX, UMV access. cand_x/cand_y are quarter-pel INCLUDING the +80 pad offset. */
+typedef struct {
+  int16_t pic_x, pic_y;     /* block origin in the current picture (pel)                              */
+  int16_t bsx, bsy;         /* block size                                                             */
+  int32_t cand_x, cand_y;
+  int16_t ref, use_satd;    /* use_satd: 0 SAD, 1 SATD 4x4, 2 SATD 8x8 (test8x8transform)             */
+} jmhip_dist_job;
+int jmhip_distortion_batch(jmhip_ctx *ctx, const jmhip_dist_job *jobs, int n, int32_t *out);
+
+/* ------------------------------------------------------------------ transform / quant / recon */
+
+/* Quantiser of one block (JM: levelscale/invlevelscale/leveloffset selected at src/block.c:874-877,
+ * src/transform8x8.c:1487-1489). Tables row-major [j][i]. */
+typedef struct {
+  int32_t qp;                    /* currMB->qp_scaled[pl] or chroma qp                               */
+  int32_t adaptive_rounding, adapt_rnd_weight;
+  int32_t field_scan, disthres, max_val, cavlc, img_qp, transform8x8_flag;
+  int32_t levelscale[64], invlevelscale[64], leveloffset[64];     /* 16 used for 4x4 kinds          */
+} jmhip_quant;
+
+enum { JMHIP_TQ_LUMA4x4 = 0,     /* dct_4x4   src/block.c:843, pointer pDCT_4x4 inc/global.h:1376      */
+       JMHIP_TQ_LUMA8x8 = 1,     /* dct_8x8   src/transform8x8.c:1452, proto inc/transform8x8.h:23     */
+       JMHIP_TQ_LUMA16x16 = 2,   /* dct_16x16 src/block.c:564, proto inc/global.h:1378                 */
+       JMHIP_TQ_CHROMA = 3 };    /* dct_chroma src/block.c:1051, proto inc/global.h:1379               */
+
+/* One macroblock-component job. For LUMA4x4 one job covers the 16 4x4 blocks of the MB (each an
+ * independent dct_4x4 call), LUMA8x8 the four 8x8 blocks. src = original samples, pred = prediction
+ * (img->mpr); the residual img->m7 = src - pred is formed on the device. */
+typedef struct {
+  uint8_t  src[16][16];
+  uint8_t  pred[16][16];
+  int32_t  quant;                /* index into the quant table array passed to the batch call         */
+  int32_t  quant_dc;             /* 4:2:2 chroma DC quantiser (qp+3), else ignored                     */
+  int32_t  uv, cr_cbp_in;        /* CHROMA: component and incoming cr_cbp                              */
+  int32_t  intra16_unused;
+} jmhip_tq_job;
+
+typedef struct {
+  int32_t  levels[16][17];       /* (level) lists per 4x4 block in JM block order b8*4+b4, 0-terminated;
+                                    LUMA8x8: rows 4*b8 .. 4*b8+3 hold cofAC[b8][0..3] (17 entries each
+                                    for CAVLC interleave) -- see levels8 for the 64-entry CABAC list  */
+  int32_t  runs[16][17];
+  int32_t  levels8[4][65], runs8[4][65];  /* LUMA8x8 non-interleaved (CABAC / flag off) lists        */
+  int32_t  dc_levels[17], dc_runs[17];    /* LUMA16x16 / CHROMA DC lists                               */
+  uint8_t  recon[16][16];
+  int32_t  fadjust[16][16];
+  int32_t  coeff_cost[16];       /* per 4x4 (LUMA4x4) / per 8x8 in [0..3] (LUMA8x8)                    */
+  int32_t  nonzero[16];          /* return value of dct_4x4 / dct_8x8 per block                        */
+  int32_t  ret;                  /* dct_16x16: ac_coef; dct_chroma: cr_cbp                             */
+  int64_t  cbp_blk;              /* dct_chroma: bits OR-ed into currMB->cbp_blk                        */
+} jmhip_tq_result;
+
+int jmhip_tq_batch(jmhip_ctx *ctx, int kind, int yuv_format, const jmhip_quant *quants, int nquants,
+                   const jmhip_tq_job *jobs, int n, jmhip_tq_result *results);
+
+/* Flat (no scaling matrix) tables: CalculateQuantParam / CalculateQuant8Param (src/q_matrix.c:451,590) and
+ * default CalculateOffsetParam / CalculateOffset8Param (src/q_offsets.c:491,629); offset11 = 682 or 342. */
+void jmhip_flat_quant(jmhip_quant *q, int qp, int offset11, int is8x8);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

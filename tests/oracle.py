@@ -1,0 +1,136 @@
+"""ctypes wrapper over oracle/liboracle.so (the CPU restatement of JM, test infrastructure only).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ODIR = os.path.join(ROOT, "oracle")
+PAD = 20
+_lib = None
+
+
+class ChromaGeom(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("sub_x", "sub_y", "pad_x", "pad_y", "shift_x", "shift_y", "mask_x", "mask_y",
+                                       "mul_x", "mul_y", "mb_cr_size_x", "mb_cr_size_y")]
+
+
+class Ref(C.Structure):
+    _fields_ = [("W", C.c_int), ("H", C.c_int), ("Wp", C.c_int), ("Hp", C.c_int),
+                ("width_pad", C.c_int), ("height_pad", C.c_int),
+                ("luma", C.c_void_p * 16), ("yuv_format", C.c_int), ("cg", ChromaGeom),
+                ("Wc", C.c_int), ("Hc", C.c_int), ("Wcp", C.c_int), ("Hcp", C.c_int),
+                ("width_pad_cr", C.c_int), ("height_pad_cr", C.c_int), ("cr", (C.c_void_p * 64) * 2)]
+
+
+class MeParams(C.Structure):
+    _fields_ = [("rdopt", C.c_int), ("is_b_slice", C.c_int), ("chroma_me", C.c_int), ("chroma_me_weight", C.c_int),
+                ("transform8x8_mode", C.c_int), ("metric", C.c_int * 3), ("apply_weights", C.c_int),
+                ("max_val", C.c_int), ("max_val_uv", C.c_int), ("level_mv_min", C.c_int), ("level_mv_max", C.c_int),
+                ("weight_luma", C.c_int), ("offset_luma", C.c_int), ("wp_luma_round", C.c_int), ("luma_log_weight_denom", C.c_int),
+                ("weight_cr", C.c_int * 2), ("offset_cr", C.c_int * 2), ("wp_chroma_round", C.c_int), ("chroma_log_weight_denom", C.c_int)]
+
+
+class Dist(C.Structure):
+    _fields_ = [("ref", C.POINTER(Ref)), ("umv", C.c_int), ("chroma_me", C.c_int), ("chroma_me_weight", C.c_int),
+                ("test8x8", C.c_int), ("max_val", C.c_int), ("max_val_uv", C.c_int),
+                ("weight_luma", C.c_int), ("offset_luma", C.c_int), ("wp_luma_round", C.c_int), ("luma_log_weight_denom", C.c_int),
+                ("weight_cr", C.c_int * 2), ("offset_cr", C.c_int * 2), ("wp_chroma_round", C.c_int), ("chroma_log_weight_denom", C.c_int)]
+
+
+def build():
+    r = subprocess.run(["make", "-C", ODIR, "-j4", "liboracle.so"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building liboracle.so failed:\n" + r.stderr[-3000:])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(ODIR, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        vp, ip = C.c_void_p, C.c_int
+        L.jmo_interp_luma.argtypes = [vp, ip, ip, ip, ip, vp]
+        L.jmo_interp_luma.restype = None
+        L.jmo_interp_chroma.argtypes = [vp, ip, ip, ip, ip, vp]
+        L.jmo_interp_chroma.restype = None
+        L.jmo_ref_init.argtypes = [C.POINTER(Ref), ip, ip, ip, vp, vp, vp]
+        L.jmo_ref_init.restype = None
+        L.jmo_block_search_full.argtypes = [C.POINTER(MeParams), C.POINTER(Ref), vp, ip, ip, ip, ip, ip, ip, ip,
+                                            C.POINTER(ip), vp, vp, C.POINTER(ip)]
+        L.jmo_fastfull_setup.argtypes = None
+        L.jmo_sad.argtypes = [C.POINTER(Dist), vp, ip, ip, ip, ip, ip]
+        L.jmo_satd.argtypes = [C.POINTER(Dist), vp, ip, ip, ip, ip, ip]
+        _lib = L
+    return _lib
+
+
+def chroma_geom(yuv_format):
+    return {1: ((8, 8), (10, 10)), 2: ((8, 4), (10, 20)), 3: ((4, 4), (20, 20))}[yuv_format]
+
+
+def interp_luma(img, max_val=255):
+    """img: (H, W) -> (4, 4, H+40, W+40) uint16, JM's imgY_sub."""
+    img = np.ascontiguousarray(img, dtype=np.uint16)
+    H, W = img.shape
+    out = np.zeros((4, 4, H + 2 * PAD, W + 2 * PAD), dtype=np.uint16)
+    lib().jmo_interp_luma(img.ctypes.data, W, H, W, max_val, out.ctypes.data)
+    return out
+
+
+def interp_chroma(img, yuv_format):
+    """img: (Hc, Wc) -> (sub_y, sub_x, Hc+2pad_y, Wc+2pad_x) uint16, JM's imgUV_sub[uv] (calloc zeros kept)."""
+    img = np.ascontiguousarray(img, dtype=np.uint16)
+    Hc, Wc = img.shape
+    (sx, sy), (px, py) = chroma_geom(yuv_format)
+    out = np.zeros((sy, sx, Hc + 2 * py, Wc + 2 * px), dtype=np.uint16)
+    lib().jmo_interp_chroma(img.ctypes.data, Wc, Hc, Wc, yuv_format, out.ctypes.data)
+    return out
+
+
+class RefPic:
+    """A reference picture with all sub-pel planes built by the oracle."""
+
+    def __init__(self, Y, U=None, V=None, yuv_format=1):
+        self.Y = np.ascontiguousarray(Y, dtype=np.uint16)
+        self.H, self.W = self.Y.shape
+        self.yuv_format = yuv_format
+        self.luma = interp_luma(self.Y)
+        self.cb = interp_chroma(U, yuv_format) if U is not None else None
+        self.cr = interp_chroma(V, yuv_format) if V is not None else None
+        self.ref = Ref()
+        lib().jmo_ref_init(C.byref(self.ref), self.W, self.H, yuv_format, self.luma.ctypes.data,
+                           self.cb.ctypes.data if self.cb is not None else None,
+                           self.cr.ctypes.data if self.cr is not None else None)
+
+
+def me_params(rdopt=1, is_b_slice=0, transform8x8_mode=0, metric=(0, 2, 2), level_mv=(-511, 511)):
+    p = MeParams()
+    p.rdopt, p.is_b_slice, p.transform8x8_mode = rdopt, is_b_slice, transform8x8_mode
+    p.metric[0], p.metric[1], p.metric[2] = metric
+    p.max_val = p.max_val_uv = 255
+    p.level_mv_min, p.level_mv_max = level_mv
+    return p
+
+
+BLOCK_SIZE = {1: (16, 16), 2: (16, 8), 3: (8, 16), 4: (8, 8), 5: (8, 4), 6: (4, 8), 7: (4, 4)}
+
+
+def block_search_full(p, refpic, cur, pic_x, pic_y, blocktype, pred, R, lam, ref_is_0=1):
+    """BlockMotionSearch chain for SearchMode=-1 -> (mv_qpel, cost, mv_int, cost_int)."""
+    bsx, bsy = BLOCK_SIZE[blocktype]
+    orig = np.zeros(768, dtype=np.uint16)
+    orig[: bsx * bsy] = np.asarray(cur[pic_y:pic_y + bsy, pic_x:pic_x + bsx], dtype=np.uint16).reshape(-1)
+    lam_a = (C.c_int * 3)(*lam)
+    mv = np.zeros(2, dtype=np.int16)
+    mvi = np.zeros(2, dtype=np.int16)
+    ci = C.c_int()
+    cost = lib().jmo_block_search_full(C.byref(p), C.byref(refpic.ref), orig.ctypes.data, ref_is_0, pic_x, pic_y, blocktype,
+                                       int(pred[0]), int(pred[1]), R, lam_a, mv.ctypes.data, mvi.ctypes.data, C.byref(ci))
+    return (int(mv[0]), int(mv[1])), cost, (int(mvi[0]), int(mvi[1])), ci.value
