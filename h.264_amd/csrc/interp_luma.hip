@@ -23,7 +23,10 @@ constexpr int S00_W = TX + 8;    // cols i0-4 .. i0+TX+3
 constexpr int ROWS = TY + 6;     // rows j0-2 .. j0+TY+3
 
 __device__ __forceinline__ int clampi(int x, int lo, int hi) { return min(max(x, lo), hi); }
-__device__ __forceinline__ uint32_t clip255(int v) { return (uint32_t)min(max(v, 0), 255); }
+// iClip1(255, v). The empty asm hides the preceding shift from hipcc: ROCm 7.2 otherwise fuses pairs of
+// clip((x >> s), 0, 255) into gfx950's v_ashr_pk_u8_i32 and ORs further bytes into its result assuming the
+// upper 16 bits are zero -- on MI355X they are not (bytes 2/3 of the packed dword came out corrupted).
+__device__ __forceinline__ uint32_t clip255(int v) { asm volatile("" : "+v"(v)); return (uint32_t)min(max(v, 0), 255); }
 __device__ __forceinline__ uint32_t pack4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return a | (b << 8) | (c << 16) | (d << 24); }
 // per-byte (a + b + 1) >> 1 : v_lerp_u8 with all carry-in bits set
 __device__ __forceinline__ uint32_t avg4(uint32_t a, uint32_t b) { return __builtin_amdgcn_lerp(a, b, 0x01010101u); }
