@@ -61,7 +61,7 @@ extern "C" int jmhip_ctx_create(const jmhip_config *cfg, jmhip_ctx **out)
   const size_t ysz = (size_t)c->W * c->H, csz = (size_t)c->Wc * c->Hc;
   for (auto &r : c->refs) {
     ok = ok && alloc(&r.y, ysz);
-    ok = ok && alloc(&r.luma_sub, 16 * (size_t)c->Wp * c->Hp);
+    ok = ok && alloc(&r.luma_sub, 16 * (size_t)c->Wp * c->Hp + 64);   // +64: unaligned row fetches read up to 11 bytes past a row start
     if (csz) {
       ok = ok && alloc(&r.u, csz) && alloc(&r.v, csz);
       // zero-initialised like JM's calloc (memalloc.c:142): the last row/column are never written
@@ -86,7 +86,7 @@ extern "C" void jmhip_ctx_destroy(jmhip_ctx *c)
     (void)hipFree(r.cr_sub[0]); (void)hipFree(r.cr_sub[1]);
   }
   (void)hipFree(c->cur_y); (void)hipFree(c->cur_u); (void)hipFree(c->cur_v);
-  (void)hipFree(c->stage_dev); (void)hipFree(c->me_jobs_dev); (void)hipFree(c->me_res_dev);
+  (void)hipFree(c->stage_dev); (void)hipFree(c->me_jobs_dev); (void)hipFree(c->me_res_dev); (void)hipFree(c->ref_ptrs_dev);
   (void)hipFree(c->tq_jobs_dev); (void)hipFree(c->tq_res_dev); (void)hipFree(c->tq_quant_dev);
   for (auto &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto e : c->evt_pool) (void)hipEventDestroy(e);

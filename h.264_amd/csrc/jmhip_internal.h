@@ -34,6 +34,7 @@ struct jmhip_ctx {
   void *stage_dev = nullptr; size_t stage_bytes = 0;
   // ME job/result arrays
   void *me_jobs_dev = nullptr; void *me_res_dev = nullptr; int me_capacity = 0; int me_n = 0;
+  void *ref_ptrs_dev = nullptr;                       // [0..31] integer recon, [32..63] quarter-pel plane stacks
   // TQ arrays
   void *tq_jobs_dev = nullptr, *tq_res_dev = nullptr, *tq_quant_dev = nullptr; int tq_capacity = 0, tq_qcap = 0;
   // timing

@@ -1,0 +1,583 @@
+// me_search.hip -- block motion estimation: integer full search (SAD) + half/quarter-pel refinement (SATD).
+//
+// Replaces, per partition, the chain BlockMotionSearch runs from the predictor on (lencod/src/mv-search.c:751-826):
+//   search centre                      mv-search.c:752-762 (FullSearch) / me_fullfast.c:550-566 (FastFullSearch)
+//   FullPelBlockMotionSearch           me_fullsearch.c:47-155     (SearchMode -1)
+//   FastFullPelBlockMotionSearch       me_fullfast.c:833-903 on the SAD surface of SetupFastFullPelSearch :491 (SearchMode 0)
+//   computeSAD / computeSATD           me_distortion.c:351 / :657 (HadamardSAD4x4 :182, HadamardSAD8x8 :272)
+//   SubPelBlockMotionSearch            me_fullsearch.c:341-511
+//   MV_COST_SMP / mvbits / spiral      defines.h:126-128, mv-search.c:333-341, :366-393
+//
+// Bit-exactness notes (each checked against the oracle, which is pinned by the real JM):
+//  * JM's candidate loop is sequential with strict '<' updates, so the result is argmin over (cost, spiral index):
+//    the kernel reduces packed keys (cost << 13 | tie) with the spiral index as the tie field. The early exits
+//    (me_distortion.c:373, :690) return partial sums that are never accepted, so full evaluation is identical.
+//  * Integer-pel reference samples: UMV access clamps the BLOCK ORIGIN into the 20-pel replicated ring
+//    (refbuf.c:37-43); for the integer plane that equals clamping every sample coordinate to the picture, so the
+//    search window is staged from the unpadded recon with per-sample clamping (no padded plane needed).
+//  * check_for_00 compares a quarter-pel coordinate with a pel coordinate (me_fullsearch.c:129): mirrored.
+//  * FastFullSearch evaluates the (0,0) vector first when !rdopt (me_fullfast.c:867-876): it wins all ties.
+//  * Sub-pel: 4x4/8x8 sub-block origins are clamped one by one under UMV access (me_distortion.c:678); FAST vs
+//    UMV is decided per phase as me_fullsearch.c:412-420, :468-476.
+//
+// Mapping: one workgroup per macroblock, all 41 partitions of block types 1..7 together. The integer kernel
+// stages the union of the partitions' search windows once in LDS, every lane owns candidates (one 16x16 SAD as
+// sixteen 4x4 SADs with v_sad_u8 on packed bytes, tree-summed to the 41 partition SADs, cf. SetupLargerBlocks
+// me_fullfast.c:210), keeps 41 running minima in registers, and a wavefront shuffle + LDS reduction finishes.
+// Roofline: ~10^3 integer ops per byte of compulsory traffic -> VALU/LDS bound, not HBM bound.
+#include "jmhip_internal.h"
+
+namespace {
+
+struct PartInfo { int8_t bt, x4, y4, w4, h4; };
+__constant__ PartInfo c_part[JMHIP_NPART];
+PartInfo h_part[JMHIP_NPART];
+bool h_part_ready = false;
+
+void build_part_table()
+{
+  if (h_part_ready) return;
+  int p = 0;
+  h_part[p++] = {1, 0, 0, 4, 4};
+  for (int k = 0; k < 2; k++) h_part[p++] = {2, 0, (int8_t)(2 * k), 4, 2};
+  for (int k = 0; k < 2; k++) h_part[p++] = {3, (int8_t)(2 * k), 0, 2, 4};
+  for (int b8 = 0; b8 < 4; b8++) h_part[p++] = {4, (int8_t)(2 * (b8 & 1)), (int8_t)(2 * (b8 >> 1)), 2, 2};
+  for (int b8 = 0; b8 < 4; b8++) for (int k = 0; k < 2; k++) h_part[p++] = {5, (int8_t)(2 * (b8 & 1)), (int8_t)(2 * (b8 >> 1) + k), 2, 1};
+  for (int b8 = 0; b8 < 4; b8++) for (int k = 0; k < 2; k++) h_part[p++] = {6, (int8_t)(2 * (b8 & 1) + k), (int8_t)(2 * (b8 >> 1)), 1, 2};
+  for (int b8 = 0; b8 < 4; b8++) for (int k = 0; k < 4; k++) h_part[p++] = {7, (int8_t)(2 * (b8 & 1) + (k & 1)), (int8_t)(2 * (b8 >> 1) + (k >> 1)), 1, 1};
+  h_part_ready = true;
+}
+
+struct MeDev {
+  int mode, R, rdopt, is_b, lvl_min, lvl_max, lam_f, lam_h, lam_q, t8x8, subpel;
+  unsigned long long mask;
+  int W, H, Wp, Hp;
+  int win_pitch, win_rows;            // LDS window geometry (bytes per row, rows)
+  const uint8_t *cur;
+  const uint8_t *const *ref_y;        // [slot] integer recon
+  const uint8_t *const *ref_sub;      // [slot] 16 quarter-pel planes
+};
+
+__device__ __forceinline__ int clampi(int x, int lo, int hi) { return min(max(x, lo), hi); }
+__device__ __forceinline__ int iabs(int x) { return x < 0 ? -x : x; }
+// mvbits[d] (mv-search.c:333-341): 1 for 0, 2*floor(log2|d|)+3 otherwise == 65 - 2*clz(|d|) with clz(0) = 32
+__device__ __forceinline__ int mvbits(int d) { return 65 - 2 * __clz(iabs(d)); }
+__device__ __forceinline__ int mv_cost(int lambda, int dx, int dy) { return (lambda * (mvbits(dx) + mvbits(dy))) >> 16; }
+
+// spiral_search index of offset (dx,dy), mv-search.c:366-393
+__device__ __forceinline__ int spiral_pos(int dx, int dy)
+{
+  const int adx = iabs(dx), ady = iabs(dy), l = max(adx, ady);
+  if (l == 0) return 0;
+  const int k0 = (2 * l - 1) * (2 * l - 1);
+  if (ady == l && adx < l) return k0 + 2 * (dx + l - 1) + (dy > 0 ? 1 : 0);
+  return k0 + 2 * (2 * l - 1) + 2 * (dy + l) + (dx > 0 ? 1 : 0);
+}
+__device__ void spiral_offset(int pos, int *dx, int *dy)
+{
+  if (pos == 0) { *dx = 0; *dy = 0; return; }
+  int l = 1;
+  while ((2 * l + 1) * (2 * l + 1) <= pos) l++;
+  int k = pos - (2 * l - 1) * (2 * l - 1);
+  if (k < 2 * (2 * l - 1)) { *dx = (k >> 1) - l + 1; *dy = (k & 1) ? l : -l; }
+  else { k -= 2 * (2 * l - 1); *dy = (k >> 1) - l; *dx = (k & 1) ? l : -l; }
+}
+
+// search centre from the predictor: mv-search.c:752-762 / me_fullfast.c:552-563
+__device__ __forceinline__ void search_center(const MeDev &P, int pmx, int pmy, int *cx, int *cy)
+{
+  int mx = pmx / 4, my = pmy / 4;
+  if (!P.rdopt) { mx = clampi(mx, -P.R, P.R); my = clampi(my, -P.R, P.R); }
+  mx = clampi(mx, -2047 + P.R, 2047 - P.R);
+  my = clampi(my, P.lvl_min + P.R, P.lvl_max - P.R);
+  *cx = mx; *cy = my;
+}
+
+constexpr int TIE_BITS = 13;            // (2*64+1)^2 + 1 < 2^15 would need 15; R <= 44 fits 13 bits: checked on the host
+constexpr unsigned KEY_INVALID = 0xffffffffu;
+
+// ------------------------------------------------------------------------------------------------ integer search
+
+__global__ __launch_bounds__(256) void me_int_kernel(MeDev P, const jmhip_me_mb *__restrict__ jobs, jmhip_me_result *__restrict__ res)
+{
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ int s_cx[JMHIP_NPART], s_cy[JMHIP_NPART], s_px[JMHIP_NPART], s_py[JMHIP_NPART];
+  __shared__ int s_u[8];                           // umin_x, umin_y, UW, UH, uniform
+  __shared__ uint32_t s_cur[64];
+  __shared__ unsigned s_red[JMHIP_NPART][4];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const jmhip_me_mb &job = jobs[blockIdx.x];
+  const int mbx = job.mb_x, mby = job.mb_y;
+  const unsigned long long mask = P.mask;
+
+  if (tid < JMHIP_NPART) {
+    const int src = (P.mode == JMHIP_SEARCH_FASTFULL) ? 0 : tid;
+    int cx, cy;
+    search_center(P, job.pred_mv[src][0], job.pred_mv[src][1], &cx, &cy);
+    s_cx[tid] = cx; s_cy[tid] = cy;
+    s_px[tid] = job.pred_mv[tid][0]; s_py[tid] = job.pred_mv[tid][1];
+  }
+  if (tid < 64) {
+    const int r = tid >> 2, k = tid & 3;
+    s_cur[tid] = *reinterpret_cast<const uint32_t *>(P.cur + (size_t)(mby * 16 + r) * P.W + mbx * 16 + k * 4);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int x0 = 1 << 30, x1 = -(1 << 30), y0 = 1 << 30, y1 = -(1 << 30), uni = 1, fx = 0, fy = 0, first = 1;
+    for (int p = 0; p < JMHIP_NPART; p++) if ((mask >> p) & 1) {
+      x0 = min(x0, s_cx[p]); x1 = max(x1, s_cx[p]); y0 = min(y0, s_cy[p]); y1 = max(y1, s_cy[p]);
+      if (first) { fx = s_cx[p]; fy = s_cy[p]; first = 0; } else if (s_cx[p] != fx || s_cy[p] != fy) uni = 0;
+    }
+    s_u[0] = x0 - P.R; s_u[1] = y0 - P.R; s_u[2] = x1 - x0 + 2 * P.R + 1; s_u[3] = y1 - y0 + 2 * P.R + 1; s_u[4] = uni;
+    s_u[5] = fx; s_u[6] = fy;
+  }
+  __syncthreads();
+  const int umin_x = s_u[0], umin_y = s_u[1], UW = s_u[2], UH = s_u[3], uniform = s_u[4];
+  const int pitch = P.win_pitch;
+  // the host sized the window for the worst MB of the launch; a larger one would overflow LDS
+  if (UW + 15 > pitch || UH + 15 > P.win_rows) { if (tid < JMHIP_NPART) res[blockIdx.x].cost_int[tid] = -2; return; }
+
+  // ---- stage the reference window (integer recon, per-sample clamp == JM's padded plane + UMV origin clamp)
+  {
+    const uint8_t *ref = P.ref_y[job.ref];
+    const int bx = mbx * 16 + umin_x, by = mby * 16 + umin_y;
+    const int nw = (UW + 15 + 3) >> 2;             // dwords per row
+    for (int d = tid; d < nw * (UH + 15); d += 256) {
+      const int y = d / nw, xw = d - y * nw;
+      const uint8_t *row = ref + (size_t)clampi(by + y, 0, P.H - 1) * P.W;
+      uint32_t v = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) v |= (uint32_t)row[clampi(bx + xw * 4 + k, 0, P.W - 1)] << (8 * k);
+      *reinterpret_cast<uint32_t *>(smem + (size_t)y * pitch + xw * 4) = v;
+    }
+  }
+  __syncthreads();
+
+  unsigned best[JMHIP_NPART];
+#pragma unroll
+  for (int p = 0; p < JMHIP_NPART; p++) best[p] = KEY_INVALID;
+
+  const int w16 = (P.lam_f * 16) >> 16;            // WEIGHTED_COST(lambda,16)
+  const int quirk00 = (P.mode == JMHIP_SEARCH_FULL) && !P.rdopt && !P.is_b && job.ref_is_0;   // check_for_00, :75
+  const int ff00 = (P.mode == JMHIP_SEARCH_FASTFULL) && !P.rdopt;                            // pos_00 pre-check
+  const int ucx = s_u[5], ucy = s_u[6];            // the common centre when all active partitions agree
+
+  for (int c = tid; c < UW * UH; c += 256) {
+    const int ay = c / UW, ax = c - ay * UW;
+    const int mvx = umin_x + ax, mvy = umin_y + ay;       // candidate motion vector (pel)
+    // ---- sixteen 4x4 SADs of the 16x16 block at this displacement
+    unsigned sad[16];
+#pragma unroll
+    for (int b = 0; b < 16; b++) sad[b] = 0;
+    const uint8_t *wrow = smem + (size_t)ay * pitch + (ax & ~3);
+    const unsigned sh = ax & 3;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const uint32_t *wp = reinterpret_cast<const uint32_t *>(wrow + (size_t)r * pitch);
+      const uint32_t d0 = wp[0], d1 = wp[1], d2 = wp[2], d3 = wp[3], d4 = wp[4];
+      const uint32_t r0 = __builtin_amdgcn_alignbyte(d1, d0, sh), r1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+      const uint32_t r2 = __builtin_amdgcn_alignbyte(d3, d2, sh), r3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
+      const int b = (r >> 2) * 4;
+      sad[b + 0] = __builtin_amdgcn_sad_u8(r0, s_cur[r * 4 + 0], sad[b + 0]);
+      sad[b + 1] = __builtin_amdgcn_sad_u8(r1, s_cur[r * 4 + 1], sad[b + 1]);
+      sad[b + 2] = __builtin_amdgcn_sad_u8(r2, s_cur[r * 4 + 2], sad[b + 2]);
+      sad[b + 3] = __builtin_amdgcn_sad_u8(r3, s_cur[r * 4 + 3], sad[b + 3]);
+    }
+    // ---- SetupLargerBlocks (me_fullfast.c:210-273): partition SADs in partition-table order
+    unsigned ps[JMHIP_NPART];
+#pragma unroll
+    for (int b8 = 0; b8 < 4; b8++) {
+      const int o = 8 * (b8 >> 1) + 2 * (b8 & 1);         // top-left 4x4 index of the 8x8
+      const unsigned a = sad[o], b = sad[o + 1], cc = sad[o + 4], d = sad[o + 5];
+      ps[25 + 4 * b8 + 0] = a; ps[25 + 4 * b8 + 1] = b; ps[25 + 4 * b8 + 2] = cc; ps[25 + 4 * b8 + 3] = d;   // 4x4
+      ps[9 + 2 * b8 + 0] = a + b; ps[9 + 2 * b8 + 1] = cc + d;                                            // 8x4
+      ps[17 + 2 * b8 + 0] = a + cc; ps[17 + 2 * b8 + 1] = b + d;                                          // 4x8
+      ps[5 + b8] = a + b + cc + d;                                                                       // 8x8
+    }
+    ps[1] = ps[5] + ps[6]; ps[2] = ps[7] + ps[8];          // 16x8 top, bottom
+    ps[3] = ps[5] + ps[7]; ps[4] = ps[6] + ps[8];          // 8x16 left, right
+    ps[0] = ps[1] + ps[2];                                 // 16x16
+
+    int upos = 0;
+    if (uniform) {
+      const int dx = mvx - ucx, dy = mvy - ucy;           // always inside: the union IS the window
+      upos = spiral_pos(dx, dy) + 1;
+      if (ff00 && mvx == 0 && mvy == 0) upos = 0;         // pos_00 is evaluated first: wins every tie
+    }
+#pragma unroll
+    for (int p = 0; p < JMHIP_NPART; p++) {
+      if (!((mask >> p) & 1)) continue;
+      int tie = upos;
+      bool valid = true;
+      if (!uniform) {
+        const int dx = mvx - s_cx[p], dy = mvy - s_cy[p];
+        valid = (iabs(dx) <= P.R) && (iabs(dy) <= P.R);
+        tie = spiral_pos(dx, dy) + 1;
+        if (ff00 && mvx == 0 && mvy == 0) tie = 0;
+      }
+      int cost = mv_cost(P.lam_f, 4 * mvx - s_px[p], 4 * mvy - s_py[p]) + (int)ps[p];
+      if (p == 0) {
+        // check_for_00 (me_fullsearch.c:129-132): cand_x (quarter-pel, absolute) == pic_pix_x (pel); keys are biased by w16
+        if (quirk00 && 4 * (mbx * 16 + mvx) == mbx * 16 && 4 * (mby * 16 + mvy) == mby * 16) cost -= w16;
+        cost += w16;
+      }
+      const unsigned key = valid ? (((unsigned)cost << TIE_BITS) | (unsigned)tie) : KEY_INVALID;
+      best[p] = min(best[p], key);
+    }
+  }
+
+  // ---- reduce the 41 minima over the workgroup
+#pragma unroll
+  for (int p = 0; p < JMHIP_NPART; p++) {
+    unsigned v = best[p];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, off, 64));
+    if (lane == 0) s_red[p][wave] = v;
+  }
+  __syncthreads();
+  if (tid < JMHIP_NPART) {
+    const int p = tid;
+    jmhip_me_result &o = res[blockIdx.x];
+    if ((mask >> p) & 1) {
+      const unsigned k = min(min(s_red[p][0], s_red[p][1]), min(s_red[p][2], s_red[p][3]));
+      int cost = (int)(k >> TIE_BITS), tie = (int)(k & ((1u << TIE_BITS) - 1));
+      if (p == 0) cost -= w16;
+      int mvx, mvy;
+      if (tie == 0) { mvx = 0; mvy = 0; }               // FastFull pos_00
+      else { int dx, dy; spiral_offset(tie - 1, &dx, &dy); mvx = s_cx[p] + dx; mvy = s_cy[p] + dy; }
+      o.mv_int[p][0] = (int16_t)mvx; o.mv_int[p][1] = (int16_t)mvy; o.cost_int[p] = cost;
+      if (!P.subpel) { o.mv[p][0] = (int16_t)(mvx << 2); o.mv[p][1] = (int16_t)(mvy << 2); o.cost[p] = cost; }
+    } else {
+      o.mv_int[p][0] = o.mv_int[p][1] = 0; o.cost_int[p] = -1;
+      o.mv[p][0] = o.mv[p][1] = 0; o.cost[p] = -1;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ sub-pel search
+
+// Hadamard SATD of a 4x4 difference block held as four rows of four ints: (sum|H D H| + 1) >> 1, me_distortion.c:182
+__device__ __forceinline__ int satd4x4(const int d[4][4])
+{
+  int m[4][4], s = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {        // columns
+    const int a = d[0][k] + d[3][k], b = d[1][k] + d[2][k], c = d[1][k] - d[2][k], e = d[0][k] - d[3][k];
+    m[0][k] = a + b; m[1][k] = e + c; m[2][k] = a - b; m[3][k] = e - c;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) {        // rows
+    const int a = m[k][0] + m[k][3], b = m[k][1] + m[k][2], c = m[k][1] - m[k][2], e = m[k][0] - m[k][3];
+    s += iabs(a + b) + iabs(a - b) + iabs(c + e) + iabs(e - c);
+  }
+  return (s + 1) >> 1;
+}
+
+// one 8-point Hadamard butterfly network (me_distortion.c:280-305 per row, :311-336 per column)
+__device__ __forceinline__ void had8(int v[8])
+{
+  int a[8], b[8];
+#pragma unroll
+  for (int i = 0; i < 4; i++) { a[i] = v[i] + v[i + 4]; a[i + 4] = v[i] - v[i + 4]; }
+  b[0] = a[0] + a[2]; b[1] = a[1] + a[3]; b[2] = a[0] - a[2]; b[3] = a[1] - a[3];
+  b[4] = a[4] + a[6]; b[5] = a[5] + a[7]; b[6] = a[4] - a[6]; b[7] = a[5] - a[7];
+#pragma unroll
+  for (int i = 0; i < 8; i += 2) { v[i] = b[i] + b[i + 1]; v[i + 1] = b[i] - b[i + 1]; }
+}
+
+// fetch `n` (4 or 8) samples of one row at byte address p (any alignment) from a quarter-pel plane
+__device__ __forceinline__ void fetch_row(const uint8_t *p, int n, uint32_t *lo, uint32_t *hi)
+{
+  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+  const uint32_t *q = reinterpret_cast<const uint32_t *>(a & ~uintptr_t(3));
+  const unsigned sh = (unsigned)(a & 3);
+  const uint32_t d0 = q[0], d1 = q[1];
+  *lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
+  if (n == 8) { const uint32_t d2 = q[2]; *hi = __builtin_amdgcn_alignbyte(d2, d1, sh); }
+}
+
+__constant__ int c_s9x[9] = {0, 0, 0, -1, 1, -1, 1, -1, 1};    // spiral positions 0..8, mv-search.c:366-393
+__constant__ int c_s9y[9] = {0, -1, 1, -1, -1, 0, 0, 1, 1};
+
+struct SubItem { int8_t p, bx, by, bs; };          // partition, sub-block origin inside the MB (pels), size 4 or 8
+__constant__ SubItem c_sub4[112];                   // all partitions, 4x4 sub-blocks
+__constant__ SubItem c_sub8[64];                    // test8x8transform: 16 8x8 blocks (types <= 4) + 48 4x4 (types 5..7)
+SubItem h_sub4[112], h_sub8[64];
+
+void build_sub_tables()
+{
+  build_part_table();
+  int n4 = 0, n8 = 0;
+  for (int p = 0; p < JMHIP_NPART; p++) {
+    const PartInfo &q = h_part[p];
+    for (int y = 0; y < q.h4; y++) for (int x = 0; x < q.w4; x++)       // computeSATD order: y outer, x inner (:673-675)
+      h_sub4[n4++] = {(int8_t)p, (int8_t)(4 * (q.x4 + x)), (int8_t)(4 * (q.y4 + y)), 4};
+    if (q.bt <= 4) {
+      for (int y = 0; y < q.h4 / 2; y++) for (int x = 0; x < q.w4 / 2; x++)
+        h_sub8[n8++] = {(int8_t)p, (int8_t)(4 * q.x4 + 8 * x), (int8_t)(4 * q.y4 + 8 * y), 8};
+    } else {
+      for (int y = 0; y < q.h4; y++) for (int x = 0; x < q.w4; x++)
+        h_sub8[n8++] = {(int8_t)p, (int8_t)(4 * (q.x4 + x)), (int8_t)(4 * (q.y4 + y)), 4};
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void me_sub_kernel(MeDev P, const jmhip_me_mb *__restrict__ jobs, jmhip_me_result *__restrict__ res)
+{
+  __shared__ __attribute__((aligned(16))) uint8_t s_cur[16][16];
+  __shared__ int s_mvx[JMHIP_NPART], s_mvy[JMHIP_NPART], s_umv[JMHIP_NPART], s_min[JMHIP_NPART];
+  __shared__ int s_satd[JMHIP_NPART][9];
+
+  const int tid = threadIdx.x;
+  const jmhip_me_mb &job = jobs[blockIdx.x];
+  jmhip_me_result &o = res[blockIdx.x];
+  const int mbx = job.mb_x, mby = job.mb_y;
+  const unsigned long long mask = P.mask;
+  const uint8_t *sub = P.ref_sub[job.ref];
+  const size_t plane = (size_t)P.Wp * P.Hp;
+  const int width_pad = P.Wp - 1 - 16, height_pad = P.Hp - 1 - 16;      // size_x_pad / size_y_pad, mbuffer.c:421-422
+  const int nsub = P.t8x8 ? 64 : 112;
+  const SubItem *items = P.t8x8 ? c_sub8 : c_sub4;
+
+  if (tid < 64) {
+    const int r = tid >> 2, k = tid & 3;
+    *reinterpret_cast<uint32_t *>(&s_cur[r][k * 4]) = *reinterpret_cast<const uint32_t *>(P.cur + (size_t)(mby * 16 + r) * P.W + mbx * 16 + k * 4);
+  }
+  if (tid < JMHIP_NPART) {
+    s_mvx[tid] = o.mv_int[tid][0] << 2; s_mvy[tid] = o.mv_int[tid][1] << 2;      // mv-search.c:770-774
+    s_min[tid] = 0x7fffffff;                                                      // :785-788 (start_me_refinement_hp == 0)
+  }
+
+  for (int phase = 0; phase < 2; phase++) {        // 0: half-pel (positions 0..8, step 2), 1: quarter-pel (1..8, step 1)
+    const int step = phase ? 1 : 2, first = phase ? 1 : 0, ncand = 9 - first;
+    __syncthreads();
+    if (tid < JMHIP_NPART) {
+      const PartInfo q = c_part[tid];
+      const int bsx = 4 * q.w4, bsy = 4 * q.h4;
+      const int p4x = ((mbx * 16 + 4 * q.x4 + JMHIP_PAD) << 2) + s_mvx[tid], p4y = ((mby * 16 + 4 * q.y4 + JMHIP_PAD) << 2) + s_mvy[tid];
+      const int max_x4 = (P.W - bsx + 2 * JMHIP_PAD) << 2, max_y4 = (P.H - bsy + 2 * JMHIP_PAD) << 2;
+      const int m = phase ? 0 : 1;                   // me_fullsearch.c:412-413 vs :468-469
+      s_umv[tid] = !((p4x > m) && (p4x < max_x4 - m) && (p4y > m) && (p4y < max_y4 - m));
+#pragma unroll
+      for (int k = 0; k < 9; k++) s_satd[tid][k] = 0;
+    }
+    __syncthreads();
+
+    for (int idx = tid; idx < nsub * ncand; idx += 256) {
+      const int it = idx / ncand, cand = first + (idx - it * ncand);
+      const SubItem si = items[it];
+      const int p = si.p;
+      if (!((mask >> p) & 1)) continue;
+      // quarter-pel coordinate of the sub-block origin incl. the pad offset (me_fullsearch.c:364-365, me_distortion.c:678)
+      const int xq = ((mbx * 16 + si.bx + JMHIP_PAD) << 2) + s_mvx[p] + step * c_s9x[cand];
+      const int yq = ((mby * 16 + si.by + JMHIP_PAD) << 2) + s_mvy[p] + step * c_s9y[cand];
+      int xpos = xq >> 2, ypos = yq >> 2;
+      if (s_umv[p]) { xpos = clampi(xpos, 0, width_pad); ypos = clampi(ypos, 0, height_pad); }     // UMVLine4X, refbuf.c:37
+      const uint8_t *rp = sub + (size_t)((yq & 3) * 4 + (xq & 3)) * plane + (size_t)ypos * P.Wp + xpos;
+      int v;
+      if (si.bs == 4) {
+        int d[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          uint32_t lo, hi;
+          fetch_row(rp + (size_t)r * P.Wp, 4, &lo, &hi);
+          const uint32_t cw = *reinterpret_cast<const uint32_t *>(&s_cur[si.by + r][si.bx]);
+#pragma unroll
+          for (int x = 0; x < 4; x++) d[r][x] = (int)((cw >> (8 * x)) & 255) - (int)((lo >> (8 * x)) & 255);
+        }
+        v = satd4x4(d);
+      } else {
+        int m2[8][8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+          uint32_t lo, hi;
+          fetch_row(rp + (size_t)r * P.Wp, 8, &lo, &hi);
+          const uint32_t c0 = *reinterpret_cast<const uint32_t *>(&s_cur[si.by + r][si.bx]);
+          const uint32_t c1 = *reinterpret_cast<const uint32_t *>(&s_cur[si.by + r][si.bx + 4]);
+          int row[8];
+#pragma unroll
+          for (int x = 0; x < 4; x++) { row[x] = (int)((c0 >> (8 * x)) & 255) - (int)((lo >> (8 * x)) & 255); row[4 + x] = (int)((c1 >> (8 * x)) & 255) - (int)((hi >> (8 * x)) & 255); }
+          had8(row);
+#pragma unroll
+          for (int x = 0; x < 8; x++) m2[r][x] = row[x];
+        }
+        int s = 0;
+#pragma unroll
+        for (int x = 0; x < 8; x++) {
+          int col[8];
+#pragma unroll
+          for (int r = 0; r < 8; r++) col[r] = m2[r][x];
+          had8(col);
+#pragma unroll
+          for (int r = 0; r < 8; r++) s += iabs(col[r]);
+        }
+        v = (s + 2) >> 2;                            // HadamardSAD8x8, me_distortion.c:342
+      }
+      atomicAdd(&s_satd[p][cand], v);
+    }
+    __syncthreads();
+
+    if (tid < JMHIP_NPART && ((mask >> tid) & 1)) {
+      const int p = tid;
+      const int lam = phase ? P.lam_q : P.lam_h;
+      const int px = job.pred_mv[p][0], py = job.pred_mv[p][1];
+      int min_mcost = s_min[p], best = 0;
+      const int mvx = s_mvx[p], mvy = s_mvy[p];
+      // check_position0, me_fullsearch.c:361
+      const int check0 = !phase && !P.rdopt && !P.is_b && job.ref_is_0 && p == 0 && mvx == 0 && mvy == 0;
+      for (int pos = first; pos < 9; pos++) {
+        const int cxm = mvx + step * c_s9x[pos], cym = mvy + step * c_s9y[pos];
+        int mcost = mv_cost(lam, cxm - px, cym - py);
+        if (mcost >= min_mcost) continue;
+        mcost += s_satd[p][pos];
+        if (pos == 0 && check0) mcost -= (lam * 16) >> 16;
+        if (mcost < min_mcost) { min_mcost = mcost; best = pos; }
+      }
+      s_mvx[p] = mvx + step * c_s9x[best]; s_mvy[p] = mvy + step * c_s9y[best];
+      s_min[p] = min_mcost;                          // start_me_refinement_qp == 1: carried into the quarter-pel phase
+    }
+  }
+  __syncthreads();
+  if (tid < JMHIP_NPART && ((mask >> tid) & 1)) {
+    o.mv[tid][0] = (int16_t)s_mvx[tid]; o.mv[tid][1] = (int16_t)s_mvy[tid]; o.cost[tid] = s_min[tid];
+  }
+}
+
+int ensure_tables(jmhip_ctx *c)
+{
+  static bool uploaded[64] = {false};
+  const int dev = c->cfg.device;
+  if (dev < 64 && uploaded[dev]) return JMHIP_OK;
+  build_sub_tables();
+  JM_HIP_CHECK(c, hipMemcpyToSymbol(HIP_SYMBOL(c_part), h_part, sizeof(h_part)));
+  JM_HIP_CHECK(c, hipMemcpyToSymbol(HIP_SYMBOL(c_sub4), h_sub4, sizeof(h_sub4)));
+  JM_HIP_CHECK(c, hipMemcpyToSymbol(HIP_SYMBOL(c_sub8), h_sub8, sizeof(h_sub8)));
+  if (dev < 64) uploaded[dev] = true;
+  return JMHIP_OK;
+}
+
+}  // namespace
+
+extern "C" void jmhip_partition_info(int p, int *blocktype, int *x4, int *y4, int *w4, int *h4)
+{
+  build_part_table();
+  if (p < 0 || p >= JMHIP_NPART) return;
+  if (blocktype) *blocktype = h_part[p].bt;
+  if (x4) *x4 = h_part[p].x4;
+  if (y4) *y4 = h_part[p].y4;
+  if (w4) *w4 = h_part[p].w4;
+  if (h4) *h4 = h_part[p].h4;
+}
+
+// host mirror of search_center (mv-search.c:752-762) to size the LDS window
+static void host_center(const jmhip_me_params *prm, int pmx, int pmy, int *cx, int *cy)
+{
+  const int R = prm->search_range;
+  auto clip = [](int lo, int hi, int x) { return x < lo ? lo : (x > hi ? hi : x); };
+  int mx = pmx / 4, my = pmy / 4;
+  if (!prm->rdopt) { mx = clip(-R, R, mx); my = clip(-R, R, my); }
+  mx = clip(-2047 + R, 2047 - R, mx);
+  my = clip(prm->level_mv_min + R, prm->level_mv_max - R, my);
+  *cx = mx; *cy = my;
+}
+
+extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, const jmhip_me_mb *mbs, int n)
+{
+  if (!c || !prm || !mbs || n <= 0) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_frame: NULL/empty arguments") : JMHIP_ERR_ARG;
+  if (prm->search_mode != JMHIP_SEARCH_FULL && prm->search_mode != JMHIP_SEARCH_FASTFULL)
+    return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_me_frame: search_mode must be -1 (FullSearch) or 0 (FastFullSearch); EPZS/UMHex run on the host over jmhip_distortion_batch");
+  const int R = prm->search_range;
+  if (R < 0 || R > c->cfg.search_range) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_frame: search_range exceeds the context's");
+  if ((2 * R + 1) * (2 * R + 1) + 1 >= (1 << TIE_BITS))
+    return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_me_frame: search_range > 44 does not fit the packed argmin key");
+  for (int k = 0; k < 3; k++)
+    if (prm->lambda[k] < 0 || prm->lambda[k] > 30000000) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_me_frame: lambda factor out of the 32-bit cost range");
+  if (!c->has_cur) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_frame: current picture not uploaded");
+  if (!(prm->partition_mask & ((1ull << JMHIP_NPART) - 1))) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_frame: empty partition mask");
+  JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
+  int rc = ensure_tables(c);
+  if (rc) return rc;
+
+  // validate jobs and size the LDS window from the worst spread of search centres
+  int max_uw = 0, max_uh = 0;
+  for (int i = 0; i < n; i++) {
+    const jmhip_me_mb &m = mbs[i];
+    if (m.mb_x < 0 || m.mb_x >= c->mbw || m.mb_y < 0 || m.mb_y >= c->mbh) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_frame: macroblock outside the picture");
+    if (m.ref < 0 || m.ref >= (int)c->refs.size() || !c->refs[m.ref].has_pic) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_frame: reference slot not uploaded");
+    if (prm->subpel && !c->refs[m.ref].has_luma_sub) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_frame: sub-pel planes of the reference not built (jmhip_interp_luma)");
+    int x0 = 1 << 30, x1 = -(1 << 30), y0 = 1 << 30, y1 = -(1 << 30);
+    for (int p = 0; p < JMHIP_NPART; p++) if ((prm->partition_mask >> p) & 1) {
+      int cx, cy;
+      const int s = prm->search_mode == JMHIP_SEARCH_FASTFULL ? 0 : p;
+      host_center(prm, m.pred_mv[s][0], m.pred_mv[s][1], &cx, &cy);
+      x0 = cx < x0 ? cx : x0; x1 = cx > x1 ? cx : x1; y0 = cy < y0 ? cy : y0; y1 = cy > y1 ? cy : y1;
+    }
+    const int uw = x1 - x0 + 2 * R + 1, uh = y1 - y0 + 2 * R + 1;
+    max_uw = uw > max_uw ? uw : max_uw; max_uh = uh > max_uh ? uh : max_uh;
+  }
+  const int pitch = ((max_uw + 15 + 3) & ~3) + 8;       // +8: the 5th dword read of the last candidate column
+  const int rows = max_uh + 15;
+  const size_t lds = (size_t)pitch * rows + 16;
+  if (lds > 60 * 1024) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_me_frame: search centres of one macroblock are too far apart for one LDS window");
+
+  if (c->me_capacity < n) {
+    if (c->me_jobs_dev) JM_HIP_CHECK(c, hipFree(c->me_jobs_dev));
+    if (c->me_res_dev) JM_HIP_CHECK(c, hipFree(c->me_res_dev));
+    c->me_jobs_dev = c->me_res_dev = nullptr; c->me_capacity = 0;
+    if (hipMalloc(&c->me_jobs_dev, sizeof(jmhip_me_mb) * (size_t)n) != hipSuccess) return jm_fail(c, JMHIP_ERR_NOMEM, "ME job array");
+    if (hipMalloc(&c->me_res_dev, sizeof(jmhip_me_result) * (size_t)n) != hipSuccess) return jm_fail(c, JMHIP_ERR_NOMEM, "ME result array");
+    c->me_capacity = n;
+  }
+  if (!c->ref_ptrs_dev) {
+    std::vector<const uint8_t *> tab(64, nullptr);
+    for (size_t i = 0; i < c->refs.size(); i++) { tab[i] = c->refs[i].y; tab[32 + i] = c->refs[i].luma_sub; }
+    if (hipMalloc(&c->ref_ptrs_dev, sizeof(void *) * 64) != hipSuccess) return jm_fail(c, JMHIP_ERR_NOMEM, "reference pointer table");
+    JM_HIP_CHECK(c, hipMemcpy(c->ref_ptrs_dev, tab.data(), sizeof(void *) * 64, hipMemcpyHostToDevice));
+  }
+  JM_HIP_CHECK(c, hipMemcpyAsync(c->me_jobs_dev, mbs, sizeof(jmhip_me_mb) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  c->me_n = n;
+
+  MeDev P{};
+  P.mode = prm->search_mode; P.R = R; P.rdopt = prm->rdopt; P.is_b = prm->is_b_slice;
+  P.lvl_min = prm->level_mv_min; P.lvl_max = prm->level_mv_max;
+  P.lam_f = prm->lambda[0]; P.lam_h = prm->lambda[1]; P.lam_q = prm->lambda[2];
+  P.t8x8 = prm->transform8x8_mode ? 1 : 0; P.subpel = prm->subpel ? 1 : 0;
+  P.mask = prm->partition_mask & ((1ull << JMHIP_NPART) - 1);
+  P.W = c->W; P.H = c->H; P.Wp = c->Wp; P.Hp = c->Hp;
+  P.win_pitch = pitch; P.win_rows = rows;
+  P.cur = c->cur_y;
+  P.ref_y = reinterpret_cast<const uint8_t *const *>(c->ref_ptrs_dev);
+  P.ref_sub = reinterpret_cast<const uint8_t *const *>(c->ref_ptrs_dev) + 32;
+
+  jm_stage_begin(c, JMHIP_STAGE_ME_INT);
+  me_int_kernel<<<n, 256, lds, c->stream>>>(P, (const jmhip_me_mb *)c->me_jobs_dev, (jmhip_me_result *)c->me_res_dev);
+  jm_stage_end(c, JMHIP_STAGE_ME_INT);
+  JM_HIP_CHECK(c, hipGetLastError());
+  if (P.subpel) {
+    jm_stage_begin(c, JMHIP_STAGE_ME_SUB);
+    me_sub_kernel<<<n, 256, 0, c->stream>>>(P, (const jmhip_me_mb *)c->me_jobs_dev, (jmhip_me_result *)c->me_res_dev);
+    jm_stage_end(c, JMHIP_STAGE_ME_SUB);
+    JM_HIP_CHECK(c, hipGetLastError());
+  }
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_me_results_download(jmhip_ctx *c, jmhip_me_result *results, int n)
+{
+  if (!c || !results || n <= 0) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_results_download: NULL/empty arguments") : JMHIP_ERR_ARG;
+  if (n > c->me_n) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_results_download: more results requested than jobs enqueued");
+  JM_HIP_CHECK(c, hipMemcpyAsync(results, c->me_res_dev, sizeof(jmhip_me_result) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  JM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < n; i++)
+    for (int p = 0; p < JMHIP_NPART; p++)
+      if (results[i].cost_int[p] == -2) return jm_fail(c, JMHIP_ERR_DEVICE, "me_int_kernel: LDS window smaller than a macroblock's search area (internal sizing error)");
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_me_frame(jmhip_ctx *c, const jmhip_me_params *prm, const jmhip_me_mb *mbs, int n, jmhip_me_result *results)
+{
+  int rc = jmhip_me_frame_async(c, prm, mbs, n);
+  if (rc) return rc;
+  return jmhip_me_results_download(c, results, n);
+}

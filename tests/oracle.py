@@ -134,3 +134,83 @@ def block_search_full(p, refpic, cur, pic_x, pic_y, blocktype, pred, R, lam, ref
     cost = lib().jmo_block_search_full(C.byref(p), C.byref(refpic.ref), orig.ctypes.data, ref_is_0, pic_x, pic_y, blocktype,
                                        int(pred[0]), int(pred[1]), R, lam_a, mv.ctypes.data, mvi.ctypes.data, C.byref(ci))
     return (int(mv[0]), int(mv[1])), cost, (int(mvi[0]), int(mvi[1])), ci.value
+
+
+# ------------------------------------------------------------------ frame-level ME reference (loops in Python)
+
+class FastFull(C.Structure):
+    _fields_ = [("search_range", C.c_int), ("max_pos", C.c_int), ("center_x", C.c_int), ("center_y", C.c_int),
+                ("pos_00", C.c_int), ("block_sad", C.POINTER(C.c_int))]
+
+
+PARTS = ([(1, 0, 0, 4, 4)] + [(2, 0, 2 * k, 4, 2) for k in range(2)] + [(3, 2 * k, 0, 2, 4) for k in range(2)]
+         + [(4, 2 * (b & 1), 2 * (b >> 1), 2, 2) for b in range(4)]
+         + [(5, 2 * (b & 1), 2 * (b >> 1) + k, 2, 1) for b in range(4) for k in range(2)]
+         + [(6, 2 * (b & 1) + k, 2 * (b >> 1), 1, 2) for b in range(4) for k in range(2)]
+         + [(7, 2 * (b & 1) + (k & 1), 2 * (b >> 1) + (k >> 1), 1, 1) for b in range(4) for k in range(4)])
+
+
+def _setup_search_protos():
+    L = lib()
+    ip, vp = C.c_int, C.c_void_p
+    L.jmo_fastfull_setup.argtypes = [C.POINTER(MeParams), C.POINTER(Ref), vp, ip, ip, ip, ip, ip, C.POINTER(FastFull)]
+    L.jmo_fastfull_setup.restype = None
+    L.jmo_fastfull_search.argtypes = [C.POINTER(MeParams), C.POINTER(FastFull), ip, ip, ip, ip, ip, ip, ip, vp, vp, ip, ip]
+    L.jmo_subpel_search.argtypes = [C.POINTER(MeParams), C.POINTER(Ref), vp, ip, ip, ip, ip, ip, ip, vp, vp, ip, ip, ip, C.POINTER(ip)]
+    return L
+
+
+def me_frame(p, refpics, cur, mbs, mode, R, lam, subpel=True, mask=(1 << 41) - 1):
+    """Reference for jmhip_me_frame: returns dict of arrays mv, cost, mv_int, cost_int shaped like the ABI result."""
+    L = _setup_search_protos()
+    n = len(mbs)
+    out = {"mv": np.zeros((n, 41, 2), np.int16), "cost": np.full((n, 41), -1, np.int32),
+           "mv_int": np.zeros((n, 41, 2), np.int16), "cost_int": np.full((n, 41), -1, np.int32)}
+    cur16 = np.ascontiguousarray(cur, dtype=np.uint16)
+    lam_a = (C.c_int * 3)(*lam)
+    for i, mb in enumerate(mbs):
+        rp = refpics[int(mb["ref"])]
+        ox, oy = int(mb["mb_x"]) * 16, int(mb["mb_y"]) * 16
+        ff = None
+        if mode == 0:
+            mbpix = np.zeros(768, np.uint16)
+            mbpix[:256] = cur16[oy:oy + 16, ox:ox + 16].reshape(-1)
+            ff = FastFull()
+            buf = np.zeros(8 * 16 * (2 * R + 1) ** 2, np.int32)
+            ff.block_sad = buf.ctypes.data_as(C.POINTER(C.c_int))
+            L.jmo_fastfull_setup(C.byref(p), C.byref(rp.ref), mbpix.ctypes.data, ox, oy,
+                                 int(mb["pred_mv"][0][0]), int(mb["pred_mv"][0][1]), R, C.byref(ff))
+        for q, (bt, x4, y4, w4, h4) in enumerate(PARTS):
+            if not (mask >> q) & 1:
+                continue
+            px, py = ox + 4 * x4, oy + 4 * y4
+            pred = (int(mb["pred_mv"][q][0]), int(mb["pred_mv"][q][1]))
+            if mode == -1 and subpel:
+                mv, cost, mvi, ci = block_search_full(p, rp, cur16, px, py, bt, pred, R, lam, int(mb["ref_is_0"]))
+            else:
+                bsx, bsy = 4 * w4, 4 * h4
+                orig = np.zeros(768, np.uint16)
+                orig[: bsx * bsy] = cur16[py:py + bsy, px:px + bsx].reshape(-1)
+                mvs = np.zeros(2, np.int16)
+                if mode == 0:
+                    ci = L.jmo_fastfull_search(C.byref(p), C.byref(ff), ox, oy, px, py, bt, pred[0], pred[1],
+                                               mvs.ctypes.data, mvs[1:].ctypes.data, 2147483647, lam[0])
+                else:
+                    L.jmo_search_center.argtypes = [C.POINTER(MeParams), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+                    L.jmo_search_center(C.byref(p), pred[0], pred[1], R, mvs.ctypes.data, mvs[1:].ctypes.data)
+                    L.jmo_fullpel_search.argtypes = [C.POINTER(MeParams), C.POINTER(Ref), C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+                    ci = L.jmo_fullpel_search(C.byref(p), C.byref(rp.ref), orig.ctypes.data, int(mb["ref_is_0"]), px, py, bt,
+                                              pred[0], pred[1], mvs.ctypes.data, mvs[1:].ctypes.data, R, 2147483647, lam[0])
+                mvi = (int(mvs[0]), int(mvs[1]))
+                if subpel:
+                    mvq = np.array([mvi[0] << 2, mvi[1] << 2], np.int16)
+                    cost = L.jmo_subpel_search(C.byref(p), C.byref(rp.ref), orig.ctypes.data, int(mb["ref_is_0"]), px, py, bt,
+                                               pred[0], pred[1], mvq.ctypes.data, mvq[1:].ctypes.data, 9, 9, 2147483647, lam_a)
+                    mv = (int(mvq[0]), int(mvq[1]))
+                else:
+                    mv, cost = (mvi[0] << 2, mvi[1] << 2), ci
+            out["mv"][i, q] = mv
+            out["cost"][i, q] = cost
+            out["mv_int"][i, q] = mvi
+            out["cost_int"][i, q] = ci
+    return out

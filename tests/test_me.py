@@ -1,0 +1,101 @@
+"""Motion estimation: jmhip_me_frame (integer full search + sub-pel refinement) vs the oracle, bit-exact on
+(mv_int, cost_int, mv, cost) for all 41 partitions."""
+import numpy as np
+import pytest
+
+from tests import oracle
+
+
+def lambda_factors(qp=28):
+    """SetLagrangianMultipliers for P slices, rdopt on (slice.c:1329-1358): lambda_mf = LAMBDA_FACTOR(sqrt(0.85*2^((qp-12)/3)))."""
+    lam = int(65536 * np.sqrt(0.85 * 2 ** ((qp - 12) / 3.0)) + 0.5)
+    return [lam, lam, lam]
+
+
+def make_pair(rng, w, h, kind):
+    yy, xx = np.mgrid[0:h + 32, 0:w + 32]
+    base = ((np.sin(xx / 6.0) * np.cos(yy / 9.0)) * 70 + 128 + rng.normal(0, 12, (h + 32, w + 32))).clip(0, 255)
+    if kind == "noise":
+        ref = rng.integers(0, 256, (h, w)).astype(np.uint8)
+        cur = rng.integers(0, 256, (h, w)).astype(np.uint8)
+    elif kind == "flat":      # every candidate ties: exercises the spiral tie-break
+        ref = np.full((h, w), 100, np.uint8)
+        cur = np.full((h, w), 100, np.uint8)
+    else:                     # translation (5,-3) + noise, like the synthetic clip of SURVEY 8(d)
+        ref = base[16:16 + h, 16:16 + w].astype(np.uint8)
+        cur = (base[16 - 3:16 - 3 + h, 16 + 5:16 + 5 + w] + rng.normal(0, 2, (h, w))).clip(0, 255).astype(np.uint8)
+    return cur, ref
+
+
+def make_mbs(pkg, rng, mbw, mbh, spread, per_partition=True):
+    from h264_amd.jmhip import ME_MB_DTYPE
+    mbs = np.zeros(mbw * mbh, dtype=ME_MB_DTYPE)
+    for i in range(mbw * mbh):
+        mbs[i]["mb_x"], mbs[i]["mb_y"] = i % mbw, i // mbw
+        mbs[i]["ref"], mbs[i]["ref_is_0"] = 0, 1
+        if per_partition:
+            mbs[i]["pred_mv"] = rng.integers(-spread, spread + 1, (41, 2))
+        else:
+            mbs[i]["pred_mv"][:] = rng.integers(-spread, spread + 1, 2)
+    return mbs
+
+
+def run_case(pkg, w, h, kind, mode, R, rdopt, spread, t8x8=0, per_partition=True, subpel=1, seed=0, mask=(1 << 41) - 1):
+    rng = np.random.default_rng(seed)
+    cur, ref = make_pair(rng, w, h, kind)
+    ctx = pkg.Context(w, h, yuv_format=0, max_refs=1, search_range=R)
+    ctx.ref_upload(0, ref)
+    ctx.interp_luma(0)
+    ctx.cur_upload(cur)
+    mbs = make_mbs(pkg, rng, w // 16, h // 16, spread, per_partition)
+    lam = lambda_factors(28)
+    prm = pkg.MeParams()
+    prm.search_mode, prm.search_range, prm.rdopt, prm.is_b_slice = mode, R, rdopt, 0
+    prm.level_mv_min, prm.level_mv_max = -511, 511
+    prm.lambda_[0], prm.lambda_[1], prm.lambda_[2] = lam
+    prm.transform8x8_mode, prm.subpel, prm.partition_mask = t8x8, subpel, mask
+    got = ctx.me_frame(prm, mbs)
+    ctx.close()
+
+    p = oracle.me_params(rdopt=rdopt, transform8x8_mode=t8x8)
+    want = oracle.me_frame(p, [oracle.RefPic(ref, yuv_format=0)], cur, mbs, mode, R, lam, subpel=bool(subpel), mask=mask)
+    for key in ("mv_int", "cost_int", "mv", "cost"):
+        g, wv = got[key], want[key]
+        if not np.array_equal(g, wv):
+            bad = np.argwhere(g != wv)[0]
+            raise AssertionError("%s differs at mb %d partition %d: got %s want %s (pred %s)" % (
+                key, bad[0], bad[1], g[bad[0], bad[1]], wv[bad[0], bad[1]], mbs[bad[0]]["pred_mv"][bad[1]]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,mode,R,rdopt,spread,t8x8", [
+    ("shift", -1, 8, 1, 8, 0),       # FullSearch, per-partition centres
+    ("shift", -1, 8, 0, 8, 0),       # rdopt off: centre clip, check_for_00, check_position0
+    ("shift", 0, 8, 1, 8, 0),        # FastFullSearch
+    ("shift", 0, 8, 0, 8, 0),        # FastFullSearch + pos_00 pre-check
+    ("noise", -1, 8, 1, 40, 0),      # far predictors: windows leave the picture (UMV), big union window
+    ("noise", 0, 8, 0, 60, 1),       # 8x8 Hadamard in sub-pel
+    ("flat", -1, 8, 0, 4, 0),        # all ties
+    ("flat", 0, 8, 0, 4, 1),
+    ("shift", -1, 16, 1, 6, 1),
+])
+def test_me_frame_small(pkg, kind, mode, R, rdopt, spread, t8x8):
+    run_case(pkg, 64, 48, kind, mode, R, rdopt, spread, t8x8, seed=R * 7 + spread)
+
+
+@pytest.mark.gpu
+def test_me_frame_qcif_range32(pkg):
+    """BASELINE config 1/2 search range on a QCIF-sized picture (99 MBs x 41 partitions x 4225 candidates)."""
+    run_case(pkg, 176, 144, "shift", -1, 32, 1, 8, seed=3)
+
+
+@pytest.mark.gpu
+def test_me_integer_only_and_partition_mask(pkg):
+    run_case(pkg, 64, 48, "shift", -1, 8, 1, 8, subpel=0, seed=11)
+    run_case(pkg, 64, 48, "shift", -1, 8, 1, 8, mask=0b11111, seed=12)          # 16x16, 16x8, 8x16 only
+    run_case(pkg, 64, 48, "shift", 0, 8, 0, 8, mask=((1 << 41) - 1) & ~1, seed=13)  # without the 16x16 partition
+
+
+@pytest.mark.gpu
+def test_partition_table_matches_jm_order(pkg):
+    assert pkg.partition_table() == oracle.PARTS
