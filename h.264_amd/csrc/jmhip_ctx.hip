@@ -11,6 +11,21 @@ static void chroma_geometry(int yuv, ChromaGeom *g)   // lencod/src/lencod.c:285
 
 extern "C" int jmhip_abi_version(void) { return JMHIP_ABI_VERSION; }
 
+extern "C" int jmhip_sizeof(int which)
+{
+  switch (which) {
+  case 0: return (int)sizeof(jmhip_me_mb);
+  case 1: return (int)sizeof(jmhip_me_result);
+  case 2: return (int)sizeof(jmhip_quant);
+  case 3: return (int)sizeof(jmhip_tq_job);
+  case 4: return (int)sizeof(jmhip_tq_result);
+  case 5: return (int)sizeof(jmhip_dist_job);
+  case 6: return (int)sizeof(jmhip_me_params);
+  case 7: return (int)sizeof(jmhip_config);
+  default: return -1;
+  }
+}
+
 extern "C" const char *jmhip_strerror(int code)
 {
   switch (code) {

@@ -1,0 +1,578 @@
+// tq.hip -- batched integer transform + quantisation + dequantisation + inverse transform + reconstruction.
+//
+// Replaces, per block of a batch:
+//   dct_4x4    lencod/src/block.c:843-947          (via pointer pDCT_4x4, inc/global.h:1376)
+//   dct_8x8    lencod/src/transform8x8.c:1452-1653
+//   dct_16x16  lencod/src/block.c:564-826
+//   dct_chroma lencod/src/block.c:1051-1495        (4:2:0 2x2 DC :1125-1174, 4:2:2 2x4 DC :1205-1319)
+//   forward4x4/inverse4x4/hadamard4x4/ihadamard4x4/forward8x8/inverse8x8  lencod/src/transform.c:31-421
+// Lossless (qpprime) and SP-slice variants are not part of the path and are rejected on the host.
+//
+// JM quirks mirrored: dct_chroma's forward4x4(curr_res,curr_res,n1,n2) row/column swap (block.c:1120) -- for
+// 4:2:2 it transforms rows 0..7 x cols 0..15 of the 16x16 tile, so the job carries the whole tile; the 4:2:2 DC
+// quantiser mixes the AC level scale with the qp+3 offset table (block.c:1263); CAVLC_LEVEL_LIMIT only clamps DC
+// levels (block.c:647, :1147); _CHROMA_COEFF_COST_ thresholding zeroes AC levels but leaves the runs (:1384-1410).
+//
+// Roofline: HBM-bound once batched (no data reuse, ~40 integer ops per coefficient). One lane owns one block
+// (4x4: 16 lanes per macroblock), all butterflies are 32-bit integer add/shift in registers -- no MFMA: this is
+// not a dense contraction (the 4x4 "matrix" has entries +-1, +-2 applied as shifts).
+#include "jmhip_internal.h"
+
+namespace {
+
+constexpr int Q_BITS = 15, Q_BITS_8 = 16, DQ_BITS = 6, MAXV = 999999, CAVLC_LEVEL_LIMIT = 2063;
+
+__constant__ uint8_t c_scan4[2][16][2] = {
+  {{0,0},{1,0},{0,1},{0,2},{1,1},{2,0},{3,0},{2,1},{1,2},{0,3},{1,3},{2,2},{3,1},{3,2},{2,3},{3,3}},      // SNGL_SCAN  block.h:26
+  {{0,0},{0,1},{1,0},{0,2},{0,3},{1,1},{1,2},{1,3},{2,0},{2,1},{2,2},{2,3},{3,0},{3,1},{3,2},{3,3}}};     // FIELD_SCAN block.h:35
+__constant__ uint8_t c_scan8[2][64][2] = {
+  {{0,0},{1,0},{0,1},{0,2},{1,1},{2,0},{3,0},{2,1},{1,2},{0,3},{0,4},{1,3},{2,2},{3,1},{4,0},{5,0},
+   {4,1},{3,2},{2,3},{1,4},{0,5},{0,6},{1,5},{2,4},{3,3},{4,2},{5,1},{6,0},{7,0},{6,1},{5,2},{4,3},
+   {3,4},{2,5},{1,6},{0,7},{1,7},{2,6},{3,5},{4,4},{5,3},{6,2},{7,1},{7,2},{6,3},{5,4},{4,5},{3,6},
+   {2,7},{3,7},{4,6},{5,5},{6,4},{7,3},{7,4},{6,5},{5,6},{4,7},{5,7},{6,6},{7,5},{7,6},{6,7},{7,7}},      // transform8x8.c:171
+  {{0,0},{0,1},{0,2},{1,0},{1,1},{0,3},{0,4},{1,2},{2,0},{1,3},{0,5},{0,6},{0,7},{1,4},{2,1},{3,0},
+   {2,2},{1,5},{1,6},{1,7},{2,3},{3,1},{4,0},{3,2},{2,4},{2,5},{2,6},{2,7},{3,3},{4,1},{5,0},{4,2},
+   {3,4},{3,5},{3,6},{3,7},{4,3},{5,1},{6,0},{5,2},{4,4},{4,5},{4,6},{4,7},{5,3},{6,1},{6,2},{5,4},
+   {5,5},{5,6},{5,7},{6,3},{7,0},{7,1},{6,4},{6,5},{6,6},{6,7},{7,2},{7,3},{7,4},{7,5},{7,6},{7,7}}};     // transform8x8.c:184
+__constant__ uint8_t c_cost4[2][16] = {{3,2,2,1,1,1,0,0,0,0,0,0,0,0,0,0}, {9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9}};   // block.h:45
+__constant__ uint8_t c_cost8[2][64] = {
+  {3,3,3,3,2,2,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0},
+  {9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9}};
+__constant__ uint8_t c_scan422[8][2] = {{0,0},{0,1},{1,0},{0,2},{0,3},{1,1},{1,2},{1,3}};                 // block.h:52
+__constant__ uint8_t c_hor[4][4][4] = {{{0,0,0,0},{0,0,0,0},{0,0,0,0},{0,0,0,0}}, {{0,4,0,4},{0,0,0,0},{0,0,0,0},{0,0,0,0}},
+                                       {{0,4,0,4},{0,4,0,4},{0,0,0,0},{0,0,0,0}}, {{0,4,0,4},{8,12,8,12},{0,4,0,4},{8,12,8,12}}};   // block.h:61
+__constant__ uint8_t c_ver[4][4][4] = {{{0,0,0,0},{0,0,0,0},{0,0,0,0},{0,0,0,0}}, {{0,0,4,4},{0,0,0,0},{0,0,0,0},{0,0,0,0}},
+                                       {{0,0,4,4},{8,8,12,12},{0,0,0,0},{0,0,0,0}}, {{0,0,4,4},{0,0,4,4},{8,8,12,12},{8,8,12,12}}}; // block.h:85
+
+__device__ __forceinline__ int iabs(int x) { return x < 0 ? -x : x; }
+__device__ __forceinline__ int sgnab(int a, int b) { return b < 0 ? -iabs(a) : iabs(a); }      // isignab
+__device__ __forceinline__ int rsr(int x, int a) { return (x + (1 << (a - 1))) >> a; }          // rshift_rnd_sf
+// iClip1 -- the empty asm keeps hipcc from forming v_ashr_pk_u8_i32 (see interp_luma.hip)
+__device__ __forceinline__ int clip1(int hi, int v) { asm volatile("" : "+v"(v)); return min(max(v, 0), hi); }
+
+// forward4x4 / inverse4x4 on a register block b[row][col]   (transform.c:31, :81)
+__device__ __forceinline__ void fwd4(int b[4][4])
+{
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int t0 = b[i][0] + b[i][3], t1 = b[i][1] + b[i][2], t2 = b[i][1] - b[i][2], t3 = b[i][0] - b[i][3];
+    b[i][0] = t0 + t1; b[i][1] = (t3 << 1) + t2; b[i][2] = t0 - t1; b[i][3] = t3 - (t2 << 1);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int t0 = b[0][i] + b[3][i], t1 = b[1][i] + b[2][i], t2 = b[1][i] - b[2][i], t3 = b[0][i] - b[3][i];
+    b[0][i] = t0 + t1; b[1][i] = t2 + (t3 << 1); b[2][i] = t0 - t1; b[3][i] = t3 - (t2 << 1);
+  }
+}
+__device__ __forceinline__ void inv4(int b[4][4])
+{
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int p0 = b[i][0] + b[i][2], p1 = b[i][0] - b[i][2], p2 = (b[i][1] >> 1) - b[i][3], p3 = b[i][1] + (b[i][3] >> 1);
+    b[i][0] = p0 + p3; b[i][1] = p1 + p2; b[i][2] = p1 - p2; b[i][3] = p0 - p3;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int p0 = b[0][i] + b[2][i], p1 = b[0][i] - b[2][i], p2 = (b[1][i] >> 1) - b[3][i], p3 = b[1][i] + (b[3][i] >> 1);
+    b[0][i] = p0 + p3; b[1][i] = p1 + p2; b[2][i] = p1 - p2; b[3][i] = p0 - p3;
+  }
+}
+
+// generic (memory tile) versions used by the rarer kinds; m is an int[16][16] tile
+__device__ void fwd4_tile(int (*m)[16], int py, int px)
+{
+  int b[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) b[j][i] = m[py + j][px + i];
+  fwd4(b);
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) m[py + j][px + i] = b[j][i];
+}
+__device__ void inv4_tile(int (*m)[16], int py, int px)
+{
+  int b[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) b[j][i] = m[py + j][px + i];
+  inv4(b);
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) m[py + j][px + i] = b[j][i];
+}
+
+__device__ __forceinline__ void fwd8_1d(const int p[8], int o[8])      // transform.c:248-275
+{
+  int a0 = p[0] + p[7], a1 = p[1] + p[6], a2 = p[2] + p[5], a3 = p[3] + p[4];
+  const int b0 = a0 + a3, b1 = a1 + a2, b2 = a0 - a3, b3 = a1 - a2;
+  a0 = p[0] - p[7]; a1 = p[1] - p[6]; a2 = p[2] - p[5]; a3 = p[3] - p[4];
+  const int b4 = a1 + a2 + ((a0 >> 1) + a0), b5 = a0 - a3 - ((a2 >> 1) + a2);
+  const int b6 = a0 + a3 - ((a1 >> 1) + a1), b7 = a1 - a2 + ((a3 >> 1) + a3);
+  o[0] = b0 + b1; o[1] = b4 + (b7 >> 2); o[2] = b2 + (b3 >> 1); o[3] = b5 + (b6 >> 2);
+  o[4] = b0 - b1; o[5] = b6 - (b5 >> 2); o[6] = (b2 >> 1) - b3; o[7] = (b4 >> 2) - b7;
+}
+__device__ __forceinline__ void inv8_1d(const int p[8], int o[8])      // transform.c:346-373
+{
+  int a0 = p[0] + p[4], a1 = p[0] - p[4], a2 = p[6] - (p[2] >> 1), a3 = p[2] + (p[6] >> 1);
+  const int b0 = a0 + a3, b2 = a1 - a2, b4 = a1 + a2, b6 = a0 - a3;
+  a0 = -p[3] + p[5] - p[7] - (p[7] >> 1);
+  a1 =  p[1] + p[7] - p[3] - (p[3] >> 1);
+  a2 = -p[1] + p[7] + p[5] + (p[5] >> 1);
+  a3 =  p[3] + p[5] + p[1] + (p[1] >> 1);
+  const int b1 = a0 + (a3 >> 2), b3 = a1 + (a2 >> 2), b5 = a2 - (a1 >> 2), b7 = a3 - (a0 >> 2);
+  o[0] = b0 + b7; o[1] = b2 - b5; o[2] = b4 + b3; o[3] = b6 + b1;
+  o[4] = b6 - b1; o[5] = b4 - b3; o[6] = b2 + b5; o[7] = b0 - b7;
+}
+__device__ void xf8_tile(int (*m)[16], int py, int px, bool inverse)  // forward8x8 :229 / inverse8x8 :325
+{
+  int t[8][8];
+  for (int j = 0; j < 8; j++) {
+    int p[8], o[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) p[i] = m[py + j][px + i];
+    if (inverse) inv8_1d(p, o); else fwd8_1d(p, o);
+#pragma unroll
+    for (int i = 0; i < 8; i++) t[j][i] = o[i];
+  }
+  for (int i = 0; i < 8; i++) {
+    int p[8], o[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) p[j] = t[j][i];
+    if (inverse) inv8_1d(p, o); else fwd8_1d(p, o);
+#pragma unroll
+    for (int j = 0; j < 8; j++) m[py + j][px + i] = o[j];
+  }
+}
+
+// ---------------------------------------------------------------------------------------- dct_4x4: one lane per 4x4 block
+
+__global__ __launch_bounds__(256) void tq_luma4x4_kernel(const jmhip_tq_job *__restrict__ jobs, const jmhip_quant *__restrict__ quants,
+                                                        jmhip_tq_result *__restrict__ res, int n)
+{
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int jobi = gid >> 4, blk = gid & 15;                 // blk = b8*4 + b4 (JM block order)
+  if (jobi >= n) return;
+  const jmhip_tq_job &job = jobs[jobi];
+  const jmhip_quant &q = quants[job.quant];
+  jmhip_tq_result &o = res[jobi];
+  const int b8 = blk >> 2, b4 = blk & 3;
+  const int bx = 8 * (b8 & 1) + 4 * (b4 & 1), by = 8 * (b8 >> 1) + 4 * (b4 >> 1);
+  const int qp_per = q.qp / 6, q_bits = Q_BITS + qp_per;
+
+  int m[4][4], pr[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const uint32_t s = *reinterpret_cast<const uint32_t *>(&job.src[by + j][bx]);
+    const uint32_t p = *reinterpret_cast<const uint32_t *>(&job.pred[by + j][bx]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) { pr[j][i] = (p >> (8 * i)) & 255; m[j][i] = (int)((s >> (8 * i)) & 255) - pr[j][i]; }   // img->m7, macroblock.c:1059-1068
+  }
+  fwd4(m);
+
+  int scan_pos = 0, run = -1, nonzero = 0, cost = 0;
+  int *levels = o.levels[blk], *runs = o.runs[blk];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    // static (i,j) per scan position for both scan orders (block.h:26-41)
+    constexpr int I0[16] = {0,1,0,0,1,2,3,2,1,0,1,2,3,3,2,3}, J0[16] = {0,0,1,2,1,0,0,1,2,3,3,2,1,2,3,3};
+    constexpr int I1[16] = {0,0,1,0,0,1,1,1,2,2,2,2,3,3,3,3}, J1[16] = {0,1,0,2,3,1,2,3,0,1,2,3,0,1,2,3};
+    const int i0 = I0[k], j0 = J0[k], i1 = I1[k], j1 = J1[k];
+    // field scan selects a different register: evaluate both statically and pick (uniform per job)
+    const int c0 = m[j0][i0], c1 = m[j1][i1];
+    const int c = q.field_scan ? c1 : c0;
+    const int idx = q.field_scan ? (j1 * 4 + i1) : (j0 * 4 + i0);
+    run++;
+    const int scaled = iabs(c) * q.levelscale[idx];
+    int level = (scaled + q.leveloffset[idx]) >> q_bits;
+    int deq = 0, fadj = 0;
+    if (level != 0) {
+      if (q.adaptive_rounding) fadj = rsr(q.adapt_rnd_weight * (scaled - (level << q_bits)), q_bits + 1);   // block.c:898
+      nonzero = 1;
+      cost += (level > 1) ? MAXV : c_cost4[q.disthres][run];
+      level = sgnab(level, c);
+      levels[scan_pos] = level; runs[scan_pos] = run; scan_pos++;
+      deq = rsr((level * q.invlevelscale[idx]) << qp_per, 4);                                             // block.c:907
+      run = -1;
+    }
+    if (q.adaptive_rounding) o.fadjust[by + (idx >> 2)][bx + (idx & 3)] = fadj;
+    if (q.field_scan) m[j1][i1] = deq; else m[j0][i0] = deq;
+  }
+  levels[scan_pos] = 0;
+  o.coeff_cost[blk] = cost; o.nonzero[blk] = nonzero;
+
+  if (scan_pos) inv4(m);
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int v = scan_pos ? clip1(q.max_val, rsr(m[j][i], DQ_BITS) + pr[j][i]) : pr[j][i];                // block.c:934 / :942
+      w |= (uint32_t)v << (8 * i);
+    }
+    *reinterpret_cast<uint32_t *>(&o.recon[by + j][bx]) = w;
+  }
+}
+
+// ---------------------------------------------------------------------------------------- generic tile kinds: one lane per job
+
+__device__ void load_residual(const jmhip_tq_job &job, int (*m7)[16], int rows, int cols)
+{
+  for (int j = 0; j < rows; j++) for (int i = 0; i < cols; i++) m7[j][i] = (int)job.src[j][i] - (int)job.pred[j][i];
+}
+
+// dct_8x8, transform8x8.c:1452 (non-lossless). One lane per 8x8 block.
+__global__ __launch_bounds__(64) void tq_luma8x8_kernel(const jmhip_tq_job *__restrict__ jobs, const jmhip_quant *__restrict__ quants,
+                                                       jmhip_tq_result *__restrict__ res, int n)
+{
+  const int gid = blockIdx.x * 64 + threadIdx.x;
+  const int jobi = gid >> 2, b8 = gid & 3;
+  if (jobi >= n) return;
+  const jmhip_tq_job &job = jobs[jobi];
+  const jmhip_quant &q = quants[job.quant];
+  jmhip_tq_result &o = res[jobi];
+  const int block_x = 8 * (b8 & 1), block_y = 8 * (b8 >> 1);
+  const int qp_per = q.qp / 6, q_bits = Q_BITS_8 + qp_per;
+  const bool interleave = q.transform8x8_flag && q.cavlc;            // transform8x8.c:1502
+  int m7[16][16];
+  for (int j = 0; j < 8; j++) for (int i = 0; i < 8; i++)
+    m7[block_y + j][block_x + i] = (int)job.src[block_y + j][block_x + i] - (int)job.pred[block_y + j][block_x + i];
+  xf8_tile(m7, block_y, block_x, false);
+
+  int scan_poss[4] = {0, 0, 0, 0}, runs4[4] = {-1, -1, -1, -1};
+  int scan_pos = 0, run = -1, nonzero = 0, cost = 0, mc = 0;
+  for (int k = 0; k < 64; k++) {
+    const int i = c_scan8[q.field_scan][k][0], j = c_scan8[q.field_scan][k][1];
+    run++;
+    if (interleave) { mc = k & 3; runs4[mc]++; }
+    int *c = &m7[block_y + j][block_x + i];
+    const int scaled = iabs(*c) * q.levelscale[j * 8 + i];
+    int level = (scaled + q.leveloffset[j * 8 + i]) >> q_bits;
+    if (level != 0) {
+      if (q.adaptive_rounding) o.fadjust[block_y + j][block_x + i] = rsr(q.adapt_rnd_weight * (scaled - (level << q_bits)), q_bits + 1);
+      nonzero = 1;
+      if (interleave) {
+        cost += (level > 1) ? MAXV : c_cost8[q.disthres][runs4[mc]];
+        o.levels[4 * b8 + mc][scan_poss[mc]] = sgnab(level, *c);
+        o.runs[4 * b8 + mc][scan_poss[mc]] = runs4[mc];
+        scan_poss[mc]++; runs4[mc] = -1;
+      } else {
+        cost += (level > 1) ? MAXV : c_cost8[q.disthres][run];
+        o.levels8[b8][scan_pos] = sgnab(level, *c);
+        o.runs8[b8][scan_pos] = run;
+        scan_pos++; run = -1;
+      }
+      level = sgnab(level, *c);
+      *c = rsr((level * q.invlevelscale[j * 8 + i]) << qp_per, 6);
+    } else {
+      if (q.adaptive_rounding) o.fadjust[block_y + j][block_x + i] = 0;
+      *c = 0;
+    }
+  }
+  if (!interleave) o.levels8[b8][scan_pos] = 0;
+  else for (int k = 0; k < 4; k++) o.levels[4 * b8 + k][scan_poss[k]] = 0;
+  o.coeff_cost[b8] = cost; o.nonzero[b8] = nonzero;
+  if (nonzero) xf8_tile(m7, block_y, block_x, true);
+  for (int j = block_y; j < block_y + 8; j++) for (int i = block_x; i < block_x + 8; i++)
+    o.recon[j][i] = (uint8_t)(nonzero ? clip1(q.max_val, rsr(m7[j][i], DQ_BITS) + job.pred[j][i]) : job.pred[j][i]);
+}
+
+// dct_16x16, block.c:564 (non-lossless). One lane per macroblock.
+__global__ __launch_bounds__(64) void tq_luma16x16_kernel(const jmhip_tq_job *__restrict__ jobs, const jmhip_quant *__restrict__ quants,
+                                                         jmhip_tq_result *__restrict__ res, int n)
+{
+  const int jobi = blockIdx.x * 64 + threadIdx.x;
+  if (jobi >= n) return;
+  const jmhip_tq_job &job = jobs[jobi];
+  const jmhip_quant &q = quants[job.quant];
+  jmhip_tq_result &o = res[jobi];
+  const int qp_per = q.qp / 6, q_bits = Q_BITS + qp_per;
+  int M1[16][16], M4[4][4];
+  load_residual(job, M1, 16, 16);
+  for (int j = 0; j < 16; j += 4) for (int i = 0; i < 16; i += 4) fwd4_tile(M1, j, i);
+  for (int j = 0; j < 4; j++) for (int i = 0; i < 4; i++) M4[j][i] = M1[j << 2][i << 2];
+  {                                                         // hadamard4x4, transform.c:131
+    int t[4][4];
+    for (int i = 0; i < 4; i++) {
+      const int t0 = M4[i][0] + M4[i][3], t1 = M4[i][1] + M4[i][2], t2 = M4[i][1] - M4[i][2], t3 = M4[i][0] - M4[i][3];
+      t[i][0] = t0 + t1; t[i][1] = t3 + t2; t[i][2] = t0 - t1; t[i][3] = t3 - t2;
+    }
+    for (int i = 0; i < 4; i++) {
+      const int t0 = t[0][i] + t[3][i], t1 = t[1][i] + t[2][i], t2 = t[1][i] - t[2][i], t3 = t[0][i] - t[3][i];
+      M4[0][i] = (t0 + t1) >> 1; M4[1][i] = (t2 + t3) >> 1; M4[2][i] = (t0 - t1) >> 1; M4[3][i] = (t3 - t2) >> 1;
+    }
+  }
+  int run = -1, scan_pos = 0, ac_coef = 0;
+  for (int k = 0; k < 16; k++) {
+    const int i = c_scan4[q.field_scan][k][0], j = c_scan4[q.field_scan][k][1];
+    run++;
+    int level = (iabs(M4[j][i]) * q.levelscale[0] + (q.leveloffset[0] << 1)) >> (q_bits + 1);        // block.c:643
+    if (level != 0) {
+      if (q.cavlc && q.img_qp < 10) level = min(level, CAVLC_LEVEL_LIMIT);
+      level = sgnab(level, M4[j][i]);
+      o.dc_levels[scan_pos] = level; o.dc_runs[scan_pos] = run; scan_pos++;
+      run = -1;
+      M4[j][i] = level;
+    } else M4[j][i] = 0;
+  }
+  o.dc_levels[scan_pos] = 0;
+  {                                                         // ihadamard4x4, transform.c:180
+    int t[4][4];
+    for (int i = 0; i < 4; i++) {
+      const int p0 = M4[i][0] + M4[i][2], p1 = M4[i][0] - M4[i][2], p2 = M4[i][1] - M4[i][3], p3 = M4[i][1] + M4[i][3];
+      t[i][0] = p0 + p3; t[i][1] = p1 + p2; t[i][2] = p1 - p2; t[i][3] = p0 - p3;
+    }
+    for (int i = 0; i < 4; i++) {
+      const int p0 = t[0][i] + t[2][i], p1 = t[0][i] - t[2][i], p2 = t[1][i] - t[3][i], p3 = t[1][i] + t[3][i];
+      M4[0][i] = p0 + p3; M4[1][i] = p1 + p2; M4[2][i] = p1 - p2; M4[3][i] = p0 - p3;
+    }
+  }
+  for (int j = 0; j < 4; j++) for (int i = 0; i < 4; i++) M1[j << 2][i << 2] = rsr((M4[j][i] * q.invlevelscale[0]) << qp_per, 6);   // :667
+  for (int jj = 0; jj < 4; jj++) for (int ii = 0; ii < 4; ii++) {
+    const int jpos = jj << 2, ipos = ii << 2;
+    const int blk = (2 * (jj >> 1) + (ii >> 1)) * 4 + 2 * (jj & 1) + (ii & 1);
+    run = -1; scan_pos = 0;
+    for (int k = 1; k < 16; k++) {
+      const int i = c_scan4[q.field_scan][k][0], j = c_scan4[q.field_scan][k][1];
+      run++;
+      int *c = &M1[jpos + j][ipos + i];
+      const int scaled = iabs(*c) * q.levelscale[j * 4 + i];
+      int level = (scaled + q.leveloffset[j * 4 + i]) >> q_bits;
+      if (level != 0) {
+        if (q.adaptive_rounding) o.fadjust[jpos + j][ipos + i] = rsr(q.adapt_rnd_weight * (scaled - (level << q_bits)), q_bits + 1);
+        ac_coef = 15;
+        level = sgnab(level, *c);
+        o.levels[blk][scan_pos] = level; o.runs[blk][scan_pos] = run; scan_pos++;
+        run = -1;
+        *c = rsr((level * q.invlevelscale[j * 4 + i]) << qp_per, 4);
+      } else {
+        *c = 0;
+        if (q.adaptive_rounding) o.fadjust[jpos + j][ipos + i] = 0;
+      }
+    }
+    o.levels[blk][scan_pos] = 0;
+    inv4_tile(M1, jpos, ipos);
+  }
+  for (int j = 0; j < 16; j++) for (int i = 0; i < 16; i++)
+    o.recon[j][i] = (uint8_t)clip1(q.max_val, rsr(M1[j][i], DQ_BITS) + job.pred[j][i]);
+  o.ret = ac_coef;
+}
+
+// dct_chroma, block.c:1051 (non-lossless), one component per job. One lane per job.
+__global__ __launch_bounds__(64) void tq_chroma_kernel(const jmhip_tq_job *__restrict__ jobs, const jmhip_quant *__restrict__ quants,
+                                                      jmhip_tq_result *__restrict__ res, int n, int yuv)
+{
+  const int jobi = blockIdx.x * 64 + threadIdx.x;
+  if (jobi >= n) return;
+  const jmhip_tq_job &job = jobs[jobi];
+  const jmhip_quant &q = quants[job.quant];
+  const jmhip_quant &qdc = quants[job.quant_dc];
+  jmhip_tq_result &o = res[jobi];
+  const int uv = job.uv;
+  int cr_cbp = job.cr_cbp_in;
+  const int qp_per = q.qp / 6, q_bits = Q_BITS + qp_per;
+  const int mbw = (yuv == JMHIP_YUV444) ? 16 : 8, mbh = (yuv == JMHIP_YUV420) ? 8 : 16;
+  const int nb8 = ((yuv == JMHIP_YUV420) ? 2 : (yuv == JMHIP_YUV422 ? 4 : 8)) >> 1;       // img->num_blk8x8_uv >> 1
+  const int uv_scale = uv * nb8;
+  long long cbp = 0;
+  int m7[16][16];
+  load_residual(job, m7, 16, 16);     // full tile: the 4:2:2 quirk below reads columns 8..15 (carried in src/pred as JM's img->m7 holds them)
+  for (int n2 = 0; n2 < mbh; n2 += 4) for (int n1 = 0; n1 < mbw; n1 += 4) fwd4_tile(m7, n1, n2);   // block.c:1116-1122 (n1,n2 swapped as in JM)
+
+  int run = -1, scan_pos = 0, DCcoded = 0;
+  if (yuv == JMHIP_YUV420) {
+    int m1[4], m5[4];
+    m1[0] = m7[0][0] + m7[0][4] + m7[4][0] + m7[4][4];
+    m1[1] = m7[0][0] - m7[0][4] + m7[4][0] - m7[4][4];
+    m1[2] = m7[0][0] + m7[0][4] - m7[4][0] - m7[4][4];
+    m1[3] = m7[0][0] - m7[0][4] - m7[4][0] + m7[4][4];
+    for (int k = 0; k < 4; k++) {
+      run++;
+      int level = (iabs(m1[k]) * q.levelscale[0] + (q.leveloffset[0] << 1)) >> (q_bits + 1);
+      if (level != 0) {
+        if (q.cavlc && q.img_qp < 4) level = min(level, CAVLC_LEVEL_LIMIT);
+        cbp |= 0xf0000LL << (uv << 2);
+        cr_cbp = max(1, cr_cbp);
+        DCcoded = 1;
+        level = sgnab(level, m1[k]);
+        o.dc_levels[scan_pos] = level; o.dc_runs[scan_pos] = run; scan_pos++;
+        run = -1;
+        m1[k] = level;
+      } else m1[k] = 0;
+    }
+    o.dc_levels[scan_pos] = 0;
+    m5[0] = m1[0] + m1[1] + m1[2] + m1[3]; m5[1] = m1[0] - m1[1] + m1[2] - m1[3];
+    m5[2] = m1[0] + m1[1] - m1[2] - m1[3]; m5[3] = m1[0] - m1[1] - m1[2] + m1[3];
+    m7[0][0] = ((m5[0] * q.invlevelscale[0]) << qp_per) >> 5; m7[0][4] = ((m5[1] * q.invlevelscale[0]) << qp_per) >> 5;
+    m7[4][0] = ((m5[2] * q.invlevelscale[0]) << qp_per) >> 5; m7[4][4] = ((m5[3] * q.invlevelscale[0]) << qp_per) >> 5;
+  } else if (yuv == JMHIP_YUV422) {
+    const int qp_per_dc = qdc.qp / 6, q_bits_422 = Q_BITS + qp_per_dc;
+    int m3[2][4], m4[2][4], m5[4], m6[4];
+    for (int j = 0; j < 16; j += 4) for (int i = 0; i < 8; i += 4) m3[i >> 2][j >> 2] = m7[j][i];
+    for (int j = 0; j < 4; j++) { m4[0][j] = m3[0][j] + m3[1][j]; m4[1][j] = m3[0][j] - m3[1][j]; }
+    for (int i = 0; i < 2; i++) {
+      m5[0] = m4[i][0] + m4[i][3]; m5[1] = m4[i][1] + m4[i][2]; m5[2] = m4[i][1] - m4[i][2]; m5[3] = m4[i][0] - m4[i][3];
+      m4[i][0] = m5[0] + m5[1]; m4[i][2] = m5[0] - m5[1]; m4[i][1] = m5[3] + m5[2]; m4[i][3] = m5[3] - m5[2];
+    }
+    for (int k = 0; k < 8; k++) {
+      const int i = c_scan422[k][0], j = c_scan422[k][1];
+      run++;
+      const int level = (iabs(m4[i][j]) * q.levelscale[0] + (qdc.leveloffset[0] * 2)) >> (q_bits_422 + 1);   // block.c:1263
+      if (level != 0) {
+        cbp |= 0xff0000LL << (uv << 3);
+        cr_cbp = max(1, cr_cbp);
+        DCcoded = 1;
+        o.dc_levels[scan_pos] = sgnab(level, m4[i][j]); o.dc_runs[scan_pos] = run; scan_pos++;
+        run = -1;
+      }
+      m3[i][j] = sgnab(level, m4[i][j]);
+    }
+    o.dc_levels[scan_pos] = 0;
+    for (int j = 0; j < 4; j++) { m4[0][j] = m3[0][j] + m3[1][j]; m4[1][j] = m3[0][j] - m3[1][j]; }
+    const int inv = qdc.invlevelscale[0];
+    for (int i = 0; i < 2; i++) {
+      m6[0] = m4[i][0] + m4[i][2]; m6[1] = m4[i][0] - m4[i][2]; m6[2] = m4[i][1] - m4[i][3]; m6[3] = m4[i][1] + m4[i][3];
+      const int v[4] = {m6[0] + m6[3], m6[1] + m6[2], m6[1] - m6[2], m6[0] - m6[3]};
+      for (int r = 0; r < 4; r++)
+        m7[4 * r][i * 4] = (qp_per_dc < 4) ? ((((v[r] * inv + (1 << (3 - qp_per_dc))) >> (4 - qp_per_dc)) + 2) >> 2)
+                                           : ((((v[r] * inv) << (qp_per_dc - 4)) + 2) >> 2);                   // block.c:1303-1316
+    }
+  }
+
+  int coeff_cost = 0, cr_cbp_tmp = 0;
+  for (int b8 = 0; b8 < nb8; b8++) for (int b4 = 0; b4 < 4; b4++) {
+    const long long uv_cbpblk = 1LL << (16 + 4 * (b8 + uv_scale) + b4);                              // cbp_blk_chroma, block.h:109
+    const int n1 = c_hor[yuv][b8][b4], n2 = c_ver[yuv][b8][b4], blk = b8 * 4 + b4;
+    run = -1; scan_pos = 0;
+    for (int k = 1; k < 16; k++) {
+      const int i = c_scan4[q.field_scan][k][0], j = c_scan4[q.field_scan][k][1];
+      int *c = &m7[n2 + j][n1 + i];
+      ++run;
+      const int scaled = iabs(*c) * q.levelscale[j * 4 + i];
+      int level = (scaled + q.leveloffset[j * 4 + i]) >> q_bits;
+      if (level != 0) {
+        if (q.adaptive_rounding) o.fadjust[n2 + j][n1 + i] = rsr(q.adapt_rnd_weight * (scaled - (level << q_bits)), q_bits + 1);
+        cbp |= uv_cbpblk;
+        coeff_cost += (level > 1) ? MAXV : c_cost4[q.disthres][run];
+        cr_cbp_tmp = 2;
+        level = sgnab(level, *c);
+        o.levels[blk][scan_pos] = level; o.runs[blk][scan_pos] = run; scan_pos++;
+        run = -1;
+        *c = rsr((level * q.invlevelscale[j * 4 + i]) << qp_per, 4);
+      } else {
+        *c = 0;
+        if (q.adaptive_rounding) o.fadjust[n2 + j][n1 + i] = 0;
+      }
+    }
+    o.levels[blk][scan_pos] = 0;
+  }
+  long long cbp_clear = 0;
+  if (coeff_cost < 4) {                                      // _CHROMA_COEFF_COST_, defines.h:103; block.c:1384-1410
+    const long long pattern = (yuv == 1) ? 0xf0000LL : (yuv == 2 ? 0xff0000LL : 0xffff0000LL);
+    cr_cbp_tmp = 0;
+    if (DCcoded == 0) cbp_clear = pattern << (uv << (1 + yuv));
+    for (int b8 = 0; b8 < nb8; b8++) for (int b4 = 0; b4 < 4; b4++) {
+      const int n1 = c_hor[yuv][b8][b4], n2 = c_ver[yuv][b8][b4], blk = b8 * 4 + b4;
+      o.levels[blk][0] = 0;
+      for (int k = 1; k < 16; k++) {
+        m7[n2 + c_scan4[q.field_scan][k][1]][n1 + c_scan4[q.field_scan][k][0]] = 0;
+        o.levels[blk][k] = 0;
+      }
+    }
+  }
+  if (cr_cbp_tmp == 2) cr_cbp = 2;
+  for (int n2 = 0; n2 < mbh; n2 += 4) for (int n1 = 0; n1 < mbw; n1 += 4) inv4_tile(m7, n2, n1);
+  for (int j = 0; j < mbh; j++) for (int i = 0; i < mbw; i++)
+    o.recon[j][i] = (uint8_t)clip1(q.max_val, rsr(m7[j][i], DQ_BITS) + job.pred[j][i]);
+  o.ret = cr_cbp;
+  // cbp bits set by this call, and (in the high half of the pair) the bits the thresholding clears
+  o.cbp_blk = cbp & ~cbp_clear;
+  o.cbp_clear = cbp_clear;
+}
+
+}  // namespace
+
+extern "C" void jmhip_flat_quant(jmhip_quant *q, int qp, int offset11, int is8x8)
+{
+  // quant_coef / dequant_coef (block.c:39-55): three position classes (0,0) (odd,odd) (mixed) per qp%6;
+  // quant_coef8 / dequant_coef8 (transform8x8.c:39-167): six classes keyed on (j&3, i&3).
+  static const int qc4[6][3] = {{13107, 5243, 8066}, {11916, 4660, 7490}, {10082, 4194, 6554}, {9362, 3647, 5825}, {8192, 3355, 5243}, {7282, 2893, 4559}};
+  static const int dq4[6][3] = {{10, 16, 13}, {11, 18, 14}, {13, 20, 16}, {14, 23, 18}, {16, 25, 20}, {18, 29, 23}};
+  static const int qc8[6][6] = {{13107, 11428, 20972, 12222, 16777, 15481}, {11916, 10826, 19174, 11058, 14980, 14290}, {10082, 8943, 15978, 9675, 12710, 11985},
+                                {9362, 8228, 14913, 8931, 11984, 11259}, {8192, 7346, 13159, 7740, 10486, 9777}, {7282, 6428, 11570, 6830, 9118, 8640}};
+  static const int dq8[6][6] = {{20, 18, 32, 19, 25, 24}, {22, 19, 35, 21, 28, 26}, {26, 23, 42, 24, 33, 31}, {28, 25, 45, 26, 35, 33}, {32, 28, 51, 30, 40, 38}, {36, 32, 58, 34, 46, 43}};
+  if (!q || qp < 0 || qp > 87) return;
+  memset(q, 0, sizeof(*q));
+  const int k = qp % 6, per = qp / 6;
+  q->qp = qp; q->max_val = 255; q->img_qp = qp;
+  if (!is8x8) {
+    for (int j = 0; j < 4; j++) for (int i = 0; i < 4; i++) {
+      const int cls = ((j & 1) == 0 && (i & 1) == 0) ? 0 : (((j & 1) && (i & 1)) ? 1 : 2);
+      q->levelscale[j * 4 + i] = qc4[k][cls];                       // q_matrix.c:482
+      q->invlevelscale[j * 4 + i] = dq4[k][cls] << 4;               // q_matrix.c:483
+      q->leveloffset[j * 4 + i] = offset11 << (15 + per - 11);      // q_offsets.c:508-523
+    }
+  } else {
+    for (int j = 0; j < 8; j++) for (int i = 0; i < 8; i++) {
+      int a = j & 3, b = i & 3, ca = a == 0 ? 0 : (a == 2 ? 2 : 1), cb = b == 0 ? 0 : (b == 2 ? 2 : 1);
+      if (ca > cb) { int t = ca; ca = cb; cb = t; }
+      const int cls = (ca == cb) ? ca : (ca == 0 ? (cb == 1 ? 3 : 4) : 5);
+      q->levelscale[j * 8 + i] = qc8[k][cls];
+      q->invlevelscale[j * 8 + i] = dq8[k][cls] << 4;
+      q->leveloffset[j * 8 + i] = offset11 << (16 + per - 11);
+    }
+  }
+}
+
+extern "C" int jmhip_tq_batch(jmhip_ctx *c, int kind, int yuv_format, const jmhip_quant *quants, int nquants,
+                              const jmhip_tq_job *jobs, int n, jmhip_tq_result *results)
+{
+  if (!c || !quants || !jobs || !results || n <= 0 || nquants <= 0) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_tq_batch: NULL/empty arguments") : JMHIP_ERR_ARG;
+  if (kind < JMHIP_TQ_LUMA4x4 || kind > JMHIP_TQ_CHROMA) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_tq_batch: unknown kind");
+  if (kind == JMHIP_TQ_CHROMA && (yuv_format < JMHIP_YUV420 || yuv_format > JMHIP_YUV444)) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_tq_batch: chroma needs a chroma format");
+  for (int i = 0; i < nquants; i++) {
+    if (quants[i].qp < 0 || quants[i].qp > 87) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_tq_batch: qp out of range");
+    if (quants[i].disthres < 0 || quants[i].disthres > 1 || quants[i].max_val != 255) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_tq_batch: disthres/max_val out of range");
+  }
+  for (int i = 0; i < n; i++) {
+    if (jobs[i].quant < 0 || jobs[i].quant >= nquants || jobs[i].quant_dc < 0 || jobs[i].quant_dc >= nquants) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_tq_batch: quantiser index out of range");
+    if (kind == JMHIP_TQ_CHROMA && (jobs[i].uv < 0 || jobs[i].uv > 1)) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_tq_batch: uv must be 0 or 1");
+  }
+  JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
+  if (c->tq_capacity < n) {
+    if (c->tq_jobs_dev) JM_HIP_CHECK(c, hipFree(c->tq_jobs_dev));
+    if (c->tq_res_dev) JM_HIP_CHECK(c, hipFree(c->tq_res_dev));
+    c->tq_jobs_dev = c->tq_res_dev = nullptr; c->tq_capacity = 0;
+    if (hipMalloc(&c->tq_jobs_dev, sizeof(jmhip_tq_job) * (size_t)n) != hipSuccess) return jm_fail(c, JMHIP_ERR_NOMEM, "TQ job array");
+    if (hipMalloc(&c->tq_res_dev, sizeof(jmhip_tq_result) * (size_t)n) != hipSuccess) return jm_fail(c, JMHIP_ERR_NOMEM, "TQ result array");
+    c->tq_capacity = n;
+  }
+  if (c->tq_qcap < nquants) {
+    if (c->tq_quant_dev) JM_HIP_CHECK(c, hipFree(c->tq_quant_dev));
+    c->tq_quant_dev = nullptr; c->tq_qcap = 0;
+    if (hipMalloc(&c->tq_quant_dev, sizeof(jmhip_quant) * (size_t)nquants) != hipSuccess) return jm_fail(c, JMHIP_ERR_NOMEM, "TQ quantiser array");
+    c->tq_qcap = nquants;
+  }
+  JM_HIP_CHECK(c, hipMemcpyAsync(c->tq_jobs_dev, jobs, sizeof(jmhip_tq_job) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  JM_HIP_CHECK(c, hipMemcpyAsync(c->tq_quant_dev, quants, sizeof(jmhip_quant) * (size_t)nquants, hipMemcpyHostToDevice, c->stream));
+  JM_HIP_CHECK(c, hipMemsetAsync(c->tq_res_dev, 0, sizeof(jmhip_tq_result) * (size_t)n, c->stream));
+  const jmhip_tq_job *dj = (const jmhip_tq_job *)c->tq_jobs_dev;
+  const jmhip_quant *dq = (const jmhip_quant *)c->tq_quant_dev;
+  jmhip_tq_result *dr = (jmhip_tq_result *)c->tq_res_dev;
+  jm_stage_begin(c, JMHIP_STAGE_TQ);
+  switch (kind) {
+  case JMHIP_TQ_LUMA4x4:   tq_luma4x4_kernel<<<(n * 16 + 255) / 256, 256, 0, c->stream>>>(dj, dq, dr, n); break;
+  case JMHIP_TQ_LUMA8x8:   tq_luma8x8_kernel<<<(n * 4 + 63) / 64, 64, 0, c->stream>>>(dj, dq, dr, n); break;
+  case JMHIP_TQ_LUMA16x16: tq_luma16x16_kernel<<<(n + 63) / 64, 64, 0, c->stream>>>(dj, dq, dr, n); break;
+  default:                 tq_chroma_kernel<<<(n + 63) / 64, 64, 0, c->stream>>>(dj, dq, dr, n, yuv_format); break;
+  }
+  jm_stage_end(c, JMHIP_STAGE_TQ);
+  JM_HIP_CHECK(c, hipGetLastError());
+  JM_HIP_CHECK(c, hipMemcpyAsync(results, c->tq_res_dev, sizeof(jmhip_tq_result) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  JM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+  return JMHIP_OK;
+}

@@ -58,6 +58,18 @@ DIST_JOB_DTYPE = np.dtype([("pic_x", "<i2"), ("pic_y", "<i2"), ("bsx", "<i2"), (
                            ("cand_x", "<i4"), ("cand_y", "<i4"), ("ref", "<i2"), ("use_satd", "<i2")])
 
 
+QUANT_DTYPE = np.dtype([("qp", "<i4"), ("adaptive_rounding", "<i4"), ("adapt_rnd_weight", "<i4"), ("field_scan", "<i4"),
+                        ("disthres", "<i4"), ("max_val", "<i4"), ("cavlc", "<i4"), ("img_qp", "<i4"), ("transform8x8_flag", "<i4"),
+                        ("levelscale", "<i4", (64,)), ("invlevelscale", "<i4", (64,)), ("leveloffset", "<i4", (64,))], align=True)
+TQ_JOB_DTYPE = np.dtype([("src", "u1", (16, 16)), ("pred", "u1", (16, 16)), ("quant", "<i4"), ("quant_dc", "<i4"),
+                         ("uv", "<i4"), ("cr_cbp_in", "<i4"), ("intra16_unused", "<i4")], align=True)
+TQ_RESULT_DTYPE = np.dtype([("levels", "<i4", (16, 17)), ("runs", "<i4", (16, 17)), ("levels8", "<i4", (4, 65)), ("runs8", "<i4", (4, 65)),
+                            ("dc_levels", "<i4", (17,)), ("dc_runs", "<i4", (17,)), ("recon", "u1", (16, 16)), ("fadjust", "<i4", (16, 16)),
+                            ("coeff_cost", "<i4", (16,)), ("nonzero", "<i4", (16,)), ("ret", "<i4"), ("cbp_blk", "<i8"), ("cbp_clear", "<i8")],
+                           align=True)
+TQ_KINDS = {"luma4x4": 0, "luma8x8": 1, "luma16x16": 2, "chroma": 3}
+
+
 def load_library():
     """Loads libjmhip.so. Raises (never falls back) when it is missing."""
     global _lib
@@ -91,8 +103,27 @@ def load_library():
     lib.jmhip_me_frame_async.argtypes = [vp, C.POINTER(MeParams), vp, ip]
     lib.jmhip_me_results_download.argtypes = [vp, vp, ip]
     lib.jmhip_distortion_batch.argtypes = [vp, vp, ip, vp]
+    lib.jmhip_tq_batch.argtypes = [vp, ip, ip, vp, ip, vp, ip, vp]
+    lib.jmhip_flat_quant.argtypes = [vp, ip, ip, ip]
+    lib.jmhip_flat_quant.restype = None
+    lib.jmhip_sizeof.argtypes = [ip]
+    for which, dt in ((0, ME_MB_DTYPE), (1, ME_RESULT_DTYPE), (2, QUANT_DTYPE), (3, TQ_JOB_DTYPE), (4, TQ_RESULT_DTYPE),
+                      (5, DIST_JOB_DTYPE)):
+        if lib.jmhip_sizeof(which) != dt.itemsize:
+            raise JmhipError("binding layout mismatch for struct %d: C %d vs numpy %d" % (which, lib.jmhip_sizeof(which), dt.itemsize))
+    if lib.jmhip_sizeof(6) != C.sizeof(MeParams) or lib.jmhip_sizeof(7) != C.sizeof(Config):
+        raise JmhipError("binding layout mismatch for jmhip_me_params / jmhip_config")
     _lib = lib
     return lib
+
+
+def flat_quant(qp, offset11, is8x8=False, **fields):
+    """jmhip_flat_quant: flat scaling tables + default rounding offsets as one QUANT_DTYPE record."""
+    q = np.zeros(1, dtype=QUANT_DTYPE)
+    load_library().jmhip_flat_quant(q.ctypes.data_as(C.c_void_p), qp, offset11, 1 if is8x8 else 0)
+    for k, v in fields.items():
+        q[0][k] = v
+    return q[0]
 
 
 def partition_table():
@@ -227,6 +258,15 @@ class Context:
         out = np.zeros(len(jobs), dtype=np.int32)
         self._chk(self.lib.jmhip_distortion_batch(self.h, _ptr(jobs), len(jobs), _ptr(out)), "jmhip_distortion_batch")
         return out
+
+    # ---- transform / quant / recon
+    def tq_batch(self, kind, quants, jobs, yuv_format=1):
+        quants = np.ascontiguousarray(quants, dtype=QUANT_DTYPE)
+        jobs = np.ascontiguousarray(jobs, dtype=TQ_JOB_DTYPE)
+        res = np.zeros(len(jobs), dtype=TQ_RESULT_DTYPE)
+        self._chk(self.lib.jmhip_tq_batch(self.h, TQ_KINDS[kind], yuv_format, _ptr(quants), len(quants), _ptr(jobs), len(jobs), _ptr(res)),
+                  "jmhip_tq_batch")
+        return res
 
     # ---- timing
     def timing_enable(self, on=True):

@@ -205,11 +205,16 @@ typedef struct {
   int32_t  coeff_cost[16];       /* per 4x4 (LUMA4x4) / per 8x8 in [0..3] (LUMA8x8)                    */
   int32_t  nonzero[16];          /* return value of dct_4x4 / dct_8x8 per block                        */
   int32_t  ret;                  /* dct_16x16: ac_coef; dct_chroma: cr_cbp                             */
-  int64_t  cbp_blk;              /* dct_chroma: bits OR-ed into currMB->cbp_blk                        */
+  int64_t  cbp_blk;              /* dct_chroma: bits to OR into currMB->cbp_blk ...                     */
+  int64_t  cbp_clear;            /* ... after clearing these (block.c:1399): cbp = (cbp & ~clear) | set  */
 } jmhip_tq_result;
 
 int jmhip_tq_batch(jmhip_ctx *ctx, int kind, int yuv_format, const jmhip_quant *quants, int nquants,
                    const jmhip_tq_job *jobs, int n, jmhip_tq_result *results);
+
+/* sizeof() of the ABI structs, for language bindings to verify their layout: 0 jmhip_me_mb, 1 jmhip_me_result,
+ * 2 jmhip_quant, 3 jmhip_tq_job, 4 jmhip_tq_result, 5 jmhip_dist_job, 6 jmhip_me_params, 7 jmhip_config. */
+int jmhip_sizeof(int which);
 
 /* Flat (no scaling matrix) tables: CalculateQuantParam / CalculateQuant8Param (src/q_matrix.c:451,590) and
  * default CalculateOffsetParam / CalculateOffset8Param (src/q_offsets.c:491,629); offset11 = 682 or 342. */

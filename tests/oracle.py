@@ -214,3 +214,113 @@ def me_frame(p, refpics, cur, mbs, mode, R, lam, subpel=True, mask=(1 << 41) - 1
             out["mv_int"][i, q] = mvi
             out["cost_int"][i, q] = ci
     return out
+
+
+# ------------------------------------------------------------------ transform / quant reference
+
+class Quant(C.Structure):
+    _fields_ = [("qp", C.c_int), ("levelscale", C.POINTER(C.c_int)), ("invlevelscale", C.POINTER(C.c_int)),
+                ("leveloffset", C.POINTER(C.c_int)), ("adaptive_rounding", C.c_int), ("adapt_rnd_weight", C.c_int),
+                ("field_scan", C.c_int), ("disthres", C.c_int), ("max_val", C.c_int), ("cavlc", C.c_int),
+                ("img_qp", C.c_int), ("transform8x8_flag", C.c_int)]
+
+
+class QuantHolder:
+    """Keeps the table arrays alive next to the C struct. q: a jmhip QUANT_DTYPE record (same fields)."""
+
+    def __init__(self, q):
+        self.ls = np.ascontiguousarray(q["levelscale"], dtype=np.int32)
+        self.ils = np.ascontiguousarray(q["invlevelscale"], dtype=np.int32)
+        self.lo = np.ascontiguousarray(q["leveloffset"], dtype=np.int32)
+        ip = C.POINTER(C.c_int)
+        self.c = Quant(int(q["qp"]), self.ls.ctypes.data_as(ip), self.ils.ctypes.data_as(ip), self.lo.ctypes.data_as(ip),
+                       int(q["adaptive_rounding"]), int(q["adapt_rnd_weight"]), int(q["field_scan"]), int(q["disthres"]),
+                       int(q["max_val"]), int(q["cavlc"]), int(q["img_qp"]), int(q["transform8x8_flag"]))
+
+
+def flat_tables(qp, offset11, is8x8=False):
+    n = 64 if is8x8 else 16
+    ls, ils, lo = (np.zeros(64, np.int32) for _ in range(3))
+    f = lib().jmo_flat_tables8x8 if is8x8 else lib().jmo_flat_tables4x4
+    f.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    f.restype = None
+    f(qp, offset11, ls.ctypes.data, ils.ctypes.data, lo.ctypes.data)
+    return ls, ils, lo, n
+
+
+def tq_reference(kind, quants, jobs, yuv_format=1):
+    """Runs the oracle's dct_* on every job; returns a dict of arrays shaped like jmhip TQ_RESULT_DTYPE fields."""
+    L = lib()
+    n = len(jobs)
+    out = {"levels": np.zeros((n, 16, 17), np.int32), "runs": np.zeros((n, 16, 17), np.int32),
+           "levels8": np.zeros((n, 4, 65), np.int32), "runs8": np.zeros((n, 4, 65), np.int32),
+           "dc_levels": np.zeros((n, 17), np.int32), "dc_runs": np.zeros((n, 17), np.int32),
+           "recon": np.zeros((n, 16, 16), np.uint8), "fadjust": np.zeros((n, 16, 16), np.int32),
+           "coeff_cost": np.zeros((n, 16), np.int32), "nonzero": np.zeros((n, 16), np.int32),
+           "ret": np.zeros(n, np.int32), "cbp_blk": np.zeros(n, np.int64), "cbp_clear": np.zeros(n, np.int64)}
+    holders = [QuantHolder(q) for q in quants]
+    vp = C.c_void_p
+    for t, job in enumerate(jobs):
+        q = holders[int(job["quant"])]
+        src = job["src"].astype(np.int32)
+        pred16 = np.ascontiguousarray(job["pred"], dtype=np.uint16)
+        m7 = np.ascontiguousarray(src - job["pred"].astype(np.int32), dtype=np.int32)
+        recon = np.zeros((16, 16), np.uint16)
+        fadj = np.zeros((16, 16), np.int32)
+        if kind == "luma4x4":
+            for blk in range(16):
+                b8, b4 = blk >> 2, blk & 3
+                bx, by = 8 * (b8 & 1) + 4 * (b4 & 1), 8 * (b8 >> 1) + 4 * (b4 >> 1)
+                cost = C.c_int(0)
+                lev, run = np.zeros(17, np.int32), np.zeros(17, np.int32)
+                L.jmo_dct_4x4.argtypes = [C.POINTER(Quant), vp, vp, C.c_int, C.c_int, C.POINTER(C.c_int), vp, vp, vp, vp]
+                nz = L.jmo_dct_4x4(C.byref(q.c), m7.ctypes.data, pred16.ctypes.data, bx, by, C.byref(cost),
+                                   lev.ctypes.data, run.ctypes.data, recon.ctypes.data, fadj.ctypes.data)
+                out["levels"][t, blk], out["runs"][t, blk] = lev, run
+                out["coeff_cost"][t, blk], out["nonzero"][t, blk] = cost.value, nz
+        elif kind == "luma8x8":
+            for b8 in range(4):
+                cost = C.c_int(0)
+                lev, run = np.zeros((4, 65), np.int32), np.zeros((4, 65), np.int32)
+                L.jmo_dct_8x8.argtypes = [C.POINTER(Quant), vp, vp, C.c_int, C.POINTER(C.c_int), vp, vp, vp, vp]
+                nz = L.jmo_dct_8x8(C.byref(q.c), m7.ctypes.data, pred16.ctypes.data, b8, C.byref(cost),
+                                   lev.ctypes.data, run.ctypes.data, recon.ctypes.data, fadj.ctypes.data)
+                if q.c.transform8x8_flag and q.c.cavlc:
+                    out["levels"][t, 4 * b8:4 * b8 + 4], out["runs"][t, 4 * b8:4 * b8 + 4] = lev[:, :17], run[:, :17]
+                else:
+                    out["levels8"][t, b8], out["runs8"][t, b8] = lev[0], run[0]
+                out["coeff_cost"][t, b8], out["nonzero"][t, b8] = cost.value, nz
+        elif kind == "luma16x16":
+            cur16 = np.ascontiguousarray(job["src"], dtype=np.uint16)
+            acl, acr = np.zeros((16, 16), np.int32), np.zeros((16, 16), np.int32)
+            dcl, dcr = np.zeros(17, np.int32), np.zeros(17, np.int32)
+            L.jmo_dct_16x16.argtypes = [C.POINTER(Quant), vp, vp, vp, vp, vp, vp, vp, vp]
+            out["ret"][t] = L.jmo_dct_16x16(C.byref(q.c), cur16.ctypes.data, pred16.ctypes.data, dcl.ctypes.data, dcr.ctypes.data,
+                                            acl.ctypes.data, acr.ctypes.data, recon.ctypes.data, fadj.ctypes.data)
+            out["levels"][t, :, :16], out["runs"][t, :, :16] = acl, acr
+            out["dc_levels"][t], out["dc_runs"][t] = dcl, dcr
+        else:
+            qdc = holders[int(job["quant_dc"])]
+            acl, acr = np.zeros((8, 16), np.int32), np.zeros((8, 16), np.int32)
+            dcl, dcr = np.zeros(17, np.int32), np.zeros(17, np.int32)
+            cbp = C.c_longlong(0)
+            L.jmo_dct_chroma.argtypes = [C.POINTER(Quant), C.POINTER(Quant), C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp,
+                                         C.POINTER(C.c_longlong)]
+            # run twice to separate set bits from cleared bits: start from all-ones and from zero
+            m7b = m7.copy()
+            out["ret"][t] = L.jmo_dct_chroma(C.byref(q.c), C.byref(qdc.c), yuv_format, int(job["uv"]), int(job["cr_cbp_in"]),
+                                             m7.ctypes.data, pred16.ctypes.data, dcl.ctypes.data, dcr.ctypes.data,
+                                             acl.ctypes.data, acr.ctypes.data, recon.ctypes.data, fadj.ctypes.data, C.byref(cbp))
+            ones = C.c_longlong(-1)
+            d2, d3, a2, a3 = np.zeros(17, np.int32), np.zeros(17, np.int32), np.zeros((8, 16), np.int32), np.zeros((8, 16), np.int32)
+            r2, f2 = np.zeros((16, 16), np.uint16), np.zeros((16, 16), np.int32)
+            L.jmo_dct_chroma(C.byref(q.c), C.byref(qdc.c), yuv_format, int(job["uv"]), int(job["cr_cbp_in"]),
+                             m7b.ctypes.data, pred16.ctypes.data, d2.ctypes.data, d3.ctypes.data, a2.ctypes.data, a3.ctypes.data,
+                             r2.ctypes.data, f2.ctypes.data, C.byref(ones))
+            out["cbp_blk"][t] = cbp.value
+            out["cbp_clear"][t] = ~ones.value
+            out["levels"][t, :8, :16], out["runs"][t, :8, :16] = acl, acr
+            out["dc_levels"][t], out["dc_runs"][t] = dcl, dcr
+        out["recon"][t] = recon.astype(np.uint8)
+        out["fadjust"][t] = fadj
+    return out
