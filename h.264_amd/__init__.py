@@ -9,5 +9,5 @@ The directory name contains a dot, so load it by path (tests/conftest.py::load_p
 from .jmhip import (  # noqa: F401
     JmhipError, Context, MeParams, load_library, library_path, declared_symbols, partition_table,
     build_library, flat_quant, NPART, PAD, STAGES,
-    ME_MB_DTYPE, ME_RESULT_DTYPE, QUANT_DTYPE, TQ_JOB_DTYPE, TQ_RESULT_DTYPE, DIST_JOB_DTYPE,
+    ME_MB_DTYPE, ME_RESULT_DTYPE, QUANT_DTYPE, TQ_JOB_DTYPE, TQ_RESULT_DTYPE, DIST_JOB_DTYPE, MB_MODE_DTYPE,
 )

@@ -1,0 +1,340 @@
+// frame.hip -- frame stage after the search: MC prediction -> residual -> transform/quant -> thresholding -> recon.
+//
+// Device-side restatement of the inter path of LumaResidualCoding / ChromaResidualCoding for P macroblocks without
+// the 8x8 transform (the step between ME and transform):
+//   SetModesAndRefframe + LumaResidualCoding8x8   lencod/src/macroblock.c:1009-1300  (4x4 loop :1039-1110,
+//                                                  _LUMA_COEFF_COST_ thresholding :1236-1258)
+//   LumaResidualCoding (MB-level _LUMA_MB_COEFF_COST_)               macroblock.c:1357-1449
+//   LumaPrediction / OneComponentLumaPrediction                       macroblock.c:836, :807   (UMVLine4X per 4x4 block)
+//   OneComponentChromaPrediction4x4_retrieve                          macroblock.c:1593-1652   (UMVLine8X_chroma per 2 samples)
+//   ChromaResidualCoding: cr_cbp chained over U,V, cbp += cr_cbp<<4   macroblock.c:1944-2044
+// The transform/quant itself is tq.hip's dct_4x4 / dct_chroma kernels run over device-resident job arrays.
+// Which mode a macroblock takes is the host's decision (JM's mode decision is out of scope); without one the
+// device picks the partitioning with the smallest summed motion cost.
+#include "jmhip_internal.h"
+
+namespace {
+
+struct FrameDev {
+  int W, H, Wp, Hp, Wc, Hc, Wcp, Hcp, mbw;
+  int yuv, shift_x, shift_y, mask_x, mask_y, sub_x, mb_cw, mb_ch;
+  const uint8_t *cur_y, *cur_u, *cur_v;
+  const uint8_t *const *ref_sub, *const *ref_cb, *const *ref_cr;
+  uint8_t *rec_y, *rec_u, *rec_v;
+};
+
+__device__ __forceinline__ int clampi(int x, int lo, int hi) { return min(max(x, lo), hi); }
+
+// partition index (me_search.hip table order) that covers luma 4x4 block (x4,y4) for a macroblock mode
+__device__ __forceinline__ int covering_partition(const jmhip_mb_mode &m, int x4, int y4)
+{
+  const int b8 = 2 * (y4 >> 1) + (x4 >> 1);
+  switch (m.mode) {
+  case 1: return 0;
+  case 2: return 1 + (y4 >> 1);
+  case 3: return 3 + (x4 >> 1);
+  default:
+    switch (m.b8mode[b8]) {
+    case 4: return 5 + b8;
+    case 5: return 9 + 2 * b8 + (y4 & 1);
+    case 6: return 17 + 2 * b8 + (x4 & 1);
+    default: return 25 + 4 * b8 + 2 * (y4 & 1) + (x4 & 1);
+    }
+  }
+}
+
+__device__ __forceinline__ uint32_t fetch4(const uint8_t *p)
+{
+  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+  const uint32_t *q = reinterpret_cast<const uint32_t *>(a & ~uintptr_t(3));
+  return __builtin_amdgcn_alignbyte(q[1], q[0], (unsigned)(a & 3));
+}
+
+__global__ __launch_bounds__(64) void mc_kernel(FrameDev F, const jmhip_me_mb *__restrict__ mbs, const jmhip_me_result *__restrict__ me,
+                                               const jmhip_mb_mode *__restrict__ modes_in, jmhip_mb_mode *__restrict__ modes_out,
+                                               jmhip_tq_job *__restrict__ jobs_y, jmhip_tq_job *__restrict__ jobs_c)
+{
+  __shared__ jmhip_mb_mode s_mode;
+  __shared__ short s_mv[16][2];
+  const int i = blockIdx.x, tid = threadIdx.x;
+  const jmhip_me_mb &mb = mbs[i];
+  const jmhip_me_result &r = me[i];
+  const int mbx = mb.mb_x, mby = mb.mb_y;
+
+  if (tid == 0) {
+    jmhip_mb_mode m;
+    if (modes_in) m = modes_in[i];
+    else {
+      // smallest summed motion cost; ties go to the lower mode number
+      const int *c = r.cost;
+      int c8 = 0;
+      for (int b = 0; b < 4; b++) {
+        const int s4 = c[5 + b], s5 = c[9 + 2 * b] + c[10 + 2 * b], s6 = c[17 + 2 * b] + c[18 + 2 * b];
+        const int s7 = c[25 + 4 * b] + c[26 + 4 * b] + c[27 + 4 * b] + c[28 + 4 * b];
+        int best = s4, bm = 4;
+        if (s5 < best) { best = s5; bm = 5; }
+        if (s6 < best) { best = s6; bm = 6; }
+        if (s7 < best) { best = s7; bm = 7; }
+        m.b8mode[b] = (int8_t)bm; c8 += best;
+      }
+      int best = c[0]; m.mode = 1;
+      if (c[1] + c[2] < best) { best = c[1] + c[2]; m.mode = 2; }
+      if (c[3] + c[4] < best) { best = c[3] + c[4]; m.mode = 3; }
+      if (c8 < best) { best = c8; m.mode = 8; }
+      m.pad[0] = m.pad[1] = m.pad[2] = 0;
+    }
+    s_mode = m;
+    modes_out[i] = m;
+  }
+  __syncthreads();
+  if (tid < 16) {
+    const int p = covering_partition(s_mode, tid & 3, tid >> 2);
+    s_mv[tid][0] = r.mv[p][0]; s_mv[tid][1] = r.mv[p][1];
+  }
+  __syncthreads();
+
+  jmhip_tq_job &jy = jobs_y[i];
+  if (tid < 16) {                                    // luma: one 4x4 block per lane, LumaPrediction(..., 4, 4, ...)
+    const int x4 = tid & 3, y4 = tid >> 2;
+    const int xq = ((mbx * 16 + 4 * x4) << 2) + 4 * JMHIP_PAD + s_mv[tid][0];   // pic_opix_x + mv, macroblock.c:851
+    const int yq = ((mby * 16 + 4 * y4) << 2) + 4 * JMHIP_PAD + s_mv[tid][1];
+    const int xpos = clampi(xq >> 2, 0, F.Wp - 1 - 16), ypos = clampi(yq >> 2, 0, F.Hp - 1 - 16);   // UMVLine4X, refbuf.c:37
+    const uint8_t *src = F.ref_sub[mb.ref] + (size_t)((yq & 3) * 4 + (xq & 3)) * F.Wp * F.Hp + (size_t)ypos * F.Wp + xpos;
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+      *reinterpret_cast<uint32_t *>(&jy.pred[4 * y4 + rr][4 * x4]) = fetch4(src + (size_t)rr * F.Wp);
+      *reinterpret_cast<uint32_t *>(&jy.src[4 * y4 + rr][4 * x4]) =
+          *reinterpret_cast<const uint32_t *>(F.cur_y + (size_t)(mby * 16 + 4 * y4 + rr) * F.W + mbx * 16 + 4 * x4);
+    }
+    if (tid == 0) { jy.quant = 0; jy.quant_dc = 0; jy.uv = 0; jy.cr_cbp_in = 0; jy.intra16_unused = 0; }
+  }
+
+  if (F.yuv != JMHIP_YUV400) {
+    // chroma: every pair of samples is fetched with the motion vector of the luma 4x4 block above it (macroblock.c:1626-1650)
+    const int rsx = 4 - F.shift_x, rsy = 4 - F.shift_y;
+    const int npairs = F.mb_ch * (F.mb_cw / 2);
+    for (int t = tid; t < 2 * npairs; t += 64) {
+      const int uv = t / npairs, q = t - uv * npairs;
+      const int j = q / (F.mb_cw / 2), ic = 2 * (q - j * (F.mb_cw / 2));
+      const int by4 = j >> rsy, bx4 = ic >> rsx;                     // luma 4x4 block indices
+      const short *mv = s_mv[by4 * 4 + bx4];
+      const int ii = ((ic + mbx * F.mb_cw) << F.shift_x) + 4 * JMHIP_PAD + mv[0];
+      const int jj = ((j + mby * F.mb_ch) << F.shift_y) + 4 * JMHIP_PAD + mv[1];
+      const int width_pad_cr = F.Wcp - 1 - F.mb_cw, height_pad_cr = F.Hcp - 1 - F.mb_ch;      // mbuffer.c:425-426
+      const int xpos = clampi(ii >> F.shift_x, 0, width_pad_cr), ypos = clampi(jj >> F.shift_y, 0, height_pad_cr);
+      const uint8_t *planes = (uv ? F.ref_cr : F.ref_cb)[mb.ref];
+      const uint8_t *src = planes + (size_t)((jj & F.mask_y) * F.sub_x + (ii & F.mask_x)) * F.Wcp * F.Hcp + (size_t)ypos * F.Wcp + xpos;
+      jmhip_tq_job &jc = jobs_c[2 * i + uv];
+      jc.pred[j][ic] = src[0]; jc.pred[j][ic + 1] = src[1];
+      const uint8_t *cs = (uv ? F.cur_v : F.cur_u) + (size_t)(mby * F.mb_ch + j) * F.Wc + mbx * F.mb_cw + ic;
+      jc.src[j][ic] = cs[0]; jc.src[j][ic + 1] = cs[1];
+      if (q == 0) { jc.quant = 1; jc.quant_dc = 2; jc.uv = uv; jc.cr_cbp_in = 0; jc.intra16_unused = 0; }
+    }
+  }
+}
+
+struct MbCoded { int32_t cbp; int32_t pad; int64_t cbp_blk; };
+
+__global__ __launch_bounds__(64) void finalize_kernel(FrameDev F, const jmhip_me_mb *__restrict__ mbs, const jmhip_tq_job *__restrict__ jobs_y,
+                                                     const jmhip_tq_result *__restrict__ res_y, const jmhip_tq_job *__restrict__ jobs_c,
+                                                     const jmhip_tq_result *__restrict__ res_c, MbCoded *__restrict__ coded)
+{
+  __shared__ int s_keep[4], s_mbkeep;
+  const int i = blockIdx.x, tid = threadIdx.x;
+  const jmhip_me_mb &mb = mbs[i];
+  const jmhip_tq_result &ry = res_y[i];
+  if (tid == 0) {
+    int cbp = 0, sum = 0;
+    long long cbp_blk = 0;
+    for (int b8 = 0; b8 < 4; b8++) {
+      int cost = 0, any = 0;
+      for (int b4 = 0; b4 < 4; b4++) {
+        cost += ry.coeff_cost[b8 * 4 + b4];
+        if (ry.nonzero[b8 * 4 + b4]) {
+          any = 1;
+          const int x4 = 2 * (b8 & 1) + (b4 & 1), y4 = 2 * (b8 >> 1) + (b4 >> 1);
+          cbp_blk |= 1LL << (x4 + 4 * y4);           // cbp_blk_mask = (block_x>>2) + block_y, macroblock.c:1050
+        }
+      }
+      if (any) cbp |= 1 << b8;
+      int keep = 1;
+      if (cost <= 4) {                                // _LUMA_COEFF_COST_, macroblock.c:1236-1245
+        cost = 0; keep = 0;
+        cbp &= 63 - (1 << b8);
+        cbp_blk &= ~(51LL << (4 * b8 - 2 * (b8 & 1)));
+      }
+      s_keep[b8] = keep; sum += cost;
+    }
+    int mbkeep = 1;
+    if (sum <= 5) { cbp &= 0xfffff0; cbp_blk &= 0xff0000; mbkeep = 0; }     // _LUMA_MB_COEFF_COST_, macroblock.c:1386-1392
+    s_mbkeep = mbkeep;
+    if (F.yuv != JMHIP_YUV400) {
+      const jmhip_tq_result &ru = res_c[2 * i], &rv = res_c[2 * i + 1];
+      cbp_blk = (cbp_blk & ~ru.cbp_clear) | ru.cbp_blk;
+      cbp_blk = (cbp_blk & ~rv.cbp_clear) | rv.cbp_blk;
+      cbp += max(ru.ret, rv.ret) << 4;                // macroblock.c:2028-2040
+    }
+    coded[i].cbp = cbp; coded[i].pad = 0; coded[i].cbp_blk = cbp_blk;
+  }
+  __syncthreads();
+  // recon picture: 64 lanes x one dword (4 samples) per row quarter
+  {
+    const int row = tid >> 2, cq = tid & 3;          // 16 rows x 4 dwords
+    const int b8 = 2 * (row >> 3) + (cq >> 1);
+    const bool keep = s_mbkeep && s_keep[b8];
+    const uint32_t v = keep ? *reinterpret_cast<const uint32_t *>(&ry.recon[row][cq * 4])
+                            : *reinterpret_cast<const uint32_t *>(&jobs_y[i].pred[row][cq * 4]);
+    *reinterpret_cast<uint32_t *>(F.rec_y + (size_t)(mb.mb_y * 16 + row) * F.W + mb.mb_x * 16 + cq * 4) = v;
+  }
+  if (F.yuv != JMHIP_YUV400) {
+    const int ndw = F.mb_ch * (F.mb_cw / 4);
+    for (int t = tid; t < 2 * ndw; t += 64) {
+      const int uv = t / ndw, q = t - uv * ndw, row = q / (F.mb_cw / 4), cq = q - row * (F.mb_cw / 4);
+      const uint32_t v = *reinterpret_cast<const uint32_t *>(&res_c[2 * i + uv].recon[row][cq * 4]);
+      *reinterpret_cast<uint32_t *>((uv ? F.rec_v : F.rec_u) + (size_t)(mb.mb_y * F.mb_ch + row) * F.Wc + mb.mb_x * F.mb_cw + cq * 4) = v;
+    }
+  }
+  (void)jobs_c;
+}
+
+int ensure_frame_buffers(jmhip_ctx *c, int n)
+{
+  if (!c->rec_y) {
+    if (hipMalloc((void **)&c->rec_y, (size_t)c->W * c->H) != hipSuccess) return jm_fail(c, JMHIP_ERR_NOMEM, "recon picture");
+    if (c->Wc) {
+      if (hipMalloc((void **)&c->rec_u, (size_t)c->Wc * c->Hc) != hipSuccess || hipMalloc((void **)&c->rec_v, (size_t)c->Wc * c->Hc) != hipSuccess)
+        return jm_fail(c, JMHIP_ERR_NOMEM, "recon picture");
+    }
+  }
+  if (c->fr_capacity >= n) return JMHIP_OK;
+  void **bufs[] = {&c->fr_jobs_y, &c->fr_jobs_c, &c->fr_res_y, &c->fr_res_c, &c->fr_modes};
+  for (auto b : bufs) { if (*b) JM_HIP_CHECK(c, hipFree(*b)); *b = nullptr; }
+  c->fr_capacity = 0;
+  bool ok = hipMalloc(&c->fr_jobs_y, sizeof(jmhip_tq_job) * (size_t)n) == hipSuccess &&
+            hipMalloc(&c->fr_jobs_c, sizeof(jmhip_tq_job) * (size_t)n * 2) == hipSuccess &&
+            hipMalloc(&c->fr_res_y, sizeof(jmhip_tq_result) * (size_t)n) == hipSuccess &&
+            hipMalloc(&c->fr_res_c, sizeof(jmhip_tq_result) * (size_t)n * 2) == hipSuccess &&
+            hipMalloc(&c->fr_modes, (sizeof(jmhip_mb_mode) * 2 + sizeof(MbCoded)) * (size_t)n) == hipSuccess;
+  if (!ok) return jm_fail(c, JMHIP_ERR_NOMEM, "frame-stage arrays");
+  if (!c->fr_quant && hipMalloc(&c->fr_quant, sizeof(jmhip_quant) * 3) != hipSuccess) return jm_fail(c, JMHIP_ERR_NOMEM, "frame-stage quantisers");
+  c->fr_capacity = n;
+  return JMHIP_OK;
+}
+
+}  // namespace
+
+extern "C" int jmhip_residual_frame(jmhip_ctx *c, const jmhip_mb_mode *modes, const jmhip_quant quants[3])
+{
+  if (!c || !quants) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_residual_frame: NULL arguments") : JMHIP_ERR_ARG;
+  const int n = c->me_n;
+  if (n <= 0 || !c->me_res_dev) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_residual_frame: no motion search results on the device (call jmhip_me_frame first)");
+  if (c->cfg.yuv_format == JMHIP_YUV444) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_residual_frame: 4:4:4 chroma goes through the luma path in JM (not built)");
+  for (int k = 0; k < 3; k++) {
+    if (quants[k].qp < 0 || quants[k].qp > 87 || quants[k].max_val != 255 || quants[k].disthres < 0 || quants[k].disthres > 1)
+      return jm_fail(c, JMHIP_ERR_ARG, "jmhip_residual_frame: quantiser out of range");
+    if (quants[k].transform8x8_flag) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_residual_frame: 8x8 transform macroblocks not built in the frame stage");
+  }
+  if (modes)
+    for (int i = 0; i < n; i++) {
+      const jmhip_mb_mode &m = modes[i];
+      bool ok = m.mode == 1 || m.mode == 2 || m.mode == 3 || m.mode == 8;
+      if (m.mode == 8) for (int b = 0; b < 4; b++) ok = ok && m.b8mode[b] >= 4 && m.b8mode[b] <= 7;
+      if (!ok) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_residual_frame: bad macroblock mode");
+    }
+  JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
+  int rc = ensure_frame_buffers(c, n);
+  if (rc) return rc;
+  if ((rc = jm_ensure_ref_table(c))) return rc;
+  for (size_t k = 0; k < c->refs.size(); k++)
+    if ((c->me_ref_mask >> k) & 1) {
+      if (!c->refs[k].has_luma_sub) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_residual_frame: quarter-pel planes of a used reference not built (jmhip_interp_luma)");
+      if (c->Wc && !c->refs[k].has_cr_sub) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_residual_frame: chroma planes of a used reference not built (jmhip_interp_chroma)");
+    }
+
+  jmhip_mb_mode *modes_in_dev = nullptr, *modes_out_dev = (jmhip_mb_mode *)c->fr_modes;
+  if (modes) {
+    modes_in_dev = modes_out_dev + n;
+    JM_HIP_CHECK(c, hipMemcpyAsync(modes_in_dev, modes, sizeof(jmhip_mb_mode) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  }
+  MbCoded *coded_dev = reinterpret_cast<MbCoded *>(modes_out_dev + 2 * (size_t)n);
+  JM_HIP_CHECK(c, hipMemcpyAsync(c->fr_quant, quants, sizeof(jmhip_quant) * 3, hipMemcpyHostToDevice, c->stream));
+  JM_HIP_CHECK(c, hipMemsetAsync(c->fr_res_y, 0, sizeof(jmhip_tq_result) * (size_t)n, c->stream));
+  JM_HIP_CHECK(c, hipMemsetAsync(c->fr_jobs_c, 0, sizeof(jmhip_tq_job) * (size_t)n * 2, c->stream));
+  JM_HIP_CHECK(c, hipMemsetAsync(c->fr_res_c, 0, sizeof(jmhip_tq_result) * (size_t)n * 2, c->stream));
+
+  FrameDev F{};
+  F.W = c->W; F.H = c->H; F.Wp = c->Wp; F.Hp = c->Hp; F.Wc = c->Wc; F.Hc = c->Hc; F.Wcp = c->Wcp; F.Hcp = c->Hcp; F.mbw = c->mbw;
+  F.yuv = c->cfg.yuv_format; F.shift_x = c->cg.shift_x; F.shift_y = c->cg.shift_y; F.mask_x = c->cg.mask_x; F.mask_y = c->cg.mask_y;
+  F.sub_x = c->cg.sub_x; F.mb_cw = c->cg.mb_w; F.mb_ch = c->cg.mb_h;
+  F.cur_y = c->cur_y; F.cur_u = c->cur_u; F.cur_v = c->cur_v;
+  const uint8_t *const *tab = reinterpret_cast<const uint8_t *const *>(c->ref_ptrs_dev);
+  F.ref_sub = tab + 32; F.ref_cb = tab + 64; F.ref_cr = tab + 96;
+  F.rec_y = c->rec_y; F.rec_u = c->rec_u; F.rec_v = c->rec_v;
+
+  jm_stage_begin(c, JMHIP_STAGE_MC);
+  mc_kernel<<<n, 64, 0, c->stream>>>(F, (const jmhip_me_mb *)c->me_jobs_dev, (const jmhip_me_result *)c->me_res_dev, modes_in_dev, modes_out_dev,
+                                     (jmhip_tq_job *)c->fr_jobs_y, (jmhip_tq_job *)c->fr_jobs_c);
+  jm_stage_end(c, JMHIP_STAGE_MC);
+  JM_HIP_CHECK(c, hipGetLastError());
+  jm_stage_begin(c, JMHIP_STAGE_TQ);
+  rc = jm_launch_tq(c, JMHIP_TQ_LUMA4x4, F.yuv, c->fr_jobs_y, c->fr_quant, c->fr_res_y, n);
+  if (!rc && F.yuv != JMHIP_YUV400) rc = jm_launch_tq(c, JMHIP_TQ_CHROMA, F.yuv, c->fr_jobs_c, c->fr_quant, c->fr_res_c, 2 * n);
+  if (!rc) {
+    finalize_kernel<<<n, 64, 0, c->stream>>>(F, (const jmhip_me_mb *)c->me_jobs_dev, (const jmhip_tq_job *)c->fr_jobs_y, (const jmhip_tq_result *)c->fr_res_y,
+                                             (const jmhip_tq_job *)c->fr_jobs_c, (const jmhip_tq_result *)c->fr_res_c, coded_dev);
+    if (hipGetLastError() != hipSuccess) rc = jm_fail(c, JMHIP_ERR_DEVICE, "finalize_kernel launch");
+  }
+  jm_stage_end(c, JMHIP_STAGE_TQ);
+  if (rc) return rc;
+  c->fr_n = n;
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_residual_download(jmhip_ctx *c, jmhip_tq_result *luma, jmhip_tq_result *chroma, jmhip_mb_mode *modes_out,
+                                       int32_t *cbp, int64_t *cbp_blk, int n)
+{
+  if (!c) return JMHIP_ERR_ARG;
+  if (n <= 0 || n > c->fr_n) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_residual_download: more macroblocks requested than processed");
+  if (luma) JM_HIP_CHECK(c, hipMemcpyAsync(luma, c->fr_res_y, sizeof(jmhip_tq_result) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  if (chroma && c->Wc) JM_HIP_CHECK(c, hipMemcpyAsync(chroma, c->fr_res_c, sizeof(jmhip_tq_result) * (size_t)n * 2, hipMemcpyDeviceToHost, c->stream));
+  if (modes_out) JM_HIP_CHECK(c, hipMemcpyAsync(modes_out, c->fr_modes, sizeof(jmhip_mb_mode) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  std::vector<MbCoded> coded;
+  if (cbp || cbp_blk) {
+    coded.resize(n);
+    // the coded array sits after the 2*n modes of the last call (n == fr_n)
+    const MbCoded *coded_dev = reinterpret_cast<const MbCoded *>((jmhip_mb_mode *)c->fr_modes + 2 * (size_t)c->fr_n);
+    JM_HIP_CHECK(c, hipMemcpyAsync(coded.data(), coded_dev, sizeof(MbCoded) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  }
+  JM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < n && (cbp || cbp_blk); i++) { if (cbp) cbp[i] = coded[i].cbp; if (cbp_blk) cbp_blk[i] = coded[i].cbp_blk; }
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_recon_to_ref(jmhip_ctx *c, int ref)
+{
+  if (!c) return JMHIP_ERR_ARG;
+  if (ref < 0 || ref >= (int)c->refs.size()) return jm_fail(c, JMHIP_ERR_ARG, "ref slot out of range");
+  if (!c->rec_y || c->fr_n <= 0) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_recon_to_ref: no recon picture yet");
+  RefSlot &r = c->refs[ref];
+  JM_HIP_CHECK(c, hipMemcpyAsync(r.y, c->rec_y, (size_t)c->W * c->H, hipMemcpyDeviceToDevice, c->stream));
+  if (c->Wc) {
+    JM_HIP_CHECK(c, hipMemcpyAsync(r.u, c->rec_u, (size_t)c->Wc * c->Hc, hipMemcpyDeviceToDevice, c->stream));
+    JM_HIP_CHECK(c, hipMemcpyAsync(r.v, c->rec_v, (size_t)c->Wc * c->Hc, hipMemcpyDeviceToDevice, c->stream));
+  }
+  r.has_pic = true; r.has_luma_sub = false; r.has_cr_sub = false;
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_recon_download(jmhip_ctx *c, void *Y, void *U, void *V, int pel_bytes)
+{
+  if (!c || !Y) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_recon_download: NULL output") : JMHIP_ERR_ARG;
+  if (!c->rec_y || c->fr_n <= 0) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_recon_download: no recon picture yet");
+  if (pel_bytes != 1) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_recon_download: 8-bit samples only");
+  JM_HIP_CHECK(c, hipMemcpyAsync(Y, c->rec_y, (size_t)c->W * c->H, hipMemcpyDeviceToHost, c->stream));
+  if (c->Wc && U && V) {
+    JM_HIP_CHECK(c, hipMemcpyAsync(U, c->rec_u, (size_t)c->Wc * c->Hc, hipMemcpyDeviceToHost, c->stream));
+    JM_HIP_CHECK(c, hipMemcpyAsync(V, c->rec_v, (size_t)c->Wc * c->Hc, hipMemcpyDeviceToHost, c->stream));
+  }
+  JM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+  return JMHIP_OK;
+}

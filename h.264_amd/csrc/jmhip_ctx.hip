@@ -22,6 +22,7 @@ extern "C" int jmhip_sizeof(int which)
   case 5: return (int)sizeof(jmhip_dist_job);
   case 6: return (int)sizeof(jmhip_me_params);
   case 7: return (int)sizeof(jmhip_config);
+  case 8: return (int)sizeof(jmhip_mb_mode);
   default: return -1;
   }
 }
@@ -103,6 +104,8 @@ extern "C" void jmhip_ctx_destroy(jmhip_ctx *c)
   (void)hipFree(c->cur_y); (void)hipFree(c->cur_u); (void)hipFree(c->cur_v);
   (void)hipFree(c->stage_dev); (void)hipFree(c->me_jobs_dev); (void)hipFree(c->me_res_dev); (void)hipFree(c->ref_ptrs_dev);
   (void)hipFree(c->tq_jobs_dev); (void)hipFree(c->tq_res_dev); (void)hipFree(c->tq_quant_dev);
+  (void)hipFree(c->fr_jobs_y); (void)hipFree(c->fr_jobs_c); (void)hipFree(c->fr_res_y); (void)hipFree(c->fr_res_c);
+  (void)hipFree(c->fr_quant); (void)hipFree(c->fr_modes); (void)hipFree(c->rec_y); (void)hipFree(c->rec_u); (void)hipFree(c->rec_v);
   for (auto &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto e : c->evt_pool) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);

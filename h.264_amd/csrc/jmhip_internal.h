@@ -34,7 +34,12 @@ struct jmhip_ctx {
   void *stage_dev = nullptr; size_t stage_bytes = 0;
   // ME job/result arrays
   void *me_jobs_dev = nullptr; void *me_res_dev = nullptr; int me_capacity = 0; int me_n = 0;
+  unsigned me_ref_mask = 0;                           // reference slots used by the last ME call
   void *ref_ptrs_dev = nullptr;                       // [0..31] integer recon, [32..63] quarter-pel plane stacks
+  // frame pipeline (MC -> residual -> TQ -> recon): per-MB luma job/result, 2 chroma jobs/results, recon picture
+  void *fr_jobs_y = nullptr, *fr_jobs_c = nullptr, *fr_res_y = nullptr, *fr_res_c = nullptr, *fr_quant = nullptr, *fr_modes = nullptr;
+  int fr_capacity = 0, fr_n = 0;
+  uint8_t *rec_y = nullptr, *rec_u = nullptr, *rec_v = nullptr;
   // TQ arrays
   void *tq_jobs_dev = nullptr, *tq_res_dev = nullptr, *tq_quant_dev = nullptr; int tq_capacity = 0, tq_qcap = 0;
   // timing
@@ -69,3 +74,5 @@ void jm_stage_end(jmhip_ctx *ctx, int stage);
 // kernels (one translation unit each)
 int jm_launch_interp_luma(jmhip_ctx *ctx, int ref);
 int jm_launch_interp_chroma(jmhip_ctx *ctx, int ref);
+int jm_launch_tq(jmhip_ctx *ctx, int kind, int yuv_format, const void *jobs, const void *quants, void *results, int n);
+int jm_ensure_ref_table(jmhip_ctx *ctx);

@@ -459,6 +459,20 @@ int ensure_tables(jmhip_ctx *c)
 
 }  // namespace
 
+// device table of reference plane pointers: [0..31] integer recon, [32..63] luma quarter-pel stacks,
+// [64..95] Cb eighth-pel stacks, [96..127] Cr
+int jm_ensure_ref_table(jmhip_ctx *c)
+{
+  if (c->ref_ptrs_dev) return JMHIP_OK;
+  std::vector<const uint8_t *> tab(128, nullptr);
+  for (size_t i = 0; i < c->refs.size(); i++) {
+    tab[i] = c->refs[i].y; tab[32 + i] = c->refs[i].luma_sub; tab[64 + i] = c->refs[i].cr_sub[0]; tab[96 + i] = c->refs[i].cr_sub[1];
+  }
+  if (hipMalloc(&c->ref_ptrs_dev, sizeof(void *) * 128) != hipSuccess) return jm_fail(c, JMHIP_ERR_NOMEM, "reference pointer table");
+  JM_HIP_CHECK(c, hipMemcpy(c->ref_ptrs_dev, tab.data(), sizeof(void *) * 128, hipMemcpyHostToDevice));
+  return JMHIP_OK;
+}
+
 extern "C" void jmhip_partition_info(int p, int *blocktype, int *x4, int *y4, int *w4, int *h4)
 {
   build_part_table();
@@ -501,11 +515,13 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
 
   // validate jobs and size the LDS window from the worst spread of search centres
   int max_uw = 0, max_uh = 0;
+  unsigned ref_mask = 0;
   for (int i = 0; i < n; i++) {
     const jmhip_me_mb &m = mbs[i];
     if (m.mb_x < 0 || m.mb_x >= c->mbw || m.mb_y < 0 || m.mb_y >= c->mbh) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_frame: macroblock outside the picture");
     if (m.ref < 0 || m.ref >= (int)c->refs.size() || !c->refs[m.ref].has_pic) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_frame: reference slot not uploaded");
     if (prm->subpel && !c->refs[m.ref].has_luma_sub) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_frame: sub-pel planes of the reference not built (jmhip_interp_luma)");
+    ref_mask |= 1u << m.ref;
     int x0 = 1 << 30, x1 = -(1 << 30), y0 = 1 << 30, y1 = -(1 << 30);
     for (int p = 0; p < JMHIP_NPART; p++) if ((prm->partition_mask >> p) & 1) {
       int cx, cy;
@@ -529,14 +545,9 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
     if (hipMalloc(&c->me_res_dev, sizeof(jmhip_me_result) * (size_t)n) != hipSuccess) return jm_fail(c, JMHIP_ERR_NOMEM, "ME result array");
     c->me_capacity = n;
   }
-  if (!c->ref_ptrs_dev) {
-    std::vector<const uint8_t *> tab(64, nullptr);
-    for (size_t i = 0; i < c->refs.size(); i++) { tab[i] = c->refs[i].y; tab[32 + i] = c->refs[i].luma_sub; }
-    if (hipMalloc(&c->ref_ptrs_dev, sizeof(void *) * 64) != hipSuccess) return jm_fail(c, JMHIP_ERR_NOMEM, "reference pointer table");
-    JM_HIP_CHECK(c, hipMemcpy(c->ref_ptrs_dev, tab.data(), sizeof(void *) * 64, hipMemcpyHostToDevice));
-  }
+  if ((rc = jm_ensure_ref_table(c))) return rc;
   JM_HIP_CHECK(c, hipMemcpyAsync(c->me_jobs_dev, mbs, sizeof(jmhip_me_mb) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-  c->me_n = n;
+  c->me_n = n; c->me_ref_mask = ref_mask;
 
   MeDev P{};
   P.mode = prm->search_mode; P.R = R; P.rdopt = prm->rdopt; P.is_b = prm->is_b_slice;

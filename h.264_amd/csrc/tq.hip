@@ -528,6 +528,22 @@ extern "C" void jmhip_flat_quant(jmhip_quant *q, int qp, int offset11, int is8x8
   }
 }
 
+// launch the TQ kernel of `kind` over device-resident job/quant/result arrays
+int jm_launch_tq(jmhip_ctx *c, int kind, int yuv_format, const void *jobs, const void *quants, void *results, int n)
+{
+  const jmhip_tq_job *dj = (const jmhip_tq_job *)jobs;
+  const jmhip_quant *dq = (const jmhip_quant *)quants;
+  jmhip_tq_result *dr = (jmhip_tq_result *)results;
+  switch (kind) {
+  case JMHIP_TQ_LUMA4x4:   tq_luma4x4_kernel<<<(n * 16 + 255) / 256, 256, 0, c->stream>>>(dj, dq, dr, n); break;
+  case JMHIP_TQ_LUMA8x8:   tq_luma8x8_kernel<<<(n * 4 + 63) / 64, 64, 0, c->stream>>>(dj, dq, dr, n); break;
+  case JMHIP_TQ_LUMA16x16: tq_luma16x16_kernel<<<(n + 63) / 64, 64, 0, c->stream>>>(dj, dq, dr, n); break;
+  default:                 tq_chroma_kernel<<<(n + 63) / 64, 64, 0, c->stream>>>(dj, dq, dr, n, yuv_format); break;
+  }
+  JM_HIP_CHECK(c, hipGetLastError());
+  return JMHIP_OK;
+}
+
 extern "C" int jmhip_tq_batch(jmhip_ctx *c, int kind, int yuv_format, const jmhip_quant *quants, int nquants,
                               const jmhip_tq_job *jobs, int n, jmhip_tq_result *results)
 {
@@ -560,18 +576,10 @@ extern "C" int jmhip_tq_batch(jmhip_ctx *c, int kind, int yuv_format, const jmhi
   JM_HIP_CHECK(c, hipMemcpyAsync(c->tq_jobs_dev, jobs, sizeof(jmhip_tq_job) * (size_t)n, hipMemcpyHostToDevice, c->stream));
   JM_HIP_CHECK(c, hipMemcpyAsync(c->tq_quant_dev, quants, sizeof(jmhip_quant) * (size_t)nquants, hipMemcpyHostToDevice, c->stream));
   JM_HIP_CHECK(c, hipMemsetAsync(c->tq_res_dev, 0, sizeof(jmhip_tq_result) * (size_t)n, c->stream));
-  const jmhip_tq_job *dj = (const jmhip_tq_job *)c->tq_jobs_dev;
-  const jmhip_quant *dq = (const jmhip_quant *)c->tq_quant_dev;
-  jmhip_tq_result *dr = (jmhip_tq_result *)c->tq_res_dev;
   jm_stage_begin(c, JMHIP_STAGE_TQ);
-  switch (kind) {
-  case JMHIP_TQ_LUMA4x4:   tq_luma4x4_kernel<<<(n * 16 + 255) / 256, 256, 0, c->stream>>>(dj, dq, dr, n); break;
-  case JMHIP_TQ_LUMA8x8:   tq_luma8x8_kernel<<<(n * 4 + 63) / 64, 64, 0, c->stream>>>(dj, dq, dr, n); break;
-  case JMHIP_TQ_LUMA16x16: tq_luma16x16_kernel<<<(n + 63) / 64, 64, 0, c->stream>>>(dj, dq, dr, n); break;
-  default:                 tq_chroma_kernel<<<(n + 63) / 64, 64, 0, c->stream>>>(dj, dq, dr, n, yuv_format); break;
-  }
+  int rc = jm_launch_tq(c, kind, yuv_format, c->tq_jobs_dev, c->tq_quant_dev, c->tq_res_dev, n);
   jm_stage_end(c, JMHIP_STAGE_TQ);
-  JM_HIP_CHECK(c, hipGetLastError());
+  if (rc) return rc;
   JM_HIP_CHECK(c, hipMemcpyAsync(results, c->tq_res_dev, sizeof(jmhip_tq_result) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
   JM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
   return JMHIP_OK;

@@ -67,6 +67,7 @@ TQ_RESULT_DTYPE = np.dtype([("levels", "<i4", (16, 17)), ("runs", "<i4", (16, 17
                             ("dc_levels", "<i4", (17,)), ("dc_runs", "<i4", (17,)), ("recon", "u1", (16, 16)), ("fadjust", "<i4", (16, 16)),
                             ("coeff_cost", "<i4", (16,)), ("nonzero", "<i4", (16,)), ("ret", "<i4"), ("cbp_blk", "<i8"), ("cbp_clear", "<i8")],
                            align=True)
+MB_MODE_DTYPE = np.dtype([("mode", "i1"), ("b8mode", "i1", (4,)), ("pad", "i1", (3,))])
 TQ_KINDS = {"luma4x4": 0, "luma8x8": 1, "luma16x16": 2, "chroma": 3}
 
 
@@ -106,9 +107,13 @@ def load_library():
     lib.jmhip_tq_batch.argtypes = [vp, ip, ip, vp, ip, vp, ip, vp]
     lib.jmhip_flat_quant.argtypes = [vp, ip, ip, ip]
     lib.jmhip_flat_quant.restype = None
+    lib.jmhip_residual_frame.argtypes = [vp, vp, vp]
+    lib.jmhip_residual_download.argtypes = [vp, vp, vp, vp, vp, vp, ip]
+    lib.jmhip_recon_to_ref.argtypes = [vp, ip]
+    lib.jmhip_recon_download.argtypes = [vp, vp, vp, vp, ip]
     lib.jmhip_sizeof.argtypes = [ip]
     for which, dt in ((0, ME_MB_DTYPE), (1, ME_RESULT_DTYPE), (2, QUANT_DTYPE), (3, TQ_JOB_DTYPE), (4, TQ_RESULT_DTYPE),
-                      (5, DIST_JOB_DTYPE)):
+                      (5, DIST_JOB_DTYPE), (8, MB_MODE_DTYPE)):
         if lib.jmhip_sizeof(which) != dt.itemsize:
             raise JmhipError("binding layout mismatch for struct %d: C %d vs numpy %d" % (which, lib.jmhip_sizeof(which), dt.itemsize))
     if lib.jmhip_sizeof(6) != C.sizeof(MeParams) or lib.jmhip_sizeof(7) != C.sizeof(Config):
@@ -267,6 +272,34 @@ class Context:
         self._chk(self.lib.jmhip_tq_batch(self.h, TQ_KINDS[kind], yuv_format, _ptr(quants), len(quants), _ptr(jobs), len(jobs), _ptr(res)),
                   "jmhip_tq_batch")
         return res
+
+    # ---- frame stage: MC -> residual -> TQ -> recon
+    def residual_frame(self, quants3, modes=None):
+        quants3 = np.ascontiguousarray(quants3, dtype=QUANT_DTYPE)
+        assert len(quants3) == 3
+        if modes is not None:
+            modes = np.ascontiguousarray(modes, dtype=MB_MODE_DTYPE)
+        self._chk(self.lib.jmhip_residual_frame(self.h, _ptr(modes), _ptr(quants3)), "jmhip_residual_frame")
+
+    def residual_download(self, n, want_results=True):
+        luma = np.zeros(n, dtype=TQ_RESULT_DTYPE) if want_results else None
+        chroma = np.zeros(2 * n, dtype=TQ_RESULT_DTYPE) if (want_results and self.Wc) else None
+        modes = np.zeros(n, dtype=MB_MODE_DTYPE)
+        cbp = np.zeros(n, dtype=np.int32)
+        cbp_blk = np.zeros(n, dtype=np.int64)
+        self._chk(self.lib.jmhip_residual_download(self.h, _ptr(luma), _ptr(chroma), _ptr(modes), _ptr(cbp), _ptr(cbp_blk), n),
+                  "jmhip_residual_download")
+        return {"luma": luma, "chroma": chroma, "modes": modes, "cbp": cbp, "cbp_blk": cbp_blk}
+
+    def recon_to_ref(self, ref):
+        self._chk(self.lib.jmhip_recon_to_ref(self.h, ref), "jmhip_recon_to_ref")
+
+    def recon_download(self):
+        Y = np.zeros((self.H, self.W), np.uint8)
+        U = np.zeros((self.Hc, self.Wc), np.uint8) if self.Wc else None
+        V = np.zeros((self.Hc, self.Wc), np.uint8) if self.Wc else None
+        self._chk(self.lib.jmhip_recon_download(self.h, _ptr(Y), _ptr(U), _ptr(V), 1), "jmhip_recon_download")
+        return Y, U, V
 
     # ---- timing
     def timing_enable(self, on=True):

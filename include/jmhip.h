@@ -212,8 +212,34 @@ typedef struct {
 int jmhip_tq_batch(jmhip_ctx *ctx, int kind, int yuv_format, const jmhip_quant *quants, int nquants,
                    const jmhip_tq_job *jobs, int n, jmhip_tq_result *results);
 
+/* ------------------------------------------------------------------ frame stage: MC prediction -> residual -> TQ -> recon */
+
+/* Inter mode of one macroblock as JM's mode decision fixed it (the decision itself stays on the host):
+ * mode 1 = 16x16, 2 = 16x8, 3 = 8x16, 8 = P8x8 with b8mode[b] in {4,5,6,7} (8x8, 8x4, 4x8, 4x4). */
+typedef struct { int8_t mode; int8_t b8mode[4]; int8_t pad[3]; } jmhip_mb_mode;
+
+/* For the n macroblocks of the last jmhip_me_frame(_async) call, in the same order:
+ *   LumaPrediction / OneComponentLumaPrediction (src/macroblock.c:836, :807) per 4x4 block with the motion vectors
+ *   the search found for the macroblock's mode, chroma prediction from the eighth-pel planes
+ *   (OneComponentChromaPrediction4x4_retrieve, src/macroblock.c:1593), residual m7 = org - mpr
+ *   (src/macroblock.c:1059-1068), dct_4x4 x16 and dct_chroma x2 (inter tables), reconstruction into the context's
+ *   recon picture. modes == NULL: the device takes, per macroblock, the partitioning with the smallest summed
+ *   motion cost (ties to the lower mode number) -- a stand-in for the host's mode decision used by bench.py.
+ *   quants[0] = luma inter quantiser, quants[1] = chroma quantiser, quants[2] = 4:2:2 chroma DC (qp+3) quantiser.
+ * Results stay on the device until downloaded: luma[n], chroma[2n] (index 2*i+uv), modes_out[n], cbp[n], cbp_blk[n]. */
+int jmhip_residual_frame(jmhip_ctx *ctx, const jmhip_mb_mode *modes, const jmhip_quant quants[3]);
+/* cbp / cbp_blk: currMB->cbp and currMB->cbp_blk after the _LUMA_COEFF_COST_ (8x8) and _LUMA_MB_COEFF_COST_ (MB)
+ * thresholding of src/macroblock.c:1236-1258, :1386-1392 and the chroma cr_cbp. Any output pointer may be NULL. */
+int jmhip_residual_download(jmhip_ctx *ctx, jmhip_tq_result *luma, jmhip_tq_result *chroma, jmhip_mb_mode *modes_out,
+                            int32_t *cbp, int64_t *cbp_blk, int n);
+/* Make the recon picture the integer-pel picture of reference slot `ref` (device-to-device), e.g. for the next frame. */
+int jmhip_recon_to_ref(jmhip_ctx *ctx, int ref);
+/* Copy the recon picture to the host (8-bit or 16-bit samples). */
+int jmhip_recon_download(jmhip_ctx *ctx, void *Y, void *U, void *V, int pel_bytes);
+
 /* sizeof() of the ABI structs, for language bindings to verify their layout: 0 jmhip_me_mb, 1 jmhip_me_result,
- * 2 jmhip_quant, 3 jmhip_tq_job, 4 jmhip_tq_result, 5 jmhip_dist_job, 6 jmhip_me_params, 7 jmhip_config. */
+ * 2 jmhip_quant, 3 jmhip_tq_job, 4 jmhip_tq_result, 5 jmhip_dist_job, 6 jmhip_me_params, 7 jmhip_config,
+ * 8 jmhip_mb_mode. */
 int jmhip_sizeof(int which);
 
 /* Flat (no scaling matrix) tables: CalculateQuantParam / CalculateQuant8Param (src/q_matrix.c:451,590) and

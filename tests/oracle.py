@@ -324,3 +324,115 @@ def tq_reference(kind, quants, jobs, yuv_format=1):
         out["recon"][t] = recon.astype(np.uint8)
         out["fadjust"][t] = fadj
     return out
+
+
+# ------------------------------------------------------------------ frame stage reference (MC -> residual -> TQ -> thresholds)
+
+def pick_modes(cost):
+    """Smallest summed motion cost, ties to the lower mode number (the device's stand-in for mode decision)."""
+    n = cost.shape[0]
+    modes = np.zeros(n, dtype=[("mode", "i1"), ("b8mode", "i1", (4,)), ("pad", "i1", (3,))])
+    for i in range(n):
+        c = cost[i].astype(np.int64)
+        c8 = 0
+        for b in range(4):
+            cand = [(c[5 + b], 4), (c[9 + 2 * b] + c[10 + 2 * b], 5), (c[17 + 2 * b] + c[18 + 2 * b], 6),
+                    (c[25 + 4 * b:29 + 4 * b].sum(), 7)]
+            best = min(cand, key=lambda t: (t[0], t[1]))
+            modes[i]["b8mode"][b] = best[1]
+            c8 += best[0]
+        cand = [(c[0], 1), (c[1] + c[2], 2), (c[3] + c[4], 3), (c8, 8)]
+        modes[i]["mode"] = min(cand, key=lambda t: (t[0], t[1]))[1]
+    return modes
+
+
+def covering_partition(m, x4, y4):
+    b8 = 2 * (y4 >> 1) + (x4 >> 1)
+    if m["mode"] == 1:
+        return 0
+    if m["mode"] == 2:
+        return 1 + (y4 >> 1)
+    if m["mode"] == 3:
+        return 3 + (x4 >> 1)
+    bm = m["b8mode"][b8]
+    if bm == 4:
+        return 5 + b8
+    if bm == 5:
+        return 9 + 2 * b8 + (y4 & 1)
+    if bm == 6:
+        return 17 + 2 * b8 + (x4 & 1)
+    return 25 + 4 * b8 + 2 * (y4 & 1) + (x4 & 1)
+
+
+def residual_frame(refpic, cur, mbs, mv, modes, quants3, job_dtype, yuv_format=1):
+    """Reference for jmhip_residual_frame. refpic: RefPic with chroma planes; cur = (Y,U,V); mv: (n,41,2) quarter-pel."""
+    Y, U, V = cur
+    n = len(mbs)
+    (sx, sy), (px, py) = chroma_geom(yuv_format)
+    shift_x, shift_y = (3, 3) if yuv_format == 1 else (3, 2)
+    mcw, mch = (8, 8) if yuv_format == 1 else (8, 16)
+    Wp, Hp = refpic.W + 40, refpic.H + 40
+    Wcp, Hcp = refpic.cb.shape[3], refpic.cb.shape[2]
+    jobs_y = np.zeros(n, dtype=job_dtype)
+    jobs_c = np.zeros(2 * n, dtype=job_dtype)
+    for i, mb in enumerate(mbs):
+        mbx, mby = int(mb["mb_x"]), int(mb["mb_y"])
+        mv4 = np.zeros((4, 4, 2), int)
+        for y4 in range(4):
+            for x4 in range(4):
+                p = covering_partition(modes[i], x4, y4)
+                mv4[y4, x4] = mv[i, p]
+                xq = ((mbx * 16 + 4 * x4) << 2) + 80 + int(mv[i, p, 0])
+                yq = ((mby * 16 + 4 * y4) << 2) + 80 + int(mv[i, p, 1])
+                xpos = min(max(xq >> 2, 0), Wp - 17)
+                ypos = min(max(yq >> 2, 0), Hp - 17)
+                jobs_y[i]["pred"][4 * y4:4 * y4 + 4, 4 * x4:4 * x4 + 4] = refpic.luma[yq & 3, xq & 3, ypos:ypos + 4, xpos:xpos + 4]
+        jobs_y[i]["src"] = Y[mby * 16:mby * 16 + 16, mbx * 16:mbx * 16 + 16]
+        for uv, (planes, C_) in enumerate(((refpic.cb, U), (refpic.cr, V))):
+            jc = jobs_c[2 * i + uv]
+            jc["quant"], jc["quant_dc"], jc["uv"] = 1, 2, uv
+            for j in range(mch):
+                for ic in range(0, mcw, 2):
+                    by4, bx4 = j >> (4 - shift_y), ic >> (4 - shift_x)
+                    ii = ((ic + mbx * mcw) << shift_x) + 80 + int(mv4[by4, bx4, 0])
+                    jj = ((j + mby * mch) << shift_y) + 80 + int(mv4[by4, bx4, 1])
+                    xpos = min(max(ii >> shift_x, 0), Wcp - 1 - mcw)
+                    ypos = min(max(jj >> shift_y, 0), Hcp - 1 - mch)
+                    jc["pred"][j, ic:ic + 2] = planes[jj & ((1 << shift_y) - 1), ii & ((1 << shift_x) - 1), ypos, xpos:xpos + 2]
+            jc["src"][:mch, :mcw] = C_[mby * mch:mby * mch + mch, mbx * mcw:mbx * mcw + mcw]
+    ry = tq_reference("luma4x4", quants3, jobs_y)
+    rc = tq_reference("chroma", quants3, jobs_c, yuv_format=yuv_format)
+    cbp = np.zeros(n, np.int32)
+    cbp_blk = np.zeros(n, np.int64)
+    recY = np.zeros_like(Y)
+    recU, recV = np.zeros_like(U), np.zeros_like(V)
+    for i, mb in enumerate(mbs):
+        mbx, mby = int(mb["mb_x"]), int(mb["mb_y"])
+        c, cb, total = 0, 0, 0
+        rec = ry["recon"][i].copy()
+        pred = jobs_y[i]["pred"]
+        for b8 in range(4):
+            cost = int(ry["coeff_cost"][i, 4 * b8:4 * b8 + 4].sum())
+            for b4 in range(4):
+                if ry["nonzero"][i, 4 * b8 + b4]:
+                    c |= 1 << b8
+                    cb |= 1 << ((2 * (b8 & 1) + (b4 & 1)) + 4 * (2 * (b8 >> 1) + (b4 >> 1)))
+            if cost <= 4:
+                cost = 0
+                c &= 63 - (1 << b8)
+                cb &= ~(51 << (4 * b8 - 2 * (b8 & 1)))
+                ys, xs = 8 * (b8 >> 1), 8 * (b8 & 1)
+                rec[ys:ys + 8, xs:xs + 8] = pred[ys:ys + 8, xs:xs + 8]
+            total += cost
+        if total <= 5:
+            c &= 0xfffff0
+            cb &= 0xff0000
+            rec = pred.copy()
+        for uv in range(2):
+            cb = (cb & ~int(rc["cbp_clear"][2 * i + uv])) | int(rc["cbp_blk"][2 * i + uv] & ~rc["cbp_clear"][2 * i + uv])
+        c += max(int(rc["ret"][2 * i]), int(rc["ret"][2 * i + 1])) << 4
+        cbp[i], cbp_blk[i] = c, cb
+        recY[mby * 16:mby * 16 + 16, mbx * 16:mbx * 16 + 16] = rec
+        recU[mby * mch:mby * mch + mch, mbx * mcw:mbx * mcw + mcw] = rc["recon"][2 * i][:mch, :mcw]
+        recV[mby * mch:mby * mch + mch, mbx * mcw:mbx * mcw + mcw] = rc["recon"][2 * i + 1][:mch, :mcw]
+    return {"luma": ry, "chroma": rc, "cbp": cbp, "cbp_blk": cbp_blk, "recon": (recY, recU, recV), "jobs_y": jobs_y, "jobs_c": jobs_c}

@@ -1,0 +1,71 @@
+"""Frame stage (MC prediction -> residual -> dct_4x4/dct_chroma -> coefficient-cost thresholds -> recon) vs a reference
+assembled from the oracle's planes and dct_* functions."""
+import numpy as np
+import pytest
+
+from tests import oracle
+from tests.test_me import lambda_factors, make_mbs
+from tests.test_tq import compare_lists
+
+
+def synth(rng, w, h, fmt):
+    yy, xx = np.mgrid[0:h + 32, 0:w + 32]
+    base = ((np.sin(xx / 6.0) * np.cos(yy / 9.0)) * 70 + 128 + rng.normal(0, 10, (h + 32, w + 32))).clip(0, 255)
+    ref = base[16:16 + h, 16:16 + w].astype(np.uint8)
+    cur = (base[13:13 + h, 21:21 + w] + rng.normal(0, 2, (h, w))).clip(0, 255).astype(np.uint8)
+    hc, wc = (h // 2, w // 2) if fmt == 1 else (h, w // 2)
+    sub = (slice(None, None, 2), slice(None, None, 2)) if fmt == 1 else (slice(None), slice(None, None, 2))
+    mk = lambda img, s: np.clip(np.round(128 + s * 0.25 * (img[sub].astype(float) - 128)), 0, 255).astype(np.uint8)[:hc, :wc]
+    return (cur, mk(cur, 1), mk(cur, -1)), (ref, mk(ref, 1), mk(ref, -1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt,qp,given_modes", [(1, 28, False), (1, 40, True), (2, 24, False), (1, 12, False)])
+def test_residual_frame(pkg, fmt, qp, given_modes):
+    rng = np.random.default_rng(qp + fmt)
+    w, h, R = 64, 48, 8
+    cur, ref = synth(rng, w, h, fmt)
+    ctx = pkg.Context(w, h, yuv_format=fmt, max_refs=1, search_range=R)
+    ctx.ref_upload(0, *ref)
+    ctx.interp_luma(0)
+    ctx.interp_chroma(0)
+    ctx.cur_upload(*cur)
+    mbs = make_mbs(pkg, rng, w // 16, h // 16, 6)
+    lam = lambda_factors(qp)
+    prm = pkg.MeParams()
+    prm.search_mode, prm.search_range, prm.rdopt = -1, R, 1
+    prm.level_mv_min, prm.level_mv_max = -511, 511
+    prm.lambda_[0], prm.lambda_[1], prm.lambda_[2] = lam
+    prm.subpel, prm.partition_mask = 1, (1 << 41) - 1
+    me = ctx.me_frame(prm, mbs)
+    qpc = qp                                            # QP_SCALE_CR is the identity below 30; larger qp: any table works for parity
+    quants = np.array([pkg.flat_quant(qp, 342, adaptive_rounding=1, adapt_rnd_weight=4, cavlc=1),
+                       pkg.flat_quant(qpc, 342, adaptive_rounding=1, adapt_rnd_weight=4, cavlc=1),
+                       pkg.flat_quant(qpc + 3, 342, adaptive_rounding=1, adapt_rnd_weight=4, cavlc=1)], dtype=pkg.QUANT_DTYPE)
+    modes = None
+    if given_modes:
+        modes = np.zeros(len(mbs), dtype=pkg.MB_MODE_DTYPE)
+        modes["mode"] = rng.choice([1, 2, 3, 8], len(mbs))
+        modes["b8mode"] = rng.integers(4, 8, (len(mbs), 4))
+    ctx.residual_frame(quants, modes)
+    got = ctx.residual_download(len(mbs))
+    recon = ctx.recon_download()
+    ctx.close()
+
+    want_modes = modes if given_modes else oracle.pick_modes(me["cost"])
+    assert np.array_equal(got["modes"]["mode"], want_modes["mode"])
+    p8 = got["modes"]["mode"] == 8
+    assert np.array_equal(got["modes"]["b8mode"][p8] if given_modes else got["modes"]["b8mode"], want_modes["b8mode"][p8] if given_modes else want_modes["b8mode"])
+    rp = oracle.RefPic(ref[0], ref[1], ref[2], yuv_format=fmt)
+    want = oracle.residual_frame(rp, cur, mbs, me["mv"], got["modes"], quants, pkg.TQ_JOB_DTYPE, yuv_format=fmt)
+    compare_lists(got["luma"]["levels"], got["luma"]["runs"], want["luma"]["levels"], want["luma"]["runs"], "luma")
+    nb = 4 if fmt == 1 else 8
+    compare_lists(got["chroma"]["levels"][:, :nb, :16], got["chroma"]["runs"][:, :nb, :16], want["chroma"]["levels"][:, :nb, :16], want["chroma"]["runs"][:, :nb, :16], "chroma AC")
+    compare_lists(got["chroma"]["dc_levels"][:, None], got["chroma"]["dc_runs"][:, None], want["chroma"]["dc_levels"][:, None], want["chroma"]["dc_runs"][:, None], "chroma DC")
+    assert np.array_equal(got["luma"]["coeff_cost"], want["luma"]["coeff_cost"])
+    assert np.array_equal(got["cbp"], want["cbp"])
+    assert np.array_equal(got["cbp_blk"], want["cbp_blk"])
+    for g, wv, name in zip(recon, want["recon"], "YUV"):
+        assert np.array_equal(g, wv), "recon %s" % name
+    # the thresholds must actually be exercised somewhere across the parametrisation
+    assert got["cbp"].max() > 0 or qp >= 40
