@@ -325,6 +325,21 @@ extern "C" int jmhip_recon_to_ref(jmhip_ctx *c, int ref)
   return JMHIP_OK;
 }
 
+extern "C" int jmhip_recon_copy_band(jmhip_ctx *c, void *Y, void *U, void *V, int mb_row0, int mb_rows)
+{
+  if (!c || !Y) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_recon_copy_band: NULL destination") : JMHIP_ERR_ARG;
+  if (!c->rec_y || c->fr_n <= 0) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_recon_copy_band: no recon picture yet");
+  if (mb_row0 < 0 || mb_rows <= 0 || mb_row0 + mb_rows > c->mbh) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_recon_copy_band: band outside the picture");
+  const size_t y0 = (size_t)mb_row0 * 16 * c->W, yn = (size_t)mb_rows * 16 * c->W;
+  JM_HIP_CHECK(c, hipMemcpyAsync(Y, c->rec_y + y0, yn, hipMemcpyDeviceToDevice, c->stream));
+  if (c->Wc && U && V) {
+    const size_t c0 = (size_t)mb_row0 * c->cg.mb_h * c->Wc, cn = (size_t)mb_rows * c->cg.mb_h * c->Wc;
+    JM_HIP_CHECK(c, hipMemcpyAsync(U, c->rec_u + c0, cn, hipMemcpyDeviceToDevice, c->stream));
+    JM_HIP_CHECK(c, hipMemcpyAsync(V, c->rec_v + c0, cn, hipMemcpyDeviceToDevice, c->stream));
+  }
+  return JMHIP_OK;
+}
+
 extern "C" int jmhip_recon_download(jmhip_ctx *c, void *Y, void *U, void *V, int pel_bytes)
 {
   if (!c || !Y) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_recon_download: NULL output") : JMHIP_ERR_ARG;

@@ -34,6 +34,8 @@ struct jmhip_ctx {
   void *stage_dev = nullptr; size_t stage_bytes = 0;
   // ME job/result arrays
   void *me_jobs_dev = nullptr; void *me_res_dev = nullptr; int me_capacity = 0; int me_n = 0;
+  int me_max_uw = 0, me_max_uh = 0, me_last_mode = 0, me_last_R = 0, me_last_rdopt = 0, me_last_lvl[2] = {0, 0};
+  unsigned long long me_last_mask = 0;
   unsigned me_ref_mask = 0;                           // reference slots used by the last ME call
   void *ref_ptrs_dev = nullptr;                       // [0..31] integer recon, [32..63] quarter-pel plane stacks
   // frame pipeline (MC -> residual -> TQ -> recon): per-MB luma job/result, 2 chroma jobs/results, recon picture

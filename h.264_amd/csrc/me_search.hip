@@ -498,7 +498,9 @@ static void host_center(const jmhip_me_params *prm, int pmx, int pmy, int *cx, i
 
 extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, const jmhip_me_mb *mbs, int n)
 {
-  if (!c || !prm || !mbs || n <= 0) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_frame: NULL/empty arguments") : JMHIP_ERR_ARG;
+  if (!c || !prm || n <= 0) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_frame: NULL/empty arguments") : JMHIP_ERR_ARG;
+  const bool resident = (mbs == nullptr);            // reuse the job array uploaded (and validated) by the previous call
+  if (resident && (n != c->me_n || !c->me_jobs_dev)) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_frame: mbs == NULL needs a previous call with the same n");
   if (prm->search_mode != JMHIP_SEARCH_FULL && prm->search_mode != JMHIP_SEARCH_FASTFULL)
     return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_me_frame: search_mode must be -1 (FullSearch) or 0 (FastFullSearch); EPZS/UMHex run on the host over jmhip_distortion_batch");
   const int R = prm->search_range;
@@ -514,9 +516,17 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
   if (rc) return rc;
 
   // validate jobs and size the LDS window from the worst spread of search centres
-  int max_uw = 0, max_uh = 0;
-  unsigned ref_mask = 0;
-  for (int i = 0; i < n; i++) {
+  int max_uw = c->me_max_uw, max_uh = c->me_max_uh;
+  unsigned ref_mask = c->me_ref_mask;
+  if (resident) {
+    if (prm->search_mode != c->me_last_mode || prm->search_range != c->me_last_R || prm->rdopt != c->me_last_rdopt ||
+        prm->partition_mask != c->me_last_mask || prm->level_mv_min != c->me_last_lvl[0] || prm->level_mv_max != c->me_last_lvl[1])
+      return jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_frame: resident jobs need the search geometry of the call that uploaded them");
+    for (size_t k = 0; k < c->refs.size(); k++)
+      if (((ref_mask >> k) & 1) && (!c->refs[k].has_pic || (prm->subpel && !c->refs[k].has_luma_sub)))
+        return jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_frame: reference slot of the resident jobs is not ready");
+  } else { max_uw = max_uh = 0; ref_mask = 0; }
+  for (int i = 0; i < n && !resident; i++) {
     const jmhip_me_mb &m = mbs[i];
     if (m.mb_x < 0 || m.mb_x >= c->mbw || m.mb_y < 0 || m.mb_y >= c->mbh) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_frame: macroblock outside the picture");
     if (m.ref < 0 || m.ref >= (int)c->refs.size() || !c->refs[m.ref].has_pic) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_frame: reference slot not uploaded");
@@ -546,8 +556,10 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
     c->me_capacity = n;
   }
   if ((rc = jm_ensure_ref_table(c))) return rc;
-  JM_HIP_CHECK(c, hipMemcpyAsync(c->me_jobs_dev, mbs, sizeof(jmhip_me_mb) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-  c->me_n = n; c->me_ref_mask = ref_mask;
+  if (!resident) JM_HIP_CHECK(c, hipMemcpyAsync(c->me_jobs_dev, mbs, sizeof(jmhip_me_mb) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  c->me_n = n; c->me_ref_mask = ref_mask; c->me_max_uw = max_uw; c->me_max_uh = max_uh;
+  c->me_last_mode = prm->search_mode; c->me_last_R = prm->search_range; c->me_last_rdopt = prm->rdopt; c->me_last_mask = prm->partition_mask;
+  c->me_last_lvl[0] = prm->level_mv_min; c->me_last_lvl[1] = prm->level_mv_max;
 
   MeDev P{};
   P.mode = prm->search_mode; P.R = R; P.rdopt = prm->rdopt; P.is_b = prm->is_b_slice;

@@ -111,6 +111,7 @@ def load_library():
     lib.jmhip_residual_download.argtypes = [vp, vp, vp, vp, vp, vp, ip]
     lib.jmhip_recon_to_ref.argtypes = [vp, ip]
     lib.jmhip_recon_download.argtypes = [vp, vp, vp, vp, ip]
+    lib.jmhip_recon_copy_band.argtypes = [vp, vp, vp, vp, ip, ip]
     lib.jmhip_sizeof.argtypes = [ip]
     for which, dt in ((0, ME_MB_DTYPE), (1, ME_RESULT_DTYPE), (2, QUANT_DTYPE), (3, TQ_JOB_DTYPE), (4, TQ_RESULT_DTYPE),
                       (5, DIST_JOB_DTYPE), (8, MB_MODE_DTYPE)):
@@ -249,7 +250,11 @@ class Context:
         self._chk(self.lib.jmhip_me_frame(self.h, C.byref(prm), _ptr(mbs), len(mbs), _ptr(res)), "jmhip_me_frame")
         return res
 
-    def me_frame_async(self, prm, mbs):
+    def me_frame_async(self, prm, mbs=None, n=None):
+        """mbs=None re-runs the device-resident jobs of the previous call (n macroblocks)."""
+        if mbs is None:
+            self._chk(self.lib.jmhip_me_frame_async(self.h, C.byref(prm), None, n), "jmhip_me_frame_async(resident)")
+            return
         mbs = np.ascontiguousarray(mbs, dtype=ME_MB_DTYPE)
         self._chk(self.lib.jmhip_me_frame_async(self.h, C.byref(prm), _ptr(mbs), len(mbs)), "jmhip_me_frame_async")
 
@@ -293,6 +298,9 @@ class Context:
 
     def recon_to_ref(self, ref):
         self._chk(self.lib.jmhip_recon_to_ref(self.h, ref), "jmhip_recon_to_ref")
+
+    def recon_copy_band(self, y_ptr, u_ptr, v_ptr, mb_row0, mb_rows):
+        self._chk(self.lib.jmhip_recon_copy_band(self.h, y_ptr, u_ptr, v_ptr, mb_row0, mb_rows), "jmhip_recon_copy_band")
 
     def recon_download(self):
         Y = np.zeros((self.H, self.W), np.uint8)

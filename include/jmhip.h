@@ -150,7 +150,8 @@ typedef struct {
 int jmhip_me_frame(jmhip_ctx *ctx, const jmhip_me_params *prm, const jmhip_me_mb *mbs, int n,
                    jmhip_me_result *results);
 
-/* Same, split for device-resident pipelines: enqueue with host job upload, leave results on device. */
+/* Same, split for device-resident pipelines: enqueue, leave results on device. mbs == NULL re-runs the job array
+ * the previous call uploaded (same n and search geometry): nothing crosses PCIe in steady state. */
 int jmhip_me_frame_async(jmhip_ctx *ctx, const jmhip_me_params *prm, const jmhip_me_mb *mbs, int n);
 int jmhip_me_results_download(jmhip_ctx *ctx, jmhip_me_result *results, int n);
 
@@ -234,7 +235,10 @@ int jmhip_residual_download(jmhip_ctx *ctx, jmhip_tq_result *luma, jmhip_tq_resu
                             int32_t *cbp, int64_t *cbp_blk, int n);
 /* Make the recon picture the integer-pel picture of reference slot `ref` (device-to-device), e.g. for the next frame. */
 int jmhip_recon_to_ref(jmhip_ctx *ctx, int ref);
-/* Copy the recon picture to the host (8-bit or 16-bit samples). */
+/* Copy the band of macroblock rows [mb_row0, mb_row0+mb_rows) of the recon picture into caller-provided DEVICE buffers
+ * (tightly packed rows): the send buffer of the per-frame all-gather of reconstructed slice bands. */
+int jmhip_recon_copy_band(jmhip_ctx *ctx, void *Y, void *U, void *V, int mb_row0, int mb_rows);
+/* Copy the recon picture to the host (8-bit samples). */
 int jmhip_recon_download(jmhip_ctx *ctx, void *Y, void *U, void *V, int pel_bytes);
 
 /* sizeof() of the ABI structs, for language bindings to verify their layout: 0 jmhip_me_mb, 1 jmhip_me_result,

@@ -45,6 +45,17 @@ static int sad_core(const jmo_dist *d, const jmo_pel *src_pic, int bsy, int bsx,
   int mcost = 0, y, x;
   const jmo_pel *src = src_pic;
   const jmo_pel *ref = luma_line(d, cand_y, cand_x);
+  if (!wp && !sse && !d->chroma_me) {                   /* the plain computeSAD loop, :364-375 */
+    for (y = 0; y < bsy; y++) {
+      for (x = 0; x < bsx; x += 4) {
+        mcost += iabs_(src[0] - ref[x]) + iabs_(src[1] - ref[x + 1]) + iabs_(src[2] - ref[x + 2]) + iabs_(src[3] - ref[x + 3]);
+        src += 4;
+      }
+      if (mcost >= min_mcost) return mcost;
+      ref += r->Wp;
+    }
+    return mcost;
+  }
   for (y = 0; y < bsy; y++) {
     for (x = 0; x < bsx; x++) {
       int rv = wp ? WP_LUMA(d, ref[x]) : ref[x];

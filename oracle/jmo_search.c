@@ -12,12 +12,28 @@ static inline int clip1(int hi, int x) { return x < 0 ? 0 : (x > hi ? hi : x); }
 static inline int imax_(int a, int b) { return a > b ? a : b; }
 
 /* mvbits, mv-search.c:333-341: mvbits[0]=1; |d| in [2^(k-1),2^k) -> 2k+1 */
-int jmo_mvbits(int d)
+static int mvbits_slow(int d)
 {
   int a = d < 0 ? -d : d, k = 0;
   if (a == 0) return 1;
   while (a) { a >>= 1; k++; }
   return 2 * k + 1;
+}
+/* JM indexes a table (mvbits[], built once in Init_Motion_Search_Module); so does the port */
+#define MVB_RANGE 8192
+static signed char mvb_tab[2 * MVB_RANGE + 1];
+static int mvb_ready = 0;
+static void mvb_init(void)
+{
+  int d;
+  for (d = -MVB_RANGE; d <= MVB_RANGE; d++) mvb_tab[d + MVB_RANGE] = (signed char)mvbits_slow(d);
+  mvb_ready = 1;
+}
+int jmo_mvbits(int d)
+{
+  if (!mvb_ready) mvb_init();
+  if (d < -MVB_RANGE || d > MVB_RANGE) return mvbits_slow(d);
+  return mvb_tab[d + MVB_RANGE];
 }
 
 /* MV_COST_SMP + WEIGHTED_COST, defines.h:125-128 */
@@ -42,6 +58,21 @@ void jmo_spiral(int search_range, short *sx, short *sy, int max_points)
       sx[k] = (short)l;  sy[k++] = (short)i;
     }
   }
+}
+
+/* spiral tables are built once per search range, like JM's Init_Motion_Search_Module (not re-entrant, like JM) */
+static short *sp_x = 0, *sp_y = 0;
+static int sp_R = -1;
+static void spiral_cached(int R, const short **sx, const short **sy)
+{
+  if (sp_R != R) {
+    int n = (2 * imax_(1, R) + 1) * (2 * imax_(1, R) + 1);
+    free(sp_x); free(sp_y);
+    sp_x = (short *)malloc(sizeof(short) * n); sp_y = (short *)malloc(sizeof(short) * n);
+    jmo_spiral(R, sp_x, sp_y, n);
+    sp_R = R;
+  }
+  *sx = sp_x; *sy = sp_y;
 }
 
 /* blc_size, configfile.c:805-841 */
@@ -102,11 +133,10 @@ int jmo_fullpel_search(const jmo_me_params *p, const jmo_ref *ref, const jmo_pel
   const int pred_x = (pic_pix_x << 2) + pred_mv_x, pred_y = (pic_pix_y << 2) + pred_mv_y;
   const int center_x = pic_pix_x + *mv_x, center_y = pic_pix_y + *mv_y;
   const int check_for_00 = (blocktype == 1 && !p->rdopt && !p->is_b_slice && ref_is_0);   /* :75 */
-  const int npts = imax_(9, max_pos);
-  short *sx = (short *)malloc(sizeof(short) * (npts + 2)), *sy = (short *)malloc(sizeof(short) * (npts + 2));
+  const short *sx, *sy;
   jmo_dist d;
   jmo_block_size(blocktype, &bsx, &bsy);
-  jmo_spiral(search_range, sx, sy, npts);
+  spiral_cached(search_range, &sx, &sy);
   dist_from_params(p, ref, &d);
   d.chroma_me = p->chroma_me ? 1 : 0;                  /* mv-search.c:612 */
   d.test8x8 = p->transform8x8_mode && blocktype <= 4;  /* mv-search.c:640 */
@@ -125,7 +155,6 @@ int jmo_fullpel_search(const jmo_me_params *p, const jmo_ref *ref, const jmo_pel
     if (mcost < min_mcost) { best_pos = pos; min_mcost = mcost; }
   }
   if (best_pos) { *mv_x += sx[best_pos]; *mv_y += sy[best_pos]; }
-  free(sx); free(sy);
   return min_mcost;
 }
 
