@@ -212,8 +212,8 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     # ---- slice of this rank: whole macroblock rows, B = ceil(MBH / world) rows per rank
-    band = -(-MBH // world)
-    row0, row1 = min(rank * band, MBH), min((rank + 1) * band, MBH)
+    from h264_amd import slices
+    row0, row1, band = slices.band_rows(MBH, world, rank)
     rows = list(range(row0, row1))
 
     nframes = 4
@@ -233,11 +233,10 @@ def main():
                        pkg.flat_quant(QP, 342, adaptive_rounding=1, adapt_rnd_weight=4, cavlc=1),
                        pkg.flat_quant(QP + 3, 342, adaptive_rounding=1, adapt_rnd_weight=4, cavlc=1)], dtype=pkg.QUANT_DTYPE)
     # gather buffers: [world * band rows] so that rank r's band lands at its picture position
-    gY = torch.zeros((world * band * 16, W), dtype=torch.uint8, device=dev)
-    gU = torch.zeros((world * band * 8, W // 2), dtype=torch.uint8, device=dev)
-    gV = torch.zeros_like(gU)
-    sY = gY[rank * band * 16:(rank + 1) * band * 16]
-    sU, sV = gU[rank * band * 8:(rank + 1) * band * 8], gV[rank * band * 8:(rank + 1) * band * 8]
+    gbufs = slices.gather_buffers(torch, world, band, W, 8, W // 2, dev)
+    gY, gU, gV = gbufs
+    sviews = slices.band_views(gbufs, rank, band, 8)
+    sY, sU, sV = sviews
 
     first = [True]
 
@@ -259,9 +258,7 @@ def main():
             if n:
                 ctx.recon_copy_band(sY.data_ptr(), sU.data_ptr(), sV.data_ptr(), row0, row1 - row0)
             ctx.sync()
-            dist.all_gather_into_tensor(gY, sY)
-            dist.all_gather_into_tensor(gU, sU)
-            dist.all_gather_into_tensor(gV, sV)
+            slices.all_gather_recon(dist, gbufs, sviews)
             torch.cuda.current_stream().synchronize()
             ctx.ref_upload_device(0, gY.data_ptr(), gU.data_ptr(), gV.data_ptr(), W, W // 2)
 

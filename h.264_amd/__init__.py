@@ -11,3 +11,4 @@ from .jmhip import (  # noqa: F401
     build_library, flat_quant, NPART, PAD, STAGES,
     ME_MB_DTYPE, ME_RESULT_DTYPE, QUANT_DTYPE, TQ_JOB_DTYPE, TQ_RESULT_DTYPE, DIST_JOB_DTYPE, MB_MODE_DTYPE,
 )
+from . import slices  # noqa: F401,E402
