@@ -36,7 +36,9 @@ struct jmhip_ctx {
   void *me_jobs_dev = nullptr; void *me_res_dev = nullptr; int me_capacity = 0; int me_n = 0;
   int me_max_uw = 0, me_max_uh = 0, me_last_mode = 0, me_last_R = 0, me_last_rdopt = 0, me_last_lvl[2] = {0, 0};
   unsigned long long me_last_mask = 0;
-  unsigned me_ref_mask = 0;                           // reference slots used by the last ME call
+  unsigned me_ref_mask = 0;
+  void *me_idx_dev = nullptr;                         // macroblock indices: fast-path list then generic list
+  std::vector<int> me_fast_idx, me_gen_idx;                           // reference slots used by the last ME call
   void *ref_ptrs_dev = nullptr;                       // [0..31] integer recon, [32..63] quarter-pel plane stacks
   // frame pipeline (MC -> residual -> TQ -> recon): per-MB luma job/result, 2 chroma jobs/results, recon picture
   void *fr_jobs_y = nullptr, *fr_jobs_c = nullptr, *fr_res_y = nullptr, *fr_res_c = nullptr, *fr_quant = nullptr, *fr_modes = nullptr;

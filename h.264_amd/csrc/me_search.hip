@@ -53,6 +53,7 @@ struct MeDev {
   unsigned long long mask;
   int W, H, Wp, Hp;
   int win_pitch, win_rows;            // LDS window geometry (bytes per row, rows)
+  int win_copy_stride;                // fast path: dwords between the byte-shifted window copies
   const uint8_t *cur;
   const uint8_t *const *ref_y;        // [slot] integer recon
   const uint8_t *const *ref_sub;      // [slot] 16 quarter-pel planes
@@ -98,7 +99,8 @@ constexpr unsigned KEY_INVALID = 0xffffffffu;
 
 // ------------------------------------------------------------------------------------------------ integer search
 
-__global__ __launch_bounds__(256) void me_int_kernel(MeDev P, const jmhip_me_mb *__restrict__ jobs, jmhip_me_result *__restrict__ res)
+__global__ __launch_bounds__(256) void me_int_kernel(MeDev P, const jmhip_me_mb *__restrict__ jobs, const int *__restrict__ job_index,
+                                                     jmhip_me_result *__restrict__ res_all)
 {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ int s_cx[JMHIP_NPART], s_cy[JMHIP_NPART], s_px[JMHIP_NPART], s_py[JMHIP_NPART];
@@ -107,7 +109,9 @@ __global__ __launch_bounds__(256) void me_int_kernel(MeDev P, const jmhip_me_mb 
   __shared__ unsigned s_red[JMHIP_NPART][4];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const jmhip_me_mb &job = jobs[blockIdx.x];
+  const int mbi = job_index[blockIdx.x];
+  const jmhip_me_mb &job = jobs[mbi];
+  jmhip_me_result *res = res_all + mbi - blockIdx.x;   // res[blockIdx.x] below addresses macroblock mbi
   const int mbx = job.mb_x, mby = job.mb_y;
   const unsigned long long mask = P.mask;
 
@@ -252,6 +256,290 @@ __global__ __launch_bounds__(256) void me_int_kernel(MeDev P, const jmhip_me_mb 
       o.mv_int[p][0] = o.mv_int[p][1] = 0; o.cost_int[p] = -1;
       o.mv[p][0] = o.mv[p][1] = 0; o.cost[p] = -1;
     }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------ integer search, fast path
+//
+// All 41 partitions share ONE search centre (always true for FastFullSearch; for FullSearch whenever the partition
+// predictors agree to the pel) and all partitions are searched. Mapping:
+//   lane  <-> candidate column (64 columns per wave-row; columns >= 64 take the per-candidate path below)
+//   wave  <-> band of candidate rows; a lane walks DOWN its column, so consecutive candidates share 15 of their 16
+//             reference rows: the window lives in a rolling 16-row register file (static indices through a 16x
+//             unrolled loop) and only one new row (4 dwords) is fetched from LDS per candidate
+//   LDS   <-> four byte-shifted copies of the window, so lanes read dword-aligned words whatever their column
+//             (copy stride = 8 mod 32 dwords: the 32 lanes of a read group hit 32 different banks)
+//   SAD   <-> v_sad_hi_u8: the 16 4x4 SADs come out already shifted by 16, so a partition key is
+//             (sad << 16) + (mvcost << 16) + tie = ONE v_add3_u32, and the running minimum ONE v_min_u32
+//   MV cost per (lane, partition) = lambda*(bits_x[lane] + bits_y[row]) >> 16 is cached in a register and only
+//             recomputed on rows where bits_y changes for that partition (a wave-uniform test against a per-row
+//             bitmask prepared in LDS): mvbits is a step function of log2|d|
+// The 16x16 partition keeps a 64-bit key (cost up to 65280 + mvcost does not fit 16 bits).
+constexpr int FAST_TIE_BITS = 16;
+
+struct FastShared {
+  int cx, cy, px[JMHIP_NPART], py[JMHIP_NPART];
+  uint32_t cur[64];
+  unsigned long long chg[160];                  // per candidate row: partitions whose vertical mv bits change vs the row above
+  uint8_t bytab[JMHIP_NPART][160];              // vertical mv bits per partition and candidate row
+  unsigned red[JMHIP_NPART][4];
+  unsigned long long red0[4];
+};
+
+__device__ __forceinline__ int spiral_base_A(int dy)   // + 2*dx gives pos when |dy| > |dx|
+{
+  const int l = iabs(dy);
+  return (2 * l - 1) * (2 * l - 1) + 2 * (l - 1) + (dy > 0 ? 1 : 0);
+}
+__device__ __forceinline__ int spiral_base_B(int dx)   // + 2*dy gives pos when |dx| >= |dy|
+{
+  const int l = iabs(dx);
+  if (l == 0) return 0;
+  return (2 * l - 1) * (2 * l - 1) + 2 * (2 * l - 1) + 2 * l + (dx > 0 ? 1 : 0);
+}
+
+__global__ __launch_bounds__(256, 2) void me_int_fast_kernel(MeDev P, const jmhip_me_mb *__restrict__ jobs, const int *__restrict__ job_index,
+                                                            jmhip_me_result *__restrict__ res)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t swin[];      // 4 shifted window copies
+  __shared__ FastShared S;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int mbi = job_index[blockIdx.x];
+  const jmhip_me_mb &job = jobs[mbi];
+  const int mbx = job.mb_x, mby = job.mb_y;
+  const int R = P.R, UW = 2 * R + 1, UH = UW;
+  const int PITCH = P.win_pitch >> 2;            // dwords per window row
+  const int CS = P.win_copy_stride;              // dwords between shifted copies (== 8 mod 32)
+  const int WROWS = UH + 15;
+
+  if (tid == 0) {
+    int cx, cy;
+    search_center(P, job.pred_mv[0][0], job.pred_mv[0][1], &cx, &cy);   // host verified: every partition yields this centre
+    S.cx = cx; S.cy = cy;
+  }
+  if (tid < JMHIP_NPART) { S.px[tid] = job.pred_mv[tid][0]; S.py[tid] = job.pred_mv[tid][1]; }
+  if (tid < 64) {
+    const int r = tid >> 2, k = tid & 3;
+    S.cur[tid] = *reinterpret_cast<const uint32_t *>(P.cur + (size_t)(mby * 16 + r) * P.W + mbx * 16 + k * 4);
+  }
+  __syncthreads();
+  const int ucx = S.cx, ucy = S.cy;
+  const int umin_x = ucx - R, umin_y = ucy - R;
+
+  // ---- window copy 0 from the integer recon (per-sample clamp), then the three byte-shifted copies from copy 0
+  {
+    const uint8_t *ref = P.ref_y[job.ref];
+    const int bx = mbx * 16 + umin_x, by = mby * 16 + umin_y;
+    for (int d = tid; d < PITCH * WROWS; d += 256) {
+      const int y = d / PITCH, xw = d - y * PITCH;
+      const uint8_t *row = ref + (size_t)clampi(by + y, 0, P.H - 1) * P.W;
+      uint32_t v = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) v |= (uint32_t)row[clampi(bx + xw * 4 + k, 0, P.W - 1)] << (8 * k);
+      swin[y * PITCH + xw] = v;
+    }
+  }
+  // vertical mv bits per partition and row, and the change masks
+  for (int e = tid; e < JMHIP_NPART * UH; e += 256) {
+    const int p = e / UH, row = e - p * UH;
+    S.bytab[p][row] = (uint8_t)mvbits(4 * (umin_y + row) - S.py[p]);
+  }
+  __syncthreads();
+  for (int d = tid; d < 3 * (PITCH - 1) * WROWS; d += 256) {
+    const int k = 1 + d / ((PITCH - 1) * WROWS), rem = d - (k - 1) * (PITCH - 1) * WROWS;
+    const int y = rem / (PITCH - 1), xw = rem - y * (PITCH - 1);
+    swin[k * CS + y * PITCH + xw] = __builtin_amdgcn_alignbyte(swin[y * PITCH + xw + 1], swin[y * PITCH + xw], (unsigned)k);
+  }
+  if (tid < UH) {
+    unsigned long long m = 0;
+    for (int p = 0; p < JMHIP_NPART; p++)
+      if (tid == 0 || S.bytab[p][tid] != S.bytab[p][tid - 1]) m |= 1ull << p;
+    S.chg[tid] = m;
+  }
+  __syncthreads();
+
+  // ---- per-lane constants
+  const int col = lane;                              // candidate column of the main grid
+  const int mvx = umin_x + col;
+  const int dx = mvx - ucx, adx = iabs(dx);
+  const int tieB = spiral_base_B(dx) + 1;            // tie = spiral index + 1 (0 is reserved for FastFull's pos_00)
+  const int twodx = 2 * dx;
+  uint32_t bxp[11];                                  // horizontal mv bits of the 41 partitions, 4 per dword
+#pragma unroll
+  for (int g = 0; g < 11; g++) {
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const int p = 4 * g + k; if (p < JMHIP_NPART) v |= (uint32_t)mvbits(4 * mvx - S.px[p]) << (8 * k); }
+    bxp[g] = v;
+  }
+  const uint32_t *lbase = swin + (col & 3) * CS + (col >> 2);
+
+  const int lam = P.lam_f;
+  const int w16 = (lam * 16) >> 16;
+  const int quirk00 = (P.mode == JMHIP_SEARCH_FULL) && !P.rdopt && !P.is_b && job.ref_is_0;
+  const int ff00 = (P.mode == JMHIP_SEARCH_FASTFULL) && !P.rdopt;
+  const bool qx = quirk00 && (4 * (mbx * 16 + mvx) == mbx * 16);       // check_for_00 column test (me_fullsearch.c:129)
+
+  unsigned best[JMHIP_NPART];                        // best[0] unused (64-bit key below)
+#pragma unroll
+  for (int p = 0; p < JMHIP_NPART; p++) best[p] = KEY_INVALID;
+  unsigned long long best0 = ~0ull;
+  unsigned mvc[JMHIP_NPART];                         // cached (mv cost << 16) per partition; mvc[0] unshifted + bias
+
+  const int r0 = (UH * wave) >> 2, r1 = (UH * (wave + 1)) >> 2, nrows = r1 - r0;
+  uint32_t win[16][4];
+#pragma unroll
+  for (int j = 0; j < 15; j++) {
+    const uint32_t *wp = lbase + (r0 + j) * PITCH;
+    win[j][0] = wp[0]; win[j][1] = wp[1]; win[j][2] = wp[2]; win[j][3] = wp[3];
+  }
+
+  for (int t0 = 0; t0 < nrows; t0 += 16) {
+#pragma unroll
+    for (int tt = 0; tt < 16; tt++) {
+      const int t = t0 + tt;
+      if (t >= nrows) break;
+      const int row = r0 + t;
+      {                                              // the one new window row of this candidate
+        const uint32_t *wp = lbase + (row + 15) * PITCH;
+        constexpr int dummy = 0; (void)dummy;
+        win[(tt + 15) & 15][0] = wp[0]; win[(tt + 15) & 15][1] = wp[1]; win[(tt + 15) & 15][2] = wp[2]; win[(tt + 15) & 15][3] = wp[3];
+      }
+      const int mvy = umin_y + row, dy = mvy - ucy;
+      // ---- refresh cached mv costs where the vertical bits changed (wave-uniform mask)
+      {
+        unsigned long long m = (t == 0) ? ((1ull << JMHIP_NPART) - 1) : S.chg[row];
+        const unsigned mlo = __builtin_amdgcn_readfirstlane((unsigned)m), mhi = __builtin_amdgcn_readfirstlane((unsigned)(m >> 32));
+        if (mlo | mhi) {
+#pragma unroll
+          for (int p = 0; p < JMHIP_NPART; p++) {
+            const bool c = p < 32 ? ((mlo >> p) & 1) : ((mhi >> (p - 32)) & 1);
+            if (c) {
+              const unsigned bits = ((bxp[p >> 2] >> (8 * (p & 3))) & 255u) + S.bytab[p][row];
+              const unsigned prod = (unsigned)lam * bits;
+              mvc[p] = p ? (prod & 0xffff0000u) : ((prod >> 16) + (unsigned)w16);
+            }
+          }
+        }
+      }
+      // ---- sixteen 4x4 SADs, pre-shifted by 16 (v_sad_hi_u8)
+      unsigned sad[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int sl = (tt + r) & 15, b = (r >> 2) * 4;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          sad[b + k] = __builtin_amdgcn_sad_hi_u8(win[sl][k], S.cur[r * 4 + k], (r & 3) ? sad[b + k] : 0u);
+      }
+      unsigned ps[JMHIP_NPART];
+#pragma unroll
+      for (int b8 = 0; b8 < 4; b8++) {
+        const int o = 8 * (b8 >> 1) + 2 * (b8 & 1);
+        const unsigned a = sad[o], b = sad[o + 1], cc = sad[o + 4], d = sad[o + 5];
+        ps[25 + 4 * b8 + 0] = a; ps[25 + 4 * b8 + 1] = b; ps[25 + 4 * b8 + 2] = cc; ps[25 + 4 * b8 + 3] = d;
+        ps[9 + 2 * b8 + 0] = a + b; ps[9 + 2 * b8 + 1] = cc + d;
+        ps[17 + 2 * b8 + 0] = a + cc; ps[17 + 2 * b8 + 1] = b + d;
+        ps[5 + b8] = a + b + cc + d;
+      }
+      ps[1] = ps[5] + ps[6]; ps[2] = ps[7] + ps[8];
+      ps[3] = ps[5] + ps[7]; ps[4] = ps[6] + ps[8];
+      // ---- tie = spiral index + 1 from the per-lane / per-row halves
+      const int ady = iabs(dy);
+      unsigned tie = (ady > adx) ? (unsigned)(spiral_base_A(dy) + 1 + twodx) : (unsigned)(tieB + 2 * dy);
+      if (ff00 && mvx == 0 && mvy == 0) tie = 0;
+#pragma unroll
+      for (int p = 1; p < JMHIP_NPART; p++) best[p] = min(best[p], ps[p] + mvc[p] + tie);
+      {
+        unsigned c0 = ((ps[1] >> 16) + (ps[2] >> 16)) + mvc[0];
+        if (qx && 4 * (mby * 16 + mvy) == mby * 16) c0 -= (unsigned)w16;
+        const unsigned long long k0 = ((unsigned long long)c0 << 32) | tie;
+        best0 = k0 < best0 ? k0 : best0;
+      }
+    }
+  }
+
+  // ---- columns beyond the 64 of the main grid: one candidate per lane, straightforward evaluation
+  {
+    const int nrest = (UW - 64) * UH;
+    // hand the extra wave-iterations to the waves with the shortest bands first
+    for (int c = tid; c < nrest; c += 256) {
+      const int ay = c / (UW - 64), ax = 64 + (c - ay * (UW - 64));
+      const int cmx = umin_x + ax, cmy = umin_y + ay;
+      unsigned sad[16];
+#pragma unroll
+      for (int b = 0; b < 16; b++) sad[b] = 0;
+      const uint32_t *wrow = swin + (ax & 3) * CS + ay * PITCH + (ax >> 2);
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const uint32_t *wp = wrow + r * PITCH;
+        const int b = (r >> 2) * 4;
+#pragma unroll
+        for (int k = 0; k < 4; k++) sad[b + k] = __builtin_amdgcn_sad_hi_u8(wp[k], S.cur[r * 4 + k], sad[b + k]);
+      }
+      unsigned ps[JMHIP_NPART];
+#pragma unroll
+      for (int b8 = 0; b8 < 4; b8++) {
+        const int o = 8 * (b8 >> 1) + 2 * (b8 & 1);
+        const unsigned a = sad[o], b = sad[o + 1], cc = sad[o + 4], d = sad[o + 5];
+        ps[25 + 4 * b8 + 0] = a; ps[25 + 4 * b8 + 1] = b; ps[25 + 4 * b8 + 2] = cc; ps[25 + 4 * b8 + 3] = d;
+        ps[9 + 2 * b8 + 0] = a + b; ps[9 + 2 * b8 + 1] = cc + d;
+        ps[17 + 2 * b8 + 0] = a + cc; ps[17 + 2 * b8 + 1] = b + d;
+        ps[5 + b8] = a + b + cc + d;
+      }
+      ps[1] = ps[5] + ps[6]; ps[2] = ps[7] + ps[8];
+      ps[3] = ps[5] + ps[7]; ps[4] = ps[6] + ps[8];
+      unsigned tie = (unsigned)spiral_pos(cmx - ucx, cmy - ucy) + 1;
+      if (ff00 && cmx == 0 && cmy == 0) tie = 0;
+#pragma unroll
+      for (int p = 1; p < JMHIP_NPART; p++) {
+        const unsigned mc = (unsigned)mv_cost(lam, 4 * cmx - S.px[p], 4 * cmy - S.py[p]) << 16;
+        best[p] = min(best[p], ps[p] + mc + tie);
+      }
+      unsigned c0 = ((ps[1] >> 16) + (ps[2] >> 16)) + (unsigned)mv_cost(lam, 4 * cmx - S.px[0], 4 * cmy - S.py[0]) + (unsigned)w16;
+      if (quirk00 && 4 * (mbx * 16 + cmx) == mbx * 16 && 4 * (mby * 16 + cmy) == mby * 16) c0 -= (unsigned)w16;
+      const unsigned long long k0 = ((unsigned long long)c0 << 32) | tie;
+      best0 = k0 < best0 ? k0 : best0;
+    }
+  }
+
+  // ---- reduce over the workgroup
+#pragma unroll
+  for (int p = 1; p < JMHIP_NPART; p++) {
+    unsigned v = best[p];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, off, 64));
+    if (lane == 0) S.red[p][wave] = v;
+  }
+  {
+    unsigned long long v = best0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, off, 64), hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), off, 64);
+      const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+      v = o < v ? o : v;
+    }
+    if (lane == 0) S.red0[wave] = v;
+  }
+  __syncthreads();
+  if (tid < JMHIP_NPART) {
+    const int p = tid;
+    jmhip_me_result &o = res[mbi];
+    int cost, tie;
+    if (p == 0) {
+      unsigned long long k = S.red0[0];
+      for (int w = 1; w < 4; w++) k = S.red0[w] < k ? S.red0[w] : k;
+      cost = (int)(unsigned)(k >> 32) - w16; tie = (int)(unsigned)k;
+    } else {
+      const unsigned k = min(min(S.red[p][0], S.red[p][1]), min(S.red[p][2], S.red[p][3]));
+      cost = (int)(k >> FAST_TIE_BITS); tie = (int)(k & 0xffffu);
+    }
+    int rx, ry;
+    if (tie == 0) { rx = 0; ry = 0; }
+    else { int ddx, ddy; spiral_offset(tie - 1, &ddx, &ddy); rx = ucx + ddx; ry = ucy + ddy; }
+    o.mv_int[p][0] = (int16_t)rx; o.mv_int[p][1] = (int16_t)ry; o.cost_int[p] = cost;
+    if (!P.subpel) { o.mv[p][0] = (int16_t)(rx << 2); o.mv[p][1] = (int16_t)(ry << 2); o.cost[p] = cost; }
   }
 }
 
@@ -525,7 +813,8 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
     for (size_t k = 0; k < c->refs.size(); k++)
       if (((ref_mask >> k) & 1) && (!c->refs[k].has_pic || (prm->subpel && !c->refs[k].has_luma_sub)))
         return jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_frame: reference slot of the resident jobs is not ready");
-  } else { max_uw = max_uh = 0; ref_mask = 0; }
+  } else { max_uw = max_uh = 0; ref_mask = 0; c->me_fast_idx.clear(); c->me_gen_idx.clear(); }
+  const bool full_mask = (prm->partition_mask & ((1ull << JMHIP_NPART) - 1)) == ((1ull << JMHIP_NPART) - 1);
   for (int i = 0; i < n && !resident; i++) {
     const jmhip_me_mb &m = mbs[i];
     if (m.mb_x < 0 || m.mb_x >= c->mbw || m.mb_y < 0 || m.mb_y >= c->mbh) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_frame: macroblock outside the picture");
@@ -540,11 +829,23 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
       x0 = cx < x0 ? cx : x0; x1 = cx > x1 ? cx : x1; y0 = cy < y0 ? cy : y0; y1 = cy > y1 ? cy : y1;
     }
     const int uw = x1 - x0 + 2 * R + 1, uh = y1 - y0 + 2 * R + 1;
-    max_uw = uw > max_uw ? uw : max_uw; max_uh = uh > max_uh ? uh : max_uh;
+    // fast path: one centre for all 41 partitions, every partition searched, at least 64 candidate columns
+    const bool fast = (x0 == x1 && y0 == y1) && full_mask && (2 * R + 1 >= 64) && (2 * R + 1 <= 160);
+    if (fast) c->me_fast_idx.push_back(i);
+    else {
+      c->me_gen_idx.push_back(i);
+      max_uw = uw > max_uw ? uw : max_uw; max_uh = uh > max_uh ? uh : max_uh;
+    }
   }
   const int pitch = ((max_uw + 15 + 3) & ~3) + 8;       // +8: the 5th dword read of the last candidate column
   const int rows = max_uh + 15;
   const size_t lds = (size_t)pitch * rows + 16;
+  // fast path window: 4 byte-shifted copies, copy stride == 8 (mod 32) dwords
+  const int fpitch_dw = ((2 * R + 1 + 15 + 3) >> 2) + 2, frows = 2 * R + 1 + 15;
+  int fcs = fpitch_dw * frows;
+  while ((fcs & 31) != 8) fcs++;
+  const size_t flds = ((size_t)3 * fcs + (size_t)fpitch_dw * frows) * 4;
+  if (!c->me_fast_idx.empty() && flds > 60 * 1024) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_me_frame: search range too large for the fast-path LDS window");
   if (lds > 60 * 1024) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_me_frame: search centres of one macroblock are too far apart for one LDS window");
 
   if (c->me_capacity < n) {
@@ -553,10 +854,20 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
     c->me_jobs_dev = c->me_res_dev = nullptr; c->me_capacity = 0;
     if (hipMalloc(&c->me_jobs_dev, sizeof(jmhip_me_mb) * (size_t)n) != hipSuccess) return jm_fail(c, JMHIP_ERR_NOMEM, "ME job array");
     if (hipMalloc(&c->me_res_dev, sizeof(jmhip_me_result) * (size_t)n) != hipSuccess) return jm_fail(c, JMHIP_ERR_NOMEM, "ME result array");
+    if (c->me_idx_dev) JM_HIP_CHECK(c, hipFree(c->me_idx_dev));
+    c->me_idx_dev = nullptr;
+    if (hipMalloc(&c->me_idx_dev, sizeof(int) * (size_t)n) != hipSuccess) return jm_fail(c, JMHIP_ERR_NOMEM, "ME index array");
     c->me_capacity = n;
   }
   if ((rc = jm_ensure_ref_table(c))) return rc;
-  if (!resident) JM_HIP_CHECK(c, hipMemcpyAsync(c->me_jobs_dev, mbs, sizeof(jmhip_me_mb) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  if (!resident) {
+    JM_HIP_CHECK(c, hipMemcpyAsync(c->me_jobs_dev, mbs, sizeof(jmhip_me_mb) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    // index lists of the two integer-search kernels: [0, nfast) fast, [nfast, n) generic
+    std::vector<int> idx(c->me_fast_idx);
+    idx.insert(idx.end(), c->me_gen_idx.begin(), c->me_gen_idx.end());
+    JM_HIP_CHECK(c, hipMemcpyAsync(c->me_idx_dev, idx.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    JM_HIP_CHECK(c, hipStreamSynchronize(c->stream));     // idx is a stack vector
+  }
   c->me_n = n; c->me_ref_mask = ref_mask; c->me_max_uw = max_uw; c->me_max_uh = max_uh;
   c->me_last_mode = prm->search_mode; c->me_last_R = prm->search_range; c->me_last_rdopt = prm->rdopt; c->me_last_mask = prm->partition_mask;
   c->me_last_lvl[0] = prm->level_mv_min; c->me_last_lvl[1] = prm->level_mv_max;
@@ -573,8 +884,15 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
   P.ref_y = reinterpret_cast<const uint8_t *const *>(c->ref_ptrs_dev);
   P.ref_sub = reinterpret_cast<const uint8_t *const *>(c->ref_ptrs_dev) + 32;
 
+  const int nfast = (int)c->me_fast_idx.size(), ngen = (int)c->me_gen_idx.size();
   jm_stage_begin(c, JMHIP_STAGE_ME_INT);
-  me_int_kernel<<<n, 256, lds, c->stream>>>(P, (const jmhip_me_mb *)c->me_jobs_dev, (jmhip_me_result *)c->me_res_dev);
+  if (nfast) {
+    MeDev PF = P;
+    PF.win_pitch = fpitch_dw * 4; PF.win_rows = frows; PF.win_copy_stride = fcs;
+    me_int_fast_kernel<<<nfast, 256, flds, c->stream>>>(PF, (const jmhip_me_mb *)c->me_jobs_dev, (const int *)c->me_idx_dev, (jmhip_me_result *)c->me_res_dev);
+  }
+  if (ngen)
+    me_int_kernel<<<ngen, 256, lds, c->stream>>>(P, (const jmhip_me_mb *)c->me_jobs_dev, (const int *)c->me_idx_dev + nfast, (jmhip_me_result *)c->me_res_dev);
   jm_stage_end(c, JMHIP_STAGE_ME_INT);
   JM_HIP_CHECK(c, hipGetLastError());
   if (P.subpel) {

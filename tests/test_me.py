@@ -90,6 +90,52 @@ def test_me_frame_qcif_range32(pkg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind,mode,rdopt,per_partition,spread", [
+    ("shift", 0, 1, True, 8),        # FastFullSearch: one centre per MB -> fast kernel
+    ("shift", 0, 0, True, 8),        # + pos_00 pre-check
+    ("shift", -1, 1, False, 8),      # FullSearch with one predictor per MB -> fast kernel
+    ("shift", -1, 0, False, 8),      # + check_for_00 / check_position0
+    ("flat", 0, 0, True, 4),         # every candidate ties: tie-break through the fast kernel's A/B spiral halves
+    ("flat", -1, 0, False, 4),
+    ("noise", 0, 1, True, 200),      # centre clipped by the +-2047 / level limits, windows far outside the picture
+    ("noise", -1, 0, False, 100),
+])
+def test_me_fast_kernel_range32(pkg, kind, mode, rdopt, per_partition, spread):
+    run_case(pkg, 96, 64, kind, mode, 32, rdopt, spread, per_partition=per_partition, seed=spread + mode * 3 + rdopt)
+
+
+@pytest.mark.gpu
+def test_me_mixed_fast_and_generic_macroblocks(pkg):
+    """FullSearch where some MBs have one predictor (fast kernel) and others per-partition predictors (generic)."""
+    rng = np.random.default_rng(5)
+    w, h, R = 96, 64, 32
+    cur, ref = make_pair(rng, w, h, "shift")
+    ctx = pkg.Context(w, h, yuv_format=0, max_refs=1, search_range=R)
+    ctx.ref_upload(0, ref)
+    ctx.interp_luma(0)
+    ctx.cur_upload(cur)
+    mbs = make_mbs(pkg, rng, w // 16, h // 16, 8, True)
+    for i in range(0, len(mbs), 2):
+        mbs[i]["pred_mv"][:] = mbs[i]["pred_mv"][0]
+    lam = lambda_factors(28)
+    prm = pkg.MeParams()
+    prm.search_mode, prm.search_range, prm.rdopt = -1, R, 1
+    prm.level_mv_min, prm.level_mv_max = -511, 511
+    prm.lambda_[0], prm.lambda_[1], prm.lambda_[2] = lam
+    prm.subpel, prm.partition_mask = 1, (1 << 41) - 1
+    got = ctx.me_frame(prm, mbs)
+    got2 = None
+    ctx.me_frame_async(prm, None, len(mbs))          # resident re-run must give the same answer
+    got2 = ctx.me_results(len(mbs))
+    ctx.close()
+    p = oracle.me_params(rdopt=1)
+    want = oracle.me_frame(p, [oracle.RefPic(ref, yuv_format=0)], cur, mbs, -1, R, lam)
+    for key in ("mv_int", "cost_int", "mv", "cost"):
+        assert np.array_equal(got[key], want[key]), key
+        assert np.array_equal(got2[key], want[key]), key + " (resident)"
+
+
+@pytest.mark.gpu
 def test_me_integer_only_and_partition_mask(pkg):
     run_case(pkg, 64, 48, "shift", -1, 8, 1, 8, subpel=0, seed=11)
     run_case(pkg, 64, 48, "shift", -1, 8, 1, 8, mask=0b11111, seed=12)          # 16x16, 16x8, 8x16 only
