@@ -26,6 +26,7 @@
 // me_fullfast.c:210), keeps 41 running minima in registers, and a wavefront shuffle + LDS reduction finishes.
 // Roofline: ~10^3 integer ops per byte of compulsory traffic -> VALU/LDS bound, not HBM bound.
 #include "jmhip_internal.h"
+#include <type_traits>
 
 namespace {
 
@@ -54,6 +55,7 @@ struct MeDev {
   int W, H, Wp, Hp;
   int win_pitch, win_rows;            // LDS window geometry (bytes per row, rows)
   int win_copy_stride;                // fast path: dwords between the byte-shifted window copies
+  unsigned long long *stamps;         // diagnostic build (-DJMHIP_STAMPS) only: per-wave section clocks
   const uint8_t *cur;
   const uint8_t *const *ref_y;        // [slot] integer recon
   const uint8_t *const *ref_sub;      // [slot] 16 quarter-pel planes
@@ -278,13 +280,62 @@ __global__ __launch_bounds__(256) void me_int_kernel(MeDev P, const jmhip_me_mb 
 // The 16x16 partition keeps a 64-bit key (cost up to 65280 + mvcost does not fit 16 bits).
 constexpr int FAST_TIE_BITS = 16;
 
+#ifdef JMHIP_STAMPS
+#define STAMP(k) do { if (P.stamps && blockIdx.x < 512 && lane == 0) P.stamps[(blockIdx.x * 4 + wave) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
+// min over the 64 lanes of a wave without touching LDS: xor-butterfly inside each row of 16 lanes with DPP
+// (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror), then the four row results through v_readlane
+__device__ __forceinline__ unsigned row16_min_u32(unsigned v)
+{
+  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false));
+  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false));
+  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xf, 0xf, false));
+  v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xf, 0xf, false));
+  return v;
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+  v = row16_min_u32(v);
+  const unsigned a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+  const unsigned c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+  return min(min(a, b), min(c, d));
+}
+__device__ __forceinline__ unsigned long long min_u64(unsigned long long a, unsigned long long b) { return b < a ? b : a; }
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v, int ctrl_sel)
+{
+  unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+  switch (ctrl_sel) {
+  case 0: lo = __builtin_amdgcn_update_dpp((int)lo, (int)lo, 0xB1, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp((int)hi, (int)hi, 0xB1, 0xf, 0xf, false); break;
+  case 1: lo = __builtin_amdgcn_update_dpp((int)lo, (int)lo, 0x4E, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp((int)hi, (int)hi, 0x4E, 0xf, 0xf, false); break;
+  case 2: lo = __builtin_amdgcn_update_dpp((int)lo, (int)lo, 0x141, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp((int)hi, (int)hi, 0x141, 0xf, 0xf, false); break;
+  default: lo = __builtin_amdgcn_update_dpp((int)lo, (int)lo, 0x140, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp((int)hi, (int)hi, 0x140, 0xf, 0xf, false); break;
+  }
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
+{
+#pragma unroll
+  for (int k = 0; k < 4; k++) v = min_u64(v, dpp_u64(v, k));
+  unsigned long long r = ~0ull;
+#pragma unroll
+  for (int l = 0; l < 64; l += 16) {
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, l), hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), l);
+    r = min_u64(r, ((unsigned long long)hi << 32) | lo);
+  }
+  return r;
+}
+
 struct FastShared {
   int cx, cy, px[JMHIP_NPART], py[JMHIP_NPART];
   uint32_t cur[64];
-  unsigned long long chg[160];                  // per candidate row: partitions whose vertical mv bits change vs the row above
-  uint8_t bytab[JMHIP_NPART][160];              // vertical mv bits per partition and candidate row
-  unsigned red[JMHIP_NPART][4];
-  unsigned long long red0[4];
+  unsigned chg[160];                            // per candidate row: does any partition's vertical mv bits differ from the row above
+  uint8_t bytab[160][48] __attribute__((aligned(16)));   // vertical mv bits per candidate row and partition (48: three 16-byte reads)
+  uint8_t bxtab[64][44];                        // horizontal mv bits per main-grid column and partition (44: dword rows)
+  unsigned redk[JMHIP_NPART];                   // workgroup minima (LDS atomic min)
+  unsigned long long red0k;
 };
 
 __device__ __forceinline__ int spiral_base_A(int dy)   // + 2*dx gives pos when |dy| > |dx|
@@ -306,6 +357,7 @@ __global__ __launch_bounds__(256, 2) void me_int_fast_kernel(MeDev P, const jmhi
   __shared__ FastShared S;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  STAMP(0);
   const int mbi = job_index[blockIdx.x];
   const jmhip_me_mb &job = jobs[mbi];
   const int mbx = job.mb_x, mby = job.mb_y;
@@ -328,38 +380,76 @@ __global__ __launch_bounds__(256, 2) void me_int_fast_kernel(MeDev P, const jmhi
   const int ucx = S.cx, ucy = S.cy;
   const int umin_x = ucx - R, umin_y = ucy - R;
 
-  // ---- window copy 0 from the integer recon (per-sample clamp), then the three byte-shifted copies from copy 0
+  // ---- window copy 0 from the integer recon (per-sample clamp), then the three byte-shifted copies from copy 0.
+  //      Lane slots are (row = tid/32 + 8*i, dword column = tid%32): no runtime divisions.
   {
     const uint8_t *ref = P.ref_y[job.ref];
     const int bx = mbx * 16 + umin_x, by = mby * 16 + umin_y;
-    for (int d = tid; d < PITCH * WROWS; d += 256) {
-      const int y = d / PITCH, xw = d - y * PITCH;
-      const uint8_t *row = ref + (size_t)clampi(by + y, 0, P.H - 1) * P.W;
-      uint32_t v = 0;
+    const int xw = tid & 31, y0 = tid >> 5;
+    const bool inside = bx >= 4 && bx + PITCH * 4 + 4 <= P.W;     // no horizontal clamping anywhere in the window
+    constexpr int NB = 12;                                         // row slots per lane: 8 * 12 = 96 >= window rows (R <= 40)
+    if (xw < PITCH) {
+      uint32_t lo[NB], hi[NB];
+      if (inside) {
+        const unsigned sh = (unsigned)(bx & 3);
 #pragma unroll
-      for (int k = 0; k < 4; k++) v |= (uint32_t)row[clampi(bx + xw * 4 + k, 0, P.W - 1)] << (8 * k);
-      swin[y * PITCH + xw] = v;
+        for (int u = 0; u < NB; u++) {
+          const int y = min(y0 + 8 * u, WROWS - 1);
+          const uintptr_t a = reinterpret_cast<uintptr_t>(ref + (size_t)clampi(by + y, 0, P.H - 1) * P.W + bx + xw * 4);
+          const uint32_t *q = reinterpret_cast<const uint32_t *>(a & ~uintptr_t(3));
+          lo[u] = q[0]; hi[u] = q[1];
+        }
+#pragma unroll
+        for (int u = 0; u < NB; u++)
+          if (y0 + 8 * u < WROWS) swin[(y0 + 8 * u) * PITCH + xw] = __builtin_amdgcn_alignbyte(hi[u], lo[u], sh);
+      } else {
+#pragma unroll
+        for (int u = 0; u < NB; u++)
+          if (y0 + 8 * u < WROWS) {
+            const uint8_t *row = ref + (size_t)clampi(by + y0 + 8 * u, 0, P.H - 1) * P.W;
+            uint32_t v = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) v |= (uint32_t)row[clampi(bx + xw * 4 + k, 0, P.W - 1)] << (8 * k);
+            swin[(y0 + 8 * u) * PITCH + xw] = v;
+          }
+      }
     }
   }
-  // vertical mv bits per partition and row, and the change masks
-  for (int e = tid; e < JMHIP_NPART * UH; e += 256) {
-    const int p = e / UH, row = e - p * UH;
-    S.bytab[p][row] = (uint8_t)mvbits(4 * (umin_y + row) - S.py[p]);
+  // mv bits tables: vertical [row][partition], horizontal [column][partition]; lane slots (index = tid/64 + 4*i, partition = tid%64)
+  {
+    const int p = tid & 63, i0 = tid >> 6;
+    if (p < 44) {
+      const int py = p < JMHIP_NPART ? S.py[p] : 0, px = p < JMHIP_NPART ? S.px[p] : 0;
+      for (int row = i0; row < UH; row += 4) S.bytab[row][p] = p < JMHIP_NPART ? (uint8_t)mvbits(4 * (umin_y + row) - py) : 0;
+#pragma unroll
+      for (int c = i0; c < 64; c += 4) S.bxtab[c][p] = p < JMHIP_NPART ? (uint8_t)mvbits(4 * (umin_x + c) - px) : 0;
+    }
   }
   __syncthreads();
-  for (int d = tid; d < 3 * (PITCH - 1) * WROWS; d += 256) {
-    const int k = 1 + d / ((PITCH - 1) * WROWS), rem = d - (k - 1) * (PITCH - 1) * WROWS;
-    const int y = rem / (PITCH - 1), xw = rem - y * (PITCH - 1);
-    swin[k * CS + y * PITCH + xw] = __builtin_amdgcn_alignbyte(swin[y * PITCH + xw + 1], swin[y * PITCH + xw], (unsigned)k);
+  {
+    const int xw = tid & 31, y0 = tid >> 5;
+    if (xw < PITCH - 1)
+      for (int y = y0; y < WROWS; y += 8) {
+        const uint32_t a = swin[y * PITCH + xw], b = swin[y * PITCH + xw + 1];
+        swin[1 * CS + y * PITCH + xw] = __builtin_amdgcn_alignbyte(b, a, 1u);
+        swin[2 * CS + y * PITCH + xw] = __builtin_amdgcn_alignbyte(b, a, 2u);
+        swin[3 * CS + y * PITCH + xw] = __builtin_amdgcn_alignbyte(b, a, 3u);
+      }
   }
   if (tid < UH) {
-    unsigned long long m = 0;
-    for (int p = 0; p < JMHIP_NPART; p++)
-      if (tid == 0 || S.bytab[p][tid] != S.bytab[p][tid - 1]) m |= 1ull << p;
+    unsigned m = (tid == 0);
+    if (tid) {
+      const uint32_t *a = reinterpret_cast<const uint32_t *>(S.bytab[tid]), *b = reinterpret_cast<const uint32_t *>(S.bytab[tid - 1]);
+#pragma unroll
+      for (int g = 0; g < 11; g++) m |= (a[g] != b[g]);
+    }
     S.chg[tid] = m;
   }
+  if (tid < JMHIP_NPART) S.redk[tid] = KEY_INVALID;
+  if (tid == 0) S.red0k = ~0ull;
   __syncthreads();
 
+  STAMP(1);
   // ---- per-lane constants
   const int col = lane;                              // candidate column of the main grid
   const int mvx = umin_x + col;
@@ -368,12 +458,7 @@ __global__ __launch_bounds__(256, 2) void me_int_fast_kernel(MeDev P, const jmhi
   const int twodx = 2 * dx;
   uint32_t bxp[11];                                  // horizontal mv bits of the 41 partitions, 4 per dword
 #pragma unroll
-  for (int g = 0; g < 11; g++) {
-    uint32_t v = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) { const int p = 4 * g + k; if (p < JMHIP_NPART) v |= (uint32_t)mvbits(4 * mvx - S.px[p]) << (8 * k); }
-    bxp[g] = v;
-  }
+  for (int g = 0; g < 11; g++) bxp[g] = reinterpret_cast<const uint32_t *>(S.bxtab[col])[g];
   const uint32_t *lbase = swin + (col & 3) * CS + (col >> 2);
 
   const int lam = P.lam_f;
@@ -396,70 +481,96 @@ __global__ __launch_bounds__(256, 2) void me_int_fast_kernel(MeDev P, const jmhi
     win[j][0] = wp[0]; win[j][1] = wp[1]; win[j][2] = wp[2]; win[j][3] = wp[3];
   }
 
-  for (int t0 = 0; t0 < nrows; t0 += 16) {
+  // cur MB in scalar registers: v_sad_hi_u8 takes an SGPR operand
+  uint32_t curs[64];
 #pragma unroll
-    for (int tt = 0; tt < 16; tt++) {
-      const int t = t0 + tt;
-      if (t >= nrows) break;
-      const int row = r0 + t;
-      {                                              // the one new window row of this candidate
-        const uint32_t *wp = lbase + (row + 15) * PITCH;
-        constexpr int dummy = 0; (void)dummy;
-        win[(tt + 15) & 15][0] = wp[0]; win[(tt + 15) & 15][1] = wp[1]; win[(tt + 15) & 15][2] = wp[2]; win[(tt + 15) & 15][3] = wp[3];
-      }
-      const int mvy = umin_y + row, dy = mvy - ucy;
-      // ---- refresh cached mv costs where the vertical bits changed (wave-uniform mask)
-      {
-        unsigned long long m = (t == 0) ? ((1ull << JMHIP_NPART) - 1) : S.chg[row];
-        const unsigned mlo = __builtin_amdgcn_readfirstlane((unsigned)m), mhi = __builtin_amdgcn_readfirstlane((unsigned)(m >> 32));
-        if (mlo | mhi) {
+  for (int i = 0; i < 64; i++) curs[i] = __builtin_amdgcn_readfirstlane(S.cur[i]);
+
+  unsigned mnext = 0;
+  // one candidate (window row offset TT inside the current 16-row chunk): TT is a compile-time constant so that the
+  // rolling window slots (TT + r) & 15 are static register names
+  auto step = [&](auto ttc, int t0) __attribute__((always_inline)) {
+    constexpr int tt = decltype(ttc)::value;
+    const int t = t0 + tt;
+    if (t >= nrows) return;
+    const int row = r0 + t;
+    {                                                // the one new window row of this candidate
+      const uint32_t *wp = lbase + (row + 15) * PITCH;
+      constexpr int sl = (tt + 15) & 15;
+      win[sl][0] = wp[0]; win[sl][1] = wp[1]; win[sl][2] = wp[2]; win[sl][3] = wp[3];
+    }
+    const int mvy = umin_y + row, dy = mvy - ucy;
+    // ---- refresh the cached mv costs on rows where some partition's vertical bits change (wave-uniform test,
+    //      flag fetched one step ahead): packed-byte add of the horizontal and vertical bits of 4 partitions at a time
+    {
+      const unsigned m = (t == 0) ? 1u : mnext;
+      mnext = S.chg[min(row + 1, UH - 1)];
+      if (__builtin_amdgcn_readfirstlane(m)) {
+        const uint4 *bt = reinterpret_cast<const uint4 *>(S.bytab[row]);
+        const uint4 b0 = bt[0], b1 = bt[1], b2 = bt[2];
+        const uint32_t byp[11] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z};
 #pragma unroll
-          for (int p = 0; p < JMHIP_NPART; p++) {
-            const bool c = p < 32 ? ((mlo >> p) & 1) : ((mhi >> (p - 32)) & 1);
-            if (c) {
-              const unsigned bits = ((bxp[p >> 2] >> (8 * (p & 3))) & 255u) + S.bytab[p][row];
-              const unsigned prod = (unsigned)lam * bits;
+        for (int g = 0; g < 11; g++) {
+          const uint32_t sum4 = bxp[g] + byp[g];             // no carries: bits <= 2*25
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int p = 4 * g + k;
+            if (p < JMHIP_NPART) {
+              const unsigned prod = __umul24((unsigned)lam, (sum4 >> (8 * k)) & 255u);
               mvc[p] = p ? (prod & 0xffff0000u) : ((prod >> 16) + (unsigned)w16);
             }
           }
         }
       }
-      // ---- sixteen 4x4 SADs, pre-shifted by 16 (v_sad_hi_u8)
-      unsigned sad[16];
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int sl = (tt + r) & 15, b = (r >> 2) * 4;
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-          sad[b + k] = __builtin_amdgcn_sad_hi_u8(win[sl][k], S.cur[r * 4 + k], (r & 3) ? sad[b + k] : 0u);
-      }
-      unsigned ps[JMHIP_NPART];
-#pragma unroll
-      for (int b8 = 0; b8 < 4; b8++) {
-        const int o = 8 * (b8 >> 1) + 2 * (b8 & 1);
-        const unsigned a = sad[o], b = sad[o + 1], cc = sad[o + 4], d = sad[o + 5];
-        ps[25 + 4 * b8 + 0] = a; ps[25 + 4 * b8 + 1] = b; ps[25 + 4 * b8 + 2] = cc; ps[25 + 4 * b8 + 3] = d;
-        ps[9 + 2 * b8 + 0] = a + b; ps[9 + 2 * b8 + 1] = cc + d;
-        ps[17 + 2 * b8 + 0] = a + cc; ps[17 + 2 * b8 + 1] = b + d;
-        ps[5 + b8] = a + b + cc + d;
-      }
-      ps[1] = ps[5] + ps[6]; ps[2] = ps[7] + ps[8];
-      ps[3] = ps[5] + ps[7]; ps[4] = ps[6] + ps[8];
-      // ---- tie = spiral index + 1 from the per-lane / per-row halves
-      const int ady = iabs(dy);
-      unsigned tie = (ady > adx) ? (unsigned)(spiral_base_A(dy) + 1 + twodx) : (unsigned)(tieB + 2 * dy);
-      if (ff00 && mvx == 0 && mvy == 0) tie = 0;
-#pragma unroll
-      for (int p = 1; p < JMHIP_NPART; p++) best[p] = min(best[p], ps[p] + mvc[p] + tie);
-      {
-        unsigned c0 = ((ps[1] >> 16) + (ps[2] >> 16)) + mvc[0];
-        if (qx && 4 * (mby * 16 + mvy) == mby * 16) c0 -= (unsigned)w16;
-        const unsigned long long k0 = ((unsigned long long)c0 << 32) | tie;
-        best0 = k0 < best0 ? k0 : best0;
-      }
     }
+    // ---- sixteen 4x4 SADs, pre-shifted by 16 (v_sad_hi_u8)
+    unsigned sad[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      constexpr int dummy = 0; (void)dummy;
+      const int sl = (tt + r) & 15, b = (r >> 2) * 4;
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        sad[b + k] = __builtin_amdgcn_sad_hi_u8(win[sl][k], curs[r * 4 + k], (r & 3) ? sad[b + k] : 0u);
+    }
+    unsigned ps[JMHIP_NPART];
+#pragma unroll
+    for (int b8 = 0; b8 < 4; b8++) {
+      const int o = 8 * (b8 >> 1) + 2 * (b8 & 1);
+      const unsigned a = sad[o], b = sad[o + 1], cc = sad[o + 4], d = sad[o + 5];
+      ps[25 + 4 * b8 + 0] = a; ps[25 + 4 * b8 + 1] = b; ps[25 + 4 * b8 + 2] = cc; ps[25 + 4 * b8 + 3] = d;
+      ps[9 + 2 * b8 + 0] = a + b; ps[9 + 2 * b8 + 1] = cc + d;
+      ps[17 + 2 * b8 + 0] = a + cc; ps[17 + 2 * b8 + 1] = b + d;
+      ps[5 + b8] = a + b + cc + d;
+    }
+    ps[1] = ps[5] + ps[6]; ps[2] = ps[7] + ps[8];
+    ps[3] = ps[5] + ps[7]; ps[4] = ps[6] + ps[8];
+    // ---- tie = spiral index + 1 from the per-lane / per-row halves
+    const int ady = iabs(dy);
+    unsigned tie = (ady > adx) ? (unsigned)(spiral_base_A(dy) + 1 + twodx) : (unsigned)(tieB + 2 * dy);
+    if (ff00 && mvx == 0 && mvy == 0) tie = 0;
+#pragma unroll
+    for (int p = 1; p < JMHIP_NPART; p++) best[p] = min(best[p], ps[p] + mvc[p] + tie);
+    {
+      unsigned c0 = ((ps[1] >> 16) + (ps[2] >> 16)) + mvc[0];
+      if (qx && 4 * (mby * 16 + mvy) == mby * 16) c0 -= (unsigned)w16;
+      const unsigned long long k0 = ((unsigned long long)c0 << 32) | tie;
+      best0 = k0 < best0 ? k0 : best0;
+    }
+  };
+  STAMP(2);
+  for (int t0 = 0; t0 < nrows; t0 += 16) {
+    step(std::integral_constant<int, 0>{}, t0);  step(std::integral_constant<int, 1>{}, t0);
+    step(std::integral_constant<int, 2>{}, t0);  step(std::integral_constant<int, 3>{}, t0);
+    step(std::integral_constant<int, 4>{}, t0);  step(std::integral_constant<int, 5>{}, t0);
+    step(std::integral_constant<int, 6>{}, t0);  step(std::integral_constant<int, 7>{}, t0);
+    step(std::integral_constant<int, 8>{}, t0);  step(std::integral_constant<int, 9>{}, t0);
+    step(std::integral_constant<int, 10>{}, t0); step(std::integral_constant<int, 11>{}, t0);
+    step(std::integral_constant<int, 12>{}, t0); step(std::integral_constant<int, 13>{}, t0);
+    step(std::integral_constant<int, 14>{}, t0); step(std::integral_constant<int, 15>{}, t0);
   }
 
+  STAMP(3);
   // ---- columns beyond the 64 of the main grid: one candidate per lane, straightforward evaluation
   {
     const int nrest = (UW - 64) * UH;
@@ -476,7 +587,7 @@ __global__ __launch_bounds__(256, 2) void me_int_fast_kernel(MeDev P, const jmhi
         const uint32_t *wp = wrow + r * PITCH;
         const int b = (r >> 2) * 4;
 #pragma unroll
-        for (int k = 0; k < 4; k++) sad[b + k] = __builtin_amdgcn_sad_hi_u8(wp[k], S.cur[r * 4 + k], sad[b + k]);
+        for (int k = 0; k < 4; k++) sad[b + k] = __builtin_amdgcn_sad_hi_u8(wp[k], curs[r * 4 + k], sad[b + k]);
       }
       unsigned ps[JMHIP_NPART];
 #pragma unroll
@@ -504,35 +615,31 @@ __global__ __launch_bounds__(256, 2) void me_int_fast_kernel(MeDev P, const jmhi
     }
   }
 
-  // ---- reduce over the workgroup
-#pragma unroll
-  for (int p = 1; p < JMHIP_NPART; p++) {
-    unsigned v = best[p];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, off, 64));
-    if (lane == 0) S.red[p][wave] = v;
-  }
+  STAMP(4);
+  // ---- reduce over the workgroup: DPP butterfly inside each row of 16 lanes, then one LDS atomic min per row
   {
+    const bool lead = (lane & 15) == 0;
+#pragma unroll
+    for (int p = 1; p < JMHIP_NPART; p++) {
+      const unsigned v = row16_min_u32(best[p]);
+      if (lead) atomicMin(&S.redk[p], v);
+    }
     unsigned long long v = best0;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, off, 64), hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), off, 64);
-      const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-      v = o < v ? o : v;
-    }
-    if (lane == 0) S.red0[wave] = v;
+    for (int k = 0; k < 4; k++) v = min_u64(v, dpp_u64(v, k));
+    if (lead) atomicMin(&S.red0k, v);
   }
+  STAMP(5);
   __syncthreads();
   if (tid < JMHIP_NPART) {
     const int p = tid;
     jmhip_me_result &o = res[mbi];
     int cost, tie;
     if (p == 0) {
-      unsigned long long k = S.red0[0];
-      for (int w = 1; w < 4; w++) k = S.red0[w] < k ? S.red0[w] : k;
+      const unsigned long long k = S.red0k;
       cost = (int)(unsigned)(k >> 32) - w16; tie = (int)(unsigned)k;
     } else {
-      const unsigned k = min(min(S.red[p][0], S.red[p][1]), min(S.red[p][2], S.red[p][3]));
+      const unsigned k = S.redk[p];
       cost = (int)(k >> FAST_TIE_BITS); tie = (int)(k & 0xffffu);
     }
     int rx, ry;
@@ -541,6 +648,7 @@ __global__ __launch_bounds__(256, 2) void me_int_fast_kernel(MeDev P, const jmhi
     o.mv_int[p][0] = (int16_t)rx; o.mv_int[p][1] = (int16_t)ry; o.cost_int[p] = cost;
     if (!P.subpel) { o.mv[p][0] = (int16_t)(rx << 2); o.mv[p][1] = (int16_t)(ry << 2); o.cost[p] = cost; }
   }
+  STAMP(6);
 }
 
 // ------------------------------------------------------------------------------------------------ sub-pel search
@@ -830,7 +938,7 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
     }
     const int uw = x1 - x0 + 2 * R + 1, uh = y1 - y0 + 2 * R + 1;
     // fast path: one centre for all 41 partitions, every partition searched, at least 64 candidate columns
-    const bool fast = (x0 == x1 && y0 == y1) && full_mask && (2 * R + 1 >= 64) && (2 * R + 1 <= 160);
+    const bool fast = (x0 == x1 && y0 == y1) && full_mask && (2 * R + 1 >= 64) && (2 * R + 1 + 15 <= 96);
     if (fast) c->me_fast_idx.push_back(i);
     else {
       c->me_gen_idx.push_back(i);
@@ -885,6 +993,12 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
   P.ref_sub = reinterpret_cast<const uint8_t *const *>(c->ref_ptrs_dev) + 32;
 
   const int nfast = (int)c->me_fast_idx.size(), ngen = (int)c->me_gen_idx.size();
+#ifdef JMHIP_STAMPS
+  static unsigned long long *stamps_dev = nullptr;
+  if (!stamps_dev) { (void)hipMalloc((void **)&stamps_dev, 512 * 4 * 8 * 8); }
+  (void)hipMemsetAsync(stamps_dev, 0, 512 * 4 * 8 * 8, c->stream);
+  P.stamps = stamps_dev;
+#endif
   jm_stage_begin(c, JMHIP_STAGE_ME_INT);
   if (nfast) {
     MeDev PF = P;
@@ -895,6 +1009,21 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
     me_int_kernel<<<ngen, 256, lds, c->stream>>>(P, (const jmhip_me_mb *)c->me_jobs_dev, (const int *)c->me_idx_dev + nfast, (jmhip_me_result *)c->me_res_dev);
   jm_stage_end(c, JMHIP_STAGE_ME_INT);
   JM_HIP_CHECK(c, hipGetLastError());
+#ifdef JMHIP_STAMPS
+  {
+    static int shots = 0;
+    if (++shots == 3) {
+      std::vector<unsigned long long> h(512 * 4 * 8);
+      (void)hipStreamSynchronize(c->stream);
+      (void)hipMemcpy(h.data(), stamps_dev, h.size() * 8, hipMemcpyDeviceToHost);
+      double acc[4][7] = {{0}};
+      int cnt = 0;
+      for (int b = 0; b < 512 && b < nfast; b++) { cnt++; for (int w = 0; w < 4; w++) for (int k = 1; k < 7; k++) acc[w][k] += (double)(h[(b * 4 + w) * 8 + k] - h[(b * 4 + w) * 8 + k - 1]); }
+      const char *names[7] = {"", "setup", "lane-const", "main", "rest", "reduce", "final"};
+      for (int w = 0; w < 4; w++) { fprintf(stderr, "STAMPS wave %d:", w); for (int k = 1; k < 7; k++) fprintf(stderr, " %s=%.0f", names[k], acc[w][k] / cnt); fprintf(stderr, "\n"); }
+    }
+  }
+#endif
   if (P.subpel) {
     jm_stage_begin(c, JMHIP_STAGE_ME_SUB);
     me_sub_kernel<<<n, 256, 0, c->stream>>>(P, (const jmhip_me_mb *)c->me_jobs_dev, (jmhip_me_result *)c->me_res_dev);
