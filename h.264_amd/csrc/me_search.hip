@@ -334,8 +334,8 @@ struct FastShared {
   unsigned chg[160];                            // per candidate row: does any partition's vertical mv bits differ from the row above
   uint8_t bytab[160][48] __attribute__((aligned(16)));   // vertical mv bits per candidate row and partition (48: three 16-byte reads)
   uint8_t bxtab[64][44];                        // horizontal mv bits per main-grid column and partition (44: dword rows)
-  unsigned redk[JMHIP_NPART];                   // workgroup minima (LDS atomic min)
-  unsigned long long red0k;
+  unsigned part[JMHIP_NPART][4];                // partial minima of the final reduction
+  unsigned long long part0[4];
 };
 
 __device__ __forceinline__ int spiral_base_A(int dy)   // + 2*dx gives pos when |dy| > |dx|
@@ -445,8 +445,6 @@ __global__ __launch_bounds__(256, 2) void me_int_fast_kernel(MeDev P, const jmhi
     }
     S.chg[tid] = m;
   }
-  if (tid < JMHIP_NPART) S.redk[tid] = KEY_INVALID;
-  if (tid == 0) S.red0k = ~0ull;
   __syncthreads();
 
   STAMP(1);
@@ -616,18 +614,37 @@ __global__ __launch_bounds__(256, 2) void me_int_fast_kernel(MeDev P, const jmhi
   }
 
   STAMP(4);
-  // ---- reduce over the workgroup: DPP butterfly inside each row of 16 lanes, then one LDS atomic min per row
+  // ---- reduce over the workgroup through an LDS transpose (the window is dead by now): every lane stores its 41 keys
+  //      as red[p][tid] (+ the low half of the 64-bit 16x16 key as row 41); then (partition, quarter) slots of 64 keys
+  //      are reduced with 16-byte reads
+  __syncthreads();                                   // all waves are done reading the window
   {
-    const bool lead = (lane & 15) == 0;
+    uint32_t *red = swin;
 #pragma unroll
-    for (int p = 1; p < JMHIP_NPART; p++) {
-      const unsigned v = row16_min_u32(best[p]);
-      if (lead) atomicMin(&S.redk[p], v);
+    for (int p = 1; p < JMHIP_NPART; p++) red[p * 256 + tid] = best[p];
+    red[0 * 256 + tid] = (unsigned)(best0 >> 32);
+    red[JMHIP_NPART * 256 + tid] = (unsigned)best0;
+  }
+  __syncthreads();
+  if (tid < 4 * JMHIP_NPART) {
+    const int p = tid >> 2, qt = tid & 3;
+    const uint4 *src = reinterpret_cast<const uint4 *>(swin + p * 256 + qt * 64);
+    if (p) {
+      unsigned m = KEY_INVALID;
+#pragma unroll
+      for (int k = 0; k < 16; k++) { const uint4 v = src[k]; m = min(min(m, v.x), min(min(v.y, v.z), v.w)); }
+      S.part[p][qt] = m;
+    } else {
+      const uint4 *lo = reinterpret_cast<const uint4 *>(swin + JMHIP_NPART * 256 + qt * 64);
+      unsigned long long m = ~0ull;
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        const uint4 h = src[k], l = lo[k];
+        m = min_u64(m, ((unsigned long long)h.x << 32) | l.x); m = min_u64(m, ((unsigned long long)h.y << 32) | l.y);
+        m = min_u64(m, ((unsigned long long)h.z << 32) | l.z); m = min_u64(m, ((unsigned long long)h.w << 32) | l.w);
+      }
+      S.part0[qt] = m;
     }
-    unsigned long long v = best0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) v = min_u64(v, dpp_u64(v, k));
-    if (lead) atomicMin(&S.red0k, v);
   }
   STAMP(5);
   __syncthreads();
@@ -636,10 +653,10 @@ __global__ __launch_bounds__(256, 2) void me_int_fast_kernel(MeDev P, const jmhi
     jmhip_me_result &o = res[mbi];
     int cost, tie;
     if (p == 0) {
-      const unsigned long long k = S.red0k;
+      const unsigned long long k = min_u64(min_u64(S.part0[0], S.part0[1]), min_u64(S.part0[2], S.part0[3]));
       cost = (int)(unsigned)(k >> 32) - w16; tie = (int)(unsigned)k;
     } else {
-      const unsigned k = S.redk[p];
+      const unsigned k = min(min(S.part[p][0], S.part[p][1]), min(S.part[p][2], S.part[p][3]));
       cost = (int)(k >> FAST_TIE_BITS); tie = (int)(k & 0xffffu);
     }
     int rx, ry;
@@ -952,7 +969,8 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
   const int fpitch_dw = ((2 * R + 1 + 15 + 3) >> 2) + 2, frows = 2 * R + 1 + 15;
   int fcs = fpitch_dw * frows;
   while ((fcs & 31) != 8) fcs++;
-  const size_t flds = ((size_t)3 * fcs + (size_t)fpitch_dw * frows) * 4;
+  size_t flds = ((size_t)3 * fcs + (size_t)fpitch_dw * frows) * 4;
+  if (flds < (size_t)(JMHIP_NPART + 1) * 256 * 4) flds = (size_t)(JMHIP_NPART + 1) * 256 * 4;     // reused by the final key transpose
   if (!c->me_fast_idx.empty() && flds > 60 * 1024) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_me_frame: search range too large for the fast-path LDS window");
   if (lds > 60 * 1024) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_me_frame: search centres of one macroblock are too far apart for one LDS window");
 
