@@ -423,7 +423,7 @@ __global__ __launch_bounds__(64) void tq_chroma_kernel(const jmhip_tq_job *__res
       run++;
       const int level = (iabs(m4[i][j]) * q.levelscale[0] + (qdc.leveloffset[0] * 2)) >> (q_bits_422 + 1);   // block.c:1263
       if (level != 0) {
-        cbp |= 0xff0000LL << (uv << 3);
+        cbp |= (long long)(int)(0xff0000u << (uv << 3));     // block.c:1268 is int arithmetic: sign-extends for uv == 1 (JM quirk, kept)
         cr_cbp = max(1, cr_cbp);
         DCcoded = 1;
         o.dc_levels[scan_pos] = sgnab(level, m4[i][j]); o.dc_runs[scan_pos] = run; scan_pos++;

@@ -55,6 +55,8 @@ void jmo_interp_luma(const jmo_pel *img, int W, int H, int stride, int max_val, 
  * exactly like JM's calloc (memalloc.c:142): JM never writes the last row and column. */
 void jmo_interp_chroma(const jmo_pel *img, int Wc, int Hc, int stride, int yuv_format, jmo_pel *out);
 
+unsigned jmo_fnv1a16(const jmo_pel *p, long n);   /* plane digest used by the golden fixtures */
+
 /* A stored reference picture as the ME functions see it (StorablePicture, mbuffer.h:20-95). */
 typedef struct {
   int W, H;                 /* size_x, size_y                                   */

@@ -171,3 +171,12 @@ void jmo_ref_init(jmo_ref *r, int W, int H, int yuv_format, const jmo_pel *luma,
     }
   }
 }
+
+/* FNV-1a over 16-bit samples, the plane digest of oracle/tap/tap_capture.c (golden fixtures) */
+unsigned jmo_fnv1a16(const jmo_pel *p, long n)
+{
+  unsigned d = 2166136261u;
+  long i;
+  for (i = 0; i < n; i++) { d ^= p[i]; d *= 16777619u; }
+  return d;
+}

@@ -505,7 +505,7 @@ int jmo_dct_chroma(const jmo_quant *q, const jmo_quant *qdc, int yuv, int uv, in
       /* :1263 -- AC levelscale with the DC (qp+3) offset table, as in JM */
       level = (iabs_(m4[i][j]) * q->levelscale[0] + (qdc->leveloffset[0] * 2)) >> (q_bits_422 + 1);
       if (level != 0) {
-        *cbp_blk |= 0xff0000LL << (uv << 3);
+        *cbp_blk |= (long long)(int)(0xff0000u << (uv << 3));   /* block.c:1268: int arithmetic in JM -- for uv=1 the value is negative and sign-extends into bits 32..63 */
         cr_cbp = imax_(1, cr_cbp);
         DCcoded = 1;
         dc_levels[scan_pos] = isignab(level, m4[i][j]); dc_runs[scan_pos++] = run;
