@@ -210,12 +210,16 @@ int ensure_frame_buffers(jmhip_ctx *c, int n)
   void **bufs[] = {&c->fr_jobs_y, &c->fr_jobs_c, &c->fr_res_y, &c->fr_res_c, &c->fr_modes};
   for (auto b : bufs) { if (*b) JM_HIP_CHECK(c, hipFree(*b)); *b = nullptr; }
   c->fr_capacity = 0;
+  // the chroma job tiles are only partly written per frame (mb_cr_size columns/rows): zero the rest once
   bool ok = hipMalloc(&c->fr_jobs_y, sizeof(jmhip_tq_job) * (size_t)n) == hipSuccess &&
             hipMalloc(&c->fr_jobs_c, sizeof(jmhip_tq_job) * (size_t)n * 2) == hipSuccess &&
             hipMalloc(&c->fr_res_y, sizeof(jmhip_tq_result) * (size_t)n) == hipSuccess &&
             hipMalloc(&c->fr_res_c, sizeof(jmhip_tq_result) * (size_t)n * 2) == hipSuccess &&
             hipMalloc(&c->fr_modes, (sizeof(jmhip_mb_mode) * 2 + sizeof(MbCoded)) * (size_t)n) == hipSuccess;
   if (!ok) return jm_fail(c, JMHIP_ERR_NOMEM, "frame-stage arrays");
+  JM_HIP_CHECK(c, hipMemsetAsync(c->fr_jobs_c, 0, sizeof(jmhip_tq_job) * (size_t)n * 2, c->stream));
+  JM_HIP_CHECK(c, hipMemsetAsync(c->fr_res_y, 0, sizeof(jmhip_tq_result) * (size_t)n, c->stream));
+  JM_HIP_CHECK(c, hipMemsetAsync(c->fr_res_c, 0, sizeof(jmhip_tq_result) * (size_t)n * 2, c->stream));
   if (!c->fr_quant && hipMalloc(&c->fr_quant, sizeof(jmhip_quant) * 3) != hipSuccess) return jm_fail(c, JMHIP_ERR_NOMEM, "frame-stage quantisers");
   c->fr_capacity = n;
   return JMHIP_OK;
@@ -257,10 +261,10 @@ extern "C" int jmhip_residual_frame(jmhip_ctx *c, const jmhip_mb_mode *modes, co
     JM_HIP_CHECK(c, hipMemcpyAsync(modes_in_dev, modes, sizeof(jmhip_mb_mode) * (size_t)n, hipMemcpyHostToDevice, c->stream));
   }
   MbCoded *coded_dev = reinterpret_cast<MbCoded *>(modes_out_dev + 2 * (size_t)n);
-  JM_HIP_CHECK(c, hipMemcpyAsync(c->fr_quant, quants, sizeof(jmhip_quant) * 3, hipMemcpyHostToDevice, c->stream));
-  JM_HIP_CHECK(c, hipMemsetAsync(c->fr_res_y, 0, sizeof(jmhip_tq_result) * (size_t)n, c->stream));
-  JM_HIP_CHECK(c, hipMemsetAsync(c->fr_jobs_c, 0, sizeof(jmhip_tq_job) * (size_t)n * 2, c->stream));
-  JM_HIP_CHECK(c, hipMemsetAsync(c->fr_res_c, 0, sizeof(jmhip_tq_result) * (size_t)n * 2, c->stream));
+  // the three quantisers are copied into a context-owned host block first: the caller's array is only borrowed for the call
+  memcpy(c->fr_quant_host, quants, sizeof(jmhip_quant) * 3);
+  JM_HIP_CHECK(c, hipMemcpyAsync(c->fr_quant, c->fr_quant_host, sizeof(jmhip_quant) * 3, hipMemcpyHostToDevice, c->stream));
+  if (modes) JM_HIP_CHECK(c, hipStreamSynchronize(c->stream));      // caller-owned mode array
 
   FrameDev F{};
   F.W = c->W; F.H = c->H; F.Wp = c->Wp; F.Hp = c->Hp; F.Wc = c->Wc; F.Hc = c->Hc; F.Wcp = c->Wcp; F.Hcp = c->Hcp; F.mbw = c->mbw;

@@ -208,6 +208,8 @@ static int upload_plane(jmhip_ctx *c, uint8_t *dst, const void *src, int w, int 
   if (stride < w) return jm_fail(c, JMHIP_ERR_ARG, "stride < width");
   if (pel_bytes == 1) {
     JM_HIP_CHECK(c, hipMemcpy2DAsync(dst, w, src, stride, w, h, device_ptrs ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    // host buffers are only borrowed for the duration of the call (SURVEY 8(b) ownership): the copy must have left them
+    if (!device_ptrs) JM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     return JMHIP_OK;
   }
   if (pel_bytes != 2 || device_ptrs) return jm_fail(c, JMHIP_ERR_ARG, "pel_bytes must be 1 (or 2 for host pointers)");
@@ -215,6 +217,7 @@ static int upload_plane(jmhip_ctx *c, uint8_t *dst, const void *src, int w, int 
   int rc = ensure_stage(c, bytes);
   if (rc) return rc;
   JM_HIP_CHECK(c, hipMemcpyAsync(c->stage_dev, src, bytes, hipMemcpyHostToDevice, c->stream));
+  JM_HIP_CHECK(c, hipStreamSynchronize(c->stream));    // the caller's buffer is only borrowed for the call
   dim3 grid((w + 255) / 256, h);
   narrow_u16_kernel<<<grid, 256, 0, c->stream>>>((const uint16_t *)c->stage_dev, dst, w, h, stride);
   JM_HIP_CHECK(c, hipGetLastError());

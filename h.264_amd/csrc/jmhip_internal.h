@@ -43,6 +43,7 @@ struct jmhip_ctx {
   // frame pipeline (MC -> residual -> TQ -> recon): per-MB luma job/result, 2 chroma jobs/results, recon picture
   void *fr_jobs_y = nullptr, *fr_jobs_c = nullptr, *fr_res_y = nullptr, *fr_res_c = nullptr, *fr_quant = nullptr, *fr_modes = nullptr;
   int fr_capacity = 0, fr_n = 0;
+  jmhip_quant fr_quant_host[3];
   uint8_t *rec_y = nullptr, *rec_u = nullptr, *rec_v = nullptr;
   // TQ arrays
   void *tq_jobs_dev = nullptr, *tq_res_dev = nullptr, *tq_quant_dev = nullptr; int tq_capacity = 0, tq_qcap = 0;
