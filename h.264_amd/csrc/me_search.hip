@@ -778,7 +778,7 @@ __global__ __launch_bounds__(256) void me_sub_kernel(MeDev P, const jmhip_me_mb 
     __syncthreads();
 
     for (int idx = tid; idx < nsub * ncand; idx += 256) {
-      const int it = idx / ncand, cand = first + (idx - it * ncand);
+      const int ci = idx / nsub, it = idx - ci * nsub, cand = first + ci;     // lanes: adjacent sub-blocks, same plane
       const SubItem si = items[it];
       const int p = si.p;
       if (!((mask >> p) & 1)) continue;

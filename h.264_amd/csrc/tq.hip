@@ -494,6 +494,142 @@ __global__ __launch_bounds__(64) void tq_chroma_kernel(const jmhip_tq_job *__res
   o.cbp_clear = cbp_clear;
 }
 
+
+// dct_chroma for 4:2:0, the common case: FOUR lanes per job (one per 4x4 block, a DPP quad), everything in registers.
+// The 2x2 DC transform gathers the four DC terms with quad_perm broadcasts; lane 0 of the quad quantises the DC list
+// (sequential run/level semantics) and the dequantised DCs go back the same way. block.c:1051-1495.
+__device__ __forceinline__ int quad_bcast(int v, int src)      // value of lane (quad base + src) in every lane of the quad
+{
+  switch (src) {
+  case 0: return __builtin_amdgcn_update_dpp(v, v, 0x00, 0xf, 0xf, false);
+  case 1: return __builtin_amdgcn_update_dpp(v, v, 0x55, 0xf, 0xf, false);
+  case 2: return __builtin_amdgcn_update_dpp(v, v, 0xAA, 0xf, 0xf, false);
+  default: return __builtin_amdgcn_update_dpp(v, v, 0xFF, 0xf, 0xf, false);
+  }
+}
+
+__global__ __launch_bounds__(256) void tq_chroma420_kernel(const jmhip_tq_job *__restrict__ jobs, const jmhip_quant *__restrict__ quants,
+                                                          jmhip_tq_result *__restrict__ res, int n)
+{
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int jobi = min(gid >> 2, n - 1), b4 = gid & 3;          // b4: 0 (0,0)  1 (4,0)  2 (0,4)  3 (4,4)  (hor/ver_offset[1][0])
+  const bool live = (gid >> 2) < n;                             // whole quads are live or dead together
+  const jmhip_tq_job &job = jobs[jobi];
+  const jmhip_quant &q = quants[job.quant];
+  jmhip_tq_result &o = res[jobi];
+  const int uv = job.uv;
+  const int bx = 4 * (b4 & 1), by = 4 * (b4 >> 1);
+  const int qp_per = q.qp / 6, q_bits = Q_BITS + qp_per;
+
+  int m[4][4], pr[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const uint32_t s = *reinterpret_cast<const uint32_t *>(&job.src[by + j][bx]);
+    const uint32_t p = *reinterpret_cast<const uint32_t *>(&job.pred[by + j][bx]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) { pr[j][i] = (p >> (8 * i)) & 255; m[j][i] = (int)((s >> (8 * i)) & 255) - pr[j][i]; }
+  }
+  fwd4(m);       // block.c:1120 swaps (n1,n2); for the symmetric 8x8 tile of 4:2:0 the same four blocks are transformed
+
+  // ---- 2x2 DC: m1[k] over the DCs d0 (0,0) d1 (0,4)->cols d2 (4,0)->rows d3 (4,4): curr_res[0][0],[0][4],[4][0],[4][4]
+  const int d0 = quad_bcast(m[0][0], 0), d1 = quad_bcast(m[0][0], 1), d2 = quad_bcast(m[0][0], 2), d3 = quad_bcast(m[0][0], 3);
+  int m1[4] = {d0 + d1 + d2 + d3, d0 - d1 + d2 - d3, d0 + d1 - d2 - d3, d0 - d1 - d2 + d3};
+  int run = -1, scan_pos = 0, DCcoded = 0, cr_cbp = job.cr_cbp_in;
+  long long cbp = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {          // every lane of the quad computes the (cheap) DC list; lane 0 writes it
+    run++;
+    int level = (iabs(m1[k]) * q.levelscale[0] + (q.leveloffset[0] << 1)) >> (q_bits + 1);
+    if (level != 0) {
+      if (q.cavlc && q.img_qp < 4) level = min(level, CAVLC_LEVEL_LIMIT);
+      cbp |= 0xf0000LL << (uv << 2);
+      cr_cbp = max(1, cr_cbp);
+      DCcoded = 1;
+      level = sgnab(level, m1[k]);
+      if (live && b4 == 0) { o.dc_levels[scan_pos] = level; o.dc_runs[scan_pos] = run; }
+      scan_pos++;
+      run = -1;
+      m1[k] = level;
+    } else m1[k] = 0;
+  }
+  if (live && b4 == 0) o.dc_levels[scan_pos] = 0;
+  {
+    const int m5[4] = {m1[0] + m1[1] + m1[2] + m1[3], m1[0] - m1[1] + m1[2] - m1[3], m1[0] + m1[1] - m1[2] - m1[3], m1[0] - m1[1] - m1[2] + m1[3]};
+    m[0][0] = ((m5[b4] * q.invlevelscale[0]) << qp_per) >> 5;           // block.c:1170-1173
+  }
+
+  // ---- AC of this lane's block (scan positions 1..15)
+  int coeff_cost = 0, any = 0;
+  scan_pos = 0; run = -1;
+  int *levels = o.levels[b4], *runs = o.runs[b4];
+#pragma unroll
+  for (int k = 1; k < 16; k++) {
+    constexpr int I0[16] = {0,1,0,0,1,2,3,2,1,0,1,2,3,3,2,3}, J0[16] = {0,0,1,2,1,0,0,1,2,3,3,2,1,2,3,3};
+    constexpr int I1[16] = {0,0,1,0,0,1,1,1,2,2,2,2,3,3,3,3}, J1[16] = {0,1,0,2,3,1,2,3,0,1,2,3,0,1,2,3};
+    const int i0 = I0[k], j0 = J0[k], i1 = I1[k], j1 = J1[k];
+    const int c = q.field_scan ? m[j1][i1] : m[j0][i0];
+    const int idx = q.field_scan ? (j1 * 4 + i1) : (j0 * 4 + i0);
+    ++run;
+    const int scaled = iabs(c) * q.levelscale[idx];
+    int level = (scaled + q.leveloffset[idx]) >> q_bits;
+    int deq = 0, fadj = 0;
+    if (level != 0) {
+      if (q.adaptive_rounding) fadj = rsr(q.adapt_rnd_weight * (scaled - (level << q_bits)), q_bits + 1);
+      any = 1;
+      coeff_cost += (level > 1) ? MAXV : c_cost4[q.disthres][run];
+      level = sgnab(level, c);
+      if (live) { levels[scan_pos] = level; runs[scan_pos] = run; }
+      scan_pos++;
+      run = -1;
+      deq = rsr((level * q.invlevelscale[idx]) << qp_per, 4);
+    }
+    if (live && q.adaptive_rounding) o.fadjust[by + (idx >> 2)][bx + (idx & 3)] = fadj;
+    if (q.field_scan) m[j1][i1] = deq; else m[j0][i0] = deq;
+  }
+  if (live) levels[scan_pos] = 0;
+  if (any) cbp |= 1LL << (16 + 4 * uv + b4);                           // cbp_blk_chroma[uv][b4], block.h:109 (4:2:0: one 8x8 per component)
+
+  // ---- thresholding over the four blocks of the component (_CHROMA_COEFF_COST_ = 4), block.c:1384-1410
+  int total = coeff_cost;
+  total += __builtin_amdgcn_update_dpp(total, total, 0xB1, 0xf, 0xf, false);      // quad_perm [1,0,3,2]
+  total += __builtin_amdgcn_update_dpp(total, total, 0x4E, 0xf, 0xf, false);      // quad_perm [2,3,0,1]
+  int anyq = any;
+  anyq |= __builtin_amdgcn_update_dpp(anyq, anyq, 0xB1, 0xf, 0xf, false);
+  anyq |= __builtin_amdgcn_update_dpp(anyq, anyq, 0x4E, 0xf, 0xf, false);
+  long long cbp_clear = 0;
+  int cr_cbp_tmp = anyq ? 2 : 0;
+  if (total < 4) {
+    cr_cbp_tmp = 0;
+    if (DCcoded == 0) cbp_clear = 0xf0000LL << (uv << 2);             // cbpblk_pattern[1] << (uv << 2)
+    if (live) {
+#pragma unroll
+      for (int k = 0; k < 16; k++) levels[k] = 0;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) if (i | j) m[j][i] = 0;
+  }
+  if (cr_cbp_tmp == 2) cr_cbp = 2;
+  // OR the per-block cbp bits across the quad
+  unsigned cl = (unsigned)cbp, ch = (unsigned)(cbp >> 32);
+  cl |= (unsigned)__builtin_amdgcn_update_dpp((int)cl, (int)cl, 0xB1, 0xf, 0xf, false);
+  cl |= (unsigned)__builtin_amdgcn_update_dpp((int)cl, (int)cl, 0x4E, 0xf, 0xf, false);
+  cbp = ((long long)ch << 32) | cl;
+
+  inv4(m);
+  if (live) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      uint32_t w = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) w |= (uint32_t)clip1(q.max_val, rsr(m[j][i], DQ_BITS) + pr[j][i]) << (8 * i);
+      *reinterpret_cast<uint32_t *>(&o.recon[by + j][bx]) = w;
+    }
+    if (b4 == 0) { o.ret = cr_cbp; o.cbp_blk = cbp & ~cbp_clear; o.cbp_clear = cbp_clear; }
+  }
+}
+
 }  // namespace
 
 extern "C" void jmhip_flat_quant(jmhip_quant *q, int qp, int offset11, int is8x8)
@@ -538,7 +674,10 @@ int jm_launch_tq(jmhip_ctx *c, int kind, int yuv_format, const void *jobs, const
   case JMHIP_TQ_LUMA4x4:   tq_luma4x4_kernel<<<(n * 16 + 255) / 256, 256, 0, c->stream>>>(dj, dq, dr, n); break;
   case JMHIP_TQ_LUMA8x8:   tq_luma8x8_kernel<<<(n * 4 + 63) / 64, 64, 0, c->stream>>>(dj, dq, dr, n); break;
   case JMHIP_TQ_LUMA16x16: tq_luma16x16_kernel<<<(n + 63) / 64, 64, 0, c->stream>>>(dj, dq, dr, n); break;
-  default:                 tq_chroma_kernel<<<(n + 63) / 64, 64, 0, c->stream>>>(dj, dq, dr, n, yuv_format); break;
+  default:
+    if (yuv_format == JMHIP_YUV420) tq_chroma420_kernel<<<(n * 4 + 255) / 256, 256, 0, c->stream>>>(dj, dq, dr, n);
+    else tq_chroma_kernel<<<(n + 63) / 64, 64, 0, c->stream>>>(dj, dq, dr, n, yuv_format);
+    break;
   }
   JM_HIP_CHECK(c, hipGetLastError());
   return JMHIP_OK;
