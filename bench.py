@@ -109,13 +109,6 @@ RestrictSearchRange = 2
 AdaptiveRounding = 1
 Transform8x8Mode = 0
 LoopFilterDisable = 0
-InterSearch16x16 = 1
-InterSearch16x8 = 1
-InterSearch8x16 = 1
-InterSearch8x8 = 1
-InterSearch8x4 = 1
-InterSearch4x8 = 1
-InterSearch4x4 = 1
 """
 
 

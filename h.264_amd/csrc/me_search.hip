@@ -101,6 +101,22 @@ constexpr unsigned KEY_INVALID = 0xffffffffu;
 
 // ------------------------------------------------------------------------------------------------ integer search
 
+// JM hands computeSAD the bound  min_mcost - mcost  (me_fullsearch.c:138). At spiral position 0 min_mcost is still INT_MAX,
+// so a NEGATIVE mcost -- possible only through the check_for_00 bonus, i.e. for the zero vector of the 16x16 block at picture
+// position (0,0) when it is the search centre -- wraps the bound below zero, and computeSAD leaves after its first row
+// (me_distortion.c:364-375). That candidate then competes with  mv cost - bonus + SAD(row 0)  and, being first in the
+// spiral, keeps ties. Found by running the real encoder on the device path (tests/test_jm_shim.py); mirrored here.
+__device__ __forceinline__ void wrapped_bound_00(const MeDev &P, const jmhip_me_mb &job, int cx, int cy, int *mvx, int *mvy, int *cost)
+{
+  if (P.mode != JMHIP_SEARCH_FULL || P.rdopt || P.is_b || !job.ref_is_0 || job.mb_x || job.mb_y || cx || cy) return;
+  const int c0 = mv_cost(P.lam_f, -job.pred_mv[0][0], -job.pred_mv[0][1]) - ((P.lam_f * 16) >> 16);
+  if (c0 >= 0) return;
+  const uint8_t *ref = P.ref_y[job.ref];
+  int row = 0;
+  for (int x = 0; x < 16; x++) row += iabs((int)P.cur[x] - (int)ref[x]);
+  if (c0 + row <= *cost) { *mvx = 0; *mvy = 0; *cost = c0 + row; }
+}
+
 __global__ __launch_bounds__(256) void me_int_kernel(MeDev P, const jmhip_me_mb *__restrict__ jobs, const int *__restrict__ job_index,
                                                      jmhip_me_result *__restrict__ res_all)
 {
@@ -252,6 +268,7 @@ __global__ __launch_bounds__(256) void me_int_kernel(MeDev P, const jmhip_me_mb 
       int mvx, mvy;
       if (tie == 0) { mvx = 0; mvy = 0; }               // FastFull pos_00
       else { int dx, dy; spiral_offset(tie - 1, &dx, &dy); mvx = s_cx[p] + dx; mvy = s_cy[p] + dy; }
+      if (p == 0) wrapped_bound_00(P, job, s_cx[0], s_cy[0], &mvx, &mvy, &cost);
       o.mv_int[p][0] = (int16_t)mvx; o.mv_int[p][1] = (int16_t)mvy; o.cost_int[p] = cost;
       if (!P.subpel) { o.mv[p][0] = (int16_t)(mvx << 2); o.mv[p][1] = (int16_t)(mvy << 2); o.cost[p] = cost; }
     } else {
@@ -662,6 +679,7 @@ __global__ __launch_bounds__(256, 2) void me_int_fast_kernel(MeDev P, const jmhi
     int rx, ry;
     if (tie == 0) { rx = 0; ry = 0; }
     else { int ddx, ddy; spiral_offset(tie - 1, &ddx, &ddy); rx = ucx + ddx; ry = ucy + ddy; }
+    if (p == 0) wrapped_bound_00(P, jobs[mbi], ucx, ucy, &rx, &ry, &cost);
     o.mv_int[p][0] = (int16_t)rx; o.mv_int[p][1] = (int16_t)ry; o.cost_int[p] = cost;
     if (!P.subpel) { o.mv[p][0] = (int16_t)(rx << 2); o.mv[p][1] = (int16_t)(ry << 2); o.cost[p] = cost; }
   }
@@ -1051,6 +1069,115 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
   return JMHIP_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ distortion batch
+
+namespace {
+
+__device__ __forceinline__ int wp_pel(const jmhip_dist_job &j, int v)
+{
+  if (!j.wp) return v;
+  const int w = ((j.weight * v + j.wp_round) >> j.wp_denom) + j.offset;     // me_distortion.c:431
+  return min(max(w, 0), 255);
+}
+
+// computeSAD / computeSADWP / computeSATD / computeSATDWP (me_distortion.c:351, :413, :657, :734) for one candidate
+// per lane, full evaluation. One lane per job: this is the primitive for host-driven searches (EPZS, UMHexagonS),
+// whose candidate lists are short and data dependent.
+__global__ __launch_bounds__(64) void distortion_kernel(MeDev P, const jmhip_dist_job *__restrict__ jobs, int n, int32_t *__restrict__ out)
+{
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  const jmhip_dist_job j = jobs[i];
+  const uint8_t *sub = P.ref_sub[j.ref];
+  const size_t plane = (size_t)P.Wp * P.Hp;
+  const int width_pad = P.Wp - 1 - 16, height_pad = P.Hp - 1 - 16;
+  int total = 0;
+  if (j.use_satd == 0) {
+    int xpos = j.cand_x >> 2, ypos = j.cand_y >> 2;
+    if (j.umv) { xpos = clampi(xpos, 0, width_pad); ypos = clampi(ypos, 0, height_pad); }
+    const uint8_t *rp = sub + (size_t)((j.cand_y & 3) * 4 + (j.cand_x & 3)) * plane + (size_t)ypos * P.Wp + xpos;
+    for (int y = 0; y < j.bsy; y++) {
+      const uint8_t *cp = P.cur + (size_t)(j.pic_y + y) * P.W + j.pic_x;
+      for (int x = 0; x < j.bsx; x++) total += iabs((int)cp[x] - wp_pel(j, rp[(size_t)y * P.Wp + x]));
+    }
+  } else {
+    const int bs = j.use_satd == 2 ? 8 : 4;
+    for (int by = 0; by < j.bsy; by += bs)
+      for (int bx = 0; bx < j.bsx; bx += bs) {
+        const int xq = j.cand_x + (bx << 2), yq = j.cand_y + (by << 2);
+        int xpos = xq >> 2, ypos = yq >> 2;
+        if (j.umv) { xpos = clampi(xpos, 0, width_pad); ypos = clampi(ypos, 0, height_pad); }   // per sub-block, :678
+        const uint8_t *rp = sub + (size_t)((yq & 3) * 4 + (xq & 3)) * plane + (size_t)ypos * P.Wp + xpos;
+        if (bs == 4) {
+          int d[4][4];
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+              d[r][x] = (int)P.cur[(size_t)(j.pic_y + by + r) * P.W + j.pic_x + bx + x] - wp_pel(j, rp[(size_t)r * P.Wp + x]);
+          total += satd4x4(d);
+        } else {
+          int m2[8][8], s = 0;
+          for (int r = 0; r < 8; r++) {
+            int row[8];
+#pragma unroll
+            for (int x = 0; x < 8; x++) row[x] = (int)P.cur[(size_t)(j.pic_y + by + r) * P.W + j.pic_x + bx + x] - wp_pel(j, rp[(size_t)r * P.Wp + x]);
+            had8(row);
+#pragma unroll
+            for (int x = 0; x < 8; x++) m2[r][x] = row[x];
+          }
+          for (int x = 0; x < 8; x++) {
+            int col[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) col[r] = m2[r][x];
+            had8(col);
+#pragma unroll
+            for (int r = 0; r < 8; r++) s += iabs(col[r]);
+          }
+          total += (s + 2) >> 2;
+        }
+      }
+  }
+  out[i] = total;
+}
+
+}  // namespace
+
+extern "C" int jmhip_distortion_batch(jmhip_ctx *c, const jmhip_dist_job *jobs, int n, int32_t *out)
+{
+  if (!c || !jobs || !out || n <= 0) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_distortion_batch: NULL/empty arguments") : JMHIP_ERR_ARG;
+  if (!c->has_cur) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_distortion_batch: current picture not uploaded");
+  for (int i = 0; i < n; i++) {
+    const jmhip_dist_job &j = jobs[i];
+    if (j.ref < 0 || j.ref >= (int)c->refs.size() || !c->refs[j.ref].has_luma_sub) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_distortion_batch: reference planes not built");
+    if ((j.bsx != 4 && j.bsx != 8 && j.bsx != 16) || (j.bsy != 4 && j.bsy != 8 && j.bsy != 16)) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_distortion_batch: block size");
+    if (j.pic_x < 0 || j.pic_y < 0 || j.pic_x + j.bsx > c->W || j.pic_y + j.bsy > c->H) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_distortion_batch: block outside the picture");
+    if (j.use_satd < 0 || j.use_satd > 2 || (j.use_satd == 2 && ((j.bsx | j.bsy) & 7))) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_distortion_batch: metric");
+    // FAST_ACCESS is only legal where JM would choose it: the whole block inside the padded plane
+    const int xp = j.cand_x >> 2, yp = j.cand_y >> 2;
+    if (!j.umv && (xp < 0 || yp < 0 || xp + j.bsx > c->Wp || yp + j.bsy > c->Hp)) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_distortion_batch: FAST access outside the padded plane");
+    if (j.wp && (j.wp_denom < 0 || j.wp_denom > 15)) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_distortion_batch: weight denominator");
+  }
+  JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
+  int rc = jm_ensure_ref_table(c);
+  if (rc) return rc;
+  void *dj = nullptr, *dout = nullptr;
+  if (hipMalloc(&dj, sizeof(jmhip_dist_job) * (size_t)n) != hipSuccess || hipMalloc(&dout, sizeof(int32_t) * (size_t)n) != hipSuccess) {
+    (void)hipFree(dj); return jm_fail(c, JMHIP_ERR_NOMEM, "distortion batch arrays");
+  }
+  MeDev P{};
+  P.W = c->W; P.H = c->H; P.Wp = c->Wp; P.Hp = c->Hp; P.cur = c->cur_y;
+  P.ref_y = reinterpret_cast<const uint8_t *const *>(c->ref_ptrs_dev);
+  P.ref_sub = reinterpret_cast<const uint8_t *const *>(c->ref_ptrs_dev) + 32;
+  hipError_t e = hipMemcpyAsync(dj, jobs, sizeof(jmhip_dist_job) * (size_t)n, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) { distortion_kernel<<<(n + 63) / 64, 64, 0, c->stream>>>(P, (const jmhip_dist_job *)dj, n, (int32_t *)dout); e = hipGetLastError(); }
+  if (e == hipSuccess) e = hipMemcpyAsync(out, dout, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(dj); (void)hipFree(dout);
+  if (e != hipSuccess) { c->err = std::string("jmhip_distortion_batch: ") + hipGetErrorString(e); return JMHIP_ERR_DEVICE; }
+  return JMHIP_OK;
+}
+
 extern "C" int jmhip_me_results_download(jmhip_ctx *c, jmhip_me_result *results, int n)
 {
   if (!c || !results || n <= 0) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_results_download: NULL/empty arguments") : JMHIP_ERR_ARG;
@@ -1060,6 +1187,53 @@ extern "C" int jmhip_me_results_download(jmhip_ctx *c, jmhip_me_result *results,
   for (int i = 0; i < n; i++)
     for (int p = 0; p < JMHIP_NPART; p++)
       if (results[i].cost_int[p] == -2) return jm_fail(c, JMHIP_ERR_DEVICE, "me_int_kernel: LDS window smaller than a macroblock's search area (internal sizing error)");
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_me_subpel(jmhip_ctx *c, const jmhip_me_params *prm, const jmhip_me_mb *mbs, int n, jmhip_me_result *results)
+{
+  if (!c || !prm || !mbs || !results || n <= 0) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_subpel: NULL/empty arguments") : JMHIP_ERR_ARG;
+  // run the integer stage's validation/upload with the search itself switched off: reuse jmhip_me_frame_async with an empty
+  // candidate set is not possible, so validate here
+  if (!c->has_cur) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_subpel: current picture not uploaded");
+  for (int i = 0; i < n; i++) {
+    const jmhip_me_mb &m = mbs[i];
+    if (m.mb_x < 0 || m.mb_x >= c->mbw || m.mb_y < 0 || m.mb_y >= c->mbh) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_subpel: macroblock outside the picture");
+    if (m.ref < 0 || m.ref >= (int)c->refs.size() || !c->refs[m.ref].has_luma_sub) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_subpel: sub-pel planes of the reference not built");
+    for (int p = 0; p < JMHIP_NPART; p++)
+      if (((prm->partition_mask >> p) & 1) && (results[i].mv_int[p][0] < -2048 || results[i].mv_int[p][0] > 2048 || results[i].mv_int[p][1] < -2048 || results[i].mv_int[p][1] > 2048))
+        return jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_subpel: integer vector out of range");
+  }
+  for (int k = 0; k < 3; k++)
+    if (prm->lambda[k] < 0 || prm->lambda[k] > 30000000) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_me_subpel: lambda factor out of the 32-bit cost range");
+  JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
+  int rc = ensure_tables(c);
+  if (rc) return rc;
+  if ((rc = jm_ensure_ref_table(c))) return rc;
+  void *dj = nullptr, *dr = nullptr;
+  if (hipMalloc(&dj, sizeof(jmhip_me_mb) * (size_t)n) != hipSuccess || hipMalloc(&dr, sizeof(jmhip_me_result) * (size_t)n) != hipSuccess) {
+    (void)hipFree(dj); return jm_fail(c, JMHIP_ERR_NOMEM, "sub-pel arrays");
+  }
+  MeDev P{};
+  P.mode = prm->search_mode; P.R = prm->search_range; P.rdopt = prm->rdopt; P.is_b = prm->is_b_slice;
+  P.lam_f = prm->lambda[0]; P.lam_h = prm->lambda[1]; P.lam_q = prm->lambda[2];
+  P.t8x8 = prm->transform8x8_mode ? 1 : 0; P.subpel = 1;
+  P.mask = prm->partition_mask & ((1ull << JMHIP_NPART) - 1);
+  P.W = c->W; P.H = c->H; P.Wp = c->Wp; P.Hp = c->Hp; P.cur = c->cur_y;
+  P.ref_y = reinterpret_cast<const uint8_t *const *>(c->ref_ptrs_dev);
+  P.ref_sub = reinterpret_cast<const uint8_t *const *>(c->ref_ptrs_dev) + 32;
+  hipError_t e = hipMemcpyAsync(dj, mbs, sizeof(jmhip_me_mb) * (size_t)n, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(dr, results, sizeof(jmhip_me_result) * (size_t)n, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    jm_stage_begin(c, JMHIP_STAGE_ME_SUB);
+    me_sub_kernel<<<n, 256, 0, c->stream>>>(P, (const jmhip_me_mb *)dj, (jmhip_me_result *)dr);
+    jm_stage_end(c, JMHIP_STAGE_ME_SUB);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(results, dr, sizeof(jmhip_me_result) * (size_t)n, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(dj); (void)hipFree(dr);
+  if (e != hipSuccess) { c->err = std::string("jmhip_me_subpel: ") + hipGetErrorString(e); return JMHIP_ERR_DEVICE; }
   return JMHIP_OK;
 }
 

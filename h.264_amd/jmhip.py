@@ -55,7 +55,8 @@ ME_MB_DTYPE = np.dtype([("mb_x", "<i2"), ("mb_y", "<i2"), ("ref", "<i2"), ("ref_
 ME_RESULT_DTYPE = np.dtype([("mv", "<i2", (NPART, 2)), ("cost", "<i4", (NPART,)),
                             ("mv_int", "<i2", (NPART, 2)), ("cost_int", "<i4", (NPART,))])
 DIST_JOB_DTYPE = np.dtype([("pic_x", "<i2"), ("pic_y", "<i2"), ("bsx", "<i2"), ("bsy", "<i2"),
-                           ("cand_x", "<i4"), ("cand_y", "<i4"), ("ref", "<i2"), ("use_satd", "<i2")])
+                           ("cand_x", "<i4"), ("cand_y", "<i4"), ("ref", "<i2"), ("use_satd", "<i2"),
+                           ("umv", "<i2"), ("wp", "<i2"), ("weight", "<i2"), ("offset", "<i2"), ("wp_round", "<i2"), ("wp_denom", "<i2")])
 
 
 QUANT_DTYPE = np.dtype([("qp", "<i4"), ("adaptive_rounding", "<i4"), ("adapt_rnd_weight", "<i4"), ("field_scan", "<i4"),
@@ -104,6 +105,7 @@ def load_library():
     lib.jmhip_me_frame_async.argtypes = [vp, C.POINTER(MeParams), vp, ip]
     lib.jmhip_me_results_download.argtypes = [vp, vp, ip]
     lib.jmhip_distortion_batch.argtypes = [vp, vp, ip, vp]
+    lib.jmhip_me_subpel.argtypes = [vp, C.POINTER(MeParams), vp, ip, vp]
     lib.jmhip_tq_batch.argtypes = [vp, ip, ip, vp, ip, vp, ip, vp]
     lib.jmhip_flat_quant.argtypes = [vp, ip, ip, ip]
     lib.jmhip_flat_quant.restype = None
@@ -262,6 +264,13 @@ class Context:
         res = np.zeros(n, dtype=ME_RESULT_DTYPE)
         self._chk(self.lib.jmhip_me_results_download(self.h, _ptr(res), n), "jmhip_me_results_download")
         return res
+
+    def me_subpel(self, prm, mbs, results):
+        """SubPelBlockMotionSearch alone: results['mv_int'] in, results['mv'/'cost'] out."""
+        mbs = np.ascontiguousarray(mbs, dtype=ME_MB_DTYPE)
+        results = np.ascontiguousarray(results, dtype=ME_RESULT_DTYPE)
+        self._chk(self.lib.jmhip_me_subpel(self.h, C.byref(prm), _ptr(mbs), len(mbs), _ptr(results)), "jmhip_me_subpel")
+        return results
 
     def distortion_batch(self, jobs):
         jobs = np.ascontiguousarray(jobs, dtype=DIST_JOB_DTYPE)

@@ -160,11 +160,19 @@ int jmhip_me_results_download(jmhip_ctx *ctx, jmhip_me_result *results, int n);
  * min_mcost = INT_MAX, UMV access. cand_x/cand_y are quarter-pel INCLUDING the +80 pad offset. */
 typedef struct {
   int16_t pic_x, pic_y;     /* block origin in the current picture (pel)                              */
-  int16_t bsx, bsy;         /* block size                                                             */
+  int16_t bsx, bsy;         /* block size (4, 8 or 16 each)                                           */
   int32_t cand_x, cand_y;
   int16_t ref, use_satd;    /* use_satd: 0 SAD, 1 SATD 4x4, 2 SATD 8x8 (test8x8transform)             */
+  int16_t umv, wp;          /* ref_access_method (1 = UMV_ACCESS); wp: computeSADWP / computeSATDWP     */
+  int16_t weight, offset;   /* weight_luma, offset_luma (src/me_distortion.c:53)                       */
+  int16_t wp_round, wp_denom; /* wp_luma_round, luma_log_weight_denom                                  */
 } jmhip_dist_job;
+/* out[i] = the FULL distortion (no early exit: what JM returns for min_mcost = INT_MAX). Luma only. */
 int jmhip_distortion_batch(jmhip_ctx *ctx, const jmhip_dist_job *jobs, int n, int32_t *out);
+
+/* SubPelBlockMotionSearch alone (src/me_fullsearch.c:341): results[i].mv_int[p] is the INPUT (integer vector in pel
+ * units, as FullPel/FastFull left it), results[i].mv/cost[p] the output. Same params/jobs as jmhip_me_frame. */
+int jmhip_me_subpel(jmhip_ctx *ctx, const jmhip_me_params *prm, const jmhip_me_mb *mbs, int n, jmhip_me_result *results);
 
 /* ------------------------------------------------------------------ transform / quant / recon */
 

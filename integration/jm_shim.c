@@ -1,0 +1,563 @@
+/*
+ * jm_shim.c -- the reference-side binding of libjmhip.so: JM (lencod) with its hot path on an MI355X.
+ *
+ * Built against JM's own headers and the UNMODIFIED JM compiled as a shared object. This file
+ * DEFINES JM's hot-path symbols, so every caller inside JM -- direct calls and the pointer tables pDCT_4x4 etc. --
+ * lands here; each definition marshals JM's globals into one C-ABI call (include/jmhip.h) and writes the results
+ * back where JM expects them. Nothing here computes: a configuration the device path does not cover is FORWARDED to
+ * JM's own function (dlsym RTLD_NEXT) and counted; a failing jmhip_* call aborts loudly (JM's error convention is
+ * error()/exit). JMHIP_SHIM_STATS=1 prints, per symbol, how many calls ran on the device and how many were forwarded.
+ * JMHIP_SHIM (hex mask, default all): 0x01 sub-pel planes, 0x04 full-pel + sub-pel search, 0x08 fast full search,
+ * 0x10 dct_4x4/dct_16x16, 0x20 dct_8x8, 0x40 dct_chroma.
+ *
+ * The proof of the drop-in claim is tests/test_jm_shim_gpu.py: the bitstream and the reconstruction this encoder
+ * writes are byte-identical to the unmodified encoder's.
+ */
+#define _GNU_SOURCE
+#include <dlfcn.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <limits.h>
+
+#include "global.h"
+#include "mbuffer.h"
+#include "image.h"
+#include "refbuf.h"
+#include "me_distortion.h"
+#include "q_matrix.h"
+#include "q_offsets.h"
+
+#include "jmhip.h"
+
+extern int jm_main(int argc, char **argv);
+extern int ****ptLevelOffset4x4;
+extern void SetMotionVectorPredictor(short pmv[2], char **refPic, short ***tmp_mv, short ref_frame, int list,
+                                     int block_x, int block_y, int blockshape_x, int blockshape_y);
+extern const int LEVELMVLIMIT[17][6];
+
+enum { S_LUMA, S_CHROMA, S_FULL, S_SUB, S_FAST, S_D4, S_D8, S_D16, S_DCR, S_COUNT };
+static const char *s_names[S_COUNT] = { "getSubImagesLuma", "getSubImagesChroma", "FullPelBlockMotionSearch",
+  "SubPelBlockMotionSearch", "FastFullPelBlockMotionSearch", "dct_4x4", "dct_8x8", "dct_16x16", "dct_chroma" };
+static long n_dev[S_COUNT], n_fwd[S_COUNT];
+static unsigned shim_mask = 0xff;
+static int verify;            /* JMHIP_SHIM_VERIFY=1: run JM's own search beside the device's and report differences */
+static jmhip_ctx *g;
+static int g_w, g_h;
+
+static void *next_sym(const char *name)
+{
+  void *p = dlsym(RTLD_NEXT, name);
+  if (!p) { fprintf(stderr, "jm_shim: cannot find JM's %s\n", name); exit(97); }
+  return p;
+}
+
+static void die(const char *what, int rc)
+{
+  fprintf(stderr, "jm_shim: %s failed: %s (%s)\n", what, jmhip_strerror(rc), g ? jmhip_last_error(g) : "no context");
+  exit(96);
+}
+#define OK(call) do { int rc_ = (call); if (rc_) die(#call, rc_); } while (0)
+
+static void print_stats(void)
+{
+  int i;
+  if (!getenv("JMHIP_SHIM_STATS")) return;
+  fprintf(stderr, "jm_shim: mask=0x%x\n", shim_mask);
+  for (i = 0; i < S_COUNT; i++) fprintf(stderr, "  %-30s device %8ld  forwarded %8ld\n", s_names[i], n_dev[i], n_fwd[i]);
+}
+
+int main(int argc, char **argv)
+{
+  const char *m = getenv("JMHIP_SHIM");
+  if (m) shim_mask = (unsigned)strtoul(m, NULL, 16);
+  verify = getenv("JMHIP_SHIM_VERIFY") != NULL;
+  atexit(print_stats);
+  return jm_main(argc, argv);
+}
+
+/* ------------------------------------------------------------------ context, reference slots, current picture */
+
+#define MAX_SLOTS 16
+static struct { StorablePicture *pic; unsigned long stamp; int has_chroma; } slots[MAX_SLOTS];
+static unsigned long slot_clock;
+
+/* The context is created on first use for the sequence's FRAME size; 8-bit only. Field pictures and other sizes
+ * stay in JM. */
+static int ctx_ready(void)
+{
+  if (img->bitdepth_luma != 8 || (img->yuv_format != YUV400 && img->bitdepth_chroma != 8)) return 0;
+  if (!g) {
+    jmhip_config cfg;
+    int rc;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.device = getenv("JMHIP_DEVICE") ? atoi(getenv("JMHIP_DEVICE")) : 0;
+    cfg.width = img->width; cfg.height = img->height;
+    cfg.yuv_format = img->yuv_format; cfg.bit_depth = 8;
+    cfg.max_refs = MAX_SLOTS; cfg.search_range = input->search_range;
+    if (img->structure != FRAME) return 0;              /* img->height is the field height while a field is coded */
+    rc = jmhip_ctx_create(&cfg, &g);
+    if (rc) { fprintf(stderr, "jm_shim: jmhip_ctx_create: %s\n", jmhip_strerror(rc)); exit(96); }
+    g_w = cfg.width; g_h = cfg.height;
+  }
+  return 1;
+}
+
+static int frame_ok(StorablePicture *s)
+{
+  return ctx_ready() && s->size_x == g_w && s->size_y == g_h;
+}
+
+static int slot_find(StorablePicture *s)
+{
+  int i;
+  for (i = 0; i < MAX_SLOTS; i++) if (slots[i].pic == s) return i;
+  return -1;
+}
+
+static int slot_assign(StorablePicture *s)
+{
+  int i = slot_find(s), k;
+  if (i < 0) for (i = 0, k = 1; k < MAX_SLOTS; k++) if (slots[k].stamp < slots[i].stamp) i = k;   /* least recently built */
+  slots[i].pic = s; slots[i].stamp = ++slot_clock; slots[i].has_chroma = 0;
+  return i;
+}
+
+/* the source picture: uploaded once per coded picture */
+static int cur_ready(void)
+{
+  static struct { void *enc; int number, bfr, type; imgpel *y; } key;
+  if (!g || img->structure != FRAME || img->MbaffFrameFlag || img->width != g_w || img->height != g_h) return 0;
+  if (key.enc != (void *)enc_picture || key.number != img->number || key.bfr != img->b_frame_to_code || key.type != img->type ||
+      key.y != pCurImg[0]) {
+    OK(jmhip_cur_upload(g, pCurImg[0], img->yuv_format != YUV400 ? imgUV_org[0][0] : NULL,
+                        img->yuv_format != YUV400 ? imgUV_org[1][0] : NULL, (int)sizeof(imgpel), img->width, img->width_cr, 0));
+    key.enc = enc_picture; key.number = img->number; key.bfr = img->b_frame_to_code; key.type = img->type; key.y = pCurImg[0];
+  }
+  return 1;
+}
+
+/* JM's search functions leave these globals set (me_fullsearch.c:80-107, :378-403; me_fullfast.c:517-547) and later
+ * code depends on it: OneComponentLumaPrediction reads width_pad/height_pad through UMVLine4X BEFORE assigning them
+ * (macroblock.c:816-819). */
+static void jm_side_effects(StorablePicture *rp)
+{
+  ref_pic_sub.luma = rp->p_curr_img_sub;
+  width_pad = rp->size_x_pad; height_pad = rp->size_y_pad;
+}
+
+/* ------------------------------------------------------------------ sub-pel planes */
+
+void getSubImagesLuma(StorablePicture *s)
+{
+  static void (*orig)(StorablePicture *);
+  static imgpel *tmp; static size_t tmp_n;
+  if (!(shim_mask & 0x01) || !frame_ok(s) || s->p_curr_img != s->imgY) {
+    /* (4:4:4 independent planes interpolate U/V through this function too: left to JM) */
+    int i = slot_find(s);
+    if (i >= 0) slots[i].pic = NULL;
+    if (!orig) orig = next_sym("getSubImagesLuma");
+    n_fwd[S_LUMA]++; orig(s); return;
+  }
+  {
+    const int Wp = s->size_x_padded, Hp = s->size_y_padded;
+    const size_t need = (size_t)16 * Wp * Hp;
+    int slot = slot_assign(s), p, j;
+    if (tmp_n < need) { free(tmp); tmp = malloc(need * sizeof(imgpel)); tmp_n = need; }
+    /* UnifiedOneForthPix calls this on the finished picture, chroma included (image.c:1642-1659) */
+    OK(jmhip_ref_upload(g, slot, s->imgY[0], img->yuv_format != YUV400 ? s->imgUV[0][0] : NULL,
+                        img->yuv_format != YUV400 ? s->imgUV[1][0] : NULL, (int)sizeof(imgpel), s->size_x, s->size_x_cr, 0));
+    OK(jmhip_interp_luma(g, slot));
+    OK(jmhip_ref_download_luma(g, slot, tmp, (int)sizeof(imgpel)));      /* JM's own MC reads imgY_sub */
+    for (p = 0; p < 16; p++)
+      for (j = 0; j < Hp; j++)
+        memcpy(s->p_curr_img_sub[p >> 2][p & 3][j], tmp + ((size_t)p * Hp + j) * Wp, sizeof(imgpel) * Wp);
+    n_dev[S_LUMA]++;
+  }
+}
+
+void getSubImagesChroma(StorablePicture *s)
+{
+  static void (*orig)(StorablePicture *);
+  static imgpel *tmp; static size_t tmp_n;
+  int slot = g ? slot_find(s) : -1;
+  if (!(shim_mask & 0x01) || slot < 0 || img->yuv_format == YUV400) {
+    if (!orig) orig = next_sym("getSubImagesChroma");
+    n_fwd[S_CHROMA]++; orig(s); return;
+  }
+  {
+    const int sub_x = img->yuv_format == YUV444 ? 4 : 8, sub_y = img->yuv_format == YUV420 ? 8 : 4;
+    const int Wcp = s->size_x_cr + 2 * img_pad_size_uv_x, Hcp = s->size_y_cr + 2 * img_pad_size_uv_y;
+    const size_t need = (size_t)sub_x * sub_y * Wcp * Hcp;
+    int uv, p, j;
+    if (tmp_n < need) { free(tmp); tmp = malloc(need * sizeof(imgpel)); tmp_n = need; }
+    OK(jmhip_interp_chroma(g, slot));
+    for (uv = 0; uv < 2; uv++) {
+      OK(jmhip_ref_download_chroma(g, slot, uv, tmp, (int)sizeof(imgpel)));
+      for (p = 0; p < sub_x * sub_y; p++)
+        for (j = 0; j < Hcp; j++)
+          memcpy(s->imgUV_sub[uv][p / sub_x][p % sub_x][j], tmp + ((size_t)p * Hcp + j) * Wcp, sizeof(imgpel) * Wcp);
+    }
+    slots[slot].has_chroma = 1;
+    n_dev[S_CHROMA]++;
+  }
+}
+
+/* ------------------------------------------------------------------ motion search */
+
+static int partition_of(int blocktype, int x, int y)     /* (x, y): block origin inside the macroblock, pel */
+{
+  static int tab[8][16], built;
+  if (!built) {
+    int p, bt, x4, y4, w4, h4;
+    memset(tab, -1, sizeof(tab));
+    for (p = 0; p < JMHIP_NPART; p++) { jmhip_partition_info(p, &bt, &x4, &y4, &w4, &h4); tab[bt][y4 * 4 + x4] = p; }
+    built = 1;
+  }
+  if (blocktype < 1 || blocktype > 7 || (x & 3) || (y & 3) || x < 0 || y < 0 || x > 12 || y > 12) return -1;
+  return tab[blocktype][(y >> 2) * 4 + (x >> 2)];
+}
+
+/* what the device search covers: luma-only SAD (integer) / SATD (sub-pel), no weighted ME, frame pictures */
+static int me_ok(short ref, int list, StorablePicture **rp, int *slot)
+{
+  int list_offset = img->mb_data[img->current_mb_nr].list_offset;
+  int weighted = ((active_pps->weighted_pred_flag && (img->type == P_SLICE || img->type == SP_SLICE)) ||
+                  (active_pps->weighted_bipred_idc && (img->type == B_SLICE))) && input->UseWeightedReferenceME;
+  if (weighted || input->ChromaMEEnable || list_offset) return 0;
+  if (input->MEErrorMetric[F_PEL] != ERROR_SAD || input->MEErrorMetric[H_PEL] != ERROR_SATD || input->MEErrorMetric[Q_PEL] != ERROR_SATD) return 0;
+  if (!cur_ready()) return 0;
+  *rp = listX[list][ref];
+  *slot = slot_find(*rp);
+  return *slot >= 0;
+}
+
+static void me_params(jmhip_me_params *prm, int mode, int range, int lam_f, int lam_h, int lam_q, int p)
+{
+  memset(prm, 0, sizeof(*prm));
+  prm->search_mode = mode; prm->search_range = range; prm->rdopt = input->rdopt; prm->is_b_slice = (img->type == B_SLICE);
+  prm->level_mv_min = LEVELMVLIMIT[img->LevelIndex][0]; prm->level_mv_max = LEVELMVLIMIT[img->LevelIndex][1];
+  prm->lambda[0] = lam_f; prm->lambda[1] = lam_h; prm->lambda[2] = lam_q;
+  prm->transform8x8_mode = input->Transform8x8Mode; prm->subpel = 0;
+  prm->partition_mask = 1ull << p;
+}
+
+int FullPelBlockMotionSearch(imgpel *orig_pic, short ref, int list, int pic_pix_x, int pic_pix_y, int blocktype,
+                             short pred_mv_x, short pred_mv_y, short *mv_x, short *mv_y, int search_range,
+                             int min_mcost, int lambda_factor)
+{
+  static int (*orig)(imgpel *, short, int, int, int, int, short, short, short *, short *, int, int, int);
+  StorablePicture *rp; int slot, p = -1, ok;
+  ok = (shim_mask & 0x04) && min_mcost == INT_MAX && search_range <= input->search_range && me_ok(ref, list, &rp, &slot) &&
+       (p = partition_of(blocktype, pic_pix_x - img->opix_x, pic_pix_y - img->opix_y)) >= 0;
+  if (ok) {
+    /* the device derives the search centre from the predictor like BlockMotionSearch does (mv-search.c:752-762);
+       any other caller-supplied centre is JM's business */
+    int cx = pred_mv_x / 4, cy = pred_mv_y / 4;
+    if (!input->rdopt) { cx = iClip3(-search_range, search_range, cx); cy = iClip3(-search_range, search_range, cy); }
+    cx = iClip3(-2047 + search_range, 2047 - search_range, cx);
+    cy = iClip3(LEVELMVLIMIT[img->LevelIndex][0] + search_range, LEVELMVLIMIT[img->LevelIndex][1] - search_range, cy);
+    ok = (cx == *mv_x && cy == *mv_y);
+  }
+  if (!ok) {
+    if (!orig) orig = next_sym("FullPelBlockMotionSearch");
+    n_fwd[S_FULL]++;
+    return orig(orig_pic, ref, list, pic_pix_x, pic_pix_y, blocktype, pred_mv_x, pred_mv_y, mv_x, mv_y, search_range, min_mcost, lambda_factor);
+  }
+  {
+    jmhip_me_params prm; jmhip_me_mb mb; jmhip_me_result r;
+    me_params(&prm, JMHIP_SEARCH_FULL, search_range, lambda_factor, 0, 0, p);
+    memset(&mb, 0, sizeof(mb));
+    mb.mb_x = img->opix_x >> 4; mb.mb_y = img->opix_y >> 4; mb.ref = slot; mb.ref_is_0 = (ref == 0);
+    mb.pred_mv[p][0] = pred_mv_x; mb.pred_mv[p][1] = pred_mv_y;
+    jm_side_effects(rp);
+    OK(jmhip_me_frame(g, &prm, &mb, 1, &r));
+    if (verify) {
+      short jx = *mv_x, jy = *mv_y; int c;
+      if (!orig) orig = next_sym("FullPelBlockMotionSearch");
+      c = orig(orig_pic, ref, list, pic_pix_x, pic_pix_y, blocktype, pred_mv_x, pred_mv_y, &jx, &jy, search_range, min_mcost, lambda_factor);
+      if (c != r.cost_int[p] || jx != r.mv_int[p][0] || jy != r.mv_int[p][1])
+        fprintf(stderr, "jm_shim VERIFY FullPel: type=%d ref=%d list=%d pix=(%d,%d) bt=%d pred=(%d,%d) ctr=(%d,%d) R=%d lam=%d: jm=(%d,%d,%d) dev=(%d,%d,%d)\n",
+                img->type, ref, list, pic_pix_x, pic_pix_y, blocktype, pred_mv_x, pred_mv_y, *mv_x, *mv_y, search_range, lambda_factor,
+                jx, jy, c, r.mv_int[p][0], r.mv_int[p][1], r.cost_int[p]);
+    }
+    *mv_x = r.mv_int[p][0]; *mv_y = r.mv_int[p][1];
+    n_dev[S_FULL]++;
+    return r.cost_int[p];
+  }
+}
+
+int SubPelBlockMotionSearch(imgpel *orig_pic, short ref, int list, int pic_pix_x, int pic_pix_y, int blocktype,
+                            short pred_mv_x, short pred_mv_y, short *mv_x, short *mv_y, int search_pos2,
+                            int search_pos4, int min_mcost, int *lambda)
+{
+  static int (*orig)(imgpel *, short, int, int, int, int, short, short, short *, short *, int, int, int, int *);
+  StorablePicture *rp; int slot, p = -1, ok;
+  ok = (shim_mask & 0x04) && min_mcost == INT_MAX && search_pos2 == 9 && search_pos4 == 9 && !((*mv_x | *mv_y) & 3) &&
+       me_ok(ref, list, &rp, &slot) && (p = partition_of(blocktype, pic_pix_x - img->opix_x, pic_pix_y - img->opix_y)) >= 0 &&
+       test8x8transform == (input->Transform8x8Mode && blocktype <= 4);
+  if (!ok) {
+    if (!orig) orig = next_sym("SubPelBlockMotionSearch");
+    n_fwd[S_SUB]++;
+    return orig(orig_pic, ref, list, pic_pix_x, pic_pix_y, blocktype, pred_mv_x, pred_mv_y, mv_x, mv_y, search_pos2, search_pos4, min_mcost, lambda);
+  }
+  {
+    jmhip_me_params prm; jmhip_me_mb mb; jmhip_me_result r;
+    me_params(&prm, JMHIP_SEARCH_FULL, input->search_range, lambda[F_PEL], lambda[H_PEL], lambda[Q_PEL], p);
+    prm.subpel = 1;
+    memset(&mb, 0, sizeof(mb)); memset(&r, 0, sizeof(r));
+    mb.mb_x = img->opix_x >> 4; mb.mb_y = img->opix_y >> 4; mb.ref = slot; mb.ref_is_0 = (ref == 0);
+    mb.pred_mv[p][0] = pred_mv_x; mb.pred_mv[p][1] = pred_mv_y;
+    r.mv_int[p][0] = *mv_x >> 2; r.mv_int[p][1] = *mv_y >> 2;
+    jm_side_effects(rp);
+    OK(jmhip_me_subpel(g, &prm, &mb, 1, &r));
+    if (verify) {
+      short jx = *mv_x, jy = *mv_y; int c;
+      if (!orig) orig = next_sym("SubPelBlockMotionSearch");
+      c = orig(orig_pic, ref, list, pic_pix_x, pic_pix_y, blocktype, pred_mv_x, pred_mv_y, &jx, &jy, search_pos2, search_pos4, min_mcost, lambda);
+      if (c != r.cost[p] || jx != r.mv[p][0] || jy != r.mv[p][1])
+        fprintf(stderr, "jm_shim VERIFY SubPel: type=%d ref=%d list=%d pix=(%d,%d) bt=%d pred=(%d,%d) in=(%d,%d) lam=%d,%d t8=%d: jm=(%d,%d,%d) dev=(%d,%d,%d)\n",
+                img->type, ref, list, pic_pix_x, pic_pix_y, blocktype, pred_mv_x, pred_mv_y, *mv_x, *mv_y, lambda[1], lambda[2], test8x8transform,
+                jx, jy, c, r.mv[p][0], r.mv[p][1], r.cost[p]);
+    }
+    *mv_x = r.mv[p][0]; *mv_y = r.mv[p][1];
+    n_dev[S_SUB]++;
+    return r.cost[p];
+  }
+}
+
+/* SetupFastFullPelSearch runs once per (macroblock, list, ref) around the 16x16 predictor (me_fullfast.c:491-566);
+ * the per-block calls reuse that centre. ResetFastFullIntegerSearch marks a new macroblock. */
+static struct { int done; short pmv[2]; } ff_state[2][MAX_SLOTS];
+
+void ResetFastFullIntegerSearch(void)
+{
+  static void (*orig)(void);
+  if (!orig) orig = next_sym("ResetFastFullIntegerSearch");
+  orig();
+  memset(ff_state, 0, sizeof(ff_state));
+}
+
+int FastFullPelBlockMotionSearch(imgpel *orig_pic, short ref, int list, int pic_pix_x, int pic_pix_y, int blocktype,
+                                 short pred_mv_x, short pred_mv_y, short *mv_x, short *mv_y, int search_range,
+                                 int min_mcost, int lambda_factor)
+{
+  static int (*orig)(imgpel *, short, int, int, int, int, short, short, short *, short *, int, int, int);
+  StorablePicture *rp; int slot, p = -1, ok;
+  ok = (shim_mask & 0x08) && min_mcost == INT_MAX && ref < MAX_SLOTS && list < 2 && me_ok(ref, list, &rp, &slot) &&
+       (p = partition_of(blocktype, pic_pix_x - img->opix_x, pic_pix_y - img->opix_y)) >= 0;
+  if (ok && !ff_state[list][ref].done) {
+    SetMotionVectorPredictor(ff_state[list][ref].pmv, enc_picture->ref_idx[list], enc_picture->mv[list], ref, list, 0, 0, 16, 16);
+    ff_state[list][ref].done = 1;
+  }
+  /* the 16x16 block is searched with the predictor the window was centred on */
+  if (ok && p == 0 && (pred_mv_x != ff_state[list][ref].pmv[0] || pred_mv_y != ff_state[list][ref].pmv[1])) ok = 0;
+  if (!ok) {
+    if (!orig) orig = next_sym("FastFullPelBlockMotionSearch");
+    n_fwd[S_FAST]++;
+    return orig(orig_pic, ref, list, pic_pix_x, pic_pix_y, blocktype, pred_mv_x, pred_mv_y, mv_x, mv_y, search_range, min_mcost, lambda_factor);
+  }
+  {
+    /* range per reference as InitializeFastFullIntegerSearch, me_fullfast.c:127-140 */
+    int R = (input->full_search == 2 || ref == 0) ? input->search_range : input->search_range / 2;
+    jmhip_me_params prm; jmhip_me_mb mb; jmhip_me_result r;
+    me_params(&prm, JMHIP_SEARCH_FASTFULL, R, lambda_factor, 0, 0, p);
+    memset(&mb, 0, sizeof(mb));
+    mb.mb_x = img->opix_x >> 4; mb.mb_y = img->opix_y >> 4; mb.ref = slot; mb.ref_is_0 = (ref == 0);
+    mb.pred_mv[0][0] = ff_state[list][ref].pmv[0]; mb.pred_mv[0][1] = ff_state[list][ref].pmv[1];   /* the window centre */
+    mb.pred_mv[p][0] = pred_mv_x; mb.pred_mv[p][1] = pred_mv_y;
+    jm_side_effects(rp);
+    OK(jmhip_me_frame(g, &prm, &mb, 1, &r));
+    if (verify) {
+      short jx = *mv_x, jy = *mv_y; int c;
+      if (!orig) orig = next_sym("FastFullPelBlockMotionSearch");
+      c = orig(orig_pic, ref, list, pic_pix_x, pic_pix_y, blocktype, pred_mv_x, pred_mv_y, &jx, &jy, search_range, min_mcost, lambda_factor);
+      if (c != r.cost_int[p] || jx != r.mv_int[p][0] || jy != r.mv_int[p][1])
+        fprintf(stderr, "jm_shim VERIFY FastFull: type=%d ref=%d list=%d pix=(%d,%d) bt=%d pred=(%d,%d) lam=%d: jm=(%d,%d,%d) dev=(%d,%d,%d)\n",
+                img->type, ref, list, pic_pix_x, pic_pix_y, blocktype, pred_mv_x, pred_mv_y, lambda_factor, jx, jy, c, r.mv_int[p][0], r.mv_int[p][1], r.cost_int[p]);
+    }
+    *mv_x = r.mv_int[p][0]; *mv_y = r.mv_int[p][1];
+    n_dev[S_FAST]++;
+    return r.cost_int[p];
+  }
+}
+
+/* ------------------------------------------------------------------ transform + quantisation + reconstruction */
+
+static void fill_quant(jmhip_quant *q, int qp, int **levelscale, int **invlevelscale, int **leveloffset, int n,
+                       Macroblock *currMB, int weight, int max_val)
+{
+  int j, i;
+  memset(q, 0, sizeof(*q));
+  for (j = 0; j < n; j++) for (i = 0; i < n; i++) {
+    q->levelscale[j * n + i] = levelscale[j][i]; q->invlevelscale[j * n + i] = invlevelscale[j][i]; q->leveloffset[j * n + i] = leveloffset[j][i];
+  }
+  q->qp = qp; q->adaptive_rounding = img->AdaptiveRounding; q->adapt_rnd_weight = weight;
+  q->field_scan = currMB->is_field_mode; q->disthres = input->disthres;
+  q->max_val = max_val; q->cavlc = (input->symbol_mode == CAVLC); q->img_qp = img->qp;
+  q->transform8x8_flag = currMB->luma_transform_size_8x8_flag;
+}
+
+/* job tiles: src = m7 + mpr (the original samples where the block is coded; elsewhere JM's m7 may be stale and the
+ * value is irrelevant: every block of a job is computed on its own). Returns 0 if a coded sample leaves 8 bits. */
+static int fill_tiles(jmhip_tq_job *job, int (*m7)[16], imgpel (*mpr)[16], int x0, int y0, int w, int h)
+{
+  int j, i, ok = 1;
+  for (j = 0; j < 16; j++) for (i = 0; i < 16; i++) {
+    int s = m7[j][i] + mpr[j][i], in = (j >= y0 && j < y0 + h && i >= x0 && i < x0 + w);
+    if (in && (s < 0 || s > 255 || mpr[j][i] > 255)) ok = 0;
+    job->src[j][i] = (uint8_t)(s < 0 ? 0 : s > 255 ? 255 : s);
+    job->pred[j][i] = (uint8_t)mpr[j][i];
+  }
+  return ok;
+}
+
+static void put_list(int *lev_dst, int *run_dst, const int32_t *lev, const int32_t *run, int max)
+{
+  int k;
+  for (k = 0; k < max; k++) { lev_dst[k] = lev[k]; run_dst[k] = run[k]; if (!lev[k]) break; }
+}
+
+int dct_4x4(Macroblock *currMB, ColorPlane pl, int block_x, int block_y, int *coeff_cost, int intra)
+{
+  static int (*orig)(Macroblock *, ColorPlane, int, int, int *, int);
+  static jmhip_tq_job job; static jmhip_tq_result res; static jmhip_quant q;
+  int ok = (shim_mask & 0x10) && ctx_ready() && !(currMB->qp_scaled[pl] == 0 && img->lossless_qpprime_flag == 1) &&
+           img->type != SP_SLICE;
+  if (ok) ok = fill_tiles(&job, img->m7[pl], img->mpr[pl], block_x, block_y, 4, 4);
+  if (!ok) {
+    if (!orig) orig = next_sym("dct_4x4");
+    n_fwd[S_D4]++;
+    return orig(currMB, pl, block_x, block_y, coeff_cost, intra);
+  }
+  {
+    int qp = currMB->qp_scaled[pl], qp_rem = qp_rem_matrix[qp], j, i;
+    int pos_x = block_x >> 2, pos_y = block_y >> 2;
+    int b8 = 2 * (pos_y >> 1) + (pos_x >> 1), b4 = 2 * (pos_y & 1) + (pos_x & 1), blk = b8 * 4 + b4;
+    int **fa = img->AdaptiveRounding ? (pl ? img->fadjust4x4Cr[pl - 1][intra] : img->fadjust4x4[intra]) : NULL;
+    imgpel **img_enc = enc_picture->p_curr_img;
+    fill_quant(&q, qp, LevelScale4x4Comp[pl][intra][qp_rem], InvLevelScale4x4Comp[pl][intra][qp_rem],
+               ptLevelOffset4x4[intra][qp], 4, currMB, AdaptRndWeight, img->max_imgpel_value);
+    job.quant = 0;
+    OK(jmhip_tq_batch(g, JMHIP_TQ_LUMA4x4, img->yuv_format, &q, 1, &job, 1, &res));
+    put_list(img->cofAC[b8 + (pl << 2)][b4][0], img->cofAC[b8 + (pl << 2)][b4][1], res.levels[blk], res.runs[blk], 17);
+    *coeff_cost += res.coeff_cost[blk];
+    for (j = block_y; j < block_y + 4; j++) for (i = block_x; i < block_x + 4; i++) {
+      img_enc[img->pix_y + j][img->pix_x + i] = res.recon[j][i];
+      if (fa) fa[j][i] = res.fadjust[j][i];
+    }
+    n_dev[S_D4]++;
+    return res.nonzero[blk];
+  }
+}
+
+int dct_8x8(Macroblock *currMB, ColorPlane pl, int b8, int *coeff_cost, int intra)
+{
+  static int (*orig)(Macroblock *, ColorPlane, int, int *, int);
+  static jmhip_tq_job job; static jmhip_tq_result res; static jmhip_quant q;
+  int block_x = 8 * (b8 & 1), block_y = 8 * (b8 >> 1);
+  int ok = (shim_mask & 0x20) && ctx_ready() && !(currMB->qp_scaled[pl] == 0 && img->lossless_qpprime_flag == 1) &&
+           img->type != SP_SLICE;
+  if (ok) ok = fill_tiles(&job, img->m7[pl], img->mpr[pl], block_x, block_y, 8, 8);
+  if (!ok) {
+    if (!orig) orig = next_sym("dct_8x8");
+    n_fwd[S_D8]++;
+    return orig(currMB, pl, b8, coeff_cost, intra);
+  }
+  {
+    int qp = currMB->qp_scaled[pl], qp_rem = qp_rem_matrix[qp], j, i, k;
+    int **fa = img->AdaptiveRounding ? (pl ? img->fadjust8x8Cr[pl - 1][intra] : img->fadjust8x8[intra]) : NULL;
+    imgpel **img_enc = enc_picture->p_curr_img;
+    fill_quant(&q, qp, LevelScale8x8Comp[pl][intra][qp_rem], InvLevelScale8x8Comp[pl][intra][qp_rem],
+               LevelOffset8x8Comp[pl][intra][qp], 8, currMB, AdaptRndWeight, img->max_imgpel_value);
+    job.quant = 0;
+    OK(jmhip_tq_batch(g, JMHIP_TQ_LUMA8x8, img->yuv_format, &q, 1, &job, 1, &res));
+    if (q.transform8x8_flag && q.cavlc)          /* four interleaved 4x4 lists, transform8x8.c:1560-1580 */
+      for (k = 0; k < 4; k++)
+        put_list(img->cofAC[b8 + (pl << 2)][k][0], img->cofAC[b8 + (pl << 2)][k][1], res.levels[4 * b8 + k], res.runs[4 * b8 + k], 17);
+    else
+      put_list(img->cofAC[b8 + (pl << 2)][0][0], img->cofAC[b8 + (pl << 2)][0][1], res.levels8[b8], res.runs8[b8], 65);
+    *coeff_cost += res.coeff_cost[b8];
+    for (j = block_y; j < block_y + 8; j++) for (i = block_x; i < block_x + 8; i++) {
+      img_enc[img->pix_y + j][img->pix_x + i] = res.recon[j][i];
+      if (fa) fa[j][i] = res.fadjust[j][i];
+    }
+    n_dev[S_D8]++;
+    return res.nonzero[b8];
+  }
+}
+
+int dct_16x16(Macroblock *currMB, ColorPlane pl, int new_intra_mode)
+{
+  static int (*orig)(Macroblock *, ColorPlane, int);
+  static jmhip_tq_job job; static jmhip_tq_result res; static jmhip_quant q;
+  int ok = (shim_mask & 0x10) && ctx_ready() && pl == 0 &&
+           !(currMB->qp_scaled[pl] == 0 && img->lossless_qpprime_flag == 1) && img->type != SP_SLICE;
+  if (!ok) {
+    if (!orig) orig = next_sym("dct_16x16");
+    n_fwd[S_D16]++;
+    return orig(currMB, pl, new_intra_mode);
+  }
+  {
+    int qp = currMB->qp_scaled[pl], qp_rem = qp_rem_matrix[qp], j, i, b;
+    int **fa = img->AdaptiveRounding ? img->fadjust4x4[2] : NULL;
+    imgpel **img_enc = enc_picture->p_curr_img;
+    fill_quant(&q, qp, LevelScale4x4Comp[pl][1][qp_rem], InvLevelScale4x4Comp[pl][1][qp_rem],
+               ptLevelOffset4x4[1][qp], 4, currMB, AdaptRndWeight, img->max_imgpel_value);
+    for (j = 0; j < 16; j++) for (i = 0; i < 16; i++) {
+      job.src[j][i] = (uint8_t)pCurImg[img->opix_y + j][img->opix_x + i];
+      job.pred[j][i] = (uint8_t)img->mpr_16x16[pl][new_intra_mode][j][i];
+    }
+    job.quant = 0;
+    OK(jmhip_tq_batch(g, JMHIP_TQ_LUMA16x16, img->yuv_format, &q, 1, &job, 1, &res));
+    put_list(img->cofDC[pl][0], img->cofDC[pl][1], res.dc_levels, res.dc_runs, 17);
+    for (b = 0; b < 16; b++) put_list(img->cofAC[(b >> 2) + (pl << 2)][b & 3][0], img->cofAC[(b >> 2) + (pl << 2)][b & 3][1], res.levels[b], res.runs[b], 16);
+    for (j = 0; j < 16; j++) for (i = 0; i < 16; i++) {
+      img_enc[img->pix_y + j][img->pix_x + i] = res.recon[j][i];
+      if (fa && ((j | i) & 3)) fa[j][i] = res.fadjust[j][i];      /* JM leaves the DC positions alone, block.c:690-720 */
+    }
+    n_dev[S_D16]++;
+    return res.ret;
+  }
+}
+
+int dct_chroma(Macroblock *currMB, int uv, int cr_cbp)
+{
+  static int (*orig)(Macroblock *, int, int);
+  static jmhip_tq_job job; static jmhip_tq_result res; static jmhip_quant q[2];
+  int ok = (shim_mask & 0x40) && ctx_ready() && img->yuv_format != YUV444 && img->yuv_format != YUV400 &&
+           !((currMB->qp + img->bitdepth_luma_qp_scale) == 0 && img->lossless_qpprime_flag == 1) && img->type != SP_SLICE;
+  if (ok) ok = fill_tiles(&job, img->m7[uv + 1], img->mpr[uv + 1], 0, 0, img->mb_cr_size_x, img->mb_cr_size_y);
+  if (!ok) {
+    if (!orig) orig = next_sym("dct_chroma");
+    n_fwd[S_DCR]++;
+    return orig(currMB, uv, cr_cbp);
+  }
+  {
+    int intra = IS_INTRA(currMB), j, i, b;
+    int cur_qp = currMB->qpc[uv] + img->bitdepth_chroma_qp_scale;
+    int cur_qp_dc = currMB->qpc[uv] + 3 + img->bitdepth_chroma_qp_scale;
+    int nb = (img->num_blk8x8_uv >> 1) * 4, uv_scale = uv * (img->num_blk8x8_uv >> 1);
+    int **fa = img->AdaptiveRounding ? img->fadjust4x4Cr[intra][uv] : NULL;
+    fill_quant(&q[0], cur_qp, LevelScale4x4Comp[uv + 1][intra][qp_rem_matrix[cur_qp]],
+               InvLevelScale4x4Comp[uv + 1][intra][qp_rem_matrix[cur_qp]], LevelOffset4x4Comp[uv + 1][intra][cur_qp],
+               4, currMB, AdaptRndCrWeight, img->max_imgpel_value_comp[1]);
+    q[1] = q[0];
+    if (img->yuv_format == YUV422)
+      fill_quant(&q[1], cur_qp_dc, LevelScale4x4Comp[uv + 1][intra][qp_rem_matrix[cur_qp_dc]],
+                 InvLevelScale4x4Comp[uv + 1][intra][qp_rem_matrix[cur_qp_dc]], LevelOffset4x4Comp[uv + 1][intra][cur_qp_dc],
+                 4, currMB, AdaptRndCrWeight, img->max_imgpel_value_comp[1]);
+    job.quant = 0; job.quant_dc = 1; job.uv = uv; job.cr_cbp_in = cr_cbp;
+    OK(jmhip_tq_batch(g, JMHIP_TQ_CHROMA, img->yuv_format, q, 2, &job, 1, &res));
+    put_list(img->cofDC[uv + 1][0], img->cofDC[uv + 1][1], res.dc_levels, res.dc_runs, 17);
+    for (b = 0; b < nb; b++)
+      put_list(img->cofAC[4 + (b >> 2) + uv_scale][b & 3][0], img->cofAC[4 + (b >> 2) + uv_scale][b & 3][1], res.levels[b], res.runs[b], 16);
+    currMB->cbp_blk = (currMB->cbp_blk & ~res.cbp_clear) | res.cbp_blk;
+    for (j = 0; j < img->mb_cr_size_y; j++) for (i = 0; i < img->mb_cr_size_x; i++) {
+      enc_picture->imgUV[uv][img->pix_c_y + j][img->pix_c_x + i] = res.recon[j][i];
+      if (fa && ((j | i) & 3)) fa[j][i] = res.fadjust[j][i];      /* AC positions only, block.c:1321-1380 */
+    }
+    n_dev[S_DCR]++;
+    return res.ret;
+  }
+}

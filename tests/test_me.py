@@ -105,6 +105,16 @@ def test_me_fast_kernel_range32(pkg, kind, mode, rdopt, per_partition, spread):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("R,per_partition,spread", [(8, True, 0), (8, True, 3), (32, False, 0), (32, False, 2)])
+def test_full_search_wrapped_early_exit_bound_at_picture_origin(pkg, R, per_partition, spread):
+    """rdopt off, predictor within +-3 quarter-pels at macroblock (0,0): the check_for_00 bonus makes the first
+    candidate's motion cost negative, JM's early-exit bound INT_MAX - mcost wraps, and computeSAD returns after one
+    row (me_fullsearch.c:129-138). The real encoder does this on every P picture's first macroblock; the moving clip
+    makes the one-row cost win against the true motion, so a device that computed the full SAD would be caught."""
+    run_case(pkg, 96, 64, "shift", -1, R, 0, spread, per_partition=per_partition, seed=41 + spread)
+
+
+@pytest.mark.gpu
 def test_me_mixed_fast_and_generic_macroblocks(pkg):
     """FullSearch where some MBs have one predictor (fast kernel) and others per-partition predictors (generic)."""
     rng = np.random.default_rng(5)
