@@ -52,11 +52,12 @@ __device__ __forceinline__ uint32_t fetch4(const uint8_t *p)
 
 __global__ __launch_bounds__(64) void mc_kernel(FrameDev F, const jmhip_me_mb *__restrict__ mbs, const jmhip_me_result *__restrict__ me,
                                                const jmhip_mb_mode *__restrict__ modes_in, jmhip_mb_mode *__restrict__ modes_out,
-                                               jmhip_tq_job *__restrict__ jobs_y, jmhip_tq_job *__restrict__ jobs_c)
+                                               jmhip_tq_job *__restrict__ jobs_y, jmhip_tq_job *__restrict__ jobs_c, int n_items)
 {
   __shared__ jmhip_mb_mode s_mode;
   __shared__ short s_mv[16][2];
-  const int i = blockIdx.x, tid = threadIdx.x;
+  const int i = jm_xcd_item(n_items), tid = threadIdx.x;
+  if (i < 0) return;
   const jmhip_me_mb &mb = mbs[i];
   const jmhip_me_result &r = me[i];
   const int mbx = mb.mb_x, mby = mb.mb_y;
@@ -276,8 +277,8 @@ extern "C" int jmhip_residual_frame(jmhip_ctx *c, const jmhip_mb_mode *modes, co
   F.rec_y = c->rec_y; F.rec_u = c->rec_u; F.rec_v = c->rec_v;
 
   jm_stage_begin(c, JMHIP_STAGE_MC);
-  mc_kernel<<<n, 64, 0, c->stream>>>(F, (const jmhip_me_mb *)c->me_jobs_dev, (const jmhip_me_result *)c->me_res_dev, modes_in_dev, modes_out_dev,
-                                     (jmhip_tq_job *)c->fr_jobs_y, (jmhip_tq_job *)c->fr_jobs_c);
+  mc_kernel<<<jm_xcd_grid(n), 64, 0, c->stream>>>(F, (const jmhip_me_mb *)c->me_jobs_dev, (const jmhip_me_result *)c->me_res_dev, modes_in_dev, modes_out_dev,
+                                                  (jmhip_tq_job *)c->fr_jobs_y, (jmhip_tq_job *)c->fr_jobs_c, n);
   jm_stage_end(c, JMHIP_STAGE_MC);
   JM_HIP_CHECK(c, hipGetLastError());
   jm_stage_begin(c, JMHIP_STAGE_TQ);

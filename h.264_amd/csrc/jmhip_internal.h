@@ -81,3 +81,14 @@ int jm_launch_interp_luma(jmhip_ctx *ctx, int ref);
 int jm_launch_interp_chroma(jmhip_ctx *ctx, int ref);
 int jm_launch_tq(jmhip_ctx *ctx, int kind, int yuv_format, const void *jobs, const void *quants, void *results, int n);
 int jm_ensure_ref_table(jmhip_ctx *ctx);
+
+// Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8) and every XCD has its own L2. Kernels whose neighbouring
+// work items share data (adjacent macroblocks: overlapping reference windows) take their item through this mapping, which
+// hands each XCD one contiguous run of items. Launch jm_xcd_grid(n) workgroups; blocks past the end get -1 and leave.
+static inline int jm_xcd_grid(int n) { return ((n + 7) / 8) * 8; }
+__device__ __forceinline__ int jm_xcd_item(int n)
+{
+  const int per = (n + 7) >> 3;
+  const int i = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  return i < n ? i : -1;
+}

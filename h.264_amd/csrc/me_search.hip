@@ -118,8 +118,10 @@ __device__ __forceinline__ void wrapped_bound_00(const MeDev &P, const jmhip_me_
 }
 
 __global__ __launch_bounds__(256) void me_int_kernel(MeDev P, const jmhip_me_mb *__restrict__ jobs, const int *__restrict__ job_index,
-                                                     jmhip_me_result *__restrict__ res_all)
+                                                     jmhip_me_result *__restrict__ res_all, int n_items)
 {
+  const int item = jm_xcd_item(n_items);
+  if (item < 0) return;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ int s_cx[JMHIP_NPART], s_cy[JMHIP_NPART], s_px[JMHIP_NPART], s_py[JMHIP_NPART];
   __shared__ int s_u[8];                           // umin_x, umin_y, UW, UH, uniform
@@ -127,9 +129,9 @@ __global__ __launch_bounds__(256) void me_int_kernel(MeDev P, const jmhip_me_mb 
   __shared__ unsigned s_red[JMHIP_NPART][4];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int mbi = job_index[blockIdx.x];
+  const int mbi = job_index[item];
   const jmhip_me_mb &job = jobs[mbi];
-  jmhip_me_result *res = res_all + mbi - blockIdx.x;   // res[blockIdx.x] below addresses macroblock mbi
+  jmhip_me_result *res = res_all + mbi;
   const int mbx = job.mb_x, mby = job.mb_y;
   const unsigned long long mask = P.mask;
 
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(256) void me_int_kernel(MeDev P, const jmhip_me_mb 
   const int umin_x = s_u[0], umin_y = s_u[1], UW = s_u[2], UH = s_u[3], uniform = s_u[4];
   const int pitch = P.win_pitch;
   // the host sized the window for the worst MB of the launch; a larger one would overflow LDS
-  if (UW + 15 > pitch || UH + 15 > P.win_rows) { if (tid < JMHIP_NPART) res[blockIdx.x].cost_int[tid] = -2; return; }
+  if (UW + 15 > pitch || UH + 15 > P.win_rows) { if (tid < JMHIP_NPART) res[0].cost_int[tid] = -2; return; }
 
   // ---- stage the reference window (integer recon, per-sample clamp == JM's padded plane + UMV origin clamp)
   {
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(256) void me_int_kernel(MeDev P, const jmhip_me_mb 
   __syncthreads();
   if (tid < JMHIP_NPART) {
     const int p = tid;
-    jmhip_me_result &o = res[blockIdx.x];
+    jmhip_me_result &o = res[0];
     if ((mask >> p) & 1) {
       const unsigned k = min(min(s_red[p][0], s_red[p][1]), min(s_red[p][2], s_red[p][3]));
       int cost = (int)(k >> TIE_BITS), tie = (int)(k & ((1u << TIE_BITS) - 1));
@@ -368,14 +370,18 @@ __device__ __forceinline__ int spiral_base_B(int dx)   // + 2*dy gives pos when 
 }
 
 __global__ __launch_bounds__(256, 2) void me_int_fast_kernel(MeDev P, const jmhip_me_mb *__restrict__ jobs, const int *__restrict__ job_index,
-                                                            jmhip_me_result *__restrict__ res)
+                                                            jmhip_me_result *__restrict__ res, int n_items)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t swin[];      // 4 shifted window copies
   __shared__ FastShared S;
+  const int item = jm_xcd_item(n_items);
+  if (item < 0) return;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   STAMP(0);
-  const int mbi = job_index[blockIdx.x];
+  // item = macroblock | representative partition << 24: one item per DISTINCT search centre of the macroblock. All 41
+  // partitions are evaluated around that centre; only those whose own centre it is are written (FastFull: all of them).
+  const int mbi = job_index[item] & 0xffffff, rep = (job_index[item] >> 24) & 63;
   const jmhip_me_mb &job = jobs[mbi];
   const int mbx = job.mb_x, mby = job.mb_y;
   const int R = P.R, UW = 2 * R + 1, UH = UW;
@@ -385,7 +391,7 @@ __global__ __launch_bounds__(256, 2) void me_int_fast_kernel(MeDev P, const jmhi
 
   if (tid == 0) {
     int cx, cy;
-    search_center(P, job.pred_mv[0][0], job.pred_mv[0][1], &cx, &cy);   // host verified: every partition yields this centre
+    search_center(P, job.pred_mv[rep][0], job.pred_mv[rep][1], &cx, &cy);
     S.cx = cx; S.cy = cy;
   }
   if (tid < JMHIP_NPART) { S.px[tid] = job.pred_mv[tid][0]; S.py[tid] = job.pred_mv[tid][1]; }
@@ -538,15 +544,20 @@ __global__ __launch_bounds__(256, 2) void me_int_fast_kernel(MeDev P, const jmhi
         }
       }
     }
+    // ---- tie = spiral index + 1 from the per-lane / per-row halves. It SEEDS the sixteen 4x4 accumulators (free: the
+    //      first v_sad_hi_u8 of a block takes it as its addend), so a partition made of k 4x4 blocks carries k*tie in the
+    //      low 16 bits of its sum: still ordered by tie, k*tie <= 8*(81*81+1) < 2^16, and the key needs no tie add.
+    const int ady = iabs(dy);
+    unsigned tie = (ady > adx) ? (unsigned)(spiral_base_A(dy) + 1 + twodx) : (unsigned)(tieB + 2 * dy);
+    if (ff00 && mvx == 0 && mvy == 0) tie = 0;
     // ---- sixteen 4x4 SADs, pre-shifted by 16 (v_sad_hi_u8)
     unsigned sad[16];
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-      constexpr int dummy = 0; (void)dummy;
       const int sl = (tt + r) & 15, b = (r >> 2) * 4;
 #pragma unroll
       for (int k = 0; k < 4; k++)
-        sad[b + k] = __builtin_amdgcn_sad_hi_u8(win[sl][k], curs[r * 4 + k], (r & 3) ? sad[b + k] : 0u);
+        sad[b + k] = __builtin_amdgcn_sad_hi_u8(win[sl][k], curs[r * 4 + k], (r & 3) ? sad[b + k] : tie);
     }
     unsigned ps[JMHIP_NPART];
 #pragma unroll
@@ -560,12 +571,8 @@ __global__ __launch_bounds__(256, 2) void me_int_fast_kernel(MeDev P, const jmhi
     }
     ps[1] = ps[5] + ps[6]; ps[2] = ps[7] + ps[8];
     ps[3] = ps[5] + ps[7]; ps[4] = ps[6] + ps[8];
-    // ---- tie = spiral index + 1 from the per-lane / per-row halves
-    const int ady = iabs(dy);
-    unsigned tie = (ady > adx) ? (unsigned)(spiral_base_A(dy) + 1 + twodx) : (unsigned)(tieB + 2 * dy);
-    if (ff00 && mvx == 0 && mvy == 0) tie = 0;
 #pragma unroll
-    for (int p = 1; p < JMHIP_NPART; p++) best[p] = min(best[p], ps[p] + mvc[p] + tie);
+    for (int p = 1; p < JMHIP_NPART; p++) best[p] = min(best[p], ps[p] + mvc[p]);
     {
       unsigned c0 = ((ps[1] >> 16) + (ps[2] >> 16)) + mvc[0];
       if (qx && 4 * (mby * 16 + mvy) == mby * 16) c0 -= (unsigned)w16;
@@ -593,9 +600,11 @@ __global__ __launch_bounds__(256, 2) void me_int_fast_kernel(MeDev P, const jmhi
     for (int c = tid; c < nrest; c += 256) {
       const int ay = c / (UW - 64), ax = 64 + (c - ay * (UW - 64));
       const int cmx = umin_x + ax, cmy = umin_y + ay;
+      unsigned tie = (unsigned)spiral_pos(cmx - ucx, cmy - ucy) + 1;
+      if (ff00 && cmx == 0 && cmy == 0) tie = 0;
       unsigned sad[16];
 #pragma unroll
-      for (int b = 0; b < 16; b++) sad[b] = 0;
+      for (int b = 0; b < 16; b++) sad[b] = tie;          // seeded like the main grid
       const uint32_t *wrow = swin + (ax & 3) * CS + ay * PITCH + (ax >> 2);
 #pragma unroll
       for (int r = 0; r < 16; r++) {
@@ -616,12 +625,10 @@ __global__ __launch_bounds__(256, 2) void me_int_fast_kernel(MeDev P, const jmhi
       }
       ps[1] = ps[5] + ps[6]; ps[2] = ps[7] + ps[8];
       ps[3] = ps[5] + ps[7]; ps[4] = ps[6] + ps[8];
-      unsigned tie = (unsigned)spiral_pos(cmx - ucx, cmy - ucy) + 1;
-      if (ff00 && cmx == 0 && cmy == 0) tie = 0;
 #pragma unroll
       for (int p = 1; p < JMHIP_NPART; p++) {
         const unsigned mc = (unsigned)mv_cost(lam, 4 * cmx - S.px[p], 4 * cmy - S.py[p]) << 16;
-        best[p] = min(best[p], ps[p] + mc + tie);
+        best[p] = min(best[p], ps[p] + mc);
       }
       unsigned c0 = ((ps[1] >> 16) + (ps[2] >> 16)) + (unsigned)mv_cost(lam, 4 * cmx - S.px[0], 4 * cmy - S.py[0]) + (unsigned)w16;
       if (quirk00 && 4 * (mbx * 16 + cmx) == mbx * 16 && 4 * (mby * 16 + cmy) == mby * 16) c0 -= (unsigned)w16;
@@ -674,14 +681,19 @@ __global__ __launch_bounds__(256, 2) void me_int_fast_kernel(MeDev P, const jmhi
       cost = (int)(unsigned)(k >> 32) - w16; tie = (int)(unsigned)k;
     } else {
       const unsigned k = min(min(S.part[p][0], S.part[p][1]), min(S.part[p][2], S.part[p][3]));
-      cost = (int)(k >> FAST_TIE_BITS); tie = (int)(k & 0xffffu);
+      const PartInfo q = c_part[p];
+      cost = (int)(k >> FAST_TIE_BITS); tie = (int)(k & 0xffffu) / (q.w4 * q.h4);      // low half holds (4x4 blocks) * tie
     }
     int rx, ry;
     if (tie == 0) { rx = 0; ry = 0; }
     else { int ddx, ddy; spiral_offset(tie - 1, &ddx, &ddy); rx = ucx + ddx; ry = ucy + ddy; }
     if (p == 0) wrapped_bound_00(P, jobs[mbi], ucx, ucy, &rx, &ry, &cost);
-    o.mv_int[p][0] = (int16_t)rx; o.mv_int[p][1] = (int16_t)ry; o.cost_int[p] = cost;
-    if (!P.subpel) { o.mv[p][0] = (int16_t)(rx << 2); o.mv[p][1] = (int16_t)(ry << 2); o.cost[p] = cost; }
+    bool mine = true;
+    if (P.mode == JMHIP_SEARCH_FULL) { int pcx, pcy; search_center(P, S.px[p], S.py[p], &pcx, &pcy); mine = (pcx == ucx && pcy == ucy); }
+    if (mine) {
+      o.mv_int[p][0] = (int16_t)rx; o.mv_int[p][1] = (int16_t)ry; o.cost_int[p] = cost;
+      if (!P.subpel) { o.mv[p][0] = (int16_t)(rx << 2); o.mv[p][1] = (int16_t)(ry << 2); o.cost[p] = cost; }
+    }
   }
   STAMP(6);
 }
@@ -731,7 +743,10 @@ __device__ __forceinline__ void fetch_row(const uint8_t *p, int n, uint32_t *lo,
 __constant__ int c_s9x[9] = {0, 0, 0, -1, 1, -1, 1, -1, 1};    // spiral positions 0..8, mv-search.c:366-393
 __constant__ int c_s9y[9] = {0, -1, 1, -1, -1, 0, 0, 1, 1};
 
-struct SubItem { int8_t p, bx, by, bs; };          // partition, sub-block origin inside the MB (pels), size 4 or 8
+// One SATD sub-block of a partition. `mem`: all items (of any partition) on the same sub-block -- the seven block types
+// tile the macroblock with the same 4x4 (8x8) blocks --, ascending, -1 padded; `memp`: their partitions.
+struct SubItem { int8_t p, bx, by, bs; int8_t mem[7], memp[7]; int8_t pad[2]; };     // 20 bytes
+static_assert(sizeof(SubItem) == 20, "SubItem is staged to LDS as 5 dwords");
 __constant__ SubItem c_sub4[112];                   // all partitions, 4x4 sub-blocks
 __constant__ SubItem c_sub8[64];                    // test8x8transform: 16 8x8 blocks (types <= 4) + 48 4x4 (types 5..7)
 SubItem h_sub4[112], h_sub8[64];
@@ -740,45 +755,130 @@ void build_sub_tables()
 {
   build_part_table();
   int n4 = 0, n8 = 0;
+  auto put = [](SubItem *t, int &n, int p, int bx, int by, int bs) {
+    SubItem s{};
+    s.p = (int8_t)p; s.bx = (int8_t)bx; s.by = (int8_t)by; s.bs = (int8_t)bs;
+    t[n++] = s;
+  };
   for (int p = 0; p < JMHIP_NPART; p++) {
     const PartInfo &q = h_part[p];
     for (int y = 0; y < q.h4; y++) for (int x = 0; x < q.w4; x++)       // computeSATD order: y outer, x inner (:673-675)
-      h_sub4[n4++] = {(int8_t)p, (int8_t)(4 * (q.x4 + x)), (int8_t)(4 * (q.y4 + y)), 4};
+      put(h_sub4, n4, p, 4 * (q.x4 + x), 4 * (q.y4 + y), 4);
     if (q.bt <= 4) {
-      for (int y = 0; y < q.h4 / 2; y++) for (int x = 0; x < q.w4 / 2; x++)
-        h_sub8[n8++] = {(int8_t)p, (int8_t)(4 * q.x4 + 8 * x), (int8_t)(4 * q.y4 + 8 * y), 8};
+      for (int y = 0; y < q.h4 / 2; y++) for (int x = 0; x < q.w4 / 2; x++) put(h_sub8, n8, p, 4 * q.x4 + 8 * x, 4 * q.y4 + 8 * y, 8);
     } else {
-      for (int y = 0; y < q.h4; y++) for (int x = 0; x < q.w4; x++)
-        h_sub8[n8++] = {(int8_t)p, (int8_t)(4 * (q.x4 + x)), (int8_t)(4 * (q.y4 + y)), 4};
+      for (int y = 0; y < q.h4; y++) for (int x = 0; x < q.w4; x++) put(h_sub8, n8, p, 4 * (q.x4 + x), 4 * (q.y4 + y), 4);
     }
   }
+  auto link = [](SubItem *it, int n) {
+    for (int i = 0; i < n; i++) {
+      int k = 0;
+      for (int j = 0; j < 7; j++) { it[i].mem[j] = -1; it[i].memp[j] = -1; }
+      for (int j = 0; j < n; j++)
+        if (it[j].bx == it[i].bx && it[j].by == it[i].by && it[j].bs == it[i].bs) { it[i].mem[k] = (int8_t)j; it[i].memp[k] = it[j].p; k++; }
+    }
+  };
+  link(h_sub4, 112);
+  link(h_sub8, 64);
 }
 
-__global__ __launch_bounds__(256) void me_sub_kernel(MeDev P, const jmhip_me_mb *__restrict__ jobs, jmhip_me_result *__restrict__ res)
+// HadamardSAD4x4 (me_distortion.c:182) on packed 16-bit lanes. c01/c23: the current block's rows as (x0,x1)/(x2,x3)
+// pairs of 16-bit samples, with 0x8000 added to x1 of row 0 (done once when the macroblock is staged); ref: the four
+// reference rows as packed bytes. The bias rides through every butterfly into all sixteen outputs -- each output holds
+// exactly one biased input with a + sign, or the difference of two -- so |coef| = |biased - 0x8000| is one v_sad_u16 per
+// output pair. Intermediate values are at most 16*255 in magnitude: no 16-bit overflow.
+typedef short v2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2s as_v2s(uint32_t u) { return __builtin_bit_cast(v2s, u); }
+__device__ __forceinline__ uint32_t as_u32(v2s v) { return __builtin_bit_cast(uint32_t, v); }
+
+__device__ __forceinline__ int satd4x4_packed(const uint32_t c01[4], const uint32_t c23[4], const uint32_t ref[4])
 {
+  v2s d01[4], d23[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const uint32_t rlo = __builtin_amdgcn_perm(0u, ref[r], 0x0c010c00u), rhi = __builtin_amdgcn_perm(0u, ref[r], 0x0c030c02u);
+    d01[r] = as_v2s(c01[r]) - as_v2s(rlo);
+    d23[r] = as_v2s(c23[r]) - as_v2s(rhi);
+  }
+  v2s m01[4], m23[4];
+  {
+    const v2s a = d01[0] + d01[3], b = d01[1] + d01[2], c = d01[1] - d01[2], e = d01[0] - d01[3];
+    m01[0] = a + b; m01[1] = e + c; m01[2] = a - b; m01[3] = e - c;
+  }
+  {
+    const v2s a = d23[0] + d23[3], b = d23[1] + d23[2], c = d23[1] - d23[2], e = d23[0] - d23[3];
+    m23[0] = a + b; m23[1] = e + c; m23[2] = a - b; m23[3] = e - c;
+  }
+  uint32_t acc = 0;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const uint32_t hi = as_u32(m23[r]);
+    const v2s sw = as_v2s(__builtin_amdgcn_alignbit(hi, hi, 16));           // (x3, x2)
+    const uint32_t s = as_u32(m01[r] + sw), t = as_u32(m01[r] - sw);       // (x0+x3, x1+x2+B), (x0-x3, x1-x2+B)
+    const v2s u = as_v2s(__builtin_amdgcn_perm(t, s, 0x05040100u));        // (s.lo, t.lo)
+    const v2s v = as_v2s(__builtin_amdgcn_perm(t, s, 0x07060302u));        // (s.hi, t.hi), both biased
+    acc = __builtin_amdgcn_sad_u16(as_u32(u + v), 0x80008000u, acc);
+    acc = __builtin_amdgcn_sad_u16(as_u32(u - v), 0x80008000u, acc);
+  }
+  return (int)((acc + 1) >> 1);
+}
+
+#ifdef JMHIP_STAMPS
+#define SSTAMP(k) do { if (P.stamps && blockIdx.x < 512 && threadIdx.x == 0) P.stamps[blockIdx.x * 32 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SSTAMP(k) do { } while (0)
+#endif
+
+// Sub-pel refinement of all 41 partitions of one macroblock (SubPelBlockMotionSearch, me_fullsearch.c:341).
+// Per phase (half-pel: 9 positions, quarter-pel: 8): the SATD of a (4x4 | 8x8) sub-block at a candidate depends only on
+// the sub-block, the partition's current vector and its access method. The seven block types tile the macroblock with
+// the same sub-blocks, so wherever their vectors agree the value is shared: each distinct (sub-block, vector) is
+// evaluated once by a "leader" item (compacted list) that adds it to every partition it serves; the 9 candidates of
+// all partitions are then costed in parallel and JM's sequential strict-< scan becomes an atomic min on (cost, position).
+// The kernel is latency-bound (dependent LDS/global reads between barriers), hence the small register footprint
+// (T8 = false drops the 8x8 Hadamard path) for many resident workgroups.
+template <bool T8>
+__global__ __launch_bounds__(256) void me_sub_kernel(MeDev P, const jmhip_me_mb *__restrict__ jobs, jmhip_me_result *__restrict__ res, int n_items)
+{
+  const int item = jm_xcd_item(n_items);
+  if (item < 0) return;
+  constexpr int NSUB = T8 ? 64 : 112;
   __shared__ __attribute__((aligned(16))) uint8_t s_cur[16][16];
-  __shared__ int s_mvx[JMHIP_NPART], s_mvy[JMHIP_NPART], s_umv[JMHIP_NPART], s_min[JMHIP_NPART];
+  __shared__ __attribute__((aligned(16))) uint32_t s_c16[16][8];           // (x, x+1) sample pairs, biased (see satd4x4_packed)
+  __shared__ __attribute__((aligned(16))) uint32_t s_tab[NSUB * 5];         // the SubItem table
+  __shared__ int s_mvx[JMHIP_NPART], s_mvy[JMHIP_NPART], s_umv[JMHIP_NPART], s_px[JMHIP_NPART], s_py[JMHIP_NPART];
+  __shared__ unsigned s_pkey[JMHIP_NPART], s_best[JMHIP_NPART];
   __shared__ int s_satd[JMHIP_NPART][9];
+  __shared__ short s_list[NSUB];
+  __shared__ int s_nlead;
 
   const int tid = threadIdx.x;
-  const jmhip_me_mb &job = jobs[blockIdx.x];
-  jmhip_me_result &o = res[blockIdx.x];
+  SSTAMP(0);
+  const jmhip_me_mb &job = jobs[item];
+  jmhip_me_result &o = res[item];
   const int mbx = job.mb_x, mby = job.mb_y;
   const unsigned long long mask = P.mask;
   const uint8_t *sub = P.ref_sub[job.ref];
   const size_t plane = (size_t)P.Wp * P.Hp;
   const int width_pad = P.Wp - 1 - 16, height_pad = P.Hp - 1 - 16;      // size_x_pad / size_y_pad, mbuffer.c:421-422
-  const int nsub = P.t8x8 ? 64 : 112;
-  const SubItem *items = P.t8x8 ? c_sub8 : c_sub4;
+  const SubItem *items = reinterpret_cast<const SubItem *>(s_tab);
 
+  for (int d = tid; d < NSUB * 5; d += 256) s_tab[d] = reinterpret_cast<const uint32_t *>(T8 ? c_sub8 : c_sub4)[d];
   if (tid < 64) {
     const int r = tid >> 2, k = tid & 3;
-    *reinterpret_cast<uint32_t *>(&s_cur[r][k * 4]) = *reinterpret_cast<const uint32_t *>(P.cur + (size_t)(mby * 16 + r) * P.W + mbx * 16 + k * 4);
+    const uint32_t v = *reinterpret_cast<const uint32_t *>(P.cur + (size_t)(mby * 16 + r) * P.W + mbx * 16 + k * 4);
+    *reinterpret_cast<uint32_t *>(&s_cur[r][k * 4]) = v;
+    const uint32_t bias = (r & 3) ? 0u : 0x80000000u;
+    s_c16[r][2 * k] = __builtin_amdgcn_perm(0u, v, 0x0c010c00u) + bias;
+    s_c16[r][2 * k + 1] = __builtin_amdgcn_perm(0u, v, 0x0c030c02u);
   }
+  const bool my_active = tid < JMHIP_NPART && ((mask >> tid) & 1);
   if (tid < JMHIP_NPART) {
+    s_px[tid] = job.pred_mv[tid][0]; s_py[tid] = job.pred_mv[tid][1];
     s_mvx[tid] = o.mv_int[tid][0] << 2; s_mvy[tid] = o.mv_int[tid][1] << 2;      // mv-search.c:770-774
-    s_min[tid] = 0x7fffffff;                                                      // :785-788 (start_me_refinement_hp == 0)
   }
+  const int w16h = (P.lam_h * 16) >> 16;
+  unsigned carried = 0xffffffffu;                    // lane p: running minimum as a (cost + bias) << 4 | position key
 
   for (int phase = 0; phase < 2; phase++) {        // 0: half-pel (positions 0..8, step 2), 1: quarter-pel (1..8, step 1)
     const int step = phase ? 1 : 2, first = phase ? 1 : 0, ncand = 9 - first;
@@ -786,20 +886,51 @@ __global__ __launch_bounds__(256) void me_sub_kernel(MeDev P, const jmhip_me_mb 
     if (tid < JMHIP_NPART) {
       const PartInfo q = c_part[tid];
       const int bsx = 4 * q.w4, bsy = 4 * q.h4;
-      const int p4x = ((mbx * 16 + 4 * q.x4 + JMHIP_PAD) << 2) + s_mvx[tid], p4y = ((mby * 16 + 4 * q.y4 + JMHIP_PAD) << 2) + s_mvy[tid];
+      const int mx = s_mvx[tid], my = s_mvy[tid];
+      const int p4x = ((mbx * 16 + 4 * q.x4 + JMHIP_PAD) << 2) + mx, p4y = ((mby * 16 + 4 * q.y4 + JMHIP_PAD) << 2) + my;
       const int max_x4 = (P.W - bsx + 2 * JMHIP_PAD) << 2, max_y4 = (P.H - bsy + 2 * JMHIP_PAD) << 2;
       const int m = phase ? 0 : 1;                   // me_fullsearch.c:412-413 vs :468-469
-      s_umv[tid] = !((p4x > m) && (p4x < max_x4 - m) && (p4y > m) && (p4y < max_y4 - m));
+      const int umv = !((p4x > m) && (p4x < max_x4 - m) && (p4y > m) && (p4y < max_y4 - m));
+      s_umv[tid] = umv;
+      // identity of (vector, access method); an inactive partition gets a key nobody shares
+      s_pkey[tid] = my_active ? ((unsigned)(mx + 16384) | ((unsigned)(my + 16384) << 15) | ((unsigned)umv << 30)) : (0x80000000u | (unsigned)tid);
+      s_best[tid] = carried;                         // :785-788: INT_MAX before half-pel; the half-pel minimum is carried on
 #pragma unroll
       for (int k = 0; k < 9; k++) s_satd[tid][k] = 0;
     }
     __syncthreads();
+    SSTAMP(1 + 5 * phase);
 
-    for (int idx = tid; idx < nsub * ncand; idx += 256) {
-      const int ci = idx / nsub, it = idx - ci * nsub, cand = first + ci;     // lanes: adjacent sub-blocks, same plane
+    // ---- leaders: wave 0 takes items lane and lane + 64; an item leads if no earlier item on its sub-block has its key
+    if (tid < 64) {
+      bool lead[2];
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int it = tid + 64 * h;
+        lead[h] = false;
+        if (it < NSUB) {
+          const SubItem si = items[it];
+          const unsigned key = s_pkey[si.p];
+          bool l = !(key & 0x80000000u);
+#pragma unroll
+          for (int k = 0; k < 6; k++) if (si.mem[k] >= 0 && si.mem[k] < it && s_pkey[si.memp[k]] == key) l = false;
+          lead[h] = l;
+        }
+      }
+      const unsigned long long b0 = __ballot(lead[0]), b1 = __ballot(lead[1]);
+      const unsigned long long lt = (1ull << tid) - 1;
+      if (lead[0]) s_list[__popcll(b0 & lt)] = (short)tid;
+      if (lead[1]) s_list[__popcll(b0) + __popcll(b1 & lt)] = (short)(tid + 64);
+      if (tid == 0) s_nlead = __popcll(b0) + __popcll(b1);
+    }
+    __syncthreads();
+    SSTAMP(2 + 5 * phase);
+
+    const int K = s_nlead, total = K * ncand;
+    for (int idx = tid; idx < total; idx += 256) {
+      const int ci = idx / K, it = s_list[idx - ci * K], cand = first + ci;     // adjacent lanes: adjacent sub-blocks, same plane
       const SubItem si = items[it];
       const int p = si.p;
-      if (!((mask >> p) & 1)) continue;
       // quarter-pel coordinate of the sub-block origin incl. the pad offset (me_fullsearch.c:364-365, me_distortion.c:678)
       const int xq = ((mbx * 16 + si.bx + JMHIP_PAD) << 2) + s_mvx[p] + step * c_s9x[cand];
       const int yq = ((mby * 16 + si.by + JMHIP_PAD) << 2) + s_mvy[p] + step * c_s9y[cand];
@@ -807,17 +938,16 @@ __global__ __launch_bounds__(256) void me_sub_kernel(MeDev P, const jmhip_me_mb 
       if (s_umv[p]) { xpos = clampi(xpos, 0, width_pad); ypos = clampi(ypos, 0, height_pad); }     // UMVLine4X, refbuf.c:37
       const uint8_t *rp = sub + (size_t)((yq & 3) * 4 + (xq & 3)) * plane + (size_t)ypos * P.Wp + xpos;
       int v;
-      if (si.bs == 4) {
-        int d[4][4];
+      if (!T8 || si.bs == 4) {
+        uint32_t ref[4], c01[4], c23[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          uint32_t lo, hi;
-          fetch_row(rp + (size_t)r * P.Wp, 4, &lo, &hi);
-          const uint32_t cw = *reinterpret_cast<const uint32_t *>(&s_cur[si.by + r][si.bx]);
-#pragma unroll
-          for (int x = 0; x < 4; x++) d[r][x] = (int)((cw >> (8 * x)) & 255) - (int)((lo >> (8 * x)) & 255);
+          uint32_t hi;
+          fetch_row(rp + (size_t)r * P.Wp, 4, &ref[r], &hi);
+          const uint2 c = *reinterpret_cast<const uint2 *>(&s_c16[si.by + r][si.bx >> 1]);
+          c01[r] = c.x; c23[r] = c.y;
         }
-        v = satd4x4(d);
+        v = satd4x4_packed(c01, c23, ref);
       } else {
         int m2[8][8];
 #pragma unroll
@@ -845,34 +975,40 @@ __global__ __launch_bounds__(256) void me_sub_kernel(MeDev P, const jmhip_me_mb 
         }
         v = (s + 2) >> 2;                            // HadamardSAD8x8, me_distortion.c:342
       }
-      atomicAdd(&s_satd[p][cand], v);
+      // the value serves every item on this sub-block whose partition has the same key (itself included)
+      const unsigned key = s_pkey[p];
+#pragma unroll
+      for (int k = 0; k < 7; k++) if (si.mem[k] >= 0 && s_pkey[si.memp[k]] == key) atomicAdd(&s_satd[si.memp[k]][cand], v);
     }
     __syncthreads();
+    SSTAMP(3 + 5 * phase);
 
-    if (tid < JMHIP_NPART && ((mask >> tid) & 1)) {
-      const int p = tid;
-      const int lam = phase ? P.lam_q : P.lam_h;
-      const int px = job.pred_mv[p][0], py = job.pred_mv[p][1];
-      int min_mcost = s_min[p], best = 0;
+    // ---- all (partition, position) costs in parallel; strict-< in scan order == min over (cost, position)
+    const int lam = phase ? P.lam_q : P.lam_h;
+    for (int idx = tid; idx < JMHIP_NPART * ncand; idx += 256) {
+      const int ci = idx / JMHIP_NPART, p = idx - ci * JMHIP_NPART, pos = first + ci;
+      if (!((mask >> p) & 1)) continue;
       const int mvx = s_mvx[p], mvy = s_mvy[p];
-      // check_position0, me_fullsearch.c:361
-      const int check0 = !phase && !P.rdopt && !P.is_b && job.ref_is_0 && p == 0 && mvx == 0 && mvy == 0;
-      for (int pos = first; pos < 9; pos++) {
-        const int cxm = mvx + step * c_s9x[pos], cym = mvy + step * c_s9y[pos];
-        int mcost = mv_cost(lam, cxm - px, cym - py);
-        if (mcost >= min_mcost) continue;
-        mcost += s_satd[p][pos];
-        if (pos == 0 && check0) mcost -= (lam * 16) >> 16;
-        if (mcost < min_mcost) { min_mcost = mcost; best = pos; }
-      }
-      s_mvx[p] = mvx + step * c_s9x[best]; s_mvy[p] = mvy + step * c_s9y[best];
-      s_min[p] = min_mcost;                          // start_me_refinement_qp == 1: carried into the quarter-pel phase
+      const int cxm = mvx + step * c_s9x[pos], cym = mvy + step * c_s9y[pos];
+      int mcost = mv_cost(lam, cxm - s_px[p], cym - s_py[p]) + s_satd[p][pos];
+      // check_position0, me_fullsearch.c:361, :439-442 (half-pel position 0 only; the bias keeps the key unsigned)
+      if (pos == 0 && !P.rdopt && !P.is_b && job.ref_is_0 && p == 0 && mvx == 0 && mvy == 0) mcost -= w16h;
+      atomicMin(&s_best[p], ((unsigned)(mcost + w16h) << 4) | (unsigned)pos);
     }
+    __syncthreads();
+    SSTAMP(4 + 5 * phase);
+    if (my_active) {
+      const unsigned k = s_best[tid];
+      const int best = (int)(k & 15u);
+      s_mvx[tid] += step * c_s9x[best]; s_mvy[tid] += step * c_s9y[best];
+      carried = (k & ~15u);                          // start_me_refinement_qp == 1: the minimum competes as position 0
+    }
+    SSTAMP(5 + 5 * phase);
   }
-  __syncthreads();
-  if (tid < JMHIP_NPART && ((mask >> tid) & 1)) {
-    o.mv[tid][0] = (int16_t)s_mvx[tid]; o.mv[tid][1] = (int16_t)s_mvy[tid]; o.cost[tid] = s_min[tid];
+  if (my_active) {
+    o.mv[tid][0] = (int16_t)s_mvx[tid]; o.mv[tid][1] = (int16_t)s_mvy[tid]; o.cost[tid] = (int)(carried >> 4) - w16h;
   }
+  SSTAMP(11);
 }
 
 int ensure_tables(jmhip_ctx *c)
@@ -916,6 +1052,8 @@ extern "C" void jmhip_partition_info(int p, int *blocktype, int *x4, int *y4, in
 }
 
 // host mirror of search_center (mv-search.c:752-762) to size the LDS window
+constexpr int FAST_MAX_CENTRES = 8;
+
 static void host_center(const jmhip_me_params *prm, int pmx, int pmy, int *cx, int *cy)
 {
   const int R = prm->search_range;
@@ -972,9 +1110,21 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
       x0 = cx < x0 ? cx : x0; x1 = cx > x1 ? cx : x1; y0 = cy < y0 ? cy : y0; y1 = cy > y1 ? cy : y1;
     }
     const int uw = x1 - x0 + 2 * R + 1, uh = y1 - y0 + 2 * R + 1;
-    // fast path: one centre for all 41 partitions, every partition searched, at least 64 candidate columns
-    const bool fast = (x0 == x1 && y0 == y1) && full_mask && (2 * R + 1 >= 64) && (2 * R + 1 + 15 <= 96);
-    if (fast) c->me_fast_idx.push_back(i);
+    // fast path: every partition searched, at least 64 candidate columns, and few DISTINCT centres: one work item per
+    // distinct centre (FastFull and single-predictor macroblocks have one; JM's FullSearch typically a handful, the
+    // neighbouring predictors being close). Beyond FAST_MAX_CENTRES the union-window kernel is cheaper.
+    int reps[FAST_MAX_CENTRES], rcx[FAST_MAX_CENTRES], rcy[FAST_MAX_CENTRES], ng = 0;
+    bool fast = full_mask && (2 * R + 1 >= 64) && (2 * R + 1 + 15 <= 96) && i < (1 << 24);
+    for (int p = 0; p < JMHIP_NPART && fast; p++) {
+      int cx, cy, g;
+      const int s = prm->search_mode == JMHIP_SEARCH_FASTFULL ? 0 : p;
+      host_center(prm, m.pred_mv[s][0], m.pred_mv[s][1], &cx, &cy);
+      for (g = 0; g < ng; g++) if (rcx[g] == cx && rcy[g] == cy) break;
+      if (g < ng) continue;
+      if (ng == FAST_MAX_CENTRES) { fast = false; break; }
+      reps[ng] = p; rcx[ng] = cx; rcy[ng] = cy; ng++;
+    }
+    if (fast) for (int g = 0; g < ng; g++) c->me_fast_idx.push_back(i | (reps[g] << 24));
     else {
       c->me_gen_idx.push_back(i);
       max_uw = uw > max_uw ? uw : max_uw; max_uh = uh > max_uh ? uh : max_uh;
@@ -1000,7 +1150,7 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
     if (hipMalloc(&c->me_res_dev, sizeof(jmhip_me_result) * (size_t)n) != hipSuccess) return jm_fail(c, JMHIP_ERR_NOMEM, "ME result array");
     if (c->me_idx_dev) JM_HIP_CHECK(c, hipFree(c->me_idx_dev));
     c->me_idx_dev = nullptr;
-    if (hipMalloc(&c->me_idx_dev, sizeof(int) * (size_t)n) != hipSuccess) return jm_fail(c, JMHIP_ERR_NOMEM, "ME index array");
+    if (hipMalloc(&c->me_idx_dev, sizeof(int) * (size_t)n * FAST_MAX_CENTRES) != hipSuccess) return jm_fail(c, JMHIP_ERR_NOMEM, "ME index array");
     c->me_capacity = n;
   }
   if ((rc = jm_ensure_ref_table(c))) return rc;
@@ -1009,7 +1159,7 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
     // index lists of the two integer-search kernels: [0, nfast) fast, [nfast, n) generic
     std::vector<int> idx(c->me_fast_idx);
     idx.insert(idx.end(), c->me_gen_idx.begin(), c->me_gen_idx.end());
-    JM_HIP_CHECK(c, hipMemcpyAsync(c->me_idx_dev, idx.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    JM_HIP_CHECK(c, hipMemcpyAsync(c->me_idx_dev, idx.data(), sizeof(int) * idx.size(), hipMemcpyHostToDevice, c->stream));
     JM_HIP_CHECK(c, hipStreamSynchronize(c->stream));     // idx is a stack vector
   }
   c->me_n = n; c->me_ref_mask = ref_mask; c->me_max_uw = max_uw; c->me_max_uh = max_uh;
@@ -1039,10 +1189,10 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
   if (nfast) {
     MeDev PF = P;
     PF.win_pitch = fpitch_dw * 4; PF.win_rows = frows; PF.win_copy_stride = fcs;
-    me_int_fast_kernel<<<nfast, 256, flds, c->stream>>>(PF, (const jmhip_me_mb *)c->me_jobs_dev, (const int *)c->me_idx_dev, (jmhip_me_result *)c->me_res_dev);
+    me_int_fast_kernel<<<jm_xcd_grid(nfast), 256, flds, c->stream>>>(PF, (const jmhip_me_mb *)c->me_jobs_dev, (const int *)c->me_idx_dev, (jmhip_me_result *)c->me_res_dev, nfast);
   }
   if (ngen)
-    me_int_kernel<<<ngen, 256, lds, c->stream>>>(P, (const jmhip_me_mb *)c->me_jobs_dev, (const int *)c->me_idx_dev + nfast, (jmhip_me_result *)c->me_res_dev);
+    me_int_kernel<<<jm_xcd_grid(ngen), 256, lds, c->stream>>>(P, (const jmhip_me_mb *)c->me_jobs_dev, (const int *)c->me_idx_dev + nfast, (jmhip_me_result *)c->me_res_dev, ngen);
   jm_stage_end(c, JMHIP_STAGE_ME_INT);
   JM_HIP_CHECK(c, hipGetLastError());
 #ifdef JMHIP_STAMPS
@@ -1061,10 +1211,30 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
   }
 #endif
   if (P.subpel) {
+#ifdef JMHIP_STAMPS
+    (void)hipMemsetAsync(P.stamps, 0, 512 * 4 * 8 * 8, c->stream);
+#endif
     jm_stage_begin(c, JMHIP_STAGE_ME_SUB);
-    me_sub_kernel<<<n, 256, 0, c->stream>>>(P, (const jmhip_me_mb *)c->me_jobs_dev, (jmhip_me_result *)c->me_res_dev);
+    if (P.t8x8) me_sub_kernel<true><<<jm_xcd_grid(n), 256, 0, c->stream>>>(P, (const jmhip_me_mb *)c->me_jobs_dev, (jmhip_me_result *)c->me_res_dev, n);
+    else me_sub_kernel<false><<<jm_xcd_grid(n), 256, 0, c->stream>>>(P, (const jmhip_me_mb *)c->me_jobs_dev, (jmhip_me_result *)c->me_res_dev, n);
     jm_stage_end(c, JMHIP_STAGE_ME_SUB);
     JM_HIP_CHECK(c, hipGetLastError());
+#ifdef JMHIP_STAMPS
+    {
+      static int sshots = 0;
+      if (++sshots == 3) {
+        std::vector<unsigned long long> h(512 * 32);
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipMemcpy(h.data(), P.stamps, h.size() * 8, hipMemcpyDeviceToHost);
+        double acc[12] = {0};
+        for (int b = 0; b < 512; b++) for (int k = 1; k < 12; k++) acc[k] += (double)(h[b * 32 + k] - h[b * 32 + k - 1]);
+        const char *nm[12] = {"", "setup", "h:leaders", "h:satd", "h:sum", "h:decide", "q:setup", "q:leaders", "q:satd", "q:sum", "q:decide", "store"};
+        fprintf(stderr, "SUB STAMPS (cycles, avg over 512 blocks):");
+        for (int k = 1; k < 12; k++) fprintf(stderr, " %s=%.0f", nm[k], acc[k] / 512);
+        fprintf(stderr, "\n");
+      }
+    }
+#endif
   }
   return JMHIP_OK;
 }
@@ -1226,7 +1396,8 @@ extern "C" int jmhip_me_subpel(jmhip_ctx *c, const jmhip_me_params *prm, const j
   if (e == hipSuccess) e = hipMemcpyAsync(dr, results, sizeof(jmhip_me_result) * (size_t)n, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) {
     jm_stage_begin(c, JMHIP_STAGE_ME_SUB);
-    me_sub_kernel<<<n, 256, 0, c->stream>>>(P, (const jmhip_me_mb *)dj, (jmhip_me_result *)dr);
+    if (P.t8x8) me_sub_kernel<true><<<jm_xcd_grid(n), 256, 0, c->stream>>>(P, (const jmhip_me_mb *)dj, (jmhip_me_result *)dr, n);
+    else me_sub_kernel<false><<<jm_xcd_grid(n), 256, 0, c->stream>>>(P, (const jmhip_me_mb *)dj, (jmhip_me_result *)dr, n);
     jm_stage_end(c, JMHIP_STAGE_ME_SUB);
     e = hipGetLastError();
   }

@@ -99,6 +99,10 @@ def test_me_frame_qcif_range32(pkg):
     ("flat", -1, 0, False, 4),
     ("noise", 0, 1, True, 200),      # centre clipped by the +-2047 / level limits, windows far outside the picture
     ("noise", -1, 0, False, 100),
+    ("shift", -1, 1, True, 3),       # FullSearch, 41 different predictors, ONE centre (pred/4 == 0): one fast item
+    ("shift", -1, 1, True, 5),       # centres in {-1,0,1}^2: up to 9 distinct -> several fast items per MB, some MBs generic
+    ("shift", -1, 0, True, 6),       # same with rdopt off (check_for_00 on the 16x16 item only)
+    ("noise", -1, 1, True, 7),
 ])
 def test_me_fast_kernel_range32(pkg, kind, mode, rdopt, per_partition, spread):
     run_case(pkg, 96, 64, kind, mode, 32, rdopt, spread, per_partition=per_partition, seed=spread + mode * 3 + rdopt)
