@@ -79,8 +79,10 @@ __device__ __forceinline__ int spiral_pos(int dx, int dy)
 __device__ void spiral_offset(int pos, int *dx, int *dy)
 {
   if (pos == 0) { *dx = 0; *dy = 0; return; }
-  int l = 1;
+  int l = (int)((__builtin_sqrtf((float)pos) + 1.0f) * 0.5f);       // ring: (2l-1)^2 <= pos < (2l+1)^2; float guess, exact fix-up
+  l = max(l, 1);
   while ((2 * l + 1) * (2 * l + 1) <= pos) l++;
+  while ((2 * l - 1) * (2 * l - 1) > pos) l--;
   int k = pos - (2 * l - 1) * (2 * l - 1);
   if (k < 2 * (2 * l - 1)) { *dx = (k >> 1) - l + 1; *dy = (k & 1) ? l : -l; }
   else { k -= 2 * (2 * l - 1); *dy = (k >> 1) - l; *dx = (k & 1) ? l : -l; }
@@ -352,7 +354,7 @@ struct FastShared {
   uint32_t cur[64];
   unsigned chg[160];                            // per candidate row: does any partition's vertical mv bits differ from the row above
   uint8_t bytab[160][48] __attribute__((aligned(16)));   // vertical mv bits per candidate row and partition (48: three 16-byte reads)
-  uint8_t bxtab[64][44];                        // horizontal mv bits per main-grid column and partition (44: dword rows)
+  uint8_t bxtab[84][44];                        // horizontal mv bits per candidate column and partition (44: dword rows); 64 main-grid columns + the rest (2R+1 <= 81)
   unsigned part[JMHIP_NPART][4];                // partial minima of the final reduction
   unsigned long long part0[4];
 };
@@ -389,76 +391,73 @@ __global__ __launch_bounds__(256, 2) void me_int_fast_kernel(MeDev P, const jmhi
   const int CS = P.win_copy_stride;              // dwords between shifted copies (== 8 mod 32)
   const int WROWS = UH + 15;
 
-  if (tid == 0) {
-    int cx, cy;
-    search_center(P, job.pred_mv[rep][0], job.pred_mv[rep][1], &cx, &cy);
-    S.cx = cx; S.cy = cy;
-  }
-  if (tid < JMHIP_NPART) { S.px[tid] = job.pred_mv[tid][0]; S.py[tid] = job.pred_mv[tid][1]; }
-  if (tid < 64) {
-    const int r = tid >> 2, k = tid & 3;
-    S.cur[tid] = *reinterpret_cast<const uint32_t *>(P.cur + (size_t)(mby * 16 + r) * P.W + mbx * 16 + k * 4);
-  }
-  __syncthreads();
-  const int ucx = S.cx, ucy = S.cy;
+  // every lane derives the centre itself (uniform scalar work): no LDS round trip before the window loads can start
+  int ucx, ucy;
+  search_center(P, job.pred_mv[rep][0], job.pred_mv[rep][1], &ucx, &ucy);
   const int umin_x = ucx - R, umin_y = ucy - R;
+  if (tid < JMHIP_NPART) { S.px[tid] = job.pred_mv[tid][0]; S.py[tid] = job.pred_mv[tid][1]; }
 
-  // ---- window copy 0 from the integer recon (per-sample clamp), then the three byte-shifted copies from copy 0.
-  //      Lane slots are (row = tid/32 + 8*i, dword column = tid%32): no runtime divisions.
-  {
-    const uint8_t *ref = P.ref_y[job.ref];
-    const int bx = mbx * 16 + umin_x, by = mby * 16 + umin_y;
-    const int xw = tid & 31, y0 = tid >> 5;
-    const bool inside = bx >= 4 && bx + PITCH * 4 + 4 <= P.W;     // no horizontal clamping anywhere in the window
-    constexpr int NB = 12;                                         // row slots per lane: 8 * 12 = 96 >= window rows (R <= 40)
-    if (xw < PITCH) {
-      uint32_t lo[NB], hi[NB];
-      if (inside) {
-        const unsigned sh = (unsigned)(bx & 3);
+  // ---- reference window: copy 0 plus three byte-shifted copies, staged from the integer recon with per-sample clamping.
+  //      Lane slots are (row = tid/32 + 8*i, dword column = tid%32): no runtime divisions. Away from the left/right picture
+  //      edge the lane fetches three aligned dwords per slot and builds all four copies in registers; the loads are issued
+  //      first and the mv-bits tables are computed while they are in flight.
+  const uint8_t *ref = P.ref_y[job.ref];
+  const int bx = mbx * 16 + umin_x, by = mby * 16 + umin_y;
+  const int xw = tid & 31, y0 = tid >> 5;
+  const bool inside = bx >= 4 && bx + PITCH * 4 + 8 <= P.W;       // no horizontal clamping anywhere in the window (+ the third dword)
+  constexpr int NB = 12;                                           // row slots per lane: 8 * 12 = 96 >= window rows (R <= 40)
+  uint32_t q0[NB], q1[NB], q2[NB];
+  if (inside && xw < PITCH) {
 #pragma unroll
-        for (int u = 0; u < NB; u++) {
-          const int y = min(y0 + 8 * u, WROWS - 1);
-          const uintptr_t a = reinterpret_cast<uintptr_t>(ref + (size_t)clampi(by + y, 0, P.H - 1) * P.W + bx + xw * 4);
-          const uint32_t *q = reinterpret_cast<const uint32_t *>(a & ~uintptr_t(3));
-          lo[u] = q[0]; hi[u] = q[1];
-        }
-#pragma unroll
-        for (int u = 0; u < NB; u++)
-          if (y0 + 8 * u < WROWS) swin[(y0 + 8 * u) * PITCH + xw] = __builtin_amdgcn_alignbyte(hi[u], lo[u], sh);
-      } else {
-#pragma unroll
-        for (int u = 0; u < NB; u++)
-          if (y0 + 8 * u < WROWS) {
-            const uint8_t *row = ref + (size_t)clampi(by + y0 + 8 * u, 0, P.H - 1) * P.W;
-            uint32_t v = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) v |= (uint32_t)row[clampi(bx + xw * 4 + k, 0, P.W - 1)] << (8 * k);
-            swin[(y0 + 8 * u) * PITCH + xw] = v;
-          }
-      }
+    for (int u = 0; u < NB; u++) {
+      const int y = min(y0 + 8 * u, WROWS - 1);
+      const uintptr_t a = reinterpret_cast<uintptr_t>(ref + (size_t)clampi(by + y, 0, P.H - 1) * P.W + bx + xw * 4);
+      const uint32_t *q = reinterpret_cast<const uint32_t *>(a & ~uintptr_t(3));
+      q0[u] = q[0]; q1[u] = q[1]; q2[u] = q[2];
     }
   }
   // mv bits tables: vertical [row][partition], horizontal [column][partition]; lane slots (index = tid/64 + 4*i, partition = tid%64)
   {
     const int p = tid & 63, i0 = tid >> 6;
     if (p < 44) {
-      const int py = p < JMHIP_NPART ? S.py[p] : 0, px = p < JMHIP_NPART ? S.px[p] : 0;
+      const int py = p < JMHIP_NPART ? job.pred_mv[p][1] : 0, px = p < JMHIP_NPART ? job.pred_mv[p][0] : 0;
       for (int row = i0; row < UH; row += 4) S.bytab[row][p] = p < JMHIP_NPART ? (uint8_t)mvbits(4 * (umin_y + row) - py) : 0;
+      for (int c = i0; c < UW; c += 4) S.bxtab[c][p] = p < JMHIP_NPART ? (uint8_t)mvbits(4 * (umin_x + c) - px) : 0;
+    }
+  }
+  if (xw < PITCH) {
+    if (inside) {
+      const unsigned sh = (unsigned)(bx & 3);
 #pragma unroll
-      for (int c = i0; c < 64; c += 4) S.bxtab[c][p] = p < JMHIP_NPART ? (uint8_t)mvbits(4 * (umin_x + c) - px) : 0;
+      for (int u = 0; u < NB; u++)
+        if (y0 + 8 * u < WROWS) {
+          const uint32_t a = __builtin_amdgcn_alignbyte(q1[u], q0[u], sh), b = __builtin_amdgcn_alignbyte(q2[u], q1[u], sh);
+          uint32_t *w = swin + (y0 + 8 * u) * PITCH + xw;
+          w[0] = a;
+          w[1 * CS] = __builtin_amdgcn_alignbyte(b, a, 1u);
+          w[2 * CS] = __builtin_amdgcn_alignbyte(b, a, 2u);
+          w[3 * CS] = __builtin_amdgcn_alignbyte(b, a, 3u);
+        }
+    } else {
+#pragma unroll
+      for (int u = 0; u < NB; u++)
+        if (y0 + 8 * u < WROWS) {
+          const uint8_t *row = ref + (size_t)clampi(by + y0 + 8 * u, 0, P.H - 1) * P.W;
+          uint32_t v = 0;
+#pragma unroll
+          for (int k = 0; k < 4; k++) v |= (uint32_t)row[clampi(bx + xw * 4 + k, 0, P.W - 1)] << (8 * k);
+          swin[(y0 + 8 * u) * PITCH + xw] = v;
+        }
     }
   }
   __syncthreads();
-  {
-    const int xw = tid & 31, y0 = tid >> 5;
-    if (xw < PITCH - 1)
-      for (int y = y0; y < WROWS; y += 8) {
-        const uint32_t a = swin[y * PITCH + xw], b = swin[y * PITCH + xw + 1];
-        swin[1 * CS + y * PITCH + xw] = __builtin_amdgcn_alignbyte(b, a, 1u);
-        swin[2 * CS + y * PITCH + xw] = __builtin_amdgcn_alignbyte(b, a, 2u);
-        swin[3 * CS + y * PITCH + xw] = __builtin_amdgcn_alignbyte(b, a, 3u);
-      }
-  }
+  if (!inside && xw < PITCH - 1)                     // picture-edge macroblocks: shifted copies from copy 0
+    for (int y = y0; y < WROWS; y += 8) {
+      const uint32_t a = swin[y * PITCH + xw], b = swin[y * PITCH + xw + 1];
+      swin[1 * CS + y * PITCH + xw] = __builtin_amdgcn_alignbyte(b, a, 1u);
+      swin[2 * CS + y * PITCH + xw] = __builtin_amdgcn_alignbyte(b, a, 2u);
+      swin[3 * CS + y * PITCH + xw] = __builtin_amdgcn_alignbyte(b, a, 3u);
+    }
   if (tid < UH) {
     unsigned m = (tid == 0);
     if (tid) {
@@ -504,8 +503,12 @@ __global__ __launch_bounds__(256, 2) void me_int_fast_kernel(MeDev P, const jmhi
 
   // cur MB in scalar registers: v_sad_hi_u8 takes an SGPR operand
   uint32_t curs[64];
+  {
+    const uint32_t *cm = reinterpret_cast<const uint32_t *>(P.cur + (size_t)(mby * 16) * P.W + mbx * 16);   // uniform address: s_load
+    const int cw = P.W >> 2;
 #pragma unroll
-  for (int i = 0; i < 64; i++) curs[i] = __builtin_amdgcn_readfirstlane(S.cur[i]);
+    for (int i = 0; i < 64; i++) curs[i] = __builtin_amdgcn_readfirstlane(cm[(i >> 2) * cw + (i & 3)]);
+  }
 
   unsigned mnext = 0;
   // one candidate (window row offset TT inside the current 16-row chunk): TT is a compile-time constant so that the
@@ -625,12 +628,24 @@ __global__ __launch_bounds__(256, 2) void me_int_fast_kernel(MeDev P, const jmhi
       }
       ps[1] = ps[5] + ps[6]; ps[2] = ps[7] + ps[8];
       ps[3] = ps[5] + ps[7]; ps[4] = ps[6] + ps[8];
+      // mv costs from the bits tables, four partitions per dword (as the main grid's refresh)
+      unsigned mc0 = 0;
+      {
+        const uint32_t *bxr = reinterpret_cast<const uint32_t *>(S.bxtab[ax]), *byr = reinterpret_cast<const uint32_t *>(S.bytab[ay]);
 #pragma unroll
-      for (int p = 1; p < JMHIP_NPART; p++) {
-        const unsigned mc = (unsigned)mv_cost(lam, 4 * cmx - S.px[p], 4 * cmy - S.py[p]) << 16;
-        best[p] = min(best[p], ps[p] + mc);
+        for (int g = 0; g < 11; g++) {
+          const uint32_t sum4 = bxr[g] + byr[g];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int p = 4 * g + k;
+            if (p < JMHIP_NPART) {
+              const unsigned prod = __umul24((unsigned)lam, (sum4 >> (8 * k)) & 255u);
+              if (p) best[p] = min(best[p], ps[p] + (prod & 0xffff0000u)); else mc0 = prod >> 16;
+            }
+          }
+        }
       }
-      unsigned c0 = ((ps[1] >> 16) + (ps[2] >> 16)) + (unsigned)mv_cost(lam, 4 * cmx - S.px[0], 4 * cmy - S.py[0]) + (unsigned)w16;
+      unsigned c0 = ((ps[1] >> 16) + (ps[2] >> 16)) + mc0 + (unsigned)w16;
       if (quirk00 && 4 * (mbx * 16 + cmx) == mbx * 16 && 4 * (mby * 16 + cmy) == mby * 16) c0 -= (unsigned)w16;
       const unsigned long long k0 = ((unsigned long long)c0 << 32) | tie;
       best0 = k0 < best0 ? k0 : best0;
