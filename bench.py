@@ -35,6 +35,26 @@ MBW, MBH = W // 16, H // 16
 QP = 28
 ME_BYTES_PER_MB = 1352          # cur 512 + ref 512 + out 41*8 (u16 pels as in JM)
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
+# Integer-VALU model of the search kernel (the bound that actually binds): per candidate and lane the algorithm
+# needs 64 v_sad_u8-class ops (16 rows x 4 dwords), 25 adds for the SetupLargerBlocks tree, and per partition one add
+# (mv cost) and one min. Issue times per wave-instruction per SIMD measured on MI355X with scratch/ubench/valu_rate2.hip
+# (profiles/r01_valu_issue_rates.txt): v_sad_u8 / v_min_u32 1.89 ns, v_add_u32 1.04 ns. 1024 SIMDs.
+VALU_NS_PER_WAVE_CANDIDATE = 64 * 1.89 + 25 * 1.04 + 40 * 1.04 + 41 * 1.89
+N_SIMD = 1024
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_final_summary.json")
+
+
+def pmc_traffic(kernel, n_units):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (tools/profile.sh: FETCH_SIZE and
+    WRITE_SIZE in separate runs, KB units). Only meaningful for the full-frame single-GPU launch it was recorded on."""
+    try:
+        with open(PMC_SUMMARY) as f:
+            k = json.load(f)[kernel]
+        if n_units != MBW * MBH:
+            return None
+        return int((k["FETCH_SIZE_KB_raw_per_launch"] + k["WRITE_SIZE_KB_raw_per_launch"]) * 1024)
+    except Exception:
+        return None
 
 
 def synth_frames(nframes):
@@ -287,6 +307,7 @@ def main():
         me_avg_ms = me_ms / max(1, me_launches)
         achieved = ME_BYTES_PER_MB * n / (me_avg_ms * 1e-3) / 1e9 if me_launches else 0.0
         sad_ops = (2 * R + 1) ** 2 * 256 * n / (me_avg_ms * 1e-3) if me_launches else 0.0
+        valu_floor_ms = n * ((2 * R + 1) ** 2 / 64.0) * VALU_NS_PER_WAVE_CANDIDATE / N_SIMD * 1e-6
         out = {
             "metric": "macroblocks/sec (full-search ME + DCT/quant), 1080p; bit-exact MV+coeff vs JM",
             "value": round(total_mbs / elapsed, 1), "unit": "macroblocks/s",
@@ -296,13 +317,19 @@ def main():
                                    "41 partitions, SAD full-pel + SATD sub-pel, dct_4x4 + dct_chroma, QP %d, 1 reference; "
                                    "predictor field (16,-16)+U{-8..8} qpel per MB" % QP,
                        "slices": world, "parallelism": "slice%d" % world},
-            "roofline": {"kernel": "me_int_kernel (integer full search, all 41 partitions)", "bound": "hbm",
+            "roofline": {"kernel": "me_int_fast_kernel (integer full search, all 41 partitions)", "bound": "hbm",
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                         "traffic": None, "avg_launch_ms": round(me_avg_ms, 4), "units_per_launch": n,
+                         "traffic": pmc_traffic("me_int_fast_kernel", n), "avg_launch_ms": round(me_avg_ms, 4), "units_per_launch": n,
                          "algorithmic_bytes_per_unit": ME_BYTES_PER_MB,
-                         "note": "full search is VALU/LDS-bound by construction (about 1e3 integer ops per compulsory byte, SURVEY 8(d)); "
-                                 "HBM fraction is small by design, see valu_sad_ops_per_s",
-                         "valu_sad_ops_per_s": round(sad_ops, 1)},
+                         "traffic_note": "bytes per launch = (FETCH_SIZE + WRITE_SIZE) KB x 1024 from profiles/r01_final_pmc_*.csv, raw: the "
+                                         "guide's x2 FETCH_SIZE correction is calibrated for 16 B/lane streaming reads and this kernel "
+                                         "reads dwords, so it is not applied (with it: fetch doubles)",
+                         "note": "full search is integer-VALU bound by construction (about 1e3 integer ops per compulsory byte, SURVEY 8(d)); "
+                                 "the HBM fraction is small by design. The binding roofline is `valu`: the time the search's "
+                                 "irreducible v_sad/add/min work takes at the measured MI355X issue rates",
+                         "valu": {"model_floor_ms": round(valu_floor_ms, 4), "frac": round(valu_floor_ms / me_avg_ms, 4) if me_launches else None,
+                                  "ns_per_wave_candidate_row": round(VALU_NS_PER_WAVE_CANDIDATE, 1), "simds": N_SIMD,
+                                  "abs_diffs_per_s": round(sad_ops, 1)}},
             "stages_ms_per_launch": {k: round(v[0] / max(1, v[1]), 4) for k, v in stage.items()},
         }
         if world == 1 and args.cpu_mbs > 0:

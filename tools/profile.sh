@@ -34,7 +34,7 @@ summ = {}
 for k in sorted(set(stats) | set(fetch) | set(write)):
     m = re.search(r"(\w+)(<[^>]*>)?\(", k.replace("(anonymous namespace)::", ""))
     short = (m.group(1) + (m.group(2) or "")) if m else k
-    summ[short] = {"stats": stats.get(k), "FETCH_SIZE_raw_per_launch": fetch.get(k), "WRITE_SIZE_raw_per_launch": write.get(k)}
+    summ[short] = {"stats": stats.get(k), "FETCH_SIZE_KB_raw_per_launch": fetch.get(k), "WRITE_SIZE_KB_raw_per_launch": write.get(k)}
 json.dump(summ, open(out + "/summary.json", "w"), indent=1)
 for k, v in summ.items():
     if any(s in k for s in ("me_", "interp", "tq_", "mc_", "finalize")): print(k, v)
