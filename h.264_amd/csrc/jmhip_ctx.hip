@@ -102,7 +102,7 @@ extern "C" void jmhip_ctx_destroy(jmhip_ctx *c)
     (void)hipFree(r.cr_sub[0]); (void)hipFree(r.cr_sub[1]);
   }
   (void)hipFree(c->cur_y); (void)hipFree(c->cur_u); (void)hipFree(c->cur_v);
-  (void)hipFree(c->stage_dev); (void)hipFree(c->me_jobs_dev); (void)hipFree(c->me_res_dev); (void)hipFree(c->ref_ptrs_dev); (void)hipFree(c->me_idx_dev);
+  (void)hipFree(c->stage_dev); (void)hipFree(c->me_jobs_dev); (void)hipFree(c->me_res_dev); (void)hipFree(c->ref_ptrs_dev); (void)hipFree(c->me_idx_dev); (void)hipFree(c->surf_dev); (void)hipFree(c->surf_jobs_dev);
   (void)hipFree(c->tq_jobs_dev); (void)hipFree(c->tq_res_dev); (void)hipFree(c->tq_quant_dev);
   (void)hipFree(c->fr_jobs_y); (void)hipFree(c->fr_jobs_c); (void)hipFree(c->fr_res_y); (void)hipFree(c->fr_res_c);
   (void)hipFree(c->fr_quant); (void)hipFree(c->fr_modes); (void)hipFree(c->rec_y); (void)hipFree(c->rec_u); (void)hipFree(c->rec_v);

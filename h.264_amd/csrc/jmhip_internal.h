@@ -39,6 +39,7 @@ struct jmhip_ctx {
   unsigned me_ref_mask = 0;
   void *me_idx_dev = nullptr;                         // macroblock indices: fast-path list then generic list
   std::vector<int> me_fast_idx, me_gen_idx;                           // reference slots used by the last ME call
+  void *surf_dev = nullptr, *surf_jobs_dev = nullptr; size_t surf_cap = 0, surf_jobs_cap = 0;   // jmhip_distortion_surface
   void *ref_ptrs_dev = nullptr;                       // [0..31] integer recon, [32..63] quarter-pel plane stacks
   // frame pipeline (MC -> residual -> TQ -> recon): per-MB luma job/result, 2 chroma jobs/results, recon picture
   void *fr_jobs_y = nullptr, *fr_jobs_c = nullptr, *fr_res_y = nullptr, *fr_res_c = nullptr, *fr_quant = nullptr, *fr_modes = nullptr;

@@ -1363,6 +1363,151 @@ extern "C" int jmhip_distortion_batch(jmhip_ctx *c, const jmhip_dist_job *jobs, 
   return JMHIP_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ distortion surfaces
+
+namespace {
+
+// One workgroup per (macroblock, reference): the (2R+1)^2 integer displacements around (cx, cy). The window is staged in
+// LDS with per-sample clamping; lane <-> displacement.
+template <int KIND>
+__global__ __launch_bounds__(256) void surface_kernel(MeDev P, const jmhip_surface_job *__restrict__ jobs, uint16_t *__restrict__ out)
+{
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ __attribute__((aligned(16))) uint8_t s_cur[16][16];
+  __shared__ __attribute__((aligned(16))) uint32_t s_c16[16][8];
+  const jmhip_surface_job job = jobs[blockIdx.x];
+  const int tid = threadIdx.x, R = job.R, UW = 2 * R + 1;
+  const int pitch = (UW + 15 + 3 + 4) & ~3;
+  const int bx = job.mb_x * 16 + job.cx - R, by = job.mb_y * 16 + job.cy - R;
+  const uint8_t *ref = P.ref_y[job.ref];
+  for (int d = tid; d < (pitch >> 2) * (UW + 15); d += 256) {
+    const int y = d / (pitch >> 2), xw = d - y * (pitch >> 2);
+    const uint8_t *row = ref + (size_t)clampi(by + y, 0, P.H - 1) * P.W;
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) v |= (uint32_t)row[clampi(bx + xw * 4 + k, 0, P.W - 1)] << (8 * k);
+    *reinterpret_cast<uint32_t *>(smem + (size_t)y * pitch + xw * 4) = v;
+  }
+  if (tid < 64) {
+    const int r = tid >> 2, k = tid & 3;
+    const uint32_t v = *reinterpret_cast<const uint32_t *>(P.cur + (size_t)(job.mb_y * 16 + r) * P.W + job.mb_x * 16 + k * 4);
+    *reinterpret_cast<uint32_t *>(&s_cur[r][k * 4]) = v;
+    const uint32_t bias = (r & 3) ? 0u : 0x80000000u;
+    s_c16[r][2 * k] = __builtin_amdgcn_perm(0u, v, 0x0c010c00u) + bias;
+    s_c16[r][2 * k + 1] = __builtin_amdgcn_perm(0u, v, 0x0c030c02u);
+  }
+  __syncthreads();
+  constexpr int NV = KIND == JMHIP_SURFACE_SAD_ROWS ? 64 : 20;
+  uint16_t *o = out + (size_t)blockIdx.x * UW * UW * NV;
+  for (int c = tid; c < UW * UW; c += 256) {
+    const int ay = c / UW, ax = c - ay * UW;
+    const uint8_t *wrow = smem + (size_t)ay * pitch + (ax & ~3);
+    const unsigned sh = ax & 3;
+    uint32_t rr[16][4];                              // the 16x16 reference block at this displacement, packed bytes
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const uint32_t *wp = reinterpret_cast<const uint32_t *>(wrow + (size_t)r * pitch);
+      const uint32_t d0 = wp[0], d1 = wp[1], d2 = wp[2], d3 = wp[3], d4 = wp[4];
+      rr[r][0] = __builtin_amdgcn_alignbyte(d1, d0, sh); rr[r][1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+      rr[r][2] = __builtin_amdgcn_alignbyte(d3, d2, sh); rr[r][3] = __builtin_amdgcn_alignbyte(d4, d3, sh);
+    }
+    uint32_t *o32 = reinterpret_cast<uint32_t *>(o + (size_t)c * NV);
+    if (KIND == JMHIP_SURFACE_SAD_ROWS) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const uint32_t *cw = reinterpret_cast<const uint32_t *>(&s_cur[r][0]);
+        const uint32_t s0 = __builtin_amdgcn_sad_u8(rr[r][0], cw[0], 0u), s1 = __builtin_amdgcn_sad_u8(rr[r][1], cw[1], 0u);
+        const uint32_t s2 = __builtin_amdgcn_sad_u8(rr[r][2], cw[2], 0u), s3 = __builtin_amdgcn_sad_u8(rr[r][3], cw[3], 0u);
+        o32[2 * r] = s0 | (s1 << 16); o32[2 * r + 1] = s2 | (s3 << 16);
+      }
+    } else {
+      uint32_t v4[16];
+#pragma unroll
+      for (int b = 0; b < 16; b++) {
+        const int y0 = (b >> 2) * 4, k = b & 3;
+        uint32_t c01[4], c23[4], rf[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) { c01[r] = s_c16[y0 + r][2 * k]; c23[r] = s_c16[y0 + r][2 * k + 1]; rf[r] = rr[y0 + r][k]; }
+        v4[b] = (uint32_t)satd4x4_packed(c01, c23, rf);
+      }
+#pragma unroll
+      for (int b = 0; b < 8; b++) o32[b] = v4[2 * b] | (v4[2 * b + 1] << 16);
+      uint32_t v8[4];
+#pragma unroll 1
+      for (int b = 0; b < 4; b++) {
+        const int y0 = (b >> 1) * 8, k = (b & 1) * 2;
+        int m2[8][8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+          const uint32_t c0 = *reinterpret_cast<const uint32_t *>(&s_cur[y0 + r][4 * k]), c1 = *reinterpret_cast<const uint32_t *>(&s_cur[y0 + r][4 * k + 4]);
+          const uint32_t lo = b & 1 ? rr[y0 + r][2] : rr[y0 + r][0], hi = b & 1 ? rr[y0 + r][3] : rr[y0 + r][1];
+          int row[8];
+#pragma unroll
+          for (int x = 0; x < 4; x++) { row[x] = (int)((c0 >> (8 * x)) & 255) - (int)((lo >> (8 * x)) & 255); row[4 + x] = (int)((c1 >> (8 * x)) & 255) - (int)((hi >> (8 * x)) & 255); }
+          had8(row);
+#pragma unroll
+          for (int x = 0; x < 8; x++) m2[r][x] = row[x];
+        }
+        int s = 0;
+#pragma unroll
+        for (int x = 0; x < 8; x++) {
+          int col[8];
+#pragma unroll
+          for (int r = 0; r < 8; r++) col[r] = m2[r][x];
+          had8(col);
+#pragma unroll
+          for (int r = 0; r < 8; r++) s += iabs(col[r]);
+        }
+        v8[b] = (uint32_t)((s + 2) >> 2);
+      }
+      o32[8] = v8[0] | (v8[1] << 16); o32[9] = v8[2] | (v8[3] << 16);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int jmhip_distortion_surface(jmhip_ctx *c, int kind, const jmhip_surface_job *jobs, int n, uint16_t *out)
+{
+  if (!c || !jobs || !out || n <= 0) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_distortion_surface: NULL/empty arguments") : JMHIP_ERR_ARG;
+  if (kind != JMHIP_SURFACE_SAD_ROWS && kind != JMHIP_SURFACE_SATD_BLOCKS) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_distortion_surface: kind");
+  if (!c->has_cur) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_distortion_surface: current picture not uploaded");
+  const int R = jobs[0].R;
+  for (int i = 0; i < n; i++) {
+    const jmhip_surface_job &j = jobs[i];
+    if (j.R != R || R < 0 || R > 64) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_distortion_surface: one range (0..64) per call");
+    if (j.mb_x < 0 || j.mb_x >= c->mbw || j.mb_y < 0 || j.mb_y >= c->mbh) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_distortion_surface: macroblock outside the picture");
+    if (j.ref < 0 || j.ref >= (int)c->refs.size() || !c->refs[j.ref].has_pic) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_distortion_surface: reference slot not uploaded");
+    if (j.cx < -4096 || j.cx > 4096 || j.cy < -4096 || j.cy > 4096) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_distortion_surface: centre out of range");
+  }
+  JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
+  int rc = jm_ensure_ref_table(c);
+  if (rc) return rc;
+  const int UW = 2 * R + 1, nv = kind == JMHIP_SURFACE_SAD_ROWS ? 64 : 20;
+  const size_t bytes = (size_t)n * UW * UW * nv * sizeof(uint16_t);
+  const int pitch = (UW + 15 + 3 + 4) & ~3;
+  const size_t lds = (size_t)pitch * (UW + 15) + 16;
+  if (lds > 48 * 1024) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_distortion_surface: range too large for one LDS window");
+  if (c->surf_cap < bytes || c->surf_jobs_cap < (size_t)n) {
+    if (c->surf_dev) JM_HIP_CHECK(c, hipFree(c->surf_dev));
+    if (c->surf_jobs_dev) JM_HIP_CHECK(c, hipFree(c->surf_jobs_dev));
+    c->surf_dev = c->surf_jobs_dev = nullptr; c->surf_cap = 0; c->surf_jobs_cap = 0;
+    if (hipMalloc(&c->surf_dev, bytes) != hipSuccess || hipMalloc(&c->surf_jobs_dev, sizeof(jmhip_surface_job) * (size_t)n) != hipSuccess)
+      return jm_fail(c, JMHIP_ERR_NOMEM, "distortion surface arrays");
+    c->surf_cap = bytes; c->surf_jobs_cap = (size_t)n;
+  }
+  MeDev P{};
+  P.W = c->W; P.H = c->H; P.Wp = c->Wp; P.Hp = c->Hp; P.cur = c->cur_y;
+  P.ref_y = reinterpret_cast<const uint8_t *const *>(c->ref_ptrs_dev);
+  JM_HIP_CHECK(c, hipMemcpyAsync(c->surf_jobs_dev, jobs, sizeof(jmhip_surface_job) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  if (kind == JMHIP_SURFACE_SAD_ROWS) surface_kernel<JMHIP_SURFACE_SAD_ROWS><<<n, 256, lds, c->stream>>>(P, (const jmhip_surface_job *)c->surf_jobs_dev, (uint16_t *)c->surf_dev);
+  else surface_kernel<JMHIP_SURFACE_SATD_BLOCKS><<<n, 256, lds, c->stream>>>(P, (const jmhip_surface_job *)c->surf_jobs_dev, (uint16_t *)c->surf_dev);
+  JM_HIP_CHECK(c, hipGetLastError());
+  JM_HIP_CHECK(c, hipMemcpyAsync(out, c->surf_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+  JM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+  return JMHIP_OK;
+}
+
 extern "C" int jmhip_me_results_download(jmhip_ctx *c, jmhip_me_result *results, int n)
 {
   if (!c || !results || n <= 0) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_results_download: NULL/empty arguments") : JMHIP_ERR_ARG;

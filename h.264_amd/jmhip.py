@@ -54,6 +54,7 @@ ME_MB_DTYPE = np.dtype([("mb_x", "<i2"), ("mb_y", "<i2"), ("ref", "<i2"), ("ref_
                         ("pred_mv", "<i2", (NPART, 2))])
 ME_RESULT_DTYPE = np.dtype([("mv", "<i2", (NPART, 2)), ("cost", "<i4", (NPART,)),
                             ("mv_int", "<i2", (NPART, 2)), ("cost_int", "<i4", (NPART,))])
+SURFACE_JOB_DTYPE = np.dtype([("mb_x", "<i2"), ("mb_y", "<i2"), ("ref", "<i2"), ("R", "<i2"), ("cx", "<i2"), ("cy", "<i2")])
 DIST_JOB_DTYPE = np.dtype([("pic_x", "<i2"), ("pic_y", "<i2"), ("bsx", "<i2"), ("bsy", "<i2"),
                            ("cand_x", "<i4"), ("cand_y", "<i4"), ("ref", "<i2"), ("use_satd", "<i2"),
                            ("umv", "<i2"), ("wp", "<i2"), ("weight", "<i2"), ("offset", "<i2"), ("wp_round", "<i2"), ("wp_denom", "<i2")])
@@ -106,6 +107,7 @@ def load_library():
     lib.jmhip_me_results_download.argtypes = [vp, vp, ip]
     lib.jmhip_distortion_batch.argtypes = [vp, vp, ip, vp]
     lib.jmhip_me_subpel.argtypes = [vp, C.POINTER(MeParams), vp, ip, vp]
+    lib.jmhip_distortion_surface.argtypes = [vp, ip, vp, ip, vp]
     lib.jmhip_tq_batch.argtypes = [vp, ip, ip, vp, ip, vp, ip, vp]
     lib.jmhip_flat_quant.argtypes = [vp, ip, ip, ip]
     lib.jmhip_flat_quant.restype = None
@@ -271,6 +273,15 @@ class Context:
         results = np.ascontiguousarray(results, dtype=ME_RESULT_DTYPE)
         self._chk(self.lib.jmhip_me_subpel(self.h, C.byref(prm), _ptr(mbs), len(mbs), _ptr(results)), "jmhip_me_subpel")
         return results
+
+    def distortion_surface(self, kind, jobs):
+        """kind 'sad_rows' -> (n, 2R+1, 2R+1, 16, 4) uint16; 'satd_blocks' -> (n, 2R+1, 2R+1, 20) uint16."""
+        jobs = np.ascontiguousarray(jobs, dtype=SURFACE_JOB_DTYPE)
+        uw = 2 * int(jobs[0]["R"]) + 1
+        shape = (len(jobs), uw, uw, 16, 4) if kind == "sad_rows" else (len(jobs), uw, uw, 20)
+        out = np.zeros(shape, dtype=np.uint16)
+        self._chk(self.lib.jmhip_distortion_surface(self.h, 0 if kind == "sad_rows" else 1, _ptr(jobs), len(jobs), _ptr(out)), "jmhip_distortion_surface")
+        return out
 
     def distortion_batch(self, jobs):
         jobs = np.ascontiguousarray(jobs, dtype=DIST_JOB_DTYPE)

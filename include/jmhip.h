@@ -170,6 +170,19 @@ typedef struct {
 /* out[i] = the FULL distortion (no early exit: what JM returns for min_mcost = INT_MAX). Luma only. */
 int jmhip_distortion_batch(jmhip_ctx *ctx, const jmhip_dist_job *jobs, int n, int32_t *out);
 
+/* Distortion SURFACES for host-driven integer-pel walks (EPZSPelBlockMotionSearch src/me_epzs.c:1500,
+ * UMHEXIntegerPelBlockMotionSearch src/me_umhex.c:229): every integer displacement (cx-R..cx+R, cy-R..cy+R) of one
+ * macroblock against one reference, raster order (dy outer), in the granularity at which JM's kernels can leave early, so
+ * that the host reproduces computeSAD / computeSATD return values exactly, partial sums included:
+ *   JMHIP_SURFACE_SAD_ROWS     64 uint16 per displacement: [row 0..15][4-sample group 0..3] = the inner-loop terms of
+ *                              computeSAD (src/me_distortion.c:364-375, row-wise exit :373)
+ *   JMHIP_SURFACE_SATD_BLOCKS  20 uint16: [0..15] HadamardSAD4x4 of the 4x4 blocks (raster), [16..19] HadamardSAD8x8 of
+ *                              the 8x8 blocks (computeSATD, :657-731, block-wise exit :690/:720)
+ * Samples outside the picture follow UMV access (= per-sample clamp on the integer plane). */
+enum { JMHIP_SURFACE_SAD_ROWS = 0, JMHIP_SURFACE_SATD_BLOCKS = 1 };
+typedef struct { int16_t mb_x, mb_y, ref, R; int16_t cx, cy; } jmhip_surface_job;   /* centre (cx, cy) in pels */
+int jmhip_distortion_surface(jmhip_ctx *ctx, int kind, const jmhip_surface_job *jobs, int n, uint16_t *out);
+
 /* SubPelBlockMotionSearch alone (src/me_fullsearch.c:341): results[i].mv_int[p] is the INPUT (integer vector in pel
  * units, as FullPel/FastFull left it), results[i].mv/cost[p] the output. Same params/jobs as jmhip_me_frame. */
 int jmhip_me_subpel(jmhip_ctx *ctx, const jmhip_me_params *prm, const jmhip_me_mb *mbs, int n, jmhip_me_result *results);

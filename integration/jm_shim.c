@@ -8,7 +8,7 @@
  * JM's own function (dlsym RTLD_NEXT) and counted; a failing jmhip_* call aborts loudly (JM's error convention is
  * error()/exit). JMHIP_SHIM_STATS=1 prints, per symbol, how many calls ran on the device and how many were forwarded.
  * JMHIP_SHIM (hex mask, default all): 0x01 sub-pel planes, 0x04 full-pel + sub-pel search, 0x08 fast full search,
- * 0x10 dct_4x4/dct_16x16, 0x20 dct_8x8, 0x40 dct_chroma.
+ * 0x10 dct_4x4/dct_16x16, 0x20 dct_8x8, 0x40 dct_chroma, 0x100 distortion surfaces for EPZS / UMHexagonS integer walks.
  *
  * The proof of the drop-in claim is tests/test_jm_shim_gpu.py: the bitstream and the reconstruction this encoder
  * writes are byte-identical to the unmodified encoder's.
@@ -36,11 +36,12 @@ extern void SetMotionVectorPredictor(short pmv[2], char **refPic, short ***tmp_m
                                      int block_x, int block_y, int blockshape_x, int blockshape_y);
 extern const int LEVELMVLIMIT[17][6];
 
-enum { S_LUMA, S_CHROMA, S_FULL, S_SUB, S_FAST, S_D4, S_D8, S_D16, S_DCR, S_COUNT };
+enum { S_LUMA, S_CHROMA, S_FULL, S_SUB, S_FAST, S_D4, S_D8, S_D16, S_DCR, S_WALK, S_SAD, S_SATD, S_COUNT };
 static const char *s_names[S_COUNT] = { "getSubImagesLuma", "getSubImagesChroma", "FullPelBlockMotionSearch",
-  "SubPelBlockMotionSearch", "FastFullPelBlockMotionSearch", "dct_4x4", "dct_8x8", "dct_16x16", "dct_chroma" };
+  "SubPelBlockMotionSearch", "FastFullPelBlockMotionSearch", "dct_4x4", "dct_8x8", "dct_16x16", "dct_chroma",
+  "EPZS_UMHex_integer_walks", "computeSAD", "computeSATD" };
 static long n_dev[S_COUNT], n_fwd[S_COUNT];
-static unsigned shim_mask = 0xff;
+static unsigned shim_mask = 0x1ff;
 static int verify;            /* JMHIP_SHIM_VERIFY=1: run JM's own search beside the device's and report differences */
 static jmhip_ctx *g;
 static int g_w, g_h;
@@ -123,6 +124,8 @@ static int slot_assign(StorablePicture *s)
   return i;
 }
 
+static unsigned long pic_serial;          /* bumped whenever a new source picture goes to the device */
+
 /* the source picture: uploaded once per coded picture */
 static int cur_ready(void)
 {
@@ -133,6 +136,7 @@ static int cur_ready(void)
     OK(jmhip_cur_upload(g, pCurImg[0], img->yuv_format != YUV400 ? imgUV_org[0][0] : NULL,
                         img->yuv_format != YUV400 ? imgUV_org[1][0] : NULL, (int)sizeof(imgpel), img->width, img->width_cr, 0));
     key.enc = enc_picture; key.number = img->number; key.bfr = img->b_frame_to_code; key.type = img->type; key.y = pCurImg[0];
+    pic_serial++;
   }
   return 1;
 }
@@ -219,18 +223,20 @@ static int partition_of(int blocktype, int x, int y)     /* (x, y): block origin
 }
 
 /* what the device search covers: luma-only SAD (integer) / SATD (sub-pel), no weighted ME, frame pictures */
-static int me_ok(short ref, int list, StorablePicture **rp, int *slot)
+static int me_ok_metric(short ref, int list, StorablePicture **rp, int *slot, int fixed_metrics)
 {
   int list_offset = img->mb_data[img->current_mb_nr].list_offset;
   int weighted = ((active_pps->weighted_pred_flag && (img->type == P_SLICE || img->type == SP_SLICE)) ||
                   (active_pps->weighted_bipred_idc && (img->type == B_SLICE))) && input->UseWeightedReferenceME;
   if (weighted || input->ChromaMEEnable || list_offset) return 0;
-  if (input->MEErrorMetric[F_PEL] != ERROR_SAD || input->MEErrorMetric[H_PEL] != ERROR_SATD || input->MEErrorMetric[Q_PEL] != ERROR_SATD) return 0;
+  if (fixed_metrics && (input->MEErrorMetric[F_PEL] != ERROR_SAD || input->MEErrorMetric[H_PEL] != ERROR_SATD || input->MEErrorMetric[Q_PEL] != ERROR_SATD)) return 0;
   if (!cur_ready()) return 0;
   *rp = listX[list][ref];
   *slot = slot_find(*rp);
   return *slot >= 0;
 }
+
+static int me_ok(short ref, int list, StorablePicture **rp, int *slot) { return me_ok_metric(ref, list, rp, slot, 1); }
 
 static void me_params(jmhip_me_params *prm, int mode, int range, int lam_f, int lam_h, int lam_q, int p)
 {
@@ -381,6 +387,132 @@ int FastFullPelBlockMotionSearch(imgpel *orig_pic, short ref, int list, int pic_
     return r.cost_int[p];
   }
 }
+
+/* ------------------------------------------------------------------ EPZS / UMHexagonS: JM's walker, the device's distortions */
+
+/* EPZSPelBlockMotionSearch (src/me_epzs.c:1500) and UMHEXIntegerPelBlockMotionSearch (src/me_umhex.c:229) choose their next
+ * candidate from the costs of the previous ones, so the walk itself stays JM's code. What they spend their time in is
+ * computeSAD / computeSATD at integer positions: the shim fetches, once per (macroblock, reference), the distortion of
+ * EVERY integer displacement in the granularity of JM's early exits (jmhip_distortion_surface) and answers the kernels'
+ * calls from it, partial sums included. A candidate outside the fetched window, at a sub-pel position, with weights or
+ * chroma terms goes to JM's own kernel. */
+static struct { int on; imgpel *orig; int bx0, by0, bsx, bsy, pic_x, pic_y, slot, px, py; StorablePicture *rp; } walk;
+static struct { unsigned long serial; int mb_nr, cx, cy, R; uint16_t *buf; } surf[2][MAX_SLOTS];
+
+static void walk_begin(imgpel *orig, short ref, int list, int pic_pix_x, int pic_pix_y, int blocktype, int pmx, int pmy)
+{
+  StorablePicture *rp; int slot;
+  walk.on = 0;
+  if (!(shim_mask & 0x100) || ref < 0 || !me_ok_metric(ref, list, &rp, &slot, 0)) return;
+  walk.on = 1; walk.orig = orig; walk.rp = rp; walk.slot = slot;
+  walk.pic_x = pic_pix_x; walk.pic_y = pic_pix_y;
+  walk.bx0 = pic_pix_x - img->opix_x; walk.by0 = pic_pix_y - img->opix_y;
+  walk.bsx = input->blc_size[blocktype][0]; walk.bsy = input->blc_size[blocktype][1];
+  walk.px = pmx; walk.py = pmy;
+  n_dev[S_WALK]++;
+}
+
+/* the surface of `kind` for the current macroblock and the walk's reference; NULL if the displacement is not covered */
+static const uint16_t *surface_at(int kind, int cand_x, int cand_y, int nv)
+{
+  int mvx, mvy, ax, ay, UW;
+  if (!walk.on || ((cand_x | cand_y) & 3) || ref_pic_sub.luma != walk.rp->p_curr_img_sub) return NULL;
+  if (surf[kind][walk.slot].serial != pic_serial || surf[kind][walk.slot].mb_nr != img->current_mb_nr || !surf[kind][walk.slot].buf) {
+    jmhip_surface_job job;
+    int R = input->search_range > 32 ? 32 : input->search_range;
+    UW = 2 * R + 1;
+    if (!surf[kind][walk.slot].buf || surf[kind][walk.slot].R != R) {
+      free(surf[kind][walk.slot].buf);
+      surf[kind][walk.slot].buf = malloc((size_t)UW * UW * nv * sizeof(uint16_t));
+    }
+    job.mb_x = img->opix_x >> 4; job.mb_y = img->opix_y >> 4; job.ref = walk.slot; job.R = R;
+    /* centred between the zero vector and the first block's predictor: the walks start from both */
+    job.cx = iClip3(-R, R, walk.px / 8); job.cy = iClip3(-R, R, walk.py / 8);
+    OK(jmhip_distortion_surface(g, kind, &job, 1, surf[kind][walk.slot].buf));
+    surf[kind][walk.slot].serial = pic_serial; surf[kind][walk.slot].mb_nr = img->current_mb_nr;
+    surf[kind][walk.slot].cx = job.cx; surf[kind][walk.slot].cy = job.cy; surf[kind][walk.slot].R = R;
+  }
+  UW = 2 * surf[kind][walk.slot].R + 1;
+  mvx = (cand_x >> 2) - IMG_PAD_SIZE - walk.pic_x; mvy = (cand_y >> 2) - IMG_PAD_SIZE - walk.pic_y;
+  ax = mvx - surf[kind][walk.slot].cx + surf[kind][walk.slot].R; ay = mvy - surf[kind][walk.slot].cy + surf[kind][walk.slot].R;
+  if (ax < 0 || ay < 0 || ax >= UW || ay >= UW) return NULL;
+  return surf[kind][walk.slot].buf + ((size_t)ay * UW + ax) * nv;
+}
+
+int computeSAD(imgpel *src_pic, int bsy, int bsx, int min_mcost, int cand_x, int cand_y)
+{
+  static int (*orig)(imgpel *, int, int, int, int, int);
+  const uint16_t *s = NULL;
+  if (walk.on && src_pic == walk.orig && bsx == walk.bsx && bsy == walk.bsy && !ChromaMEEnable)
+    s = surface_at(JMHIP_SURFACE_SAD_ROWS, cand_x, cand_y, 64);
+  if (!s) {
+    if (!orig) orig = next_sym("computeSAD");
+    n_fwd[S_SAD]++;
+    return orig(src_pic, bsy, bsx, min_mcost, cand_x, cand_y);
+  }
+  {                                                  /* src/me_distortion.c:364-375, the row-wise exit at :373 */
+    int mcost = 0, y, gx, g0 = walk.bx0 >> 2, g1 = (walk.bx0 + bsx) >> 2;
+    n_dev[S_SAD]++;
+    for (y = walk.by0; y < walk.by0 + bsy; y++) {
+      for (gx = g0; gx < g1; gx++) mcost += s[y * 4 + gx];
+      if (mcost >= min_mcost) return mcost;
+    }
+    return mcost;
+  }
+}
+
+int computeSATD(imgpel *src_pic, int bsy, int bsx, int min_mcost, int cand_x, int cand_y)
+{
+  static int (*orig)(imgpel *, int, int, int, int, int);
+  const uint16_t *s = NULL;
+  if (walk.on && src_pic == walk.orig && bsx == walk.bsx && bsy == walk.bsy && (!test8x8transform || !((bsx | bsy) & 7)))
+    s = surface_at(JMHIP_SURFACE_SATD_BLOCKS, cand_x, cand_y, 20);
+  if (!s) {
+    if (!orig) orig = next_sym("computeSATD");
+    n_fwd[S_SATD]++;
+    return orig(src_pic, bsy, bsx, min_mcost, cand_x, cand_y);
+  }
+  {                                                  /* src/me_distortion.c:669-731: sub-blocks y outer, x inner; exit on '>' */
+    int mcost = 0, y, x;
+    n_dev[S_SATD]++;
+    if (!test8x8transform) {
+      for (y = walk.by0; y < walk.by0 + bsy; y += 4)
+        for (x = walk.bx0; x < walk.bx0 + bsx; x += 4) { mcost += s[(y >> 2) * 4 + (x >> 2)]; if (mcost > min_mcost) return mcost; }
+    } else {
+      for (y = walk.by0; y < walk.by0 + bsy; y += 8)
+        for (x = walk.bx0; x < walk.bx0 + bsx; x += 8) { mcost += s[16 + (y >> 3) * 2 + (x >> 3)]; if (mcost > min_mcost) return mcost; }
+    }
+    return mcost;
+  }
+}
+
+int EPZSPelBlockMotionSearch(imgpel *cur_pic, short ref, int list, int list_offset, char ***refPic, short ****tmp_mv,
+                             int pic_pix_x, int pic_pix_y, int blocktype, short pred_mv[2], short mv[2], int search_range,
+                             int min_mcost, int lambda_factor)
+{
+  static int (*orig)(imgpel *, short, int, int, char ***, short ****, int, int, int, short *, short *, int, int, int);
+  int r;
+  if (!orig) orig = next_sym("EPZSPelBlockMotionSearch");
+  if (!list_offset) walk_begin(cur_pic, ref, list, pic_pix_x, pic_pix_y, blocktype, pred_mv[0], pred_mv[1]);
+  r = orig(cur_pic, ref, list, list_offset, refPic, tmp_mv, pic_pix_x, pic_pix_y, blocktype, pred_mv, mv, search_range, min_mcost, lambda_factor);
+  walk.on = 0;
+  return r;
+}
+
+#define UMHEX_WALK(NAME)                                                                                              \
+  int NAME(imgpel *orig_pic, short ref, int list, int pic_pix_x, int pic_pix_y, int blocktype, short pred_mv_x,        \
+           short pred_mv_y, short *mv_x, short *mv_y, int search_range, int min_mcost, int lambda_factor)             \
+  {                                                                                                                   \
+    static int (*orig)(imgpel *, short, int, int, int, int, short, short, short *, short *, int, int, int);           \
+    int r;                                                                                                            \
+    if (!orig) orig = next_sym(#NAME);                                                                                \
+    walk_begin(orig_pic, ref, list, pic_pix_x, pic_pix_y, blocktype, pred_mv_x, pred_mv_y);                           \
+    r = orig(orig_pic, ref, list, pic_pix_x, pic_pix_y, blocktype, pred_mv_x, pred_mv_y, mv_x, mv_y, search_range, min_mcost, lambda_factor); \
+    walk.on = 0;                                                                                                      \
+    return r;                                                                                                         \
+  }
+UMHEX_WALK(UMHEXIntegerPelBlockMotionSearch)
+UMHEX_WALK(smpUMHEXIntegerPelBlockMotionSearch)
 
 /* ------------------------------------------------------------------ transform + quantisation + reconstruction */
 

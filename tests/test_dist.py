@@ -130,3 +130,60 @@ def test_me_subpel_alone(pkg, rdopt, t8x8):
                                        int(mb["pred_mv"][q][0]), int(mb["pred_mv"][q][1]),
                                        mvq.ctypes.data, mvq[1:].ctypes.data, 9, 9, 2147483647, lam_a)
             assert (int(got["mv"][i, q, 0]), int(got["mv"][i, q, 1]), int(got["cost"][i, q])) == (int(mvq[0]), int(mvq[1]), cost), (i, q)
+
+
+def test_distortion_surface(pkg):
+    """Row-segment SADs and per-block SATDs of every integer displacement, against the oracle's computeSAD / computeSATD
+    evaluated on exactly those pieces (1x4 rows, 4x4 and 8x8 blocks) under UMV access."""
+    from h264_amd.jmhip import SURFACE_JOB_DTYPE
+    rng = np.random.default_rng(23)
+    w, h, R = 64, 48, 4
+    cur, ref = make_pair(rng, w, h, "shift")
+    ctx = pkg.Context(w, h, yuv_format=0, max_refs=1, search_range=16)
+    ctx.ref_upload(0, ref)
+    ctx.interp_luma(0)
+    ctx.cur_upload(cur)
+    jobs = np.zeros(3, dtype=SURFACE_JOB_DTYPE)
+    # an inner macroblock, the top-left one pushed out of the picture, the bottom-right one pushed far out
+    for i, (mx, my, cx, cy) in enumerate([(1, 1, 2, -1), (0, 0, -14, -9), (3, 2, 30, 25)]):
+        jobs[i] = (mx, my, 0, R, cx, cy)
+    sad = ctx.distortion_surface("sad_rows", jobs)
+    satd = ctx.distortion_surface("satd_blocks", jobs)
+    ctx.close()
+
+    L = oracle.lib()
+    rp = oracle.RefPic(ref, yuv_format=0)
+    cur16 = cur.astype(np.uint16)
+    proto = [C.POINTER(oracle.Dist), C.c_void_p] + [C.c_int] * 5
+    L.jmo_sad.argtypes = proto
+    L.jmo_satd.argtypes = proto
+
+    def dist(test8x8):
+        d = oracle.Dist()
+        d.ref = C.pointer(rp.ref)
+        d.umv, d.chroma_me, d.test8x8, d.max_val, d.max_val_uv = 1, 0, test8x8, 255, 255
+        return d
+    d4, d8 = dist(0), dist(1)
+    for i, job in enumerate(jobs):
+        ox, oy = int(job["mb_x"]) * 16, int(job["mb_y"]) * 16
+        for ay in range(2 * R + 1):
+            for ax in range(2 * R + 1):
+                mvx, mvy = int(job["cx"]) - R + ax, int(job["cy"]) - R + ay
+                for r in range(16):
+                    for g in range(4):
+                        src = np.zeros(768, np.uint16)
+                        src[:4] = cur16[oy + r, ox + 4 * g:ox + 4 * g + 4]
+                        want = L.jmo_sad(C.byref(d4), src.ctypes.data, 1, 4, 2147483647, (ox + 4 * g + 20 + mvx) * 4, (oy + r + 20 + mvy) * 4)
+                        assert int(sad[i, ay, ax, r, g]) == want, (i, ay, ax, r, g)
+                for b in range(16):
+                    bx, by = 4 * (b & 3), 4 * (b >> 2)
+                    src = np.zeros(768, np.uint16)
+                    src[:16] = cur16[oy + by:oy + by + 4, ox + bx:ox + bx + 4].reshape(-1)
+                    want = L.jmo_satd(C.byref(d4), src.ctypes.data, 4, 4, 2147483647, (ox + bx + 20 + mvx) * 4, (oy + by + 20 + mvy) * 4)
+                    assert int(satd[i, ay, ax, b]) == want, (i, ay, ax, b)
+                for b in range(4):
+                    bx, by = 8 * (b & 1), 8 * (b >> 1)
+                    src = np.zeros(768, np.uint16)
+                    src[:64] = cur16[oy + by:oy + by + 8, ox + bx:ox + bx + 8].reshape(-1)
+                    want = L.jmo_satd(C.byref(d8), src.ctypes.data, 8, 8, 2147483647, (ox + bx + 20 + mvx) * 4, (oy + by + 20 + mvy) * 4)
+                    assert int(satd[i, ay, ax, 16 + b]) == want, (i, ay, ax, "8x8", b)

@@ -41,7 +41,7 @@ FrameSkip = {bframes}
 SymbolMode = {cabac}
 SearchMode = {search}
 RDOptimization = {rdopt}
-MEDistortionFPel = 0
+MEDistortionFPel = {fpel}
 MEDistortionHPel = 2
 MEDistortionQPel = 2
 MDDistortion = 2
@@ -59,6 +59,10 @@ CASES = {
     "full_baseline": dict(search=-1, profile=66, cabac=0, t8x8=0, bframes=0, refs=1, rdopt=1, adrnd=1, yuv=1),  # FullPel+SubPel, dct_4x4/16x16/chroma
     "fastfull_high": dict(search=0, profile=100, cabac=1, t8x8=1, bframes=1, refs=2, rdopt=1, adrnd=0, yuv=1),  # FastFull, dct_8x8, B slices, 2 refs
     "fastfull_lowcplx": dict(search=0, profile=66, cabac=0, t8x8=0, bframes=0, refs=2, rdopt=0, adrnd=0, yuv=1),  # FastFull pos_00 pre-check, search_range/2 on ref 1
+    # EPZS / UMHexagonS: JM's own walker, integer-pel computeSAD / computeSATD answered from the device's distortion surfaces
+    "epzs_main": dict(search=3, profile=77, cabac=1, t8x8=0, bframes=1, refs=2, rdopt=1, adrnd=0, yuv=1),
+    "umhex_baseline": dict(search=1, profile=66, cabac=0, t8x8=0, bframes=0, refs=2, rdopt=1, adrnd=1, yuv=1),
+    "epzs_satd_high": dict(search=3, profile=100, cabac=1, t8x8=1, bframes=0, refs=1, rdopt=1, adrnd=0, yuv=1, fpel=2),
     "full_lowcplx_422": dict(search=-1, profile=122, cabac=0, t8x8=1, bframes=0, refs=1, rdopt=0, adrnd=1, yuv=2),  # rdopt off centre rule, 4:2:2 chroma DC
 }
 
@@ -92,6 +96,7 @@ def run(exe, d, env=None):
 
 def prepare(tmp_path, name, w=176, h=144, frames=3, R=16, qp=28):
     v = dict(CASES[name], w=w, h=h, frames=frames, R=R, qp=qp)
+    v.setdefault("fpel", 0)
     with open(tmp_path / "case.cfg", "w") as f:
         f.write(CFG.format(**v))
     make_clip(tmp_path / "clip.yuv", w, h, frames + v["bframes"] * (frames - 1), v["yuv"])
@@ -123,9 +128,14 @@ def test_jm_with_hip_hot_path_is_byte_identical(tmp_path, name):
     print(name, served)
     # the device must actually have served the path (not a forward-everything pass)
     assert served["getSubImagesLuma"][0] > 0 and served["getSubImagesChroma"][0] > 0
-    assert served["SubPelBlockMotionSearch"][0] > 1000 and served["SubPelBlockMotionSearch"][1] == 0
-    key = "FullPelBlockMotionSearch" if CASES[name]["search"] == -1 else "FastFullPelBlockMotionSearch"
-    assert served[key][0] > 1000 and served[key][1] == 0
+    if CASES[name]["search"] in (-1, 0):
+        assert served["SubPelBlockMotionSearch"][0] > 1000 and served["SubPelBlockMotionSearch"][1] == 0
+        key = "FullPelBlockMotionSearch" if CASES[name]["search"] == -1 else "FastFullPelBlockMotionSearch"
+        assert served[key][0] > 1000 and served[key][1] == 0
+    else:
+        assert served["EPZS_UMHex_integer_walks"][0] > 1000
+        kernel = "computeSATD" if CASES[name].get("fpel") == 2 else "computeSAD"
+        assert served[kernel][0] > 10000, "integer-pel distortions were not served from the device surface"
     assert served["dct_4x4"][0] > 1000 and served["dct_chroma"][0] > 100
     if CASES[name]["t8x8"]:
         assert served["dct_8x8"][0] > 100
