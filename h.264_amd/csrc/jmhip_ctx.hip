@@ -23,6 +23,10 @@ extern "C" int jmhip_sizeof(int which)
   case 6: return (int)sizeof(jmhip_me_params);
   case 7: return (int)sizeof(jmhip_config);
   case 8: return (int)sizeof(jmhip_mb_mode);
+  case 9: return (int)sizeof(jmhip_surface_job);
+  case 10: return (int)sizeof(jmhip_bipred_job);
+  case 11: return (int)sizeof(jmhip_bipred_result);
+  case 12: return (int)sizeof(jmhip_bipred_params);
   default: return -1;
   }
 }

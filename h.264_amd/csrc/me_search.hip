@@ -1508,6 +1508,245 @@ extern "C" int jmhip_distortion_surface(jmhip_ctx *c, int kind, const jmhip_surf
   return JMHIP_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ bi-predictive search
+
+namespace {
+
+struct BiDev {
+  int W, H, Wp, Hp, lam_f, lam_h, lam_q, t8x8, wp, w1, w2, off, rnd, den;
+  const uint8_t *cur;
+  const uint8_t *const *ref_y;
+  const uint8_t *const *ref_sub;
+};
+
+// the bi-predicted sample quartet: (a + b + 1) >> 1 is v_lerp_u8 with an all-ones selector; weights go sample by sample
+__device__ __forceinline__ uint32_t bipel4(const BiDev &B, uint32_t a, uint32_t b)
+{
+  if (!B.wp) return __builtin_amdgcn_lerp(a, b, 0x01010101u);                     // me_distortion.c:504
+  uint32_t r = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int p1 = (a >> (8 * k)) & 255, p2 = (b >> (8 * k)) & 255;
+    const int v = ((B.w1 * p1 + B.w2 * p2 + 2 * B.rnd) >> (B.den + 1)) + B.off;    // :583
+    r |= (uint32_t)min(max(v, 0), 255) << (8 * k);
+  }
+  return r;
+}
+
+__global__ __launch_bounds__(256) void bipred_kernel(BiDev B, const jmhip_bipred_job *__restrict__ jobs, jmhip_bipred_result *__restrict__ res)
+{
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ __attribute__((aligned(16))) uint8_t s_cur[16][16];
+  __shared__ __attribute__((aligned(16))) uint32_t s_c16[16][8];
+  __shared__ uint32_t s_fix[16][4];                 // stage 0: the fixed 16x16 block of picture 1
+  __shared__ unsigned s_best;
+  __shared__ int s_satd[9], s_mv[2], s_min;
+  const jmhip_bipred_job job = jobs[blockIdx.x];
+  const int tid = threadIdx.x;
+  const int ox = job.mb_x * 16, oy = job.mb_y * 16;
+  if (tid < 64) {
+    const int r = tid >> 2, k = tid & 3;
+    const uint32_t v = *reinterpret_cast<const uint32_t *>(B.cur + (size_t)(oy + r) * B.W + ox + k * 4);
+    *reinterpret_cast<uint32_t *>(&s_cur[r][k * 4]) = v;
+    const uint32_t bias = (r & 3) ? 0u : 0x80000000u;
+    s_c16[r][2 * k] = __builtin_amdgcn_perm(0u, v, 0x0c010c00u) + bias;
+    s_c16[r][2 * k + 1] = __builtin_amdgcn_perm(0u, v, 0x0c030c02u);
+  }
+  if (tid == 0) s_best = 0xffffffffu;
+
+  if (job.stage == 0) {
+    // ---------------- FullPelBlockMotionBiPred: integer planes, per-sample clamp == UMV origin clamp on the 20-pel ring
+    const int R = job.search_range, UW = 2 * R + 1;
+    const int pitch = (UW + 15 + 3 + 4) & ~3;
+    const uint8_t *ref1 = B.ref_y[job.ref1], *ref2 = B.ref_y[job.ref2];
+    const int bx = ox + job.mv[0] - R, by = oy + job.mv[1] - R;
+    for (int d = tid; d < (pitch >> 2) * (UW + 15); d += 256) {
+      const int y = d / (pitch >> 2), xw = d - y * (pitch >> 2);
+      const uint8_t *row = ref2 + (size_t)clampi(by + y, 0, B.H - 1) * B.W;
+      uint32_t v = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) v |= (uint32_t)row[clampi(bx + xw * 4 + k, 0, B.W - 1)] << (8 * k);
+      *reinterpret_cast<uint32_t *>(smem + (size_t)y * pitch + xw * 4) = v;
+    }
+    if (tid < 64) {
+      const int r = tid >> 2, k = tid & 3;
+      const uint8_t *row = ref1 + (size_t)clampi(oy + job.s_mv[1] + r, 0, B.H - 1) * B.W;
+      uint32_t v = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) v |= (uint32_t)row[clampi(ox + job.s_mv[0] + k * 4 + j, 0, B.W - 1)] << (8 * j);
+      s_fix[r][k] = v;
+    }
+    __syncthreads();
+    const int c1 = mv_cost(B.lam_f, 4 * job.s_mv[0] - job.pred1[0], 4 * job.s_mv[1] - job.pred1[1]);
+    unsigned best = 0xffffffffu;
+    for (int c = tid; c < UW * UW; c += 256) {
+      const int ay = c / UW, ax = c - ay * UW;
+      const uint8_t *wrow = smem + (size_t)ay * pitch + (ax & ~3);
+      const unsigned sh = ax & 3;
+      unsigned sad = 0;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const uint32_t *wp = reinterpret_cast<const uint32_t *>(wrow + (size_t)r * pitch);
+        const uint32_t d0 = wp[0], d1 = wp[1], d2 = wp[2], d3 = wp[3], d4 = wp[4];
+        const uint32_t *cw = reinterpret_cast<const uint32_t *>(&s_cur[r][0]);
+        sad = __builtin_amdgcn_sad_u8(bipel4(B, s_fix[r][0], __builtin_amdgcn_alignbyte(d1, d0, sh)), cw[0], sad);
+        sad = __builtin_amdgcn_sad_u8(bipel4(B, s_fix[r][1], __builtin_amdgcn_alignbyte(d2, d1, sh)), cw[1], sad);
+        sad = __builtin_amdgcn_sad_u8(bipel4(B, s_fix[r][2], __builtin_amdgcn_alignbyte(d3, d2, sh)), cw[2], sad);
+        sad = __builtin_amdgcn_sad_u8(bipel4(B, s_fix[r][3], __builtin_amdgcn_alignbyte(d4, d3, sh)), cw[3], sad);
+      }
+      const int mvx = job.mv[0] - R + ax, mvy = job.mv[1] - R + ay;
+      const unsigned cost = (unsigned)(c1 + mv_cost(B.lam_f, 4 * mvx - job.pred2[0], 4 * mvy - job.pred2[1])) + sad;
+      best = min(best, (cost << TIE_BITS) | (unsigned)spiral_pos(ax - R, ay - R));
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, off, 64));
+    if ((tid & 63) == 0) atomicMin(&s_best, best);
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned k = s_best;
+      const int cost = (int)(k >> TIE_BITS);
+      int dx = 0, dy = 0;
+      jmhip_bipred_result o;
+      if (cost < job.min_mcost) { spiral_offset((int)(k & ((1u << TIE_BITS) - 1)), &dx, &dy); o.cost = cost; }
+      else o.cost = job.min_mcost;
+      o.mv[0] = (int16_t)(job.mv[0] + dx); o.mv[1] = (int16_t)(job.mv[1] + dy);
+      res[blockIdx.x] = o;
+    }
+    return;
+  }
+
+  // ---------------- SubPelBlockSearchBiPred: quarter-pel planes, origin clamp per SATD sub-block of BOTH pictures
+  const uint8_t *sub1 = B.ref_sub[job.ref1], *sub2 = B.ref_sub[job.ref2];
+  const size_t plane = (size_t)B.Wp * B.Hp;
+  const int width_pad = B.Wp - 1 - 16, height_pad = B.Hp - 1 - 16;
+  const int p4x = (ox + JMHIP_PAD) << 2, p4y = (oy + JMHIP_PAD) << 2;
+  const int max_x4 = (B.W - 16 + 2 * JMHIP_PAD) << 2, max_y4 = (B.H - 16 + 2 * JMHIP_PAD) << 2;
+  const int nblk = B.t8x8 ? 4 : 16, bs = B.t8x8 ? 8 : 4;
+  if (tid == 0) { s_mv[0] = job.mv[0]; s_mv[1] = job.mv[1]; s_min = job.min_mcost; }
+  for (int phase = 0; phase < 2; phase++) {        // start_me_refinement_hp == 0, _qp == 1 (SAD full-pel, SATD sub-pel)
+    const int step = phase ? 1 : 2, first = phase ? 1 : 0, ncand = 9 - first;
+    if (tid < 9) s_satd[tid] = 0;
+    __syncthreads();
+    const int mvx = s_mv[0], mvy = s_mv[1];
+    const int m = phase ? 0 : 1;                     // me_fullsearch.c:642-661 vs :694-713
+    const int umv2 = !((p4x + mvx > m) && (p4x + mvx < max_x4 - m) && (p4y + mvy > m) && (p4y + mvy < max_y4 - m));
+    const int umv1 = !((p4x + job.s_mv[0] > m) && (p4x + job.s_mv[0] < max_x4 - m) && (p4y + job.s_mv[1] > m) && (p4y + job.s_mv[1] < max_y4 - m));
+    for (int idx = tid; idx < nblk * ncand; idx += 256) {
+      const int ci = idx / nblk, b = idx - ci * nblk, cand = first + ci;
+      const int bxo = B.t8x8 ? 8 * (b & 1) : 4 * (b & 3), byo = B.t8x8 ? 8 * (b >> 1) : 4 * (b >> 2);
+      const int x2 = p4x + mvx + step * c_s9x[cand] + (bxo << 2), y2 = p4y + mvy + step * c_s9y[cand] + (byo << 2);
+      const int x1 = p4x + job.s_mv[0] + (bxo << 2), y1 = p4y + job.s_mv[1] + (byo << 2);
+      int xp2 = x2 >> 2, yp2 = y2 >> 2, xp1 = x1 >> 2, yp1 = y1 >> 2;
+      if (umv2) { xp2 = clampi(xp2, 0, width_pad); yp2 = clampi(yp2, 0, height_pad); }
+      if (umv1) { xp1 = clampi(xp1, 0, width_pad); yp1 = clampi(yp1, 0, height_pad); }
+      const uint8_t *r2 = sub2 + (size_t)((y2 & 3) * 4 + (x2 & 3)) * plane + (size_t)yp2 * B.Wp + xp2;
+      const uint8_t *r1 = sub1 + (size_t)((y1 & 3) * 4 + (x1 & 3)) * plane + (size_t)yp1 * B.Wp + xp1;
+      int v;
+      if (bs == 4) {
+        uint32_t rf[4], c01[4], c23[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          uint32_t a, bq, hi;
+          fetch_row(r1 + (size_t)r * B.Wp, 4, &a, &hi);
+          fetch_row(r2 + (size_t)r * B.Wp, 4, &bq, &hi);
+          rf[r] = bipel4(B, a, bq);
+          c01[r] = s_c16[byo + r][bxo >> 1]; c23[r] = s_c16[byo + r][(bxo >> 1) + 1];
+        }
+        v = satd4x4_packed(c01, c23, rf);
+      } else {
+        int m2[8][8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+          uint32_t a0, a1, b0, b1;
+          fetch_row(r1 + (size_t)r * B.Wp, 8, &a0, &a1);
+          fetch_row(r2 + (size_t)r * B.Wp, 8, &b0, &b1);
+          const uint32_t lo = bipel4(B, a0, b0), hi = bipel4(B, a1, b1);
+          const uint32_t c0 = *reinterpret_cast<const uint32_t *>(&s_cur[byo + r][bxo]), c1 = *reinterpret_cast<const uint32_t *>(&s_cur[byo + r][bxo + 4]);
+          int row[8];
+#pragma unroll
+          for (int x = 0; x < 4; x++) { row[x] = (int)((c0 >> (8 * x)) & 255) - (int)((lo >> (8 * x)) & 255); row[4 + x] = (int)((c1 >> (8 * x)) & 255) - (int)((hi >> (8 * x)) & 255); }
+          had8(row);
+#pragma unroll
+          for (int x = 0; x < 8; x++) m2[r][x] = row[x];
+        }
+        int s = 0;
+#pragma unroll
+        for (int x = 0; x < 8; x++) {
+          int col[8];
+#pragma unroll
+          for (int r = 0; r < 8; r++) col[r] = m2[r][x];
+          had8(col);
+#pragma unroll
+          for (int r = 0; r < 8; r++) s += iabs(col[r]);
+        }
+        v = (s + 2) >> 2;
+      }
+      atomicAdd(&s_satd[cand], v);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      const int lam = phase ? B.lam_q : B.lam_h;
+      int min_mcost = s_min, best = 0;
+      for (int pos = first; pos < 9; pos++) {
+        int mcost = mv_cost(lam, mvx + step * c_s9x[pos] - job.pred2[0], mvy + step * c_s9y[pos] - job.pred2[1]);
+        if (mcost >= min_mcost) continue;
+        mcost += s_satd[pos];
+        if (mcost < min_mcost) { min_mcost = mcost; best = pos; }
+      }
+      s_mv[0] = mvx + step * c_s9x[best]; s_mv[1] = mvy + step * c_s9y[best]; s_min = min_mcost;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) { jmhip_bipred_result o; o.mv[0] = (int16_t)s_mv[0]; o.mv[1] = (int16_t)s_mv[1]; o.cost = s_min; res[blockIdx.x] = o; }
+}
+
+}  // namespace
+
+extern "C" int jmhip_bipred_search(jmhip_ctx *c, const jmhip_bipred_params *prm, const jmhip_bipred_job *jobs, int n, jmhip_bipred_result *results)
+{
+  if (!c || !prm || !jobs || !results || n <= 0) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_bipred_search: NULL/empty arguments") : JMHIP_ERR_ARG;
+  if (!c->has_cur) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_bipred_search: current picture not uploaded");
+  int maxR = 0;
+  for (int i = 0; i < n; i++) {
+    const jmhip_bipred_job &j = jobs[i];
+    if (j.mb_x < 0 || j.mb_x >= c->mbw || j.mb_y < 0 || j.mb_y >= c->mbh) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_bipred_search: macroblock outside the picture");
+    for (int k = 0; k < 2; k++) {
+      const int s = k ? j.ref2 : j.ref1;
+      if (s < 0 || s >= (int)c->refs.size() || !c->refs[s].has_pic || (j.stage == 1 && !c->refs[s].has_luma_sub))
+        return jm_fail(c, JMHIP_ERR_ARG, "jmhip_bipred_search: reference slot not ready");
+    }
+    if (j.stage != 0 && j.stage != 1) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_bipred_search: stage");
+    if (j.stage == 0 && (j.search_range < 0 || j.search_range > 44)) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_bipred_search: search range > 44");
+    if (j.stage == 0 && j.search_range > maxR) maxR = j.search_range;
+    for (int k = 0; k < 2; k++) if (j.mv[k] < -8192 || j.mv[k] > 8192 || j.s_mv[k] < -8192 || j.s_mv[k] > 8192) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_bipred_search: vector out of range");
+  }
+  for (int k = 0; k < 3; k++) if (prm->lambda[k] < 0 || prm->lambda[k] > 4000000) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_bipred_search: lambda factor out of the packed key range");
+  if (prm->apply_weights && (prm->luma_log_weight_denom < 0 || prm->luma_log_weight_denom > 14)) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_bipred_search: weight denominator");
+  JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
+  int rc = ensure_tables(c);
+  if (rc) return rc;
+  if ((rc = jm_ensure_ref_table(c))) return rc;
+  void *dj = nullptr, *dr = nullptr;
+  if (hipMalloc(&dj, sizeof(jmhip_bipred_job) * (size_t)n) != hipSuccess || hipMalloc(&dr, sizeof(jmhip_bipred_result) * (size_t)n) != hipSuccess) {
+    (void)hipFree(dj); return jm_fail(c, JMHIP_ERR_NOMEM, "bi-pred arrays");
+  }
+  BiDev B{};
+  B.W = c->W; B.H = c->H; B.Wp = c->Wp; B.Hp = c->Hp; B.cur = c->cur_y;
+  B.lam_f = prm->lambda[0]; B.lam_h = prm->lambda[1]; B.lam_q = prm->lambda[2]; B.t8x8 = prm->transform8x8_mode ? 1 : 0;
+  B.wp = prm->apply_weights ? 1 : 0; B.w1 = prm->weight1; B.w2 = prm->weight2; B.off = prm->offset_bi; B.rnd = prm->wp_luma_round; B.den = prm->luma_log_weight_denom;
+  B.ref_y = reinterpret_cast<const uint8_t *const *>(c->ref_ptrs_dev);
+  B.ref_sub = reinterpret_cast<const uint8_t *const *>(c->ref_ptrs_dev) + 32;
+  const int UW = 2 * maxR + 1, pitch = (UW + 15 + 3 + 4) & ~3;
+  const size_t lds = (size_t)pitch * (UW + 15) + 16;
+  hipError_t e = hipMemcpyAsync(dj, jobs, sizeof(jmhip_bipred_job) * (size_t)n, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) { bipred_kernel<<<n, 256, lds, c->stream>>>(B, (const jmhip_bipred_job *)dj, (jmhip_bipred_result *)dr); e = hipGetLastError(); }
+  if (e == hipSuccess) e = hipMemcpyAsync(results, dr, sizeof(jmhip_bipred_result) * (size_t)n, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(dj); (void)hipFree(dr);
+  if (e != hipSuccess) { c->err = std::string("jmhip_bipred_search: ") + hipGetErrorString(e); return JMHIP_ERR_DEVICE; }
+  return JMHIP_OK;
+}
+
 extern "C" int jmhip_me_results_download(jmhip_ctx *c, jmhip_me_result *results, int n)
 {
   if (!c || !results || n <= 0) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_results_download: NULL/empty arguments") : JMHIP_ERR_ARG;

@@ -54,6 +54,16 @@ ME_MB_DTYPE = np.dtype([("mb_x", "<i2"), ("mb_y", "<i2"), ("ref", "<i2"), ("ref_
                         ("pred_mv", "<i2", (NPART, 2))])
 ME_RESULT_DTYPE = np.dtype([("mv", "<i2", (NPART, 2)), ("cost", "<i4", (NPART,)),
                             ("mv_int", "<i2", (NPART, 2)), ("cost_int", "<i4", (NPART,))])
+BIPRED_JOB_DTYPE = np.dtype([("mb_x", "<i2"), ("mb_y", "<i2"), ("ref1", "<i2"), ("ref2", "<i2"), ("s_mv", "<i2", (2,)), ("mv", "<i2", (2,)),
+                             ("pred1", "<i2", (2,)), ("pred2", "<i2", (2,)), ("min_mcost", "<i4"), ("search_range", "<i2"), ("stage", "<i2")])
+BIPRED_RESULT_DTYPE = np.dtype([("mv", "<i2", (2,)), ("cost", "<i4")])
+
+
+class BipredParams(C.Structure):
+    _fields_ = [("lambda_", C.c_int * 3), ("transform8x8_mode", C.c_int), ("apply_weights", C.c_int), ("weight1", C.c_int), ("weight2", C.c_int),
+                ("offset_bi", C.c_int), ("wp_luma_round", C.c_int), ("luma_log_weight_denom", C.c_int)]
+
+
 SURFACE_JOB_DTYPE = np.dtype([("mb_x", "<i2"), ("mb_y", "<i2"), ("ref", "<i2"), ("R", "<i2"), ("cx", "<i2"), ("cy", "<i2")])
 DIST_JOB_DTYPE = np.dtype([("pic_x", "<i2"), ("pic_y", "<i2"), ("bsx", "<i2"), ("bsy", "<i2"),
                            ("cand_x", "<i4"), ("cand_y", "<i4"), ("ref", "<i2"), ("use_satd", "<i2"),
@@ -108,6 +118,7 @@ def load_library():
     lib.jmhip_distortion_batch.argtypes = [vp, vp, ip, vp]
     lib.jmhip_me_subpel.argtypes = [vp, C.POINTER(MeParams), vp, ip, vp]
     lib.jmhip_distortion_surface.argtypes = [vp, ip, vp, ip, vp]
+    lib.jmhip_bipred_search.argtypes = [vp, C.POINTER(BipredParams), vp, ip, vp]
     lib.jmhip_tq_batch.argtypes = [vp, ip, ip, vp, ip, vp, ip, vp]
     lib.jmhip_flat_quant.argtypes = [vp, ip, ip, ip]
     lib.jmhip_flat_quant.restype = None
@@ -118,10 +129,10 @@ def load_library():
     lib.jmhip_recon_copy_band.argtypes = [vp, vp, vp, vp, ip, ip]
     lib.jmhip_sizeof.argtypes = [ip]
     for which, dt in ((0, ME_MB_DTYPE), (1, ME_RESULT_DTYPE), (2, QUANT_DTYPE), (3, TQ_JOB_DTYPE), (4, TQ_RESULT_DTYPE),
-                      (5, DIST_JOB_DTYPE), (8, MB_MODE_DTYPE)):
+                      (5, DIST_JOB_DTYPE), (8, MB_MODE_DTYPE), (9, SURFACE_JOB_DTYPE), (10, BIPRED_JOB_DTYPE), (11, BIPRED_RESULT_DTYPE)):
         if lib.jmhip_sizeof(which) != dt.itemsize:
             raise JmhipError("binding layout mismatch for struct %d: C %d vs numpy %d" % (which, lib.jmhip_sizeof(which), dt.itemsize))
-    if lib.jmhip_sizeof(6) != C.sizeof(MeParams) or lib.jmhip_sizeof(7) != C.sizeof(Config):
+    if lib.jmhip_sizeof(6) != C.sizeof(MeParams) or lib.jmhip_sizeof(7) != C.sizeof(Config) or lib.jmhip_sizeof(12) != C.sizeof(BipredParams):
         raise JmhipError("binding layout mismatch for jmhip_me_params / jmhip_config")
     _lib = lib
     return lib
@@ -273,6 +284,12 @@ class Context:
         results = np.ascontiguousarray(results, dtype=ME_RESULT_DTYPE)
         self._chk(self.lib.jmhip_me_subpel(self.h, C.byref(prm), _ptr(mbs), len(mbs), _ptr(results)), "jmhip_me_subpel")
         return results
+
+    def bipred_search(self, prm, jobs):
+        jobs = np.ascontiguousarray(jobs, dtype=BIPRED_JOB_DTYPE)
+        res = np.zeros(len(jobs), dtype=BIPRED_RESULT_DTYPE)
+        self._chk(self.lib.jmhip_bipred_search(self.h, C.byref(prm), _ptr(jobs), len(jobs), _ptr(res)), "jmhip_bipred_search")
+        return res
 
     def distortion_surface(self, kind, jobs):
         """kind 'sad_rows' -> (n, 2R+1, 2R+1, 16, 4) uint16; 'satd_blocks' -> (n, 2R+1, 2R+1, 20) uint16."""

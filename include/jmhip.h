@@ -183,6 +183,31 @@ enum { JMHIP_SURFACE_SAD_ROWS = 0, JMHIP_SURFACE_SATD_BLOCKS = 1 };
 typedef struct { int16_t mb_x, mb_y, ref, R; int16_t cx, cy; } jmhip_surface_job;   /* centre (cx, cy) in pels */
 int jmhip_distortion_surface(jmhip_ctx *ctx, int kind, const jmhip_surface_job *jobs, int n, uint16_t *out);
 
+/* Bi-predictive search of the 16x16 block (JM runs it for block type 1 only, src/mv-search.c:864):
+ * stage 0 = FullPelBlockMotionBiPred (src/me_fullsearch.c:164): the block at the FIXED vector s_mv of picture ref1 is
+ *   averaged (computeBiPredSAD1, src/me_distortion.c:482) or weight-combined (computeBiPredSAD2 :556) with every candidate
+ *   of picture ref2 in the +-search_range window round mv; cost = MV_COST(s_mv, pred1) + MV_COST(cand, pred2) + SAD.
+ * stage 1 = SubPelBlockSearchBiPred (:520): half- then quarter-pel refinement of mv (9 + 8 positions) with
+ *   computeBiPredSATD1/2 (:824/:907), cost = MV_COST(cand, pred2) + SATD; s_mv and mv in quarter-pel units.
+ * JM's naming is kept: "1" = fixed block, read from listX[list][ref]; "2" = swept candidate, read from listX[list^1][0].
+ * min_mcost is the carried minimum: a candidate is accepted only below it, otherwise mv and min_mcost come back. */
+typedef struct {
+  int16_t mb_x, mb_y;
+  int16_t ref1, ref2;        /* reference slots of the fixed / swept picture                                   */
+  int16_t s_mv[2], mv[2];    /* stage 0: pel units (mv = search centre); stage 1: quarter-pel                   */
+  int16_t pred1[2], pred2[2];/* predictors, quarter-pel (pred1 is only read by stage 0)                        */
+  int32_t min_mcost;
+  int16_t search_range, stage;
+} jmhip_bipred_job;
+typedef struct { int16_t mv[2]; int32_t cost; } jmhip_bipred_result;
+typedef struct {
+  int lambda[3];             /* lambda_factor[F_PEL, H_PEL, Q_PEL]                                              */
+  int transform8x8_mode;     /* 8x8 Hadamard in stage 1 (test8x8transform for block type 1)                     */
+  int apply_weights;         /* active_pps->weighted_bipred_idc > 0                                             */
+  int weight1, weight2, offset_bi, wp_luma_round, luma_log_weight_denom;
+} jmhip_bipred_params;
+int jmhip_bipred_search(jmhip_ctx *ctx, const jmhip_bipred_params *prm, const jmhip_bipred_job *jobs, int n, jmhip_bipred_result *results);
+
 /* SubPelBlockMotionSearch alone (src/me_fullsearch.c:341): results[i].mv_int[p] is the INPUT (integer vector in pel
  * units, as FullPel/FastFull left it), results[i].mv/cost[p] the output. Same params/jobs as jmhip_me_frame. */
 int jmhip_me_subpel(jmhip_ctx *ctx, const jmhip_me_params *prm, const jmhip_me_mb *mbs, int n, jmhip_me_result *results);
@@ -264,7 +289,7 @@ int jmhip_recon_download(jmhip_ctx *ctx, void *Y, void *U, void *V, int pel_byte
 
 /* sizeof() of the ABI structs, for language bindings to verify their layout: 0 jmhip_me_mb, 1 jmhip_me_result,
  * 2 jmhip_quant, 3 jmhip_tq_job, 4 jmhip_tq_result, 5 jmhip_dist_job, 6 jmhip_me_params, 7 jmhip_config,
- * 8 jmhip_mb_mode. */
+ * 8 jmhip_mb_mode, 9 jmhip_surface_job, 10 jmhip_bipred_job, 11 jmhip_bipred_result, 12 jmhip_bipred_params. */
 int jmhip_sizeof(int which);
 
 /* Flat (no scaling matrix) tables: CalculateQuantParam / CalculateQuant8Param (src/q_matrix.c:451,590) and

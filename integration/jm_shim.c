@@ -8,7 +8,8 @@
  * JM's own function (dlsym RTLD_NEXT) and counted; a failing jmhip_* call aborts loudly (JM's error convention is
  * error()/exit). JMHIP_SHIM_STATS=1 prints, per symbol, how many calls ran on the device and how many were forwarded.
  * JMHIP_SHIM (hex mask, default all): 0x01 sub-pel planes, 0x04 full-pel + sub-pel search, 0x08 fast full search,
- * 0x10 dct_4x4/dct_16x16, 0x20 dct_8x8, 0x40 dct_chroma, 0x100 distortion surfaces for EPZS / UMHexagonS integer walks.
+ * 0x10 dct_4x4/dct_16x16, 0x20 dct_8x8, 0x40 dct_chroma, 0x100 distortion surfaces for EPZS / UMHexagonS integer walks,
+ * 0x200 bi-predictive full-pel + sub-pel search.
  *
  * The proof of the drop-in claim is tests/test_jm_shim_gpu.py: the bitstream and the reconstruction this encoder
  * writes are byte-identical to the unmodified encoder's.
@@ -36,12 +37,12 @@ extern void SetMotionVectorPredictor(short pmv[2], char **refPic, short ***tmp_m
                                      int block_x, int block_y, int blockshape_x, int blockshape_y);
 extern const int LEVELMVLIMIT[17][6];
 
-enum { S_LUMA, S_CHROMA, S_FULL, S_SUB, S_FAST, S_D4, S_D8, S_D16, S_DCR, S_WALK, S_SAD, S_SATD, S_COUNT };
+enum { S_LUMA, S_CHROMA, S_FULL, S_SUB, S_FAST, S_D4, S_D8, S_D16, S_DCR, S_WALK, S_SAD, S_SATD, S_BIFULL, S_BISUB, S_COUNT };
 static const char *s_names[S_COUNT] = { "getSubImagesLuma", "getSubImagesChroma", "FullPelBlockMotionSearch",
   "SubPelBlockMotionSearch", "FastFullPelBlockMotionSearch", "dct_4x4", "dct_8x8", "dct_16x16", "dct_chroma",
-  "EPZS_UMHex_integer_walks", "computeSAD", "computeSATD" };
+  "EPZS_UMHex_integer_walks", "computeSAD", "computeSATD", "FullPelBlockMotionBiPred", "SubPelBlockSearchBiPred" };
 static long n_dev[S_COUNT], n_fwd[S_COUNT];
-static unsigned shim_mask = 0x1ff;
+static unsigned shim_mask = 0x3ff;
 static int verify;            /* JMHIP_SHIM_VERIFY=1: run JM's own search beside the device's and report differences */
 static jmhip_ctx *g;
 static int g_w, g_h;
@@ -386,6 +387,86 @@ int FastFullPelBlockMotionSearch(imgpel *orig_pic, short ref, int list, int pic_
     n_dev[S_FAST]++;
     return r.cost_int[p];
   }
+}
+
+/* ------------------------------------------------------------------ bi-predictive search (B slices, 16x16) */
+
+/* "1" = fixed block on listX[list][ref], "2" = swept candidate on listX[list^1][0] (src/me_fullsearch.c:206-207) */
+static int bipred_ok(short ref, int list, int blocktype, int *slot1, int *slot2, jmhip_bipred_params *prm, int *lambda3)
+{
+  int list_offset = img->mb_data[img->current_mb_nr].list_offset;
+  int apply_weights = (active_pps->weighted_bipred_idc > 0);
+  StorablePicture *p1, *p2;
+  if (!(shim_mask & 0x200) || blocktype != 1 || list_offset || ChromaMEEnable || input->ChromaMEEnable) return 0;
+  if (input->MEErrorMetric[F_PEL] != ERROR_SAD || input->MEErrorMetric[H_PEL] != ERROR_SATD || input->MEErrorMetric[Q_PEL] != ERROR_SATD) return 0;
+  if (start_me_refinement_hp != 0 || start_me_refinement_qp != 1 || !cur_ready()) return 0;
+  p1 = listX[list][ref]; p2 = listX[list ^ 1][0];
+  *slot1 = slot_find(p1); *slot2 = slot_find(p2);
+  if (*slot1 < 0 || *slot2 < 0) return 0;
+  memset(prm, 0, sizeof(*prm));
+  prm->lambda[0] = lambda3[0]; prm->lambda[1] = lambda3[1]; prm->lambda[2] = lambda3[2];
+  prm->transform8x8_mode = test8x8transform;
+  prm->apply_weights = apply_weights;
+  if (apply_weights) {
+    short offset1 = list == 0 ? wp_offset[0][ref][0] : wp_offset[1][0][ref];
+    short offset2 = list == 0 ? wp_offset[1][ref][0] : wp_offset[0][0][ref];
+    prm->weight1 = list == 0 ? wbp_weight[0][ref][0][0] : wbp_weight[LIST_1][0][ref][0];
+    prm->weight2 = list == 0 ? wbp_weight[LIST_1][ref][0][0] : wbp_weight[0][0][ref][0];
+    prm->offset_bi = (offset1 + offset2 + 1) >> 1;
+  }
+  prm->wp_luma_round = wp_luma_round; prm->luma_log_weight_denom = luma_log_weight_denom;
+  /* the globals JM's own function would leave behind */
+  ref_pic1_sub.luma = p1->p_curr_img_sub; ref_pic2_sub.luma = p2->p_curr_img_sub;
+  width_pad = p1->size_x_pad; height_pad = p1->size_y_pad;
+  return 1;
+}
+
+int FullPelBlockMotionBiPred(imgpel *orig_pic, short ref, int list, int pic_pix_x, int pic_pix_y, int blocktype,
+                             short pred_mv_x1, short pred_mv_y1, short pred_mv_x2, short pred_mv_y2,
+                             short *mv_x, short *mv_y, short *s_mv_x, short *s_mv_y, int search_range, int min_mcost, int lambda_factor)
+{
+  static int (*orig)(imgpel *, short, int, int, int, int, short, short, short, short, short *, short *, short *, short *, int, int, int);
+  jmhip_bipred_params prm; jmhip_bipred_job job; jmhip_bipred_result r;
+  int s1, s2, lam3[3];
+  lam3[0] = lambda_factor; lam3[1] = lam3[2] = 0;
+  if (search_range > 44 || pic_pix_x != img->opix_x || pic_pix_y != img->opix_y || !bipred_ok(ref, list, blocktype, &s1, &s2, &prm, lam3)) {
+    if (!orig) orig = next_sym("FullPelBlockMotionBiPred");
+    n_fwd[S_BIFULL]++;
+    return orig(orig_pic, ref, list, pic_pix_x, pic_pix_y, blocktype, pred_mv_x1, pred_mv_y1, pred_mv_x2, pred_mv_y2, mv_x, mv_y, s_mv_x, s_mv_y, search_range, min_mcost, lambda_factor);
+  }
+  memset(&job, 0, sizeof(job));
+  job.mb_x = pic_pix_x >> 4; job.mb_y = pic_pix_y >> 4; job.ref1 = s1; job.ref2 = s2;
+  job.s_mv[0] = *s_mv_x; job.s_mv[1] = *s_mv_y; job.mv[0] = *mv_x; job.mv[1] = *mv_y;
+  job.pred1[0] = pred_mv_x1; job.pred1[1] = pred_mv_y1; job.pred2[0] = pred_mv_x2; job.pred2[1] = pred_mv_y2;
+  job.min_mcost = min_mcost; job.search_range = search_range; job.stage = 0;
+  OK(jmhip_bipred_search(g, &prm, &job, 1, &r));
+  *mv_x = r.mv[0]; *mv_y = r.mv[1];
+  n_dev[S_BIFULL]++;
+  return r.cost;
+}
+
+int SubPelBlockSearchBiPred(imgpel *orig_pic, short ref, int list, int pic_pix_x, int pic_pix_y, int blocktype,
+                            short pred_mv_x, short pred_mv_y, short *mv_x, short *mv_y, short *s_mv_x, short *s_mv_y,
+                            int search_pos2, int search_pos4, int min_mcost, int *lambda)
+{
+  static int (*orig)(imgpel *, short, int, int, int, int, short, short, short *, short *, short *, short *, int, int, int, int *);
+  jmhip_bipred_params prm; jmhip_bipred_job job; jmhip_bipred_result r;
+  int s1, s2;
+  if (search_pos2 != 9 || search_pos4 != 9 || pic_pix_x != img->opix_x || pic_pix_y != img->opix_y ||
+      !bipred_ok(ref, list, blocktype, &s1, &s2, &prm, lambda)) {
+    if (!orig) orig = next_sym("SubPelBlockSearchBiPred");
+    n_fwd[S_BISUB]++;
+    return orig(orig_pic, ref, list, pic_pix_x, pic_pix_y, blocktype, pred_mv_x, pred_mv_y, mv_x, mv_y, s_mv_x, s_mv_y, search_pos2, search_pos4, min_mcost, lambda);
+  }
+  memset(&job, 0, sizeof(job));
+  job.mb_x = pic_pix_x >> 4; job.mb_y = pic_pix_y >> 4; job.ref1 = s1; job.ref2 = s2;
+  job.s_mv[0] = *s_mv_x; job.s_mv[1] = *s_mv_y; job.mv[0] = *mv_x; job.mv[1] = *mv_y;
+  job.pred2[0] = pred_mv_x; job.pred2[1] = pred_mv_y;
+  job.min_mcost = min_mcost; job.stage = 1;
+  OK(jmhip_bipred_search(g, &prm, &job, 1, &r));
+  *mv_x = r.mv[0]; *mv_y = r.mv[1];
+  n_dev[S_BISUB]++;
+  return r.cost;
 }
 
 /* ------------------------------------------------------------------ EPZS / UMHexagonS: JM's walker, the device's distortions */

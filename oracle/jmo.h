@@ -98,6 +98,30 @@ int jmo_sse    (const jmo_dist *d, const jmo_pel *src, int bsy, int bsx, int min
 int jmo_hadamard_sad4x4(const int *diff);   /* HadamardSAD4x4, me_distortion.c:182 */
 int jmo_hadamard_sad8x8(const int *diff);   /* HadamardSAD8x8, me_distortion.c:272 */
 
+/* ------------------------------------------------------------------ bi-predictive distortion + search (jmo_bipred.c) */
+
+/* JM's naming: "1" = the FIXED block (s_mv; picture listX[list][ref]), "2" = the SWEPT candidate (mv; listX[list^1][0]). */
+typedef struct {
+  const jmo_ref *ref1, *ref2;
+  int umv1, umv2;           /* bipred1/2_access_method (set by the searches)                          */
+  int test8x8;              /* test8x8transform                                                       */
+  int max_val;
+  int apply_weights;        /* active_pps->weighted_bipred_idc > 0: computeBiPred2 instead of 1       */
+  int weight1, weight2, offset_bi, wp_luma_round, luma_log_weight_denom;
+  int metric[3];            /* input->MEErrorMetric[F/H/Q]                                            */
+  int start_hp, start_qp;   /* start_me_refinement_hp/qp, mv-search.c:396-397                          */
+} jmo_bipred;
+
+int jmo_bipred_sad (const jmo_bipred *b, const jmo_pel *src, int bsy, int bsx, int min_mcost, int cand_x1, int cand_y1, int cand_x2, int cand_y2);
+int jmo_bipred_satd(const jmo_bipred *b, const jmo_pel *src, int bsy, int bsx, int min_mcost, int cand_x1, int cand_y1, int cand_x2, int cand_y2);
+int jmo_fullpel_bipred(jmo_bipred *b, const jmo_pel *orig_pic, int pic_pix_x, int pic_pix_y, int blocktype,
+                       int pred_mv_x1, int pred_mv_y1, int pred_mv_x2, int pred_mv_y2,
+                       short *mv_x, short *mv_y, const short *s_mv_x, const short *s_mv_y,
+                       int search_range, int min_mcost, int lambda_factor);
+int jmo_subpel_bipred(jmo_bipred *b, const jmo_pel *orig_pic, int pic_pix_x, int pic_pix_y, int blocktype,
+                      int pred_mv_x, int pred_mv_y, short *mv_x, short *mv_y, const short *s_mv_x, const short *s_mv_y,
+                      int search_pos2, int search_pos4, int min_mcost, const int *lambda);
+
 /* ------------------------------------------------------------------ search */
 
 /* mvbits / spiral tables (mv-search.c:333-393) */

@@ -12,6 +12,7 @@
  * JM's original through dlsym(RTLD_NEXT):
  *   0x01 interpolation   0x02 SAD/SATD kernels   0x04 full/sub-pel search   0x08 fast full search
  *   0x10 dct_4x4/16x16   0x20 dct_8x8            0x40 dct_chroma            0x80 transform primitives
+ *   0x100 bi-predictive full-pel + sub-pel search (FullPelBlockMotionBiPred, SubPelBlockSearchBiPred)
  * JMO_SWAP_STATS=1 prints per-symbol call counts at exit.
  */
 #define _GNU_SOURCE
@@ -37,12 +38,12 @@ extern void SetMotionVectorPredictor(short pmv[2], char **refPic, short ***tmp_m
                                      int block_x, int block_y, int blockshape_x, int blockshape_y);
 extern const int LEVELMVLIMIT[17][6];
 
-static unsigned swap_mask = 0xff;
+static unsigned swap_mask = 0x1ff;
 static long n_calls[16];
-enum { C_LUMA, C_CHROMA, C_SAD, C_SATD, C_FULL, C_SUB, C_FAST, C_D4, C_D8, C_D16, C_DCR, C_PRIM };
+enum { C_LUMA, C_CHROMA, C_SAD, C_SATD, C_FULL, C_SUB, C_FAST, C_D4, C_D8, C_D16, C_DCR, C_PRIM, C_BIFULL, C_BISUB };
 static const char *c_names[] = { "getSubImagesLuma", "getSubImagesChroma", "computeSAD*", "computeSATD*",
   "FullPelBlockMotionSearch", "SubPelBlockMotionSearch", "FastFullPelBlockMotionSearch", "dct_4x4",
-  "dct_8x8", "dct_16x16", "dct_chroma", "transform primitives" };
+  "dct_8x8", "dct_16x16", "dct_chroma", "transform primitives", "FullPelBlockMotionBiPred", "SubPelBlockSearchBiPred" };
 
 static void *next_sym(const char *name)
 {
@@ -56,7 +57,7 @@ static void print_stats(void)
   int i;
   if (!getenv("JMO_SWAP_STATS")) return;
   fprintf(stderr, "swap_oracle: mask=0x%x\n", swap_mask);
-  for (i = 0; i <= C_PRIM; i++) fprintf(stderr, "  %-30s %ld\n", c_names[i], n_calls[i]);
+  for (i = 0; i <= C_BISUB; i++) fprintf(stderr, "  %-30s %ld\n", c_names[i], n_calls[i]);
 }
 
 int main(int argc, char **argv)
@@ -278,6 +279,99 @@ int SubPelBlockMotionSearch(imgpel *orig_pic, short ref, int list, int pic_pix_x
     }
     return jmo_subpel_search(&p, &r, orig_pic, ref == 0, pic_pix_x, pic_pix_y, blocktype, pred_mv_x, pred_mv_y,
                              mv_x, mv_y, search_pos2, search_pos4, min_mcost, lambda);
+  }
+}
+
+/* ------------------------------------------------------------------ 0x100 bi-predictive search */
+
+/* "1" = fixed block on listX[list][ref], "2" = swept candidate on listX[list^1][0] (me_fullsearch.c:206-207) */
+static void fill_bipred(jmo_bipred *b, jmo_ref *r1, jmo_ref *r2, short ref, int list, int blocktype)
+{
+  int list_offset = img->mb_data[img->current_mb_nr].list_offset;
+  int apply_weights = (active_pps->weighted_bipred_idc > 0);
+  short offset1 = (apply_weights ? (list == 0 ? wp_offset[list_offset][ref][0] : wp_offset[list_offset + 1][0][ref]) : 0);
+  short offset2 = (apply_weights ? (list == 0 ? wp_offset[list_offset + 1][ref][0] : wp_offset[list_offset][0][ref]) : 0);
+  StorablePicture *p1 = listX[list + list_offset][ref], *p2 = listX[(list ^ 1) + list_offset][0];
+  memset(b, 0, sizeof(*b));
+  fill_ref(r1, p1); fill_ref(r2, p2);
+  /* JM clamps BOTH pictures with ref1's pad limits (the globals width_pad/height_pad, :213-214) */
+  r2->width_pad = r1->width_pad; r2->height_pad = r1->height_pad;
+  b->ref1 = r1; b->ref2 = r2;
+  b->test8x8 = test8x8transform; b->max_val = img->max_imgpel_value;
+  b->apply_weights = apply_weights;
+  if (apply_weights) {
+    b->weight1 = list == 0 ? wbp_weight[list_offset][ref][0][0] : wbp_weight[list_offset + LIST_1][0][ref][0];
+    b->weight2 = list == 0 ? wbp_weight[list_offset + LIST_1][ref][0][0] : wbp_weight[list_offset][0][ref][0];
+    b->offset_bi = (offset1 + offset2 + 1) >> 1;
+  } else { b->weight1 = b->weight2 = 1 << luma_log_weight_denom; b->offset_bi = 0; }
+  b->wp_luma_round = wp_luma_round; b->luma_log_weight_denom = luma_log_weight_denom;
+  b->metric[0] = input->MEErrorMetric[0]; b->metric[1] = input->MEErrorMetric[1]; b->metric[2] = input->MEErrorMetric[2];
+  b->start_hp = start_me_refinement_hp; b->start_qp = start_me_refinement_qp;
+  /* side effects later code may read (as jm_side_effects) */
+  ref_pic1_sub.luma = p1->p_curr_img_sub; ref_pic2_sub.luma = p2->p_curr_img_sub;
+  width_pad = p1->size_x_pad; height_pad = p1->size_y_pad;
+  (void)blocktype;
+}
+
+static int bipred_swappable(void)
+{
+  return (swap_mask & 0x100) && !ChromaMEEnable && input->MEErrorMetric[0] != ERROR_SSE && input->MEErrorMetric[1] != ERROR_SSE &&
+         input->MEErrorMetric[2] != ERROR_SSE;
+}
+
+int FullPelBlockMotionBiPred(imgpel *orig_pic, short ref, int list, int pic_pix_x, int pic_pix_y, int blocktype,
+                             short pred_mv_x1, short pred_mv_y1, short pred_mv_x2, short pred_mv_y2,
+                             short *mv_x, short *mv_y, short *s_mv_x, short *s_mv_y, int search_range, int min_mcost, int lambda_factor)
+{
+  static int (*orig)(imgpel *, short, int, int, int, int, short, short, short, short, short *, short *, short *, short *, int, int, int);
+  n_calls[C_BIFULL]++;
+  if (!bipred_swappable()) {
+    if (!orig) orig = next_sym("FullPelBlockMotionBiPred");
+    return orig(orig_pic, ref, list, pic_pix_x, pic_pix_y, blocktype, pred_mv_x1, pred_mv_y1, pred_mv_x2, pred_mv_y2, mv_x, mv_y, s_mv_x, s_mv_y, search_range, min_mcost, lambda_factor);
+  }
+  {
+    jmo_bipred b; jmo_ref r1, r2;
+    fill_bipred(&b, &r1, &r2, ref, list, blocktype);
+    if (getenv("JMO_SWAP_VERIFY")) {
+      short ox = *mv_x, oy = *mv_y, jx = *mv_x, jy = *mv_y; int c1, c2;
+      if (!orig) orig = next_sym("FullPelBlockMotionBiPred");
+      c1 = orig(orig_pic, ref, list, pic_pix_x, pic_pix_y, blocktype, pred_mv_x1, pred_mv_y1, pred_mv_x2, pred_mv_y2, &jx, &jy, s_mv_x, s_mv_y, search_range, min_mcost, lambda_factor);
+      c2 = jmo_fullpel_bipred(&b, orig_pic, pic_pix_x, pic_pix_y, blocktype, pred_mv_x1, pred_mv_y1, pred_mv_x2, pred_mv_y2, &ox, &oy, s_mv_x, s_mv_y, search_range, min_mcost, lambda_factor);
+      if (c1 != c2 || jx != ox || jy != oy)
+        fprintf(stderr, "BIPRED FULLPEL MISMATCH list=%d pix=(%d,%d) in=(%d,%d) s=(%d,%d) R=%d min=%d: jm=(%d,%d,%d) or=(%d,%d,%d)\n",
+                list, pic_pix_x, pic_pix_y, *mv_x, *mv_y, *s_mv_x, *s_mv_y, search_range, min_mcost, jx, jy, c1, ox, oy, c2);
+      *mv_x = jx; *mv_y = jy; return c1;
+    }
+    return jmo_fullpel_bipred(&b, orig_pic, pic_pix_x, pic_pix_y, blocktype, pred_mv_x1, pred_mv_y1, pred_mv_x2, pred_mv_y2,
+                              mv_x, mv_y, s_mv_x, s_mv_y, search_range, min_mcost, lambda_factor);
+  }
+}
+
+int SubPelBlockSearchBiPred(imgpel *orig_pic, short ref, int list, int pic_pix_x, int pic_pix_y, int blocktype,
+                            short pred_mv_x, short pred_mv_y, short *mv_x, short *mv_y, short *s_mv_x, short *s_mv_y,
+                            int search_pos2, int search_pos4, int min_mcost, int *lambda)
+{
+  static int (*orig)(imgpel *, short, int, int, int, int, short, short, short *, short *, short *, short *, int, int, int, int *);
+  n_calls[C_BISUB]++;
+  if (!bipred_swappable()) {
+    if (!orig) orig = next_sym("SubPelBlockSearchBiPred");
+    return orig(orig_pic, ref, list, pic_pix_x, pic_pix_y, blocktype, pred_mv_x, pred_mv_y, mv_x, mv_y, s_mv_x, s_mv_y, search_pos2, search_pos4, min_mcost, lambda);
+  }
+  {
+    jmo_bipred b; jmo_ref r1, r2;
+    fill_bipred(&b, &r1, &r2, ref, list, blocktype);
+    if (getenv("JMO_SWAP_VERIFY")) {
+      short ox = *mv_x, oy = *mv_y, jx = *mv_x, jy = *mv_y; int c1, c2;
+      if (!orig) orig = next_sym("SubPelBlockSearchBiPred");
+      c1 = orig(orig_pic, ref, list, pic_pix_x, pic_pix_y, blocktype, pred_mv_x, pred_mv_y, &jx, &jy, s_mv_x, s_mv_y, search_pos2, search_pos4, min_mcost, lambda);
+      c2 = jmo_subpel_bipred(&b, orig_pic, pic_pix_x, pic_pix_y, blocktype, pred_mv_x, pred_mv_y, &ox, &oy, s_mv_x, s_mv_y, search_pos2, search_pos4, min_mcost, lambda);
+      if (c1 != c2 || jx != ox || jy != oy)
+        fprintf(stderr, "BIPRED SUBPEL MISMATCH list=%d pix=(%d,%d) in=(%d,%d) s=(%d,%d) min=%d: jm=(%d,%d,%d) or=(%d,%d,%d)\n",
+                list, pic_pix_x, pic_pix_y, *mv_x, *mv_y, *s_mv_x, *s_mv_y, min_mcost, jx, jy, c1, ox, oy, c2);
+      *mv_x = jx; *mv_y = jy; return c1;
+    }
+    return jmo_subpel_bipred(&b, orig_pic, pic_pix_x, pic_pix_y, blocktype, pred_mv_x, pred_mv_y, mv_x, mv_y, s_mv_x, s_mv_y,
+                             search_pos2, search_pos4, min_mcost, lambda);
   }
 }
 

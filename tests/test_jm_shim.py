@@ -38,6 +38,11 @@ SearchRange = {R}
 NumberReferenceFrames = {refs}
 NumberBFrames = {bframes}
 FrameSkip = {bframes}
+BiPredMotionEstimation = {bipred}
+BiPredMERefinements = 3
+BiPredMESearchRange = 16
+BiPredMESubPel = 2
+WeightedBiprediction = {wbp}
 SymbolMode = {cabac}
 SearchMode = {search}
 RDOptimization = {rdopt}
@@ -59,6 +64,9 @@ CASES = {
     "full_baseline": dict(search=-1, profile=66, cabac=0, t8x8=0, bframes=0, refs=1, rdopt=1, adrnd=1, yuv=1),  # FullPel+SubPel, dct_4x4/16x16/chroma
     "fastfull_high": dict(search=0, profile=100, cabac=1, t8x8=1, bframes=1, refs=2, rdopt=1, adrnd=0, yuv=1),  # FastFull, dct_8x8, B slices, 2 refs
     "fastfull_lowcplx": dict(search=0, profile=66, cabac=0, t8x8=0, bframes=0, refs=2, rdopt=0, adrnd=0, yuv=1),  # FastFull pos_00 pre-check, search_range/2 on ref 1
+    # B slices with bi-predictive ME (16x16): FullPelBlockMotionBiPred x4 refinements + SubPelBlockSearchBiPred x2, plain and weighted
+    "main_bipred": dict(search=-1, profile=77, cabac=1, t8x8=0, bframes=1, refs=2, rdopt=1, adrnd=0, yuv=1, bipred=1),
+    "high_bipred_weighted_t8": dict(search=0, profile=100, cabac=1, t8x8=1, bframes=1, refs=2, rdopt=1, adrnd=0, yuv=1, bipred=1, wbp=2),
     # EPZS / UMHexagonS: JM's own walker, integer-pel computeSAD / computeSATD answered from the device's distortion surfaces
     "epzs_main": dict(search=3, profile=77, cabac=1, t8x8=0, bframes=1, refs=2, rdopt=1, adrnd=0, yuv=1),
     "umhex_baseline": dict(search=1, profile=66, cabac=0, t8x8=0, bframes=0, refs=2, rdopt=1, adrnd=1, yuv=1),
@@ -97,6 +105,8 @@ def run(exe, d, env=None):
 def prepare(tmp_path, name, w=176, h=144, frames=3, R=16, qp=28):
     v = dict(CASES[name], w=w, h=h, frames=frames, R=R, qp=qp)
     v.setdefault("fpel", 0)
+    v.setdefault("bipred", 0)
+    v.setdefault("wbp", 0)
     with open(tmp_path / "case.cfg", "w") as f:
         f.write(CFG.format(**v))
     make_clip(tmp_path / "clip.yuv", w, h, frames + v["bframes"] * (frames - 1), v["yuv"])
@@ -139,3 +149,6 @@ def test_jm_with_hip_hot_path_is_byte_identical(tmp_path, name):
     assert served["dct_4x4"][0] > 1000 and served["dct_chroma"][0] > 100
     if CASES[name]["t8x8"]:
         assert served["dct_8x8"][0] > 100
+    if CASES[name].get("bipred"):
+        assert served["FullPelBlockMotionBiPred"][0] > 100 and served["FullPelBlockMotionBiPred"][1] == 0
+        assert served["SubPelBlockSearchBiPred"][0] > 50 and served["SubPelBlockSearchBiPred"][1] == 0

@@ -75,6 +75,9 @@ VARIANTS = {
     "422 FFS ChromaME1": "-d encoder_yuv422.cfg -p SearchMode=0 -p ChromaMEEnable=1",
     "main FS WP": "-d encoder_main.cfg -p SearchMode=-1 -p WeightedPrediction=1 -p WeightedBiprediction=1 -p UseWeightedReferenceME=1",
     "main FFS WP": "-d encoder_main.cfg -p SearchMode=0 -p WeightedPrediction=1 -p WeightedBiprediction=1 -p UseWeightedReferenceME=1",
+    "main FS WBP implicit": "-d encoder_main.cfg -p SearchMode=-1 -p WeightedBiprediction=2",
+    "main FFS bipred SAD-all R8": "-d encoder_main.cfg -p SearchMode=0 -p MEDistortionHPel=0 -p MEDistortionQPel=0 -p BiPredMESearchRange=8 -p BiPredMERefinements=1",
+    "high 8x8 FS bipred subpel1": "-d encoder.cfg -p SearchMode=-1 -p BiPredMESubPel=1",
     "main EPZS WP": "-d encoder_main.cfg -p SearchMode=3 -p WeightedPrediction=1 -p UseWeightedReferenceME=1",
     "main FS SATD-fpel": "-d encoder_main.cfg -p SearchMode=-1 -p MEDistortionFPel=2",
     "main FS SAD-all": "-d encoder_main.cfg -p SearchMode=-1 -p MEDistortionHPel=0 -p MEDistortionQPel=0",
