@@ -27,6 +27,8 @@
 // Roofline: ~10^3 integer ops per byte of compulsory traffic -> VALU/LDS bound, not HBM bound.
 #include "jmhip_internal.h"
 #include <type_traits>
+#include <cstring>
+#include <cstdlib>
 
 namespace {
 
@@ -715,6 +717,311 @@ __global__ __launch_bounds__(256, 2) void me_int_fast_kernel(MeDev P, const jmhi
 
 // ------------------------------------------------------------------------------------------------ sub-pel search
 
+// ------------------------------------------------------------------------------------------------ pair-lane integer search
+//
+// Same algorithm as me_int_fast_kernel with the 16x16 block of a candidate split between TWO lanes (left / right 8 columns).
+// Why: the one-lane form needs ~200 VGPRs (2 waves/SIMD) and 45 % of a workgroup's life is spent in latency phases (window
+// staging, tables, reduction) that two resident waves per SIMD cannot hide. A half candidate needs a 16 x 8-byte rolling
+// window (32 VGPRs), 21 + 1 running minima and cached mv costs: ~146 VGPRs, 3 waves/SIMD, 3 workgroups per CU.
+// Each half owns the 19 partitions that lie inside it (8x16, two 8x8, four 8x4, four 4x8, eight 4x4); the three that span
+// both halves (16x8 top/bottom, 16x16) take the partner's 8x8 sums through a DPP quad swap and are tracked by both lanes.
+// Lane pair (2q, 2q+1) <-> candidate column; wave <-> (column group of 32, half of the candidate rows).
+
+constexpr int PAIR_NK = 22;                          // local partitions per half: 0..18 own, 19 = 16x8 top, 20 = 16x8 bottom, 21 = 16x16
+__constant__ int8_t c_pair_g[2][24];                // global partition of (half, local index)
+__constant__ int8_t c_pair_slot[JMHIP_NPART];       // partition -> local * 2 + half (spanning ones: half 0)
+int8_t h_pair_g[2][24], h_pair_slot[JMHIP_NPART];
+
+void build_pair_tables()
+{
+  build_part_table();
+  auto find = [](int bt, int x4, int y4) { for (int p = 0; p < JMHIP_NPART; p++) if (h_part[p].bt == bt && h_part[p].x4 == x4 && h_part[p].y4 == y4) return p; return -1; };
+  for (int h = 0; h < 2; h++) {
+    int8_t *g = h_pair_g[h];
+    for (int j = 0; j < 24; j++) g[j] = -1;
+    for (int rg = 0; rg < 4; rg++) for (int c = 0; c < 2; c++) g[rg * 2 + c] = (int8_t)find(7, 2 * h + c, rg);         // 4x4 leaves
+    for (int rg = 0; rg < 4; rg++) g[8 + rg] = (int8_t)find(5, 2 * h, rg);                                              // 8x4
+    for (int k = 0; k < 2; k++) for (int c = 0; c < 2; c++) g[12 + k * 2 + c] = (int8_t)find(6, 2 * h + c, 2 * k);      // 4x8
+    for (int k = 0; k < 2; k++) g[16 + k] = (int8_t)find(4, 2 * h, 2 * k);                                              // 8x8
+    g[18] = (int8_t)find(3, 2 * h, 0);                                                                                  // 8x16
+    g[19] = (int8_t)find(2, 0, 0); g[20] = (int8_t)find(2, 0, 2); g[21] = 0;                                            // spanning
+  }
+  for (int p = 0; p < JMHIP_NPART; p++) h_pair_slot[p] = -1;
+  for (int h = 1; h >= 0; h--) for (int j = 0; j < PAIR_NK; j++) h_pair_slot[h_pair_g[h][j]] = (int8_t)(j * 2 + h);    // half 0 wins for the spanning ones
+}
+
+struct PairShared {
+  int px[JMHIP_NPART], py[JMHIP_NPART];
+  unsigned chg[160];
+  uint8_t bytab[160][48] __attribute__((aligned(16)));   // [row][half * 24 + local]: vertical mv bits
+  uint8_t bxtab[84][48] __attribute__((aligned(16)));    // [column][half * 24 + local]: horizontal mv bits
+  uint32_t cur[64];
+  unsigned part[44][2];
+};
+
+__device__ __forceinline__ unsigned quad_swap_add(unsigned v)
+{
+  return v + (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);      // quad_perm [1,0,3,2]: the partner lane
+}
+
+__global__ __launch_bounds__(256, 3) void me_int_pair_kernel(MeDev P, const jmhip_me_mb *__restrict__ jobs, const int *__restrict__ job_index,
+                                                            jmhip_me_result *__restrict__ res, int n_items)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t swin[];      // 4 shifted window copies
+  __shared__ PairShared S;
+  const int item = jm_xcd_item(n_items);
+  if (item < 0) return;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int mbi = job_index[item] & 0xffffff, rep = (job_index[item] >> 24) & 63;
+  const jmhip_me_mb &job = jobs[mbi];
+  const int mbx = job.mb_x, mby = job.mb_y;
+  const int R = P.R, UW = 2 * R + 1, UH = UW;
+  const int PITCH = P.win_pitch >> 2, CS = P.win_copy_stride, WROWS = UH + 15;
+
+  int ucx, ucy;
+  search_center(P, job.pred_mv[rep][0], job.pred_mv[rep][1], &ucx, &ucy);
+  const int umin_x = ucx - R, umin_y = ucy - R;
+  if (tid < JMHIP_NPART) { S.px[tid] = job.pred_mv[tid][0]; S.py[tid] = job.pred_mv[tid][1]; }
+  if (tid < 64) S.cur[tid] = *reinterpret_cast<const uint32_t *>(P.cur + (size_t)(mby * 16 + (tid >> 2)) * P.W + mbx * 16 + (tid & 3) * 4);
+
+  // ---- reference window (as me_int_fast_kernel): loads first, tables while they fly, four copies from registers
+  const uint8_t *ref = P.ref_y[job.ref];
+  const int bx = mbx * 16 + umin_x, by = mby * 16 + umin_y;
+  const int xw = tid & 31, y0 = tid >> 5;
+  const bool inside = bx >= 4 && bx + PITCH * 4 + 8 <= P.W;
+  constexpr int NB = 12;
+  uint32_t q0[NB], q1[NB], q2[NB];
+  if (inside && xw < PITCH) {
+#pragma unroll
+    for (int u = 0; u < NB; u++) {
+      const int y = min(y0 + 8 * u, WROWS - 1);
+      const uintptr_t a = reinterpret_cast<uintptr_t>(ref + (size_t)clampi(by + y, 0, P.H - 1) * P.W + bx + xw * 4);
+      const uint32_t *q = reinterpret_cast<const uint32_t *>(a & ~uintptr_t(3));
+      q0[u] = q[0]; q1[u] = q[1]; q2[u] = q[2];
+    }
+  }
+  {
+    const int s = tid & 63, i0 = tid >> 6;             // table slot = half * 24 + local
+    if (s < 48) {
+      const int g = c_pair_g[s / 24][s % 24];
+      const int py = g >= 0 ? job.pred_mv[g][1] : 0, px = g >= 0 ? job.pred_mv[g][0] : 0;
+      for (int row = i0; row < UH; row += 4) S.bytab[row][s] = g >= 0 ? (uint8_t)mvbits(4 * (umin_y + row) - py) : 0;
+      for (int c = i0; c < UW; c += 4) S.bxtab[c][s] = g >= 0 ? (uint8_t)mvbits(4 * (umin_x + c) - px) : 0;
+    }
+  }
+  if (xw < PITCH) {
+    if (inside) {
+      const unsigned sh = (unsigned)(bx & 3);
+#pragma unroll
+      for (int u = 0; u < NB; u++)
+        if (y0 + 8 * u < WROWS) {
+          const uint32_t a = __builtin_amdgcn_alignbyte(q1[u], q0[u], sh), b = __builtin_amdgcn_alignbyte(q2[u], q1[u], sh);
+          uint32_t *w = swin + (y0 + 8 * u) * PITCH + xw;
+          w[0] = a;
+          w[1 * CS] = __builtin_amdgcn_alignbyte(b, a, 1u);
+          w[2 * CS] = __builtin_amdgcn_alignbyte(b, a, 2u);
+          w[3 * CS] = __builtin_amdgcn_alignbyte(b, a, 3u);
+        }
+    } else {
+#pragma unroll
+      for (int u = 0; u < NB; u++)
+        if (y0 + 8 * u < WROWS) {
+          const uint8_t *row = ref + (size_t)clampi(by + y0 + 8 * u, 0, P.H - 1) * P.W;
+          uint32_t v = 0;
+#pragma unroll
+          for (int k = 0; k < 4; k++) v |= (uint32_t)row[clampi(bx + xw * 4 + k, 0, P.W - 1)] << (8 * k);
+          swin[(y0 + 8 * u) * PITCH + xw] = v;
+        }
+    }
+  }
+  __syncthreads();
+  if (!inside && xw < PITCH - 1)
+    for (int y = y0; y < WROWS; y += 8) {
+      const uint32_t a = swin[y * PITCH + xw], b = swin[y * PITCH + xw + 1];
+      swin[1 * CS + y * PITCH + xw] = __builtin_amdgcn_alignbyte(b, a, 1u);
+      swin[2 * CS + y * PITCH + xw] = __builtin_amdgcn_alignbyte(b, a, 2u);
+      swin[3 * CS + y * PITCH + xw] = __builtin_amdgcn_alignbyte(b, a, 3u);
+    }
+  if (tid < UH) {
+    unsigned m = (tid == 0);
+    if (tid) {
+      const uint32_t *a = reinterpret_cast<const uint32_t *>(S.bytab[tid]), *b = reinterpret_cast<const uint32_t *>(S.bytab[tid - 1]);
+#pragma unroll
+      for (int g = 0; g < 12; g++) m |= (a[g] != b[g]);
+    }
+    S.chg[tid] = m;
+  }
+  __syncthreads();
+
+  // ---- per-lane constants
+  const int half = lane & 1;
+  const int lam = P.lam_f;
+  const int w16 = (lam * 16) >> 16;
+  const int quirk00 = (P.mode == JMHIP_SEARCH_FULL) && !P.rdopt && !P.is_b && job.ref_is_0;
+  const int ff00 = (P.mode == JMHIP_SEARCH_FASTFULL) && !P.rdopt;
+  uint32_t cur[16][2];                               // this half's 8 columns of the current macroblock
+#pragma unroll
+  for (int r = 0; r < 16; r++) { cur[r][0] = S.cur[r * 4 + 2 * half]; cur[r][1] = S.cur[r * 4 + 2 * half + 1]; }
+
+  // best[21]: the 16x16 key. Its cost can exceed 16 bits and goes negative through the 00-bonus, so it is kept as
+  // (cost + bias) << 13 | tie: cost + bias < 2^17 (lambda is bounded on the host), tie < 2^13 (R <= 44).
+  unsigned best[PAIR_NK];
+#pragma unroll
+  for (int j = 0; j < PAIR_NK; j++) best[j] = KEY_INVALID;
+  unsigned mvc[PAIR_NK];                             // cached (mv cost << 16); [21] (16x16) unshifted + bias
+
+  // one half candidate: sads of the 8 leaves (tie seeded), tree, partner exchange, 21 + 1 keys
+  auto evaluate = [&](const uint32_t (&w)[16][2], int base, unsigned tie, bool zero_bonus) __attribute__((always_inline)) {
+    unsigned sad[8];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int sl = (base + r) & 15, b = (r >> 2) * 2;
+      sad[b + 0] = __builtin_amdgcn_sad_hi_u8(w[sl][0], cur[r][0], (r & 3) ? sad[b + 0] : tie);
+      sad[b + 1] = __builtin_amdgcn_sad_hi_u8(w[sl][1], cur[r][1], (r & 3) ? sad[b + 1] : tie);
+    }
+    unsigned ps[PAIR_NK - 1];
+#pragma unroll
+    for (int l = 0; l < 8; l++) ps[l] = sad[l];
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) ps[8 + rg] = sad[rg * 2] + sad[rg * 2 + 1];
+#pragma unroll
+    for (int k = 0; k < 2; k++) { ps[12 + 2 * k] = sad[4 * k] + sad[4 * k + 2]; ps[13 + 2 * k] = sad[4 * k + 1] + sad[4 * k + 3]; }
+    ps[16] = ps[8] + ps[9]; ps[17] = ps[10] + ps[11];
+    ps[18] = ps[16] + ps[17];
+    ps[19] = quad_swap_add(ps[16]); ps[20] = quad_swap_add(ps[17]);
+#pragma unroll
+    for (int j = 0; j < PAIR_NK - 1; j++) best[j] = min(best[j], ps[j] + mvc[j]);
+    unsigned c0 = ((ps[19] >> 16) + (ps[20] >> 16)) + mvc[21];
+    if (zero_bonus) c0 -= (unsigned)w16;
+    best[21] = min(best[21], (c0 << TIE_BITS) + tie);
+  };
+  auto load_mvc = [&](const uint32_t (&bxp)[6], int row) __attribute__((always_inline)) {
+    const uint2 *bt = reinterpret_cast<const uint2 *>(&S.bytab[row][half * 24]);
+    const uint2 b0 = bt[0], b1 = bt[1], b2 = bt[2];
+    const uint32_t byp[6] = {b0.x, b0.y, b1.x, b1.y, b2.x, b2.y};
+#pragma unroll
+    for (int g = 0; g < 6; g++) {
+      const uint32_t sum4 = bxp[g] + byp[g];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int j = 4 * g + k;
+        if (j < PAIR_NK) {
+          const unsigned prod = __umul24((unsigned)lam, (sum4 >> (8 * k)) & 255u);
+          mvc[j] = j < PAIR_NK - 1 ? (prod & 0xffff0000u) : ((prod >> 16) + (unsigned)w16);
+        }
+      }
+    }
+  };
+
+  // ---- main grid: 64 columns (two groups of 32 lane pairs) x all rows (two halves)
+  {
+    const int col = (wave & 1) * 32 + (lane >> 1);
+    const int mvx = umin_x + col, dx = mvx - ucx, adx = iabs(dx);
+    const int tieB = spiral_base_B(dx) + 1, twodx = 2 * dx;
+    const bool qx = quirk00 && (4 * (mbx * 16 + mvx) == mbx * 16);
+    uint32_t bxp[6];
+#pragma unroll
+    for (int g = 0; g < 6; g++) bxp[g] = reinterpret_cast<const uint32_t *>(&S.bxtab[col][half * 24])[g];
+    const uint32_t *lbase = swin + (col & 3) * CS + (col >> 2) + 2 * half;
+    const int rsplit = (UH + 1) >> 1;
+    const int r0 = (wave >> 1) ? rsplit : 0, r1 = (wave >> 1) ? UH : rsplit, nrows = r1 - r0;
+    uint32_t win[16][2];
+#pragma unroll
+    for (int j = 0; j < 15; j++) { const uint32_t *wp = lbase + (r0 + j) * PITCH; win[j][0] = wp[0]; win[j][1] = wp[1]; }
+    unsigned mnext = 0;
+    auto step = [&](auto ttc, int t0) __attribute__((always_inline)) {
+      constexpr int tt = decltype(ttc)::value;
+      const int t = t0 + tt;
+      if (t >= nrows) return;
+      const int row = r0 + t;
+      { const uint32_t *wp = lbase + (row + 15) * PITCH; constexpr int sl = (tt + 15) & 15; win[sl][0] = wp[0]; win[sl][1] = wp[1]; }
+      const int mvy = umin_y + row, dy = mvy - ucy;
+      {
+        const unsigned m = (t == 0) ? 1u : mnext;
+        mnext = S.chg[min(row + 1, UH - 1)];
+        if (__builtin_amdgcn_readfirstlane(m)) load_mvc(bxp, row);
+      }
+      const int ady = iabs(dy);
+      unsigned tie = (ady > adx) ? (unsigned)(spiral_base_A(dy) + 1 + twodx) : (unsigned)(tieB + 2 * dy);
+      if (ff00 && mvx == 0 && mvy == 0) tie = 0;
+      evaluate(win, tt, tie, qx && 4 * (mby * 16 + mvy) == mby * 16);
+    };
+    for (int t0 = 0; t0 < nrows; t0 += 16) {
+      step(std::integral_constant<int, 0>{}, t0);  step(std::integral_constant<int, 1>{}, t0);
+      step(std::integral_constant<int, 2>{}, t0);  step(std::integral_constant<int, 3>{}, t0);
+      step(std::integral_constant<int, 4>{}, t0);  step(std::integral_constant<int, 5>{}, t0);
+      step(std::integral_constant<int, 6>{}, t0);  step(std::integral_constant<int, 7>{}, t0);
+      step(std::integral_constant<int, 8>{}, t0);  step(std::integral_constant<int, 9>{}, t0);
+      step(std::integral_constant<int, 10>{}, t0); step(std::integral_constant<int, 11>{}, t0);
+      step(std::integral_constant<int, 12>{}, t0); step(std::integral_constant<int, 13>{}, t0);
+      step(std::integral_constant<int, 14>{}, t0); step(std::integral_constant<int, 15>{}, t0);
+    }
+  }
+
+  // ---- columns beyond 64: one candidate per lane pair, fresh window rows, mv costs straight from the tables
+  {
+    const int nrc = UW - 64, nrest = nrc * UH;
+    for (int c = tid >> 1; c < nrest; c += 128) {
+      const int ay = c / nrc, ax = 64 + (c - ay * nrc);
+      const int cmx = umin_x + ax, cmy = umin_y + ay;
+      unsigned tie = (unsigned)spiral_pos(cmx - ucx, cmy - ucy) + 1;
+      if (ff00 && cmx == 0 && cmy == 0) tie = 0;
+      const uint32_t *wrow = swin + (ax & 3) * CS + ay * PITCH + (ax >> 2) + 2 * half;
+      uint32_t w[16][2];
+#pragma unroll
+      for (int r = 0; r < 16; r++) { w[r][0] = wrow[r * PITCH]; w[r][1] = wrow[r * PITCH + 1]; }
+      uint32_t bxp[6];
+#pragma unroll
+      for (int g = 0; g < 6; g++) bxp[g] = reinterpret_cast<const uint32_t *>(&S.bxtab[ax][half * 24])[g];
+      load_mvc(bxp, ay);
+      evaluate(w, 0, tie, quirk00 && 4 * (mbx * 16 + cmx) == mbx * 16 && 4 * (mby * 16 + cmy) == mby * 16);
+    }
+  }
+
+  // ---- reduce: keys to LDS as red[slot = local * 2 + half][pair index], 64-bit key as two slot rows (42+half hi, 44+half lo)
+  __syncthreads();
+  {
+    uint32_t *red = swin;
+    const int q = tid >> 1;
+#pragma unroll
+    for (int j = 0; j < PAIR_NK; j++) red[(j * 2 + half) * 128 + q] = best[j];
+  }
+  __syncthreads();
+  if (tid < 88) {                                     // 44 slots x 2 halves of 64 entries
+    const int s = tid >> 1, hq = tid & 1;
+    const uint4 *src = reinterpret_cast<const uint4 *>(swin + s * 128 + hq * 64);
+    unsigned mm = KEY_INVALID;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { const uint4 v = src[k]; mm = min(min(mm, v.x), min(min(v.y, v.z), v.w)); }
+    S.part[s][hq] = mm;
+  }
+  __syncthreads();
+  if (tid < JMHIP_NPART) {
+    const int p = tid, s = c_pair_slot[p];
+    jmhip_me_result &o = res[mbi];
+    int cost, tie;
+    if (p == 0) {
+      const unsigned k = min(S.part[s][0], S.part[s][1]);
+      cost = (int)(k >> TIE_BITS) - w16; tie = (int)(k & ((1u << TIE_BITS) - 1));
+    } else {
+      const unsigned k = min(S.part[s][0], S.part[s][1]);
+      const PartInfo q = c_part[p];
+      cost = (int)(k >> FAST_TIE_BITS); tie = (int)(k & 0xffffu) / (q.w4 * q.h4);
+    }
+    int rx, ry;
+    if (tie == 0) { rx = 0; ry = 0; }
+    else { int ddx, ddy; spiral_offset(tie - 1, &ddx, &ddy); rx = ucx + ddx; ry = ucy + ddy; }
+    if (p == 0) wrapped_bound_00(P, jobs[mbi], ucx, ucy, &rx, &ry, &cost);
+    bool mine = true;
+    if (P.mode == JMHIP_SEARCH_FULL) { int pcx, pcy; search_center(P, S.px[p], S.py[p], &pcx, &pcy); mine = (pcx == ucx && pcy == ucy); }
+    if (mine) {
+      o.mv_int[p][0] = (int16_t)rx; o.mv_int[p][1] = (int16_t)ry; o.cost_int[p] = cost;
+      if (!P.subpel) { o.mv[p][0] = (int16_t)(rx << 2); o.mv[p][1] = (int16_t)(ry << 2); o.cost[p] = cost; }
+    }
+  }
+}
+
 // Hadamard SATD of a 4x4 difference block held as four rows of four ints: (sum|H D H| + 1) >> 1, me_distortion.c:182
 __device__ __forceinline__ int satd4x4(const int d[4][4])
 {
@@ -1035,6 +1342,9 @@ int ensure_tables(jmhip_ctx *c)
   JM_HIP_CHECK(c, hipMemcpyToSymbol(HIP_SYMBOL(c_part), h_part, sizeof(h_part)));
   JM_HIP_CHECK(c, hipMemcpyToSymbol(HIP_SYMBOL(c_sub4), h_sub4, sizeof(h_sub4)));
   JM_HIP_CHECK(c, hipMemcpyToSymbol(HIP_SYMBOL(c_sub8), h_sub8, sizeof(h_sub8)));
+  build_pair_tables();
+  JM_HIP_CHECK(c, hipMemcpyToSymbol(HIP_SYMBOL(c_pair_g), h_pair_g, sizeof(h_pair_g)));
+  JM_HIP_CHECK(c, hipMemcpyToSymbol(HIP_SYMBOL(c_pair_slot), h_pair_slot, sizeof(h_pair_slot)));
   if (dev < 64) uploaded[dev] = true;
   return JMHIP_OK;
 }
@@ -1204,7 +1514,11 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
   if (nfast) {
     MeDev PF = P;
     PF.win_pitch = fpitch_dw * 4; PF.win_rows = frows; PF.win_copy_stride = fcs;
-    me_int_fast_kernel<<<jm_xcd_grid(nfast), 256, flds, c->stream>>>(PF, (const jmhip_me_mb *)c->me_jobs_dev, (const int *)c->me_idx_dev, (jmhip_me_result *)c->me_res_dev, nfast);
+    static const int use_pair = [] { const char *e = getenv("JMHIP_ME_KERNEL"); return e && !strcmp(e, "single") ? 0 : 1; }();      // JMHIP_ME_KERNEL=single: the one-lane-per-candidate kernel
+    size_t plds = ((size_t)3 * fcs + (size_t)fpitch_dw * frows) * 4;          // the window; its memory is reused by the 44 x 128 key transpose
+    if (plds < (size_t)44 * 128 * 4) plds = (size_t)44 * 128 * 4;
+    if (use_pair) me_int_pair_kernel<<<jm_xcd_grid(nfast), 256, plds, c->stream>>>(PF, (const jmhip_me_mb *)c->me_jobs_dev, (const int *)c->me_idx_dev, (jmhip_me_result *)c->me_res_dev, nfast);
+    else me_int_fast_kernel<<<jm_xcd_grid(nfast), 256, flds, c->stream>>>(PF, (const jmhip_me_mb *)c->me_jobs_dev, (const int *)c->me_idx_dev, (jmhip_me_result *)c->me_res_dev, nfast);
   }
   if (ngen)
     me_int_kernel<<<jm_xcd_grid(ngen), 256, lds, c->stream>>>(P, (const jmhip_me_mb *)c->me_jobs_dev, (const int *)c->me_idx_dev + nfast, (jmhip_me_result *)c->me_res_dev, ngen);
