@@ -1725,6 +1725,20 @@ __global__ __launch_bounds__(256) void surface_kernel(MeDev P, const jmhip_surfa
       rr[r][0] = __builtin_amdgcn_alignbyte(d1, d0, sh); rr[r][1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
       rr[r][2] = __builtin_amdgcn_alignbyte(d3, d2, sh); rr[r][3] = __builtin_amdgcn_alignbyte(d4, d3, sh);
     }
+    if (job.wp) {                                    // weighted reference samples, me_distortion.c:431
+#pragma unroll
+      for (int r = 0; r < 16; r++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          uint32_t v = 0;
+#pragma unroll
+          for (int b = 0; b < 4; b++) {
+            const int s = (int)((rr[r][k] >> (8 * b)) & 255);
+            v |= (uint32_t)min(max(((job.weight * s + job.wp_round) >> job.wp_denom) + job.offset, 0), 255) << (8 * b);
+          }
+          rr[r][k] = v;
+        }
+    }
     uint32_t *o32 = reinterpret_cast<uint32_t *>(o + (size_t)c * NV);
     if (KIND == JMHIP_SURFACE_SAD_ROWS) {
 #pragma unroll
@@ -1793,6 +1807,7 @@ extern "C" int jmhip_distortion_surface(jmhip_ctx *c, int kind, const jmhip_surf
     if (j.mb_x < 0 || j.mb_x >= c->mbw || j.mb_y < 0 || j.mb_y >= c->mbh) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_distortion_surface: macroblock outside the picture");
     if (j.ref < 0 || j.ref >= (int)c->refs.size() || !c->refs[j.ref].has_pic) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_distortion_surface: reference slot not uploaded");
     if (j.cx < -4096 || j.cx > 4096 || j.cy < -4096 || j.cy > 4096) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_distortion_surface: centre out of range");
+    if (j.wp && (j.wp_denom < 0 || j.wp_denom > 15)) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_distortion_surface: weight denominator");
   }
   JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
   int rc = jm_ensure_ref_table(c);

@@ -64,7 +64,8 @@ class BipredParams(C.Structure):
                 ("offset_bi", C.c_int), ("wp_luma_round", C.c_int), ("luma_log_weight_denom", C.c_int)]
 
 
-SURFACE_JOB_DTYPE = np.dtype([("mb_x", "<i2"), ("mb_y", "<i2"), ("ref", "<i2"), ("R", "<i2"), ("cx", "<i2"), ("cy", "<i2")])
+SURFACE_JOB_DTYPE = np.dtype([("mb_x", "<i2"), ("mb_y", "<i2"), ("ref", "<i2"), ("R", "<i2"), ("cx", "<i2"), ("cy", "<i2"),
+                              ("wp", "<i2"), ("weight", "<i2"), ("offset", "<i2"), ("wp_round", "<i2"), ("wp_denom", "<i2"), ("pad", "<i2")])
 DIST_JOB_DTYPE = np.dtype([("pic_x", "<i2"), ("pic_y", "<i2"), ("bsx", "<i2"), ("bsy", "<i2"),
                            ("cand_x", "<i4"), ("cand_y", "<i4"), ("ref", "<i2"), ("use_satd", "<i2"),
                            ("umv", "<i2"), ("wp", "<i2"), ("weight", "<i2"), ("offset", "<i2"), ("wp_round", "<i2"), ("wp_denom", "<i2")])

@@ -180,7 +180,11 @@ int jmhip_distortion_batch(jmhip_ctx *ctx, const jmhip_dist_job *jobs, int n, in
  *                              the 8x8 blocks (computeSATD, :657-731, block-wise exit :690/:720)
  * Samples outside the picture follow UMV access (= per-sample clamp on the integer plane). */
 enum { JMHIP_SURFACE_SAD_ROWS = 0, JMHIP_SURFACE_SATD_BLOCKS = 1 };
-typedef struct { int16_t mb_x, mb_y, ref, R; int16_t cx, cy; } jmhip_surface_job;   /* centre (cx, cy) in pels */
+typedef struct {
+  int16_t mb_x, mb_y, ref, R; int16_t cx, cy;      /* centre (cx, cy) in pels                                         */
+  int16_t wp, weight, offset, wp_round, wp_denom;   /* wp != 0: computeSADWP / computeSATDWP (:413, :734): every reference */
+  int16_t pad;                                      /* sample becomes clip1(((weight*s + wp_round) >> wp_denom) + offset)  */
+} jmhip_surface_job;
 int jmhip_distortion_surface(jmhip_ctx *ctx, int kind, const jmhip_surface_job *jobs, int n, uint16_t *out);
 
 /* Bi-predictive search of the 16x16 block (JM runs it for block type 1 only, src/mv-search.c:864):

@@ -226,10 +226,11 @@ static int partition_of(int blocktype, int x, int y)     /* (x, y): block origin
 /* what the device search covers: luma-only SAD (integer) / SATD (sub-pel), no weighted ME, frame pictures */
 static int me_ok_metric(short ref, int list, StorablePicture **rp, int *slot, int fixed_metrics)
 {
+  const int allow_weights = !fixed_metrics;        /* the walks' weighted kernels have their own surfaces */
   int list_offset = img->mb_data[img->current_mb_nr].list_offset;
   int weighted = ((active_pps->weighted_pred_flag && (img->type == P_SLICE || img->type == SP_SLICE)) ||
                   (active_pps->weighted_bipred_idc && (img->type == B_SLICE))) && input->UseWeightedReferenceME;
-  if (weighted || input->ChromaMEEnable || list_offset) return 0;
+  if ((weighted && !allow_weights) || input->ChromaMEEnable || list_offset) return 0;
   if (fixed_metrics && (input->MEErrorMetric[F_PEL] != ERROR_SAD || input->MEErrorMetric[H_PEL] != ERROR_SATD || input->MEErrorMetric[Q_PEL] != ERROR_SATD)) return 0;
   if (!cur_ready()) return 0;
   *rp = listX[list][ref];
@@ -478,7 +479,7 @@ int SubPelBlockSearchBiPred(imgpel *orig_pic, short ref, int list, int pic_pix_x
  * calls from it, partial sums included. A candidate outside the fetched window, at a sub-pel position, with weights or
  * chroma terms goes to JM's own kernel. */
 static struct { int on; imgpel *orig; int bx0, by0, bsx, bsy, pic_x, pic_y, slot, px, py; StorablePicture *rp; } walk;
-static struct { unsigned long serial; int mb_nr, cx, cy, R; uint16_t *buf; } surf[2][MAX_SLOTS];
+static struct { unsigned long serial; int mb_nr, cx, cy, R, w, o, rnd, den; uint16_t *buf; } surf[4][MAX_SLOTS];   /* kind + 2 * weighted */
 
 static void walk_begin(imgpel *orig, short ref, int list, int pic_pix_x, int pic_pix_y, int blocktype, int pmx, int pmy)
 {
@@ -493,79 +494,78 @@ static void walk_begin(imgpel *orig, short ref, int list, int pic_pix_x, int pic
   n_dev[S_WALK]++;
 }
 
-/* the surface of `kind` for the current macroblock and the walk's reference; NULL if the displacement is not covered */
-static const uint16_t *surface_at(int kind, int cand_x, int cand_y, int nv)
+/* the surface of `kind` (+ weights) for the current macroblock and the walk's reference; NULL if the displacement is not covered */
+static const uint16_t *surface_at(int kind, int wp, int cand_x, int cand_y, int nv)
 {
-  int mvx, mvy, ax, ay, UW;
+  int mvx, mvy, ax, ay, UW, k = kind + 2 * wp;
   if (!walk.on || ((cand_x | cand_y) & 3) || ref_pic_sub.luma != walk.rp->p_curr_img_sub) return NULL;
-  if (surf[kind][walk.slot].serial != pic_serial || surf[kind][walk.slot].mb_nr != img->current_mb_nr || !surf[kind][walk.slot].buf) {
+  if (surf[k][walk.slot].serial != pic_serial || surf[k][walk.slot].mb_nr != img->current_mb_nr || !surf[k][walk.slot].buf ||
+      (wp && (surf[k][walk.slot].w != weight_luma || surf[k][walk.slot].o != offset_luma || surf[k][walk.slot].rnd != wp_luma_round ||
+              surf[k][walk.slot].den != luma_log_weight_denom))) {
     jmhip_surface_job job;
     int R = input->search_range > 32 ? 32 : input->search_range;
     UW = 2 * R + 1;
-    if (!surf[kind][walk.slot].buf || surf[kind][walk.slot].R != R) {
-      free(surf[kind][walk.slot].buf);
-      surf[kind][walk.slot].buf = malloc((size_t)UW * UW * nv * sizeof(uint16_t));
+    if (!surf[k][walk.slot].buf || surf[k][walk.slot].R != R) {
+      free(surf[k][walk.slot].buf);
+      surf[k][walk.slot].buf = malloc((size_t)UW * UW * nv * sizeof(uint16_t));
     }
+    memset(&job, 0, sizeof(job));
     job.mb_x = img->opix_x >> 4; job.mb_y = img->opix_y >> 4; job.ref = walk.slot; job.R = R;
     /* centred between the zero vector and the first block's predictor: the walks start from both */
     job.cx = iClip3(-R, R, walk.px / 8); job.cy = iClip3(-R, R, walk.py / 8);
-    OK(jmhip_distortion_surface(g, kind, &job, 1, surf[kind][walk.slot].buf));
-    surf[kind][walk.slot].serial = pic_serial; surf[kind][walk.slot].mb_nr = img->current_mb_nr;
-    surf[kind][walk.slot].cx = job.cx; surf[kind][walk.slot].cy = job.cy; surf[kind][walk.slot].R = R;
+    if (wp) { job.wp = 1; job.weight = weight_luma; job.offset = offset_luma; job.wp_round = wp_luma_round; job.wp_denom = luma_log_weight_denom; }
+    OK(jmhip_distortion_surface(g, kind, &job, 1, surf[k][walk.slot].buf));
+    surf[k][walk.slot].serial = pic_serial; surf[k][walk.slot].mb_nr = img->current_mb_nr;
+    surf[k][walk.slot].cx = job.cx; surf[k][walk.slot].cy = job.cy; surf[k][walk.slot].R = R;
+    surf[k][walk.slot].w = weight_luma; surf[k][walk.slot].o = offset_luma; surf[k][walk.slot].rnd = wp_luma_round; surf[k][walk.slot].den = luma_log_weight_denom;
   }
-  UW = 2 * surf[kind][walk.slot].R + 1;
+  UW = 2 * surf[k][walk.slot].R + 1;
   mvx = (cand_x >> 2) - IMG_PAD_SIZE - walk.pic_x; mvy = (cand_y >> 2) - IMG_PAD_SIZE - walk.pic_y;
-  ax = mvx - surf[kind][walk.slot].cx + surf[kind][walk.slot].R; ay = mvy - surf[kind][walk.slot].cy + surf[kind][walk.slot].R;
+  ax = mvx - surf[k][walk.slot].cx + surf[k][walk.slot].R; ay = mvy - surf[k][walk.slot].cy + surf[k][walk.slot].R;
   if (ax < 0 || ay < 0 || ax >= UW || ay >= UW) return NULL;
-  return surf[kind][walk.slot].buf + ((size_t)ay * UW + ax) * nv;
+  return surf[k][walk.slot].buf + ((size_t)ay * UW + ax) * nv;
 }
 
-int computeSAD(imgpel *src_pic, int bsy, int bsx, int min_mcost, int cand_x, int cand_y)
+/* computeSAD / computeSADWP (src/me_distortion.c:351, :413) and computeSATD / computeSATDWP (:657, :734) share their loop
+ * structure and exits; the weighted forms only read weighted reference samples, which the weighted surface already holds. */
+static int sad_from_surface(const uint16_t *s, int bsy, int bsx, int min_mcost)
 {
-  static int (*orig)(imgpel *, int, int, int, int, int);
-  const uint16_t *s = NULL;
-  if (walk.on && src_pic == walk.orig && bsx == walk.bsx && bsy == walk.bsy && !ChromaMEEnable)
-    s = surface_at(JMHIP_SURFACE_SAD_ROWS, cand_x, cand_y, 64);
-  if (!s) {
-    if (!orig) orig = next_sym("computeSAD");
-    n_fwd[S_SAD]++;
-    return orig(src_pic, bsy, bsx, min_mcost, cand_x, cand_y);
+  int mcost = 0, y, gx, g0 = walk.bx0 >> 2, g1 = (walk.bx0 + bsx) >> 2;
+  for (y = walk.by0; y < walk.by0 + bsy; y++) {       /* :364-375, the row-wise exit at :373 */
+    for (gx = g0; gx < g1; gx++) mcost += s[y * 4 + gx];
+    if (mcost >= min_mcost) return mcost;
   }
-  {                                                  /* src/me_distortion.c:364-375, the row-wise exit at :373 */
-    int mcost = 0, y, gx, g0 = walk.bx0 >> 2, g1 = (walk.bx0 + bsx) >> 2;
-    n_dev[S_SAD]++;
-    for (y = walk.by0; y < walk.by0 + bsy; y++) {
-      for (gx = g0; gx < g1; gx++) mcost += s[y * 4 + gx];
-      if (mcost >= min_mcost) return mcost;
-    }
-    return mcost;
-  }
+  return mcost;
 }
 
-int computeSATD(imgpel *src_pic, int bsy, int bsx, int min_mcost, int cand_x, int cand_y)
+static int satd_from_surface(const uint16_t *s, int bsy, int bsx, int min_mcost)
 {
-  static int (*orig)(imgpel *, int, int, int, int, int);
-  const uint16_t *s = NULL;
-  if (walk.on && src_pic == walk.orig && bsx == walk.bsx && bsy == walk.bsy && (!test8x8transform || !((bsx | bsy) & 7)))
-    s = surface_at(JMHIP_SURFACE_SATD_BLOCKS, cand_x, cand_y, 20);
-  if (!s) {
-    if (!orig) orig = next_sym("computeSATD");
-    n_fwd[S_SATD]++;
-    return orig(src_pic, bsy, bsx, min_mcost, cand_x, cand_y);
+  int mcost = 0, y, x;                                /* :669-731: sub-blocks y outer, x inner; exit on '>' */
+  if (!test8x8transform) {
+    for (y = walk.by0; y < walk.by0 + bsy; y += 4)
+      for (x = walk.bx0; x < walk.bx0 + bsx; x += 4) { mcost += s[(y >> 2) * 4 + (x >> 2)]; if (mcost > min_mcost) return mcost; }
+  } else {
+    for (y = walk.by0; y < walk.by0 + bsy; y += 8)
+      for (x = walk.bx0; x < walk.bx0 + bsx; x += 8) { mcost += s[16 + (y >> 3) * 2 + (x >> 3)]; if (mcost > min_mcost) return mcost; }
   }
-  {                                                  /* src/me_distortion.c:669-731: sub-blocks y outer, x inner; exit on '>' */
-    int mcost = 0, y, x;
-    n_dev[S_SATD]++;
-    if (!test8x8transform) {
-      for (y = walk.by0; y < walk.by0 + bsy; y += 4)
-        for (x = walk.bx0; x < walk.bx0 + bsx; x += 4) { mcost += s[(y >> 2) * 4 + (x >> 2)]; if (mcost > min_mcost) return mcost; }
-    } else {
-      for (y = walk.by0; y < walk.by0 + bsy; y += 8)
-        for (x = walk.bx0; x < walk.bx0 + bsx; x += 8) { mcost += s[16 + (y >> 3) * 2 + (x >> 3)]; if (mcost > min_mcost) return mcost; }
-    }
-    return mcost;
-  }
+  return mcost;
 }
+
+#define DIST_HOOK(NAME, KIND, WP, NV, COUNTER, FROM, EXTRA)                                                          \
+  int NAME(imgpel *src_pic, int bsy, int bsx, int min_mcost, int cand_x, int cand_y)                                  \
+  {                                                                                                                   \
+    static int (*orig)(imgpel *, int, int, int, int, int);                                                            \
+    const uint16_t *s = NULL;                                                                                         \
+    if (walk.on && src_pic == walk.orig && bsx == walk.bsx && bsy == walk.bsy && !ChromaMEEnable && (EXTRA))          \
+      s = surface_at(KIND, WP, cand_x, cand_y, NV);                                                                   \
+    if (!s) { if (!orig) orig = next_sym(#NAME); n_fwd[COUNTER]++; return orig(src_pic, bsy, bsx, min_mcost, cand_x, cand_y); } \
+    n_dev[COUNTER]++;                                                                                                 \
+    return FROM(s, bsy, bsx, min_mcost);                                                                              \
+  }
+DIST_HOOK(computeSAD,    JMHIP_SURFACE_SAD_ROWS,    0, 64, S_SAD,  sad_from_surface,  1)
+DIST_HOOK(computeSADWP,  JMHIP_SURFACE_SAD_ROWS,    1, 64, S_SAD,  sad_from_surface,  1)
+DIST_HOOK(computeSATD,   JMHIP_SURFACE_SATD_BLOCKS, 0, 20, S_SATD, satd_from_surface, (!test8x8transform || !((bsx | bsy) & 7)))
+DIST_HOOK(computeSATDWP, JMHIP_SURFACE_SATD_BLOCKS, 1, 20, S_SATD, satd_from_surface, (!test8x8transform || !((bsx | bsy) & 7)))
 
 int EPZSPelBlockMotionSearch(imgpel *cur_pic, short ref, int list, int list_offset, char ***refPic, short ****tmp_mv,
                              int pic_pix_x, int pic_pix_y, int blocktype, short pred_mv[2], short mv[2], int search_range,

@@ -132,7 +132,8 @@ def test_me_subpel_alone(pkg, rdopt, t8x8):
             assert (int(got["mv"][i, q, 0]), int(got["mv"][i, q, 1]), int(got["cost"][i, q])) == (int(mvq[0]), int(mvq[1]), cost), (i, q)
 
 
-def test_distortion_surface(pkg):
+@pytest.mark.parametrize("wp", [None, (37, -6, 16, 5)])
+def test_distortion_surface(pkg, wp):
     """Row-segment SADs and per-block SATDs of every integer displacement, against the oracle's computeSAD / computeSATD
     evaluated on exactly those pieces (1x4 rows, 4x4 and 8x8 blocks) under UMV access."""
     from h264_amd.jmhip import SURFACE_JOB_DTYPE
@@ -146,7 +147,9 @@ def test_distortion_surface(pkg):
     jobs = np.zeros(3, dtype=SURFACE_JOB_DTYPE)
     # an inner macroblock, the top-left one pushed out of the picture, the bottom-right one pushed far out
     for i, (mx, my, cx, cy) in enumerate([(1, 1, 2, -1), (0, 0, -14, -9), (3, 2, 30, 25)]):
-        jobs[i] = (mx, my, 0, R, cx, cy)
+        jobs[i]["mb_x"], jobs[i]["mb_y"], jobs[i]["R"], jobs[i]["cx"], jobs[i]["cy"] = mx, my, R, cx, cy
+        if wp:
+            jobs[i]["wp"], jobs[i]["weight"], jobs[i]["offset"], jobs[i]["wp_round"], jobs[i]["wp_denom"] = (1,) + wp
     sad = ctx.distortion_surface("sad_rows", jobs)
     satd = ctx.distortion_surface("satd_blocks", jobs)
     ctx.close()
@@ -162,8 +165,13 @@ def test_distortion_surface(pkg):
         d = oracle.Dist()
         d.ref = C.pointer(rp.ref)
         d.umv, d.chroma_me, d.test8x8, d.max_val, d.max_val_uv = 1, 0, test8x8, 255, 255
+        if wp:
+            d.weight_luma, d.offset_luma, d.wp_luma_round, d.luma_log_weight_denom = wp
         return d
     d4, d8 = dist(0), dist(1)
+    L.jmo_sad_wp.argtypes = proto
+    L.jmo_satd_wp.argtypes = proto
+    f_sad, f_satd = (L.jmo_sad_wp, L.jmo_satd_wp) if wp else (L.jmo_sad, L.jmo_satd)
     for i, job in enumerate(jobs):
         ox, oy = int(job["mb_x"]) * 16, int(job["mb_y"]) * 16
         for ay in range(2 * R + 1):
@@ -173,17 +181,17 @@ def test_distortion_surface(pkg):
                     for g in range(4):
                         src = np.zeros(768, np.uint16)
                         src[:4] = cur16[oy + r, ox + 4 * g:ox + 4 * g + 4]
-                        want = L.jmo_sad(C.byref(d4), src.ctypes.data, 1, 4, 2147483647, (ox + 4 * g + 20 + mvx) * 4, (oy + r + 20 + mvy) * 4)
+                        want = f_sad(C.byref(d4), src.ctypes.data, 1, 4, 2147483647, (ox + 4 * g + 20 + mvx) * 4, (oy + r + 20 + mvy) * 4)
                         assert int(sad[i, ay, ax, r, g]) == want, (i, ay, ax, r, g)
                 for b in range(16):
                     bx, by = 4 * (b & 3), 4 * (b >> 2)
                     src = np.zeros(768, np.uint16)
                     src[:16] = cur16[oy + by:oy + by + 4, ox + bx:ox + bx + 4].reshape(-1)
-                    want = L.jmo_satd(C.byref(d4), src.ctypes.data, 4, 4, 2147483647, (ox + bx + 20 + mvx) * 4, (oy + by + 20 + mvy) * 4)
+                    want = f_satd(C.byref(d4), src.ctypes.data, 4, 4, 2147483647, (ox + bx + 20 + mvx) * 4, (oy + by + 20 + mvy) * 4)
                     assert int(satd[i, ay, ax, b]) == want, (i, ay, ax, b)
                 for b in range(4):
                     bx, by = 8 * (b & 1), 8 * (b >> 1)
                     src = np.zeros(768, np.uint16)
                     src[:64] = cur16[oy + by:oy + by + 8, ox + bx:ox + bx + 8].reshape(-1)
-                    want = L.jmo_satd(C.byref(d8), src.ctypes.data, 8, 8, 2147483647, (ox + bx + 20 + mvx) * 4, (oy + by + 20 + mvy) * 4)
+                    want = f_satd(C.byref(d8), src.ctypes.data, 8, 8, 2147483647, (ox + bx + 20 + mvx) * 4, (oy + by + 20 + mvy) * 4)
                     assert int(satd[i, ay, ax, 16 + b]) == want, (i, ay, ax, "8x8", b)

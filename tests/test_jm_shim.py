@@ -43,6 +43,8 @@ BiPredMERefinements = 3
 BiPredMESearchRange = 16
 BiPredMESubPel = 2
 WeightedBiprediction = {wbp}
+WeightedPrediction = {wp}
+UseWeightedReferenceME = {wp}
 SymbolMode = {cabac}
 SearchMode = {search}
 RDOptimization = {rdopt}
@@ -71,11 +73,13 @@ CASES = {
     "epzs_main": dict(search=3, profile=77, cabac=1, t8x8=0, bframes=1, refs=2, rdopt=1, adrnd=0, yuv=1),
     "umhex_baseline": dict(search=1, profile=66, cabac=0, t8x8=0, bframes=0, refs=2, rdopt=1, adrnd=1, yuv=1),
     "epzs_satd_high": dict(search=3, profile=100, cabac=1, t8x8=1, bframes=0, refs=1, rdopt=1, adrnd=0, yuv=1, fpel=2),
+    # BASELINE config 5 in small: 4:2:2, UMHexagonS, explicit weighted prediction used in ME (computeSADWP surfaces), fading clip
+    "umhex_wp_422": dict(search=1, profile=122, cabac=1, t8x8=1, bframes=0, refs=2, rdopt=1, adrnd=0, yuv=2, wp=1, fade=1),
     "full_lowcplx_422": dict(search=-1, profile=122, cabac=0, t8x8=1, bframes=0, refs=1, rdopt=0, adrnd=1, yuv=2),  # rdopt off centre rule, 4:2:2 chroma DC
 }
 
 
-def make_clip(path, w, h, frames, yuv):
+def make_clip(path, w, h, frames, yuv, fade=0):
     rng = np.random.default_rng(3)
     yy, xx = np.mgrid[0:h + 64, 0:w + 64]
     base = ((np.sin(xx / 7.0) * np.cos(yy / 5.0)) * 60 + 128 + rng.normal(0, 10, (h + 64, w + 64))).clip(0, 255)
@@ -83,7 +87,8 @@ def make_clip(path, w, h, frames, yuv):
     with open(path, "wb") as f:
         for t in range(frames):
             dx, dy = 3 * t, 2 * t
-            f.write((base[16 + dy:16 + dy + h, 16 + dx:16 + dx + w] + rng.normal(0, 2, (h, w))).clip(0, 255).astype(np.uint8).tobytes())
+            gain = 1.0 - 0.07 * t * fade              # a fade gives the explicit weights something to estimate
+            f.write(((base[16 + dy:16 + dy + h, 16 + dx:16 + dx + w] + rng.normal(0, 2, (h, w))) * gain).clip(0, 255).astype(np.uint8).tobytes())
             for k in range(2):
                 c = base[8 + dy // 2:8 + dy // 2 + ch, 8 + dx // 2 + 5 * k:8 + dx // 2 + 5 * k + cw]
                 f.write((c * 0.5 + 64).clip(0, 255).astype(np.uint8).tobytes())
@@ -104,12 +109,14 @@ def run(exe, d, env=None):
 
 def prepare(tmp_path, name, w=176, h=144, frames=3, R=16, qp=28):
     v = dict(CASES[name], w=w, h=h, frames=frames, R=R, qp=qp)
+    v = {k: x for k, x in v.items()}
     v.setdefault("fpel", 0)
     v.setdefault("bipred", 0)
     v.setdefault("wbp", 0)
+    v.setdefault("wp", 0)
     with open(tmp_path / "case.cfg", "w") as f:
         f.write(CFG.format(**v))
-    make_clip(tmp_path / "clip.yuv", w, h, frames + v["bframes"] * (frames - 1), v["yuv"])
+    make_clip(tmp_path / "clip.yuv", w, h, frames + v["bframes"] * (frames - 1), v["yuv"], v.get("fade", 0))
 
 
 @pytest.mark.reference
