@@ -1,0 +1,86 @@
+"""BASELINE config 2 at full size (1920x1088, FullSearch +-32, 8160 macroblocks x 41 partitions) on the device:
+ * a sample of macroblocks (picture corners, edges, interior rows) against the oracle's C driver, bit-exact;
+ * the whole frame through size-independent properties: the two independent integer-search kernels (pair-lane "fast" path
+   and the union-window generic path, forced by masking one partition off) must agree on every other partition of every
+   macroblock; a resident re-run reproduces the first run; costs are consistent with the vectors they come with."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests import oracle
+from tests.test_me import lambda_factors
+
+pytestmark = pytest.mark.gpu
+W, H, R = 1920, 1088, 32
+
+
+def clip():
+    rng = np.random.default_rng(20260410)
+    B = rng.integers(0, 256, (H // 8 + 16, W // 8 + 16)).astype(np.float64)
+    B = np.kron(B, np.ones((8, 8)))
+    k = np.ones(9) / 9.0
+    B = np.apply_along_axis(lambda m: np.convolve(m, k, mode="same"), 1, B)
+    B = np.apply_along_axis(lambda m: np.convolve(m, k, mode="same"), 0, B)
+    ref = np.clip(np.round(B[32:32 + H, 32:32 + W] + rng.normal(0, 2, (H, W))), 0, 255).astype(np.uint8)
+    cur = np.clip(np.round(B[32 - 3:32 - 3 + H, 32 + 5:32 + 5 + W] + rng.normal(0, 2, (H, W))), 0, 255).astype(np.uint8)
+    return cur, ref
+
+
+def test_full_frame_search_1080p(pkg):
+    from h264_amd.jmhip import ME_MB_DTYPE
+    cur, ref = clip()
+    mbw, mbh = W // 16, H // 16
+    n = mbw * mbh
+    rng = np.random.default_rng(5)
+    mbs = np.zeros(n, dtype=ME_MB_DTYPE)
+    mbs["mb_x"], mbs["mb_y"], mbs["ref_is_0"] = np.arange(n) % mbw, np.arange(n) // mbw, 1
+    mbs["pred_mv"] = (np.array([16, -16]) + rng.integers(-8, 9, (n, 1, 2))) + np.zeros((n, 41, 2), int)
+    ctx = pkg.Context(W, H, yuv_format=0, max_refs=1, search_range=R)
+    ctx.ref_upload(0, ref)
+    ctx.interp_luma(0)
+    ctx.cur_upload(cur)
+    lam = lambda_factors(28)
+    prm = pkg.MeParams()
+    prm.search_mode, prm.search_range, prm.rdopt = -1, R, 1
+    prm.level_mv_min, prm.level_mv_max = -511, 511
+    prm.lambda_[0], prm.lambda_[1], prm.lambda_[2] = lam
+    prm.subpel, prm.partition_mask = 1, (1 << 41) - 1
+    got = ctx.me_frame(prm, mbs)
+    ctx.me_frame_async(prm, None, n)
+    again = ctx.me_results(n)
+    prm.partition_mask = ((1 << 41) - 1) & ~(1 << 40)          # forces the generic union-window kernel
+    generic = ctx.me_frame(prm, mbs)
+    ctx.close()
+
+    for key in ("mv_int", "cost_int", "mv", "cost"):
+        assert np.array_equal(got[key], again[key]), "resident re-run differs: " + key
+        assert np.array_equal(got[key][:, :40], generic[key][:, :40]), "pair-lane and generic kernels disagree: " + key
+    # a quarter-pel result lies within 3 quarter-pels of the integer one and never costs more than the carried SATD chain allows
+    d = got["mv"].astype(int) - 4 * got["mv_int"].astype(int)
+    assert np.abs(d).max() <= 3
+    assert (np.abs(got["mv_int"].astype(int) - np.trunc(mbs["pred_mv"] / 4).astype(int)) <= R).all()
+    # the clip moves by (5,-3): the 16x16 vector must find it on the bulk of the frame
+    hit = ((got["mv_int"][:, 0, 0] == 5) & (got["mv_int"][:, 0, 1] == -3)).mean()
+    assert hit > 0.9, hit
+
+    # ---- oracle on a sample: corners/edges (UMV windows) and interior rows
+    rows = [0, 1, 33, 34, 66, 67]
+    sel = np.concatenate([np.arange(r * mbw, (r + 1) * mbw, 3) for r in rows])
+    L = oracle.lib()
+    p = oracle.me_params(rdopt=1)
+    rp = oracle.RefPic(ref, yuv_format=0)
+    xy = np.ascontiguousarray(np.stack([mbs["mb_x"][sel], mbs["mb_y"][sel]], 1).astype(np.int16))
+    preds = np.ascontiguousarray(mbs["pred_mv"][sel].astype(np.int16))
+    lam_a = (C.c_int * 3)(*lam)
+    cur16 = np.ascontiguousarray(cur, dtype=np.uint16)
+    mv_out = np.zeros((len(sel), 41, 2), np.int16)
+    cost_out = np.zeros((len(sel), 41), np.int32)
+    vp = C.c_void_p
+    L.jmo_hotpath_mbs.restype = C.c_longlong
+    L.jmo_hotpath_mbs.argtypes = [C.POINTER(oracle.MeParams), C.POINTER(oracle.Ref), vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int,
+                                  C.POINTER(C.c_int), vp, vp, vp, vp]
+    L.jmo_hotpath_mbs(C.byref(p), C.byref(rp.ref), cur16.ctypes.data, None, None, W, xy.ctypes.data, preds.ctypes.data, len(sel), R, lam_a,
+                      None, None, mv_out.ctypes.data, cost_out.ctypes.data)
+    assert np.array_equal(got["mv"][sel], mv_out), "vectors differ from the oracle on the sampled macroblocks"
+    assert np.array_equal(got["cost"][sel], cost_out), "costs differ from the oracle on the sampled macroblocks"
