@@ -97,9 +97,12 @@ __global__ __launch_bounds__(64) void mc_kernel(FrameDev F, const jmhip_me_mb *_
   jmhip_tq_job &jy = jobs_y[i];
   if (tid < 16) {                                    // luma: one 4x4 block per lane, LumaPrediction(..., 4, 4, ...)
     const int x4 = tid & 3, y4 = tid >> 2;
-    const int xq = ((mbx * 16 + 4 * x4) << 2) + 4 * JMHIP_PAD + s_mv[tid][0];   // pic_opix_x + mv, macroblock.c:851
-    const int yq = ((mby * 16 + 4 * y4) << 2) + 4 * JMHIP_PAD + s_mv[tid][1];
-    const int xpos = clampi(xq >> 2, 0, F.Wp - 1 - 16), ypos = clampi(yq >> 2, 0, F.Hp - 1 - 16);   // UMVLine4X, refbuf.c:37
+    // with the 8x8 transform LumaPrediction is called per 8x8 block (macroblock.c:1143): the UMV clamp then applies to the
+    // 8x8 block's origin and this 4x4 block sits at its offset inside it
+    const int t8 = s_mode.pad[0] ? 1 : 0, ox4 = t8 ? (x4 & 1) * 4 : 0, oy4 = t8 ? (y4 & 1) * 4 : 0;
+    const int xq = ((mbx * 16 + 4 * x4 - ox4) << 2) + 4 * JMHIP_PAD + s_mv[tid][0];   // pic_opix_x + mv, macroblock.c:851
+    const int yq = ((mby * 16 + 4 * y4 - oy4) << 2) + 4 * JMHIP_PAD + s_mv[tid][1];
+    const int xpos = clampi(xq >> 2, 0, F.Wp - 1 - 16) + ox4, ypos = clampi(yq >> 2, 0, F.Hp - 1 - 16) + oy4;   // UMVLine4X, refbuf.c:37
     const uint8_t *src = F.ref_sub[mb.ref] + (size_t)((yq & 3) * 4 + (xq & 3)) * F.Wp * F.Hp + (size_t)ypos * F.Wp + xpos;
 #pragma unroll
     for (int rr = 0; rr < 4; rr++) {
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(64) void mc_kernel(FrameDev F, const jmhip_me_mb *_
       *reinterpret_cast<uint32_t *>(&jy.src[4 * y4 + rr][4 * x4]) =
           *reinterpret_cast<const uint32_t *>(F.cur_y + (size_t)(mby * 16 + 4 * y4 + rr) * F.W + mbx * 16 + 4 * x4);
     }
-    if (tid == 0) { jy.quant = 0; jy.quant_dc = 0; jy.uv = 0; jy.cr_cbp_in = 0; jy.intra16_unused = 0; }
+    if (tid == 0) { jy.quant = s_mode.pad[0] ? 3 : 0; jy.quant_dc = 0; jy.uv = 0; jy.cr_cbp_in = 0; jy.intra16_unused = s_mode.pad[0] ? 1 : 0; }
   }
 
   if (F.yuv != JMHIP_YUV400) {
@@ -147,8 +150,13 @@ __global__ __launch_bounds__(64) void finalize_kernel(FrameDev F, const jmhip_me
   if (tid == 0) {
     int cbp = 0, sum = 0;
     long long cbp_blk = 0;
+    const bool t8 = jobs_y[i].intra16_unused != 0;   // luma_transform_size_8x8_flag of this macroblock (set by mc_kernel)
     for (int b8 = 0; b8 < 4; b8++) {
       int cost = 0, any = 0;
+      if (t8) {                                        // macroblock.c:1181-1188
+        cost = ry.coeff_cost[b8];
+        if (ry.nonzero[b8]) { any = 1; cbp_blk |= 51LL << (4 * b8 - 2 * (b8 & 1)); }
+      } else
       for (int b4 = 0; b4 < 4; b4++) {
         cost += ry.coeff_cost[b8 * 4 + b4];
         if (ry.nonzero[b8 * 4 + b4]) {
@@ -221,7 +229,7 @@ int ensure_frame_buffers(jmhip_ctx *c, int n)
   JM_HIP_CHECK(c, hipMemsetAsync(c->fr_jobs_c, 0, sizeof(jmhip_tq_job) * (size_t)n * 2, c->stream));
   JM_HIP_CHECK(c, hipMemsetAsync(c->fr_res_y, 0, sizeof(jmhip_tq_result) * (size_t)n, c->stream));
   JM_HIP_CHECK(c, hipMemsetAsync(c->fr_res_c, 0, sizeof(jmhip_tq_result) * (size_t)n * 2, c->stream));
-  if (!c->fr_quant && hipMalloc(&c->fr_quant, sizeof(jmhip_quant) * 3) != hipSuccess) return jm_fail(c, JMHIP_ERR_NOMEM, "frame-stage quantisers");
+  if (!c->fr_quant && hipMalloc(&c->fr_quant, sizeof(jmhip_quant) * 4) != hipSuccess) return jm_fail(c, JMHIP_ERR_NOMEM, "frame-stage quantisers");
   c->fr_capacity = n;
   return JMHIP_OK;
 }
@@ -230,20 +238,31 @@ int ensure_frame_buffers(jmhip_ctx *c, int n)
 
 extern "C" int jmhip_residual_frame(jmhip_ctx *c, const jmhip_mb_mode *modes, const jmhip_quant quants[3])
 {
-  if (!c || !quants) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_residual_frame: NULL arguments") : JMHIP_ERR_ARG;
+  return jmhip_residual_frame_q(c, modes, quants, 3);
+}
+
+extern "C" int jmhip_residual_frame_q(jmhip_ctx *c, const jmhip_mb_mode *modes, const jmhip_quant *quants, int nquants)
+{
+  if (!c || !quants || (nquants != 3 && nquants != 4)) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_residual_frame: NULL arguments / 3 or 4 quantisers") : JMHIP_ERR_ARG;
   const int n = c->me_n;
   if (n <= 0 || !c->me_res_dev) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_residual_frame: no motion search results on the device (call jmhip_me_frame first)");
   if (c->cfg.yuv_format == JMHIP_YUV444) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_residual_frame: 4:4:4 chroma goes through the luma path in JM (not built)");
-  for (int k = 0; k < 3; k++) {
+  for (int k = 0; k < nquants; k++) {
     if (quants[k].qp < 0 || quants[k].qp > 87 || quants[k].max_val != 255 || quants[k].disthres < 0 || quants[k].disthres > 1)
       return jm_fail(c, JMHIP_ERR_ARG, "jmhip_residual_frame: quantiser out of range");
-    if (quants[k].transform8x8_flag) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_residual_frame: 8x8 transform macroblocks not built in the frame stage");
+    if ((quants[k].transform8x8_flag != 0) != (k == 3)) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_residual_frame: transform8x8_flag belongs to quants[3] (the 8x8 luma quantiser) only");
   }
+  bool any_t8 = false;
   if (modes)
     for (int i = 0; i < n; i++) {
       const jmhip_mb_mode &m = modes[i];
       bool ok = m.mode == 1 || m.mode == 2 || m.mode == 3 || m.mode == 8;
       if (m.mode == 8) for (int b = 0; b < 4; b++) ok = ok && m.b8mode[b] >= 4 && m.b8mode[b] <= 7;
+      if (m.pad[0]) {                                // luma_transform_size_8x8_flag: no partition below 8x8 (macroblock.c:1458-1480)
+        any_t8 = true;
+        if (m.mode == 8) for (int b = 0; b < 4; b++) ok = ok && m.b8mode[b] == 4;
+        ok = ok && nquants == 4 && m.pad[0] == 1;
+      }
       if (!ok) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_residual_frame: bad macroblock mode");
     }
   JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
@@ -263,8 +282,8 @@ extern "C" int jmhip_residual_frame(jmhip_ctx *c, const jmhip_mb_mode *modes, co
   }
   MbCoded *coded_dev = reinterpret_cast<MbCoded *>(modes_out_dev + 2 * (size_t)n);
   // the three quantisers are copied into a context-owned host block first: the caller's array is only borrowed for the call
-  memcpy(c->fr_quant_host, quants, sizeof(jmhip_quant) * 3);
-  JM_HIP_CHECK(c, hipMemcpyAsync(c->fr_quant, c->fr_quant_host, sizeof(jmhip_quant) * 3, hipMemcpyHostToDevice, c->stream));
+  memcpy(c->fr_quant_host, quants, sizeof(jmhip_quant) * nquants);
+  JM_HIP_CHECK(c, hipMemcpyAsync(c->fr_quant, c->fr_quant_host, sizeof(jmhip_quant) * nquants, hipMemcpyHostToDevice, c->stream));
   if (modes) JM_HIP_CHECK(c, hipStreamSynchronize(c->stream));      // caller-owned mode array
 
   FrameDev F{};
@@ -282,7 +301,8 @@ extern "C" int jmhip_residual_frame(jmhip_ctx *c, const jmhip_mb_mode *modes, co
   jm_stage_end(c, JMHIP_STAGE_MC);
   JM_HIP_CHECK(c, hipGetLastError());
   jm_stage_begin(c, JMHIP_STAGE_TQ);
-  rc = jm_launch_tq(c, JMHIP_TQ_LUMA4x4, F.yuv, c->fr_jobs_y, c->fr_quant, c->fr_res_y, n);
+  rc = jm_launch_tq(c, JMHIP_TQ_LUMA4x4 | JMHIP_TQ_SELECT, F.yuv, c->fr_jobs_y, c->fr_quant, c->fr_res_y, n);
+  if (!rc && any_t8) rc = jm_launch_tq(c, JMHIP_TQ_LUMA8x8 | JMHIP_TQ_SELECT, F.yuv, c->fr_jobs_y, c->fr_quant, c->fr_res_y, n);
   if (!rc && F.yuv != JMHIP_YUV400) rc = jm_launch_tq(c, JMHIP_TQ_CHROMA, F.yuv, c->fr_jobs_c, c->fr_quant, c->fr_res_c, 2 * n);
   if (!rc) {
     finalize_kernel<<<n, 64, 0, c->stream>>>(F, (const jmhip_me_mb *)c->me_jobs_dev, (const jmhip_tq_job *)c->fr_jobs_y, (const jmhip_tq_result *)c->fr_res_y,

@@ -44,7 +44,7 @@ struct jmhip_ctx {
   // frame pipeline (MC -> residual -> TQ -> recon): per-MB luma job/result, 2 chroma jobs/results, recon picture
   void *fr_jobs_y = nullptr, *fr_jobs_c = nullptr, *fr_res_y = nullptr, *fr_res_c = nullptr, *fr_quant = nullptr, *fr_modes = nullptr;
   int fr_capacity = 0, fr_n = 0;
-  jmhip_quant fr_quant_host[3];
+  jmhip_quant fr_quant_host[4];
   uint8_t *rec_y = nullptr, *rec_u = nullptr, *rec_v = nullptr;
   // TQ arrays
   void *tq_jobs_dev = nullptr, *tq_res_dev = nullptr, *tq_quant_dev = nullptr; int tq_capacity = 0, tq_qcap = 0;
@@ -80,6 +80,7 @@ void jm_stage_end(jmhip_ctx *ctx, int stage);
 // kernels (one translation unit each)
 int jm_launch_interp_luma(jmhip_ctx *ctx, int ref);
 int jm_launch_interp_chroma(jmhip_ctx *ctx, int ref);
+constexpr int JMHIP_TQ_SELECT = 0x100;   // frame stage: each luma kernel takes only the macroblocks of its transform size
 int jm_launch_tq(jmhip_ctx *ctx, int kind, int yuv_format, const void *jobs, const void *quants, void *results, int n);
 int jm_ensure_ref_table(jmhip_ctx *ctx);
 

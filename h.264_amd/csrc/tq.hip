@@ -151,13 +151,15 @@ __device__ void xf8_tile(int (*m)[16], int py, int px, bool inverse)  // forward
 
 // ---------------------------------------------------------------------------------------- dct_4x4: one lane per 4x4 block
 
+// `select`: frame stage -- a job marked as an 8x8-transform macroblock (intra16_unused != 0) belongs to tq_luma8x8_kernel
 __global__ __launch_bounds__(256) void tq_luma4x4_kernel(const jmhip_tq_job *__restrict__ jobs, const jmhip_quant *__restrict__ quants,
-                                                        jmhip_tq_result *__restrict__ res, int n)
+                                                        jmhip_tq_result *__restrict__ res, int n, int select)
 {
   const int gid = blockIdx.x * 256 + threadIdx.x;
   const int jobi = gid >> 4, blk = gid & 15;                 // blk = b8*4 + b4 (JM block order)
   if (jobi >= n) return;
   const jmhip_tq_job &job = jobs[jobi];
+  if (select && job.intra16_unused) return;
   const jmhip_quant &q = quants[job.quant];
   jmhip_tq_result &o = res[jobi];
   const int b8 = blk >> 2, b4 = blk & 3;
@@ -227,12 +229,13 @@ __device__ void load_residual(const jmhip_tq_job &job, int (*m7)[16], int rows, 
 
 // dct_8x8, transform8x8.c:1452 (non-lossless). One lane per 8x8 block.
 __global__ __launch_bounds__(64) void tq_luma8x8_kernel(const jmhip_tq_job *__restrict__ jobs, const jmhip_quant *__restrict__ quants,
-                                                       jmhip_tq_result *__restrict__ res, int n)
+                                                       jmhip_tq_result *__restrict__ res, int n, int select)
 {
   const int gid = blockIdx.x * 64 + threadIdx.x;
   const int jobi = gid >> 2, b8 = gid & 3;
   if (jobi >= n) return;
   const jmhip_tq_job &job = jobs[jobi];
+  if (select && !job.intra16_unused) return;
   const jmhip_quant &q = quants[job.quant];
   jmhip_tq_result &o = res[jobi];
   const int block_x = 8 * (b8 & 1), block_y = 8 * (b8 >> 1);
@@ -670,9 +673,11 @@ int jm_launch_tq(jmhip_ctx *c, int kind, int yuv_format, const void *jobs, const
   const jmhip_tq_job *dj = (const jmhip_tq_job *)jobs;
   const jmhip_quant *dq = (const jmhip_quant *)quants;
   jmhip_tq_result *dr = (jmhip_tq_result *)results;
+  const int select = (kind & JMHIP_TQ_SELECT) ? 1 : 0;
+  kind &= ~JMHIP_TQ_SELECT;
   switch (kind) {
-  case JMHIP_TQ_LUMA4x4:   tq_luma4x4_kernel<<<(n * 16 + 255) / 256, 256, 0, c->stream>>>(dj, dq, dr, n); break;
-  case JMHIP_TQ_LUMA8x8:   tq_luma8x8_kernel<<<(n * 4 + 63) / 64, 64, 0, c->stream>>>(dj, dq, dr, n); break;
+  case JMHIP_TQ_LUMA4x4:   tq_luma4x4_kernel<<<(n * 16 + 255) / 256, 256, 0, c->stream>>>(dj, dq, dr, n, select); break;
+  case JMHIP_TQ_LUMA8x8:   tq_luma8x8_kernel<<<(n * 4 + 63) / 64, 64, 0, c->stream>>>(dj, dq, dr, n, select); break;
   case JMHIP_TQ_LUMA16x16: tq_luma16x16_kernel<<<(n + 63) / 64, 64, 0, c->stream>>>(dj, dq, dr, n); break;
   default:
     if (yuv_format == JMHIP_YUV420) tq_chroma420_kernel<<<(n * 4 + 255) / 256, 256, 0, c->stream>>>(dj, dq, dr, n);

@@ -124,6 +124,7 @@ def load_library():
     lib.jmhip_flat_quant.argtypes = [vp, ip, ip, ip]
     lib.jmhip_flat_quant.restype = None
     lib.jmhip_residual_frame.argtypes = [vp, vp, vp]
+    lib.jmhip_residual_frame_q.argtypes = [vp, vp, vp, ip]
     lib.jmhip_residual_download.argtypes = [vp, vp, vp, vp, vp, vp, ip]
     lib.jmhip_recon_to_ref.argtypes = [vp, ip]
     lib.jmhip_recon_download.argtypes = [vp, vp, vp, vp, ip]
@@ -317,12 +318,13 @@ class Context:
         return res
 
     # ---- frame stage: MC -> residual -> TQ -> recon
-    def residual_frame(self, quants3, modes=None):
-        quants3 = np.ascontiguousarray(quants3, dtype=QUANT_DTYPE)
-        assert len(quants3) == 3
+    def residual_frame(self, quants, modes=None):
+        """quants: 3 quantisers (luma 4x4, chroma, chroma DC) or 4 (+ the 8x8 luma quantiser, for modes with pad[0] = 1)."""
+        quants = np.ascontiguousarray(quants, dtype=QUANT_DTYPE)
+        assert len(quants) in (3, 4)
         if modes is not None:
             modes = np.ascontiguousarray(modes, dtype=MB_MODE_DTYPE)
-        self._chk(self.lib.jmhip_residual_frame(self.h, _ptr(modes), _ptr(quants3)), "jmhip_residual_frame")
+        self._chk(self.lib.jmhip_residual_frame_q(self.h, _ptr(modes), _ptr(quants), len(quants)), "jmhip_residual_frame")
 
     def residual_download(self, n, want_results=True):
         luma = np.zeros(n, dtype=TQ_RESULT_DTYPE) if want_results else None

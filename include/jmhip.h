@@ -267,7 +267,7 @@ int jmhip_tq_batch(jmhip_ctx *ctx, int kind, int yuv_format, const jmhip_quant *
 
 /* Inter mode of one macroblock as JM's mode decision fixed it (the decision itself stays on the host):
  * mode 1 = 16x16, 2 = 16x8, 3 = 8x16, 8 = P8x8 with b8mode[b] in {4,5,6,7} (8x8, 8x4, 4x8, 4x4). */
-typedef struct { int8_t mode; int8_t b8mode[4]; int8_t pad[3]; } jmhip_mb_mode;
+typedef struct { int8_t mode; int8_t b8mode[4]; int8_t pad[3]; } jmhip_mb_mode;   /* pad[0] = luma_transform_size_8x8_flag (0/1) */
 
 /* For the n macroblocks of the last jmhip_me_frame(_async) call, in the same order:
  *   LumaPrediction / OneComponentLumaPrediction (src/macroblock.c:836, :807) per 4x4 block with the motion vectors
@@ -279,6 +279,11 @@ typedef struct { int8_t mode; int8_t b8mode[4]; int8_t pad[3]; } jmhip_mb_mode;
  *   quants[0] = luma inter quantiser, quants[1] = chroma quantiser, quants[2] = 4:2:2 chroma DC (qp+3) quantiser.
  * Results stay on the device until downloaded: luma[n], chroma[2n] (index 2*i+uv), modes_out[n], cbp[n], cbp_blk[n]. */
 int jmhip_residual_frame(jmhip_ctx *ctx, const jmhip_mb_mode *modes, const jmhip_quant quants[3]);
+/* Same with nquants = 4: quants[3] is the 8x8 luma quantiser (transform8x8_flag = 1, 64-entry tables). Macroblocks whose mode has
+ * pad[0] = 1 (JM's TransformDecision outcome, src/macroblock.c:1458; only legal without partitions below 8x8) take the dct_8x8
+ * branch of LumaResidualCoding8x8 (src/macroblock.c:1131-1188): prediction and UMV clamp per 8x8 block, dct_8x8, cbp_blk bits
+ * 51 << (4*b8 - 2*(b8&1)), the same coefficient-cost thresholds. */
+int jmhip_residual_frame_q(jmhip_ctx *ctx, const jmhip_mb_mode *modes, const jmhip_quant *quants, int nquants);
 /* cbp / cbp_blk: currMB->cbp and currMB->cbp_blk after the _LUMA_COEFF_COST_ (8x8) and _LUMA_MB_COEFF_COST_ (MB)
  * thresholding of src/macroblock.c:1236-1258, :1386-1392 and the chroma cr_cbp. Any output pointer may be NULL. */
 int jmhip_residual_download(jmhip_ctx *ctx, jmhip_tq_result *luma, jmhip_tq_result *chroma, jmhip_mb_mode *modes_out,

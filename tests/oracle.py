@@ -382,10 +382,13 @@ def residual_frame(refpic, cur, mbs, mv, modes, quants3, job_dtype, yuv_format=1
             for x4 in range(4):
                 p = covering_partition(modes[i], x4, y4)
                 mv4[y4, x4] = mv[i, p]
-                xq = ((mbx * 16 + 4 * x4) << 2) + 80 + int(mv[i, p, 0])
-                yq = ((mby * 16 + 4 * y4) << 2) + 80 + int(mv[i, p, 1])
-                xpos = min(max(xq >> 2, 0), Wp - 17)
-                ypos = min(max(yq >> 2, 0), Hp - 17)
+                # with the 8x8 transform LumaPrediction runs per 8x8 block (macroblock.c:1143): its origin is what UMVLine4X clamps
+                t8 = int(modes[i]["pad"][0])
+                ox4, oy4 = ((x4 & 1) * 4, (y4 & 1) * 4) if t8 else (0, 0)
+                xq = ((mbx * 16 + 4 * x4 - ox4) << 2) + 80 + int(mv[i, p, 0])
+                yq = ((mby * 16 + 4 * y4 - oy4) << 2) + 80 + int(mv[i, p, 1])
+                xpos = min(max(xq >> 2, 0), Wp - 17) + ox4
+                ypos = min(max(yq >> 2, 0), Hp - 17) + oy4
                 jobs_y[i]["pred"][4 * y4:4 * y4 + 4, 4 * x4:4 * x4 + 4] = refpic.luma[yq & 3, xq & 3, ypos:ypos + 4, xpos:xpos + 4]
         jobs_y[i]["src"] = Y[mby * 16:mby * 16 + 16, mbx * 16:mbx * 16 + 16]
         for uv, (planes, C_) in enumerate(((refpic.cb, U), (refpic.cr, V))):
@@ -401,6 +404,13 @@ def residual_frame(refpic, cur, mbs, mv, modes, quants3, job_dtype, yuv_format=1
                     jc["pred"][j, ic:ic + 2] = planes[jj & ((1 << shift_y) - 1), ii & ((1 << shift_x) - 1), ypos, xpos:xpos + 2]
             jc["src"][:mch, :mcw] = C_[mby * mch:mby * mch + mch, mbx * mcw:mbx * mcw + mcw]
     ry = tq_reference("luma4x4", quants3, jobs_y)
+    t8 = np.array([int(m["pad"][0]) for m in modes], bool)
+    if t8.any():
+        jobs8 = jobs_y.copy()
+        jobs8["quant"] = 3
+        r8 = tq_reference("luma8x8", quants3, jobs8)
+        for k in ry:
+            ry[k][t8] = r8[k][t8]
     rc = tq_reference("chroma", quants3, jobs_c, yuv_format=yuv_format)
     cbp = np.zeros(n, np.int32)
     cbp_blk = np.zeros(n, np.int64)
@@ -412,9 +422,15 @@ def residual_frame(refpic, cur, mbs, mv, modes, quants3, job_dtype, yuv_format=1
         rec = ry["recon"][i].copy()
         pred = jobs_y[i]["pred"]
         for b8 in range(4):
-            cost = int(ry["coeff_cost"][i, 4 * b8:4 * b8 + 4].sum())
+            if t8[i]:                                       # macroblock.c:1181-1188
+                cost = int(ry["coeff_cost"][i, b8])
+                if ry["nonzero"][i, b8]:
+                    c |= 1 << b8
+                    cb |= 51 << (4 * b8 - 2 * (b8 & 1))
+            else:
+                cost = int(ry["coeff_cost"][i, 4 * b8:4 * b8 + 4].sum())
             for b4 in range(4):
-                if ry["nonzero"][i, 4 * b8 + b4]:
+                if not t8[i] and ry["nonzero"][i, 4 * b8 + b4]:
                     c |= 1 << b8
                     cb |= 1 << ((2 * (b8 & 1) + (b4 & 1)) + 4 * (2 * (b8 >> 1) + (b4 >> 1)))
             if cost <= 4:

@@ -69,3 +69,60 @@ def test_residual_frame(pkg, fmt, qp, given_modes):
         assert np.array_equal(g, wv), "recon %s" % name
     # the thresholds must actually be exercised somewhere across the parametrisation
     assert got["cbp"].max() > 0 or qp >= 40
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cavlc,qp,far", [(1, 28, 6), (0, 22, 6), (1, 34, 45)])
+def test_residual_frame_with_8x8_transform_macroblocks(pkg, cavlc, qp, far):
+    """A mix of 4x4- and 8x8-transform macroblocks (luma_transform_size_8x8_flag per mode): dct_8x8 branch of
+    LumaResidualCoding8x8, 8x8-granular prediction clamp (far = vectors beyond the padded plane), CAVLC interleave / CABAC lists."""
+    rng = np.random.default_rng(qp + cavlc)
+    w, h, R = 64, 48, 8
+    cur, ref = synth(rng, w, h, 1)
+    ctx = pkg.Context(w, h, yuv_format=1, max_refs=1, search_range=R)
+    ctx.ref_upload(0, *ref)
+    ctx.interp_luma(0)
+    ctx.interp_chroma(0)
+    ctx.cur_upload(*cur)
+    mbs = make_mbs(pkg, rng, w // 16, h // 16, 4 * far)
+    lam = lambda_factors(qp)
+    prm = pkg.MeParams()
+    prm.search_mode, prm.search_range, prm.rdopt = -1, R, 1
+    prm.level_mv_min, prm.level_mv_max = -511, 511
+    prm.lambda_[0], prm.lambda_[1], prm.lambda_[2] = lam
+    prm.transform8x8_mode, prm.subpel, prm.partition_mask = 1, 1, (1 << 41) - 1
+    me = ctx.me_frame(prm, mbs)
+    q8 = pkg.flat_quant(qp, 342, is8x8=True, adaptive_rounding=1, adapt_rnd_weight=4, cavlc=cavlc, transform8x8_flag=1)
+    quants = np.array([pkg.flat_quant(qp, 342, adaptive_rounding=1, adapt_rnd_weight=4, cavlc=cavlc),
+                       pkg.flat_quant(qp, 342, adaptive_rounding=1, adapt_rnd_weight=4, cavlc=cavlc),
+                       pkg.flat_quant(qp + 3, 342, adaptive_rounding=1, adapt_rnd_weight=4, cavlc=cavlc), q8], dtype=pkg.QUANT_DTYPE)
+    modes = np.zeros(len(mbs), dtype=pkg.MB_MODE_DTYPE)
+    modes["mode"] = rng.choice([1, 2, 3, 8], len(mbs))
+    modes["b8mode"] = rng.integers(4, 8, (len(mbs), 4))
+    t8 = rng.integers(0, 2, len(mbs)).astype(bool)
+    t8[0] = True
+    modes["b8mode"][t8] = 4                               # the 8x8 transform needs partitions of at least 8x8
+    modes["pad"][:, 0] = t8
+    ctx.residual_frame(quants, modes)
+    got = ctx.residual_download(len(mbs))
+    recon = ctx.recon_download()
+    bad = modes.copy()
+    bad["b8mode"][0] = 7
+    bad["mode"][0] = 8
+    with pytest.raises(pkg.JmhipError):
+        ctx.residual_frame(quants, bad)                   # 8x8 transform over 4x4 partitions: refused
+    ctx.close()
+
+    rp = oracle.RefPic(ref[0], ref[1], ref[2], yuv_format=1)
+    want = oracle.residual_frame(rp, cur, mbs, me["mv"], modes, quants, pkg.TQ_JOB_DTYPE, yuv_format=1)
+    for key in ("levels", "runs", "levels8", "runs8"):
+        a, b = got["luma"][key], want["luma"][key]
+        if key in ("levels", "runs"):
+            compare_lists(got["luma"]["levels"], got["luma"]["runs"], want["luma"]["levels"], want["luma"]["runs"], "luma 4x4 lists")
+        else:
+            compare_lists(got["luma"]["levels8"][t8], got["luma"]["runs8"][t8], want["luma"]["levels8"][t8], want["luma"]["runs8"][t8], "luma 8x8 lists")
+    assert np.array_equal(got["cbp"], want["cbp"])
+    assert np.array_equal(got["cbp_blk"], want["cbp_blk"])
+    for g, wv, name in zip(recon, want["recon"], "YUV"):
+        assert np.array_equal(g, wv), "recon %s" % name
+    assert (got["cbp"][t8] & 15).max() > 0 or qp >= 34
