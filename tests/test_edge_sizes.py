@@ -1,0 +1,71 @@
+"""Edge cases of the whole chain against the oracle: the smallest legal pictures (one macroblock; one row; one column), search
+range 0 and 1 (a single candidate / the 3x3 ring), every vector pointing outside the picture, both search modes."""
+import numpy as np
+import pytest
+
+from tests import oracle
+from tests.test_frame import synth
+from tests.test_me import lambda_factors, make_mbs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("w,h,R,mode,spread", [(16, 16, 0, -1, 0), (16, 16, 4, 0, 40), (32, 16, 1, -1, 3), (16, 48, 8, 0, 90),
+                                               (48, 32, 0, 0, 7), (64, 16, 16, -1, 200)])
+def test_tiny_pictures_and_ranges(pkg, w, h, R, mode, spread):
+    rng = np.random.default_rng(w + h + R)
+    cur, ref = synth(rng, w, h, 1)
+    ctx = pkg.Context(w, h, yuv_format=1, max_refs=1, search_range=max(R, 1))
+    ctx.ref_upload(0, *ref)
+    ctx.interp_luma(0)
+    ctx.interp_chroma(0)
+    assert np.array_equal(ctx.download_luma_planes(0), oracle.interp_luma(ref[0]))
+    for uv in range(2):
+        assert np.array_equal(ctx.download_chroma_planes(0, uv), oracle.interp_chroma(ref[1 + uv], 1))
+    ctx.cur_upload(*cur)
+    mbs = make_mbs(pkg, rng, w // 16, h // 16, spread)
+    lam = lambda_factors(30)
+    prm = pkg.MeParams()
+    prm.search_mode, prm.search_range, prm.rdopt = mode, R, 0
+    prm.level_mv_min, prm.level_mv_max = -511, 511
+    prm.lambda_[0], prm.lambda_[1], prm.lambda_[2] = lam
+    prm.subpel, prm.partition_mask = 1, (1 << 41) - 1
+    me = ctx.me_frame(prm, mbs)
+    rp = oracle.RefPic(ref[0], ref[1], ref[2], yuv_format=1)
+    want = oracle.me_frame(oracle.me_params(rdopt=0), [rp], cur[0], mbs, mode, R, lam)
+    for k in ("mv_int", "cost_int", "mv", "cost"):
+        assert np.array_equal(me[k], want[k]), k
+    quants = np.array([pkg.flat_quant(30 + d, 342, adaptive_rounding=0, cavlc=1) for d in (0, 0, 3)], dtype=pkg.QUANT_DTYPE)
+    ctx.residual_frame(quants, None)
+    got = ctx.residual_download(len(mbs))
+    recon = ctx.recon_download()
+    ctx.close()
+    ref_out = oracle.residual_frame(rp, cur, mbs, me["mv"], got["modes"], quants, pkg.TQ_JOB_DTYPE, yuv_format=1)
+    for g, wv, name in zip(recon, ref_out["recon"], "YUV"):
+        assert np.array_equal(g, wv), name
+    assert np.array_equal(got["cbp"], ref_out["cbp"])
+
+
+def test_argument_errors_are_reported_not_guessed(pkg):
+    """Sizes that are not macroblock multiples, ranges beyond the context's, unknown search modes: refused with a message."""
+    with pytest.raises(pkg.JmhipError):
+        pkg.Context(40, 32, yuv_format=1, max_refs=1, search_range=8)
+    ctx = pkg.Context(32, 32, yuv_format=0, max_refs=1, search_range=4)
+    z = np.zeros((32, 32), np.uint8)
+    ctx.ref_upload(0, z)
+    ctx.cur_upload(z)
+    mbs = make_mbs(pkg, np.random.default_rng(0), 2, 2, 0)
+    prm = pkg.MeParams()
+    prm.search_mode, prm.search_range, prm.rdopt = -1, 8, 1
+    prm.level_mv_min, prm.level_mv_max = -511, 511
+    prm.lambda_[0] = prm.lambda_[1] = prm.lambda_[2] = 1000
+    prm.subpel, prm.partition_mask = 0, (1 << 41) - 1
+    with pytest.raises(pkg.JmhipError):
+        ctx.me_frame(prm, mbs)                       # range beyond the context's
+    prm.search_range, prm.search_mode = 4, 3
+    with pytest.raises(pkg.JmhipError):
+        ctx.me_frame(prm, mbs)                       # EPZS is not a device search mode
+    prm.search_mode, prm.subpel = -1, 1
+    with pytest.raises(pkg.JmhipError):
+        ctx.me_frame(prm, mbs)                       # sub-pel planes were never built
+    ctx.close()
