@@ -725,7 +725,8 @@ __global__ __launch_bounds__(256, 2) void me_int_fast_kernel(MeDev P, const jmhi
 // window (32 VGPRs), 21 + 1 running minima and cached mv costs: ~146 VGPRs, 3 waves/SIMD, 3 workgroups per CU.
 // Each half owns the 19 partitions that lie inside it (8x16, two 8x8, four 8x4, four 4x8, eight 4x4); the three that span
 // both halves (16x8 top/bottom, 16x16) take the partner's 8x8 sums through a DPP quad swap and are tracked by both lanes.
-// Lane pair (2q, 2q+1) <-> candidate column; wave <-> (column group of 32, half of the candidate rows).
+// Lane pair (2q, 2q+1) <-> candidate column; wave <-> (column group of 32, band of the candidate rows): two groups x two
+// bands for 2R+1 >= 64, one group x four bands for 32 <= 2R+1 < 64; the remaining columns go pairwise through the same code.
 
 constexpr int PAIR_NK = 22;                          // local partitions per half: 0..18 own, 19 = 16x8 top, 20 = 16x8 bottom, 21 = 16x16
 __constant__ int8_t c_pair_g[2][24];                // global partition of (half, local index)
@@ -856,6 +857,7 @@ __global__ __launch_bounds__(256, 3) void me_int_pair_kernel(MeDev P, const jmhi
 
   // ---- per-lane constants
   const int half = lane & 1;
+  const int NG = UW >= 64 ? 2 : 1;                   // column groups of 32 lane pairs (2R+1 >= 32 on this path)
   const int lam = P.lam_f;
   const int w16 = (lam * 16) >> 16;
   const int quirk00 = (P.mode == JMHIP_SEARCH_FULL) && !P.rdopt && !P.is_b && job.ref_is_0;
@@ -916,7 +918,7 @@ __global__ __launch_bounds__(256, 3) void me_int_pair_kernel(MeDev P, const jmhi
 
   // ---- main grid: 64 columns (two groups of 32 lane pairs) x all rows (two halves)
   {
-    const int col = (wave & 1) * 32 + (lane >> 1);
+    const int col = (wave % NG) * 32 + (lane >> 1);
     const int mvx = umin_x + col, dx = mvx - ucx, adx = iabs(dx);
     const int tieB = spiral_base_B(dx) + 1, twodx = 2 * dx;
     const bool qx = quirk00 && (4 * (mbx * 16 + mvx) == mbx * 16);
@@ -924,8 +926,8 @@ __global__ __launch_bounds__(256, 3) void me_int_pair_kernel(MeDev P, const jmhi
 #pragma unroll
     for (int g = 0; g < 6; g++) bxp[g] = reinterpret_cast<const uint32_t *>(&S.bxtab[col][half * 24])[g];
     const uint32_t *lbase = swin + (col & 3) * CS + (col >> 2) + 2 * half;
-    const int rsplit = (UH + 1) >> 1;
-    const int r0 = (wave >> 1) ? rsplit : 0, r1 = (wave >> 1) ? UH : rsplit, nrows = r1 - r0;
+    const int nparts = 4 / NG, part = wave / NG;      // row bands: 2 (two column groups) or 4 (one)
+    const int r0 = (UH * part) / nparts, r1 = (UH * (part + 1)) / nparts, nrows = r1 - r0;
     uint32_t win[16][2];
 #pragma unroll
     for (int j = 0; j < 15; j++) { const uint32_t *wp = lbase + (r0 + j) * PITCH; win[j][0] = wp[0]; win[j][1] = wp[1]; }
@@ -961,9 +963,9 @@ __global__ __launch_bounds__(256, 3) void me_int_pair_kernel(MeDev P, const jmhi
 
   // ---- columns beyond 64: one candidate per lane pair, fresh window rows, mv costs straight from the tables
   {
-    const int nrc = UW - 64, nrest = nrc * UH;
+    const int nrc = UW - 32 * NG, nrest = nrc * UH;
     for (int c = tid >> 1; c < nrest; c += 128) {
-      const int ay = c / nrc, ax = 64 + (c - ay * nrc);
+      const int ay = c / nrc, ax = 32 * NG + (c - ay * nrc);
       const int cmx = umin_x + ax, cmy = umin_y + ay;
       unsigned tie = (unsigned)spiral_pos(cmx - ucx, cmy - ucy) + 1;
       if (ff00 && cmx == 0 && cmy == 0) tie = 0;
@@ -1379,6 +1381,13 @@ extern "C" void jmhip_partition_info(int p, int *blocktype, int *x4, int *y4, in
 // host mirror of search_center (mv-search.c:752-762) to size the LDS window
 constexpr int FAST_MAX_CENTRES = 8;
 
+// JMHIP_ME_KERNEL=single selects the one-lane-per-candidate kernel (2R+1 >= 64 only); default: the pair-lane kernel (2R+1 >= 32)
+static int me_use_pair_kernel()
+{
+  static const int v = [] { const char *e = getenv("JMHIP_ME_KERNEL"); return e && !strcmp(e, "single") ? 0 : 1; }();
+  return v;
+}
+
 static void host_center(const jmhip_me_params *prm, int pmx, int pmy, int *cx, int *cy)
 {
   const int R = prm->search_range;
@@ -1439,7 +1448,7 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
     // distinct centre (FastFull and single-predictor macroblocks have one; JM's FullSearch typically a handful, the
     // neighbouring predictors being close). Beyond FAST_MAX_CENTRES the union-window kernel is cheaper.
     int reps[FAST_MAX_CENTRES], rcx[FAST_MAX_CENTRES], rcy[FAST_MAX_CENTRES], ng = 0;
-    bool fast = full_mask && (2 * R + 1 >= 64) && (2 * R + 1 + 15 <= 96) && i < (1 << 24);
+    bool fast = full_mask && (2 * R + 1 >= (me_use_pair_kernel() ? 32 : 64)) && (2 * R + 1 + 15 <= 96) && i < (1 << 24);
     for (int p = 0; p < JMHIP_NPART && fast; p++) {
       int cx, cy, g;
       const int s = prm->search_mode == JMHIP_SEARCH_FASTFULL ? 0 : p;
@@ -1514,7 +1523,7 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
   if (nfast) {
     MeDev PF = P;
     PF.win_pitch = fpitch_dw * 4; PF.win_rows = frows; PF.win_copy_stride = fcs;
-    static const int use_pair = [] { const char *e = getenv("JMHIP_ME_KERNEL"); return e && !strcmp(e, "single") ? 0 : 1; }();      // JMHIP_ME_KERNEL=single: the one-lane-per-candidate kernel
+    const int use_pair = me_use_pair_kernel();
     size_t plds = ((size_t)3 * fcs + (size_t)fpitch_dw * frows) * 4;          // the window; its memory is reused by the 44 x 128 key transpose
     if (plds < (size_t)44 * 128 * 4) plds = (size_t)44 * 128 * 4;
     if (use_pair) me_int_pair_kernel<<<jm_xcd_grid(nfast), 256, plds, c->stream>>>(PF, (const jmhip_me_mb *)c->me_jobs_dev, (const int *)c->me_idx_dev, (jmhip_me_result *)c->me_res_dev, nfast);

@@ -119,6 +119,15 @@ def test_full_search_wrapped_early_exit_bound_at_picture_origin(pkg, R, per_part
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("R,mode,rdopt,per_partition,spread", [(16, -1, 1, False, 8), (16, 0, 0, True, 8), (20, -1, 0, False, 30), (24, 0, 1, True, 60),
+                                                             (31, -1, 1, True, 3), (40, 0, 0, True, 8)])
+def test_me_pair_kernel_other_ranges(pkg, R, mode, rdopt, per_partition, spread):
+    """The pair-lane kernel with one column group (32 <= 2R+1 < 64: four row bands + 1..31 remainder columns) and with the
+    widest window (R = 40: 17 remainder columns)."""
+    run_case(pkg, 96, 64, "shift", mode, R, rdopt, spread, per_partition=per_partition, seed=R + spread)
+
+
+@pytest.mark.gpu
 def test_me_mixed_fast_and_generic_macroblocks(pkg):
     """FullSearch where some MBs have one predictor (fast kernel) and others per-partition predictors (generic)."""
     rng = np.random.default_rng(5)
