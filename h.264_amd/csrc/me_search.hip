@@ -20,11 +20,15 @@
 //  * Sub-pel: 4x4/8x8 sub-block origins are clamped one by one under UMV access (me_distortion.c:678); FAST vs
 //    UMV is decided per phase as me_fullsearch.c:412-420, :468-476.
 //
-// Mapping: one workgroup per macroblock, all 41 partitions of block types 1..7 together. The integer kernel
-// stages the union of the partitions' search windows once in LDS, every lane owns candidates (one 16x16 SAD as
-// sixteen 4x4 SADs with v_sad_u8 on packed bytes, tree-summed to the 41 partition SADs, cf. SetupLargerBlocks
-// me_fullfast.c:210), keeps 41 running minima in registers, and a wavefront shuffle + LDS reduction finishes.
-// Roofline: ~10^3 integer ops per byte of compulsory traffic -> VALU/LDS bound, not HBM bound.
+// Contents (one translation unit: the kernels share the partition tables and the small device helpers):
+//   me_int_kernel        generic integer search: any partition mask, any spread of centres (union window in LDS, lane <-> candidate)
+//   me_int_fast_kernel   one lane per candidate column, rolling register window, 2R+1 >= 64 (JMHIP_ME_KERNEL=single)
+//   me_int_pair_kernel   DEFAULT: a candidate's 16x16 block split across a lane pair, 3 waves/SIMD, 2R+1 >= 32
+//   me_sub_kernel<T8>    half/quarter-pel refinement: shared SATDs across block types, packed 16-bit Hadamard
+//   distortion_kernel    computeSAD/SATD(+WP) for arbitrary candidate lists                      (jmhip_distortion_batch)
+//   surface_kernel<K>    every integer displacement in early-exit granularity, for EPZS / UMHex    (jmhip_distortion_surface)
+//   bipred_kernel        FullPelBlockMotionBiPred / SubPelBlockSearchBiPred                        (jmhip_bipred_search)
+// Roofline: ~10^3 integer ops per byte of compulsory traffic -> integer-VALU bound, not HBM bound.
 #include "jmhip_internal.h"
 #include <type_traits>
 #include <cstring>
@@ -715,8 +719,6 @@ __global__ __launch_bounds__(256, 2) void me_int_fast_kernel(MeDev P, const jmhi
   STAMP(6);
 }
 
-// ------------------------------------------------------------------------------------------------ sub-pel search
-
 // ------------------------------------------------------------------------------------------------ pair-lane integer search
 //
 // Same algorithm as me_int_fast_kernel with the 16x16 block of a candidate split between TWO lanes (left / right 8 columns).
@@ -751,10 +753,10 @@ void build_pair_tables()
   for (int h = 1; h >= 0; h--) for (int j = 0; j < PAIR_NK; j++) h_pair_slot[h_pair_g[h][j]] = (int8_t)(j * 2 + h);    // half 0 wins for the spanning ones
 }
 
-struct PairShared {
+struct PairShared {                                   // 2R+1 <= 81 on this path (host check)
   int px[JMHIP_NPART], py[JMHIP_NPART];
-  unsigned chg[160];
-  uint8_t bytab[160][48] __attribute__((aligned(16)));   // [row][half * 24 + local]: vertical mv bits
+  unsigned chg[96];
+  uint8_t bytab[96][48] __attribute__((aligned(16)));    // [row][half * 24 + local]: vertical mv bits
   uint8_t bxtab[84][48] __attribute__((aligned(16)));    // [column][half * 24 + local]: horizontal mv bits
   uint32_t cur[64];
   unsigned part[44][2];
@@ -898,10 +900,10 @@ __global__ __launch_bounds__(256, 3) void me_int_pair_kernel(MeDev P, const jmhi
     if (zero_bonus) c0 -= (unsigned)w16;
     best[21] = min(best[21], (c0 << TIE_BITS) + tie);
   };
-  auto load_mvc = [&](const uint32_t (&bxp)[6], int row) __attribute__((always_inline)) {
-    const uint2 *bt = reinterpret_cast<const uint2 *>(&S.bytab[row][half * 24]);
-    const uint2 b0 = bt[0], b1 = bt[1], b2 = bt[2];
-    const uint32_t byp[6] = {b0.x, b0.y, b1.x, b1.y, b2.x, b2.y};
+  auto load_mvc = [&](int colx, int row) __attribute__((always_inline)) {
+    const uint2 *bt = reinterpret_cast<const uint2 *>(&S.bytab[row][half * 24]), *bxq = reinterpret_cast<const uint2 *>(&S.bxtab[colx][half * 24]);
+    const uint2 b0 = bt[0], b1 = bt[1], b2 = bt[2], x0 = bxq[0], x1 = bxq[1], x2 = bxq[2];
+    const uint32_t byp[6] = {b0.x, b0.y, b1.x, b1.y, b2.x, b2.y}, bxp[6] = {x0.x, x0.y, x1.x, x1.y, x2.x, x2.y};
 #pragma unroll
     for (int g = 0; g < 6; g++) {
       const uint32_t sum4 = bxp[g] + byp[g];
@@ -922,9 +924,6 @@ __global__ __launch_bounds__(256, 3) void me_int_pair_kernel(MeDev P, const jmhi
     const int mvx = umin_x + col, dx = mvx - ucx, adx = iabs(dx);
     const int tieB = spiral_base_B(dx) + 1, twodx = 2 * dx;
     const bool qx = quirk00 && (4 * (mbx * 16 + mvx) == mbx * 16);
-    uint32_t bxp[6];
-#pragma unroll
-    for (int g = 0; g < 6; g++) bxp[g] = reinterpret_cast<const uint32_t *>(&S.bxtab[col][half * 24])[g];
     const uint32_t *lbase = swin + (col & 3) * CS + (col >> 2) + 2 * half;
     const int nparts = 4 / NG, part = wave / NG;      // row bands: 2 (two column groups) or 4 (one)
     const int r0 = (UH * part) / nparts, r1 = (UH * (part + 1)) / nparts, nrows = r1 - r0;
@@ -942,7 +941,7 @@ __global__ __launch_bounds__(256, 3) void me_int_pair_kernel(MeDev P, const jmhi
       {
         const unsigned m = (t == 0) ? 1u : mnext;
         mnext = S.chg[min(row + 1, UH - 1)];
-        if (__builtin_amdgcn_readfirstlane(m)) load_mvc(bxp, row);
+        if (__builtin_amdgcn_readfirstlane(m)) load_mvc(col, row);
       }
       const int ady = iabs(dy);
       unsigned tie = (ady > adx) ? (unsigned)(spiral_base_A(dy) + 1 + twodx) : (unsigned)(tieB + 2 * dy);
@@ -973,10 +972,7 @@ __global__ __launch_bounds__(256, 3) void me_int_pair_kernel(MeDev P, const jmhi
       uint32_t w[16][2];
 #pragma unroll
       for (int r = 0; r < 16; r++) { w[r][0] = wrow[r * PITCH]; w[r][1] = wrow[r * PITCH + 1]; }
-      uint32_t bxp[6];
-#pragma unroll
-      for (int g = 0; g < 6; g++) bxp[g] = reinterpret_cast<const uint32_t *>(&S.bxtab[ax][half * 24])[g];
-      load_mvc(bxp, ay);
+      load_mvc(ax, ay);
       evaluate(w, 0, tie, quirk00 && 4 * (mbx * 16 + cmx) == mbx * 16 && 4 * (mby * 16 + cmy) == mby * 16);
     }
   }
@@ -1023,6 +1019,8 @@ __global__ __launch_bounds__(256, 3) void me_int_pair_kernel(MeDev P, const jmhi
     }
   }
 }
+
+// ------------------------------------------------------------------------------------------------ sub-pel search
 
 // Hadamard SATD of a 4x4 difference block held as four rows of four ints: (sum|H D H| + 1) >> 1, me_distortion.c:182
 __device__ __forceinline__ int satd4x4(const int d[4][4])
