@@ -926,7 +926,8 @@ __global__ __launch_bounds__(256, 3) void me_int_pair_kernel(MeDev P, const jmhi
     const bool qx = quirk00 && (4 * (mbx * 16 + mvx) == mbx * 16);
     const uint32_t *lbase = swin + (col & 3) * CS + (col >> 2) + 2 * half;
     const int nparts = 4 / NG, part = wave / NG;      // row bands: 2 (two column groups) or 4 (one)
-    const int r0 = (UH * part) / nparts, r1 = (UH * (part + 1)) / nparts, nrows = r1 - r0;
+    // wave-uniform by construction; telling the compiler keeps the per-row arithmetic (spiral ring of the row, bonus test) scalar
+    const int r0 = __builtin_amdgcn_readfirstlane((UH * part) / nparts), r1 = __builtin_amdgcn_readfirstlane((UH * (part + 1)) / nparts), nrows = r1 - r0;
     uint32_t win[16][2];
 #pragma unroll
     for (int j = 0; j < 15; j++) { const uint32_t *wp = lbase + (r0 + j) * PITCH; win[j][0] = wp[0]; win[j][1] = wp[1]; }
