@@ -12,6 +12,7 @@
 // Which mode a macroblock takes is the host's decision (JM's mode decision is out of scope); without one the
 // device picks the partitioning with the smallest summed motion cost.
 #include "jmhip_internal.h"
+#include <utility>
 
 namespace {
 
@@ -335,16 +336,24 @@ extern "C" int jmhip_residual_download(jmhip_ctx *c, jmhip_tq_result *luma, jmhi
   return JMHIP_OK;
 }
 
+namespace {
+__global__ void set_plane_pointer(const uint8_t **table, int slot, const uint8_t *p) { table[slot] = p; }
+}
+
+// The reconstruction BECOMES reference slot `ref`: the slot's picture planes and the recon planes trade places (both are the
+// context's, same geometry), so nothing is copied; the one device-side pointer the search kernels read is patched in stream order.
 extern "C" int jmhip_recon_to_ref(jmhip_ctx *c, int ref)
 {
   if (!c) return JMHIP_ERR_ARG;
   if (ref < 0 || ref >= (int)c->refs.size()) return jm_fail(c, JMHIP_ERR_ARG, "ref slot out of range");
   if (!c->rec_y || c->fr_n <= 0) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_recon_to_ref: no recon picture yet");
   RefSlot &r = c->refs[ref];
-  JM_HIP_CHECK(c, hipMemcpyAsync(r.y, c->rec_y, (size_t)c->W * c->H, hipMemcpyDeviceToDevice, c->stream));
-  if (c->Wc) {
-    JM_HIP_CHECK(c, hipMemcpyAsync(r.u, c->rec_u, (size_t)c->Wc * c->Hc, hipMemcpyDeviceToDevice, c->stream));
-    JM_HIP_CHECK(c, hipMemcpyAsync(r.v, c->rec_v, (size_t)c->Wc * c->Hc, hipMemcpyDeviceToDevice, c->stream));
+  JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
+  std::swap(r.y, c->rec_y);
+  if (c->Wc) { std::swap(r.u, c->rec_u); std::swap(r.v, c->rec_v); }
+  if (c->ref_ptrs_dev) {
+    set_plane_pointer<<<1, 1, 0, c->stream>>>(reinterpret_cast<const uint8_t **>(c->ref_ptrs_dev), ref, r.y);
+    JM_HIP_CHECK(c, hipGetLastError());
   }
   r.has_pic = true; r.has_luma_sub = false; r.has_cr_sub = false;
   return JMHIP_OK;

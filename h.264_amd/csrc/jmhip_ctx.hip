@@ -88,8 +88,9 @@ extern "C" int jmhip_ctx_create(const jmhip_config *cfg, jmhip_ctx **out)
       for (int k = 0; k < 2; k++) ok = ok && alloc(&r.cr_sub[k], (size_t)c->cg.sub_x * c->cg.sub_y * c->Wcp * c->Hcp);
     }
   }
-  ok = ok && alloc(&c->cur_y, ysz);
-  if (csz) ok = ok && alloc(&c->cur_u, csz) && alloc(&c->cur_v, csz);
+  ok = ok && alloc(&c->cur_own[0], ysz);
+  if (csz) ok = ok && alloc(&c->cur_own[1], csz) && alloc(&c->cur_own[2], csz);
+  c->cur_y = c->cur_own[0]; c->cur_u = c->cur_own[1]; c->cur_v = c->cur_own[2];
   if (!ok) { jmhip_ctx_destroy(c); return JMHIP_ERR_NOMEM; }
   if (hipStreamSynchronize(c->stream) != hipSuccess) { jmhip_ctx_destroy(c); return JMHIP_ERR_DEVICE; }
   *out = c;
@@ -105,7 +106,7 @@ extern "C" void jmhip_ctx_destroy(jmhip_ctx *c)
     (void)hipFree(r.y); (void)hipFree(r.u); (void)hipFree(r.v); (void)hipFree(r.luma_sub);
     (void)hipFree(r.cr_sub[0]); (void)hipFree(r.cr_sub[1]);
   }
-  (void)hipFree(c->cur_y); (void)hipFree(c->cur_u); (void)hipFree(c->cur_v);
+  (void)hipFree(c->cur_own[0]); (void)hipFree(c->cur_own[1]); (void)hipFree(c->cur_own[2]);
   (void)hipFree(c->stage_dev); (void)hipFree(c->me_jobs_dev); (void)hipFree(c->me_res_dev); (void)hipFree(c->ref_ptrs_dev); (void)hipFree(c->me_idx_dev); (void)hipFree(c->surf_dev); (void)hipFree(c->surf_jobs_dev);
   (void)hipFree(c->tq_jobs_dev); (void)hipFree(c->tq_res_dev); (void)hipFree(c->tq_quant_dev);
   (void)hipFree(c->fr_jobs_y); (void)hipFree(c->fr_jobs_c); (void)hipFree(c->fr_res_y); (void)hipFree(c->fr_res_c);
@@ -142,7 +143,7 @@ static hipEvent_t get_evt(jmhip_ctx *c)
 
 void jm_stage_begin(jmhip_ctx *c, int stage)
 {
-  if (!c->timing) return;
+  if (!c->timing || !((c->timing_mask >> stage) & 1)) return;
   jmhip_ctx::PendingEvt p{stage, get_evt(c), get_evt(c)};
   (void)hipEventRecord(p.a, c->stream);
   c->pending.push_back(p);
@@ -150,8 +151,7 @@ void jm_stage_begin(jmhip_ctx *c, int stage)
 
 void jm_stage_end(jmhip_ctx *c, int stage)
 {
-  if (!c->timing || c->pending.empty()) return;
-  (void)stage;
+  if (!c->timing || !((c->timing_mask >> stage) & 1) || c->pending.empty()) return;
   (void)hipEventRecord(c->pending.back().b, c->stream);
 }
 
@@ -166,6 +166,13 @@ extern "C" int jmhip_timing_enable(jmhip_ctx *c, int on)
 {
   if (!c) return JMHIP_ERR_ARG;
   c->timing = on != 0;
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_timing_select(jmhip_ctx *c, unsigned stage_mask)
+{
+  if (!c) return JMHIP_ERR_ARG;
+  c->timing_mask = stage_mask;
   return JMHIP_OK;
 }
 
@@ -251,12 +258,22 @@ extern "C" int jmhip_cur_upload(jmhip_ctx *c, const void *Y, const void *U, cons
 {
   if (!c) return JMHIP_ERR_ARG;
   JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
+  c->cur_y = c->cur_own[0]; c->cur_u = c->cur_own[1]; c->cur_v = c->cur_own[2];
   int rc = upload_plane(c, c->cur_y, Y, c->W, c->H, pel_bytes, stride_y, device_ptrs);
   if (rc) return rc;
   if (c->Wc && U && V) {
     if ((rc = upload_plane(c, c->cur_u, U, c->Wc, c->Hc, pel_bytes, stride_c, device_ptrs))) return rc;
     if ((rc = upload_plane(c, c->cur_v, V, c->Wc, c->Hc, pel_bytes, stride_c, device_ptrs))) return rc;
   }
+  c->has_cur = true;
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_cur_bind(jmhip_ctx *c, const void *Y, const void *U, const void *V)
+{
+  if (!c || !Y || (c->Wc && (!U || !V))) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_cur_bind: NULL plane") : JMHIP_ERR_ARG;
+  if ((reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(U) | reinterpret_cast<uintptr_t>(V)) & 3) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_cur_bind: planes must be 4-byte aligned");
+  c->cur_y = (uint8_t *)Y; c->cur_u = (uint8_t *)U; c->cur_v = (uint8_t *)V;
   c->has_cur = true;
   return JMHIP_OK;
 }

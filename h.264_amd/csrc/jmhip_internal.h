@@ -28,7 +28,8 @@ struct jmhip_ctx {
   int mbw = 0, mbh = 0;
   ChromaGeom cg{};
   std::vector<RefSlot> refs;
-  uint8_t *cur_y = nullptr, *cur_u = nullptr, *cur_v = nullptr;
+  uint8_t *cur_y = nullptr, *cur_u = nullptr, *cur_v = nullptr;            // the active current picture (owned or bound)
+  uint8_t *cur_own[3] = {nullptr, nullptr, nullptr};                          // the context's own planes (jmhip_cur_upload target)
   bool has_cur = false;
   // staging for 16-bit sample conversion
   void *stage_dev = nullptr; size_t stage_bytes = 0;
@@ -50,6 +51,7 @@ struct jmhip_ctx {
   void *tq_jobs_dev = nullptr, *tq_res_dev = nullptr, *tq_quant_dev = nullptr; int tq_capacity = 0, tq_qcap = 0;
   // timing
   bool timing = false;
+  unsigned timing_mask = ~0u;                        // stages that record events while timing is on (jmhip_timing_select)
   double stage_ms[JMHIP_STAGE_COUNT] = {0};
   int stage_launches[JMHIP_STAGE_COUNT] = {0};
   struct PendingEvt { int stage; hipEvent_t a, b; };

@@ -130,6 +130,8 @@ def load_library():
     lib.jmhip_recon_download.argtypes = [vp, vp, vp, vp, ip]
     lib.jmhip_recon_copy_band.argtypes = [vp, vp, vp, vp, ip, ip]
     lib.jmhip_sizeof.argtypes = [ip]
+    lib.jmhip_cur_bind.argtypes = [vp, vp, vp, vp]
+    lib.jmhip_timing_select.argtypes = [vp, C.c_uint]
     for which, dt in ((0, ME_MB_DTYPE), (1, ME_RESULT_DTYPE), (2, QUANT_DTYPE), (3, TQ_JOB_DTYPE), (4, TQ_RESULT_DTYPE),
                       (5, DIST_JOB_DTYPE), (8, MB_MODE_DTYPE), (9, SURFACE_JOB_DTYPE), (10, BIPRED_JOB_DTYPE), (11, BIPRED_RESULT_DTYPE)):
         if lib.jmhip_sizeof(which) != dt.itemsize:
@@ -350,6 +352,13 @@ class Context:
         return Y, U, V
 
     # ---- timing
+    def cur_bind(self, y_ptr, u_ptr=None, v_ptr=None):
+        """Current picture = the caller's device planes (uint8, tight pitch), no copy."""
+        self._chk(self.lib.jmhip_cur_bind(self.h, y_ptr, u_ptr, v_ptr), "jmhip_cur_bind")
+
+    def timing_select(self, stages):
+        self._chk(self.lib.jmhip_timing_select(self.h, sum(1 << STAGES.index(s) for s in stages)), "jmhip_timing_select")
+
     def timing_enable(self, on=True):
         self._chk(self.lib.jmhip_timing_enable(self.h, 1 if on else 0), "jmhip_timing_enable")
 

@@ -70,6 +70,8 @@ enum { JMHIP_STAGE_INTERP_LUMA = 0, JMHIP_STAGE_INTERP_CHROMA, JMHIP_STAGE_ME_IN
        JMHIP_STAGE_MC, JMHIP_STAGE_TQ, JMHIP_STAGE_COUNT };
 int jmhip_timing_enable(jmhip_ctx *ctx, int on);
 int jmhip_timing_read(jmhip_ctx *ctx, double ms[JMHIP_STAGE_COUNT], int launches[JMHIP_STAGE_COUNT]);
+/* Only the stages whose bit (1 << JMHIP_STAGE_x) is set record events while timing is on (default: all). */
+int jmhip_timing_select(jmhip_ctx *ctx, unsigned stage_mask);
 
 /* ------------------------------------------------------------------ pictures */
 
@@ -99,6 +101,10 @@ int jmhip_ref_device_planes(jmhip_ctx *ctx, int ref, void **Y, void **U, void **
 /* Upload the current (source) picture: pCurImg / imgUV_org (inc/global.h). */
 int jmhip_cur_upload(jmhip_ctx *ctx, const void *Y, const void *U, const void *V,
                      int pel_bytes, int stride_y, int stride_c, int device_ptrs);
+
+/* Use the caller's DEVICE planes as the current picture without copying: 8-bit, tight pitch (width / chroma width), 4-byte
+ * aligned, valid until the next jmhip_cur_upload / jmhip_cur_bind. U/V may be NULL for 4:0:0. */
+int jmhip_cur_bind(jmhip_ctx *ctx, const void *Y, const void *U, const void *V);
 
 /* ------------------------------------------------------------------ motion estimation */
 
