@@ -255,7 +255,7 @@ def main():
     # gather buffers: [world * band rows] so that rank r's band lands at its picture position
     gbufs = slices.gather_buffers(torch, world, band, W, 8, W // 2, dev)
     gY, gU, gV = gbufs
-    sviews = slices.band_views(gbufs, rank, band, 8)
+    sviews = slices.send_buffers(torch, band, W, 8, W // 2, dev)
     sY, sU, sV = sviews
 
     first = [True]

@@ -29,7 +29,14 @@ def band_views(bufs, rank, band, chroma_rows_per_mb):
             gv[rank * band * chroma_rows_per_mb:(rank + 1) * band * chroma_rows_per_mb])
 
 
-def all_gather_recon(dist, bufs, views):
+def send_buffers(torch, band, width, chroma_rows_per_mb, chroma_width, device):
+    """This rank's band as its own contiguous tensors (Y, U, V): the all-gather's send side (not aliased with the gather buffer)."""
+    sy = torch.zeros((band * 16, width), dtype=torch.uint8, device=device)
+    su = torch.zeros((band * chroma_rows_per_mb, chroma_width), dtype=torch.uint8, device=device)
+    return sy, su, torch.zeros_like(su)
+
+
+def all_gather_recon(dist, bufs, sends):
     """One all-gather per plane: after it every rank holds the whole reconstructed picture (+ padding rows)."""
-    for g, s in zip(bufs, views):
+    for g, s in zip(bufs, sends):
         dist.all_gather_into_tensor(g, s)

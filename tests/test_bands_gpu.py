@@ -1,0 +1,78 @@
+"""The N > 1 data path without RCCL: two "ranks" emulated one after the other on one GPU. Each searches and reconstructs
+only its band of macroblock rows (jmhip_me_frame over a row subset, jmhip_residual_frame, jmhip_recon_copy_band into its
+send buffer); the bands, concatenated the way the all-gather lays them out, are loaded with jmhip_ref_upload(device pointers)
+and must give the same next reference -- integer planes and sub-pel planes -- as one context that coded the whole frame."""
+import numpy as np
+import pytest
+import torch
+
+from tests.test_frame import synth
+from tests.test_me import lambda_factors, make_mbs
+
+pytestmark = pytest.mark.gpu
+
+
+def code(pkg, ctx, cur_dev, ref, rows, mbw, quants, lam, R):
+    from h264_amd.jmhip import ME_MB_DTYPE
+    mbs = np.zeros(len(rows) * mbw, dtype=ME_MB_DTYPE)
+    k = 0
+    for r in rows:
+        for x in range(mbw):
+            mbs[k]["mb_x"], mbs[k]["mb_y"], mbs[k]["ref_is_0"] = x, r, 1
+            mbs[k]["pred_mv"][:] = ((x * 7 + r * 3) % 9 - 4, (x * 5 + r) % 7 - 3)
+            k += 1
+    prm = pkg.MeParams()
+    prm.search_mode, prm.search_range, prm.rdopt = 0, R, 1
+    prm.level_mv_min, prm.level_mv_max = -511, 511
+    prm.lambda_[0], prm.lambda_[1], prm.lambda_[2] = lam
+    prm.subpel, prm.partition_mask = 1, (1 << 41) - 1
+    ctx.ref_upload(0, *ref)
+    ctx.interp_luma(0)
+    ctx.interp_chroma(0)
+    ctx.cur_bind(*[t.data_ptr() for t in cur_dev])
+    ctx.me_frame_async(prm, mbs)
+    ctx.residual_frame(quants)
+    return mbs
+
+
+def test_two_bands_rebuild_the_reference(pkg):
+    rng = np.random.default_rng(17)
+    w, h, R, world = 96, 80, 8, 2
+    mbw, mbh = w // 16, h // 16
+    cur, ref = synth(rng, w, h, 1)
+    dev = torch.device("cuda", 0)
+    cur_dev = [torch.from_numpy(p).to(dev) for p in cur]
+    lam = lambda_factors(28)
+    quants = np.array([pkg.flat_quant(28 + d, 342, adaptive_rounding=1, adapt_rnd_weight=4, cavlc=1) for d in (0, 0, 3)], dtype=pkg.QUANT_DTYPE)
+
+    # one context, whole frame
+    one = pkg.Context(w, h, yuv_format=1, max_refs=1, search_range=R)
+    code(pkg, one, cur_dev, ref, list(range(mbh)), mbw, quants, lam, R)
+    one.recon_to_ref(0)
+    one.interp_luma(0)
+    one.interp_chroma(0)
+    want_luma, want_cb = one.download_luma_planes(0), one.download_chroma_planes(0, 0)
+    one.close()
+
+    # two "ranks"
+    gbufs = pkg.slices.gather_buffers(torch, world, -(-mbh // world), w, 8, w // 2, dev)
+    for rank in range(world):
+        row0, row1, band = pkg.slices.band_rows(mbh, world, rank)
+        ctx = pkg.Context(w, h, yuv_format=1, max_refs=1, search_range=R)
+        code(pkg, ctx, cur_dev, ref, list(range(row0, row1)), mbw, quants, lam, R)
+        sY, sU, sV = pkg.slices.send_buffers(torch, band, w, 8, w // 2, dev)
+        ctx.recon_copy_band(sY.data_ptr(), sU.data_ptr(), sV.data_ptr(), row0, row1 - row0)
+        ctx.sync()
+        for g, s, rows_per_mb in zip(gbufs, (sY, sU, sV), (16, 8, 8)):      # what all_gather_into_tensor does with rank `rank`'s send buffer
+            g[rank * band * rows_per_mb:(rank + 1) * band * rows_per_mb] = s
+        ctx.close()
+    torch.cuda.synchronize()
+    chk = pkg.Context(w, h, yuv_format=1, max_refs=1, search_range=R)
+    chk.ref_upload_device(0, gbufs[0].data_ptr(), gbufs[1].data_ptr(), gbufs[2].data_ptr(), w, w // 2)
+    chk.interp_luma(0)
+    chk.interp_chroma(0)
+    got_luma, got_cb = chk.download_luma_planes(0), chk.download_chroma_planes(0, 0)
+    chk.close()
+    assert np.array_equal(got_luma, want_luma), "sub-pel planes of the gathered reference differ from the single-context frame"
+    assert np.array_equal(got_cb, want_cb)
+    assert got_luma[0, 0, 20:20 + h, 20:20 + w].std() > 10      # a real picture, not zeros

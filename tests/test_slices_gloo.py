@@ -29,7 +29,7 @@ def _worker(rank, world, port, mbh, w, q):
     U = rng.integers(0, 256, (mbh * 8, w // 2), dtype=np.uint8)
     V = rng.integers(0, 256, (mbh * 8, w // 2), dtype=np.uint8)
     bufs = pkg.slices.gather_buffers(torch, world, band, w, 8, w // 2, "cpu")
-    views = pkg.slices.band_views(bufs, rank, band, 8)
+    views = pkg.slices.send_buffers(torch, band, w, 8, w // 2, "cpu")
     # each rank only "reconstructed" its own band
     views[0][: (row1 - row0) * 16] = torch.from_numpy(Y[row0 * 16:row1 * 16])
     views[1][: (row1 - row0) * 8] = torch.from_numpy(U[row0 * 8:row1 * 8])
