@@ -263,8 +263,12 @@ def main():
     def step(k):
         Y, U, V = src[1 + (k % (nframes - 1))]
         ctx.cur_bind(Y.data_ptr(), U.data_ptr(), V.data_ptr())          # the source frame is resident: no copy
-        ctx.interp_luma(0)
-        ctx.interp_chroma(0)
+        if world == 1:
+            ctx.interp_luma(0)
+            ctx.interp_chroma(0)
+        elif n:
+            # a rank only needs the sub-pel planes its band can reach: own rows +- (range + predictor reach 6 + slack)
+            ctx.interp_rows(0, row0 * 16 - (R + 16), row1 * 16 + (R + 16))
         if n:
             if first[0]:
                 ctx.me_frame_async(prm, mbs)

@@ -17,10 +17,10 @@ __device__ __forceinline__ int clampi(int x, int lo, int hi) { return min(max(x,
 
 template <int SUBX, int SUBY, int MULX, int MULY>
 __global__ __launch_bounds__(256) void interp_chroma_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ out,
-                                                           int Wc, int Hc, int Wcp, int Hcp, int pad_x, int pad_y)
+                                                           int Wc, int Hc, int Wcp, int Hcp, int pad_x, int pad_y, int row4_0)
 {
   const int gi = (blockIdx.x * 64 + threadIdx.x) * 4;
-  const int gj = blockIdx.y * 4 + threadIdx.y;
+  const int gj = (blockIdx.y + row4_0) * 4 + threadIdx.y;
   if (gi >= Wcp || gj >= Hcp - 1) return;          // last row keeps its zeros
   const uint8_t *r0 = src + (size_t)clampi(gj - pad_y, 0, Hc - 1) * Wc;
   const uint8_t *r1 = src + (size_t)clampi(gj - pad_y + 1, 0, Hc - 1) * Wc;
@@ -53,18 +53,22 @@ __global__ __launch_bounds__(256) void interp_chroma_kernel(const uint8_t *__res
 
 }  // namespace
 
-int jm_launch_interp_chroma(jmhip_ctx *c, int ref)
+// rows [prow0, prow1) of the padded chroma planes, widened to groups of 4; everything when prow1 <= prow0
+int jm_launch_interp_chroma(jmhip_ctx *c, int ref, int prow0, int prow1)
 {
   if ((c->Wcp & 3) || ((size_t)c->Wcp * c->Hcp) % 4) return jm_fail(c, JMHIP_ERR_ARG, "interp_chroma: padded width must be a multiple of 4");
   RefSlot &r = c->refs[ref];
-  dim3 grid((c->Wcp / 4 + 63) / 64, (c->Hcp + 3) / 4), block(64, 4);
+  int g0 = 0, g1 = (c->Hcp + 3) / 4;
+  if (prow1 > prow0) { g0 = (prow0 < 0 ? 0 : prow0) / 4; const int e = ((prow1 > c->Hcp ? c->Hcp : prow1) + 3) / 4; g1 = e < g1 ? e : g1; }
+  if (g1 <= g0) return JMHIP_OK;
+  dim3 grid((c->Wcp / 4 + 63) / 64, g1 - g0), block(64, 4);
   for (int uv = 0; uv < 2; uv++) {
     const uint8_t *src = uv ? r.v : r.u;
     uint8_t *dst = r.cr_sub[uv];
     switch (c->cfg.yuv_format) {
-    case JMHIP_YUV420: interp_chroma_kernel<8, 8, 1, 1><<<grid, block, 0, c->stream>>>(src, dst, c->Wc, c->Hc, c->Wcp, c->Hcp, c->cg.pad_x, c->cg.pad_y); break;
-    case JMHIP_YUV422: interp_chroma_kernel<8, 4, 1, 2><<<grid, block, 0, c->stream>>>(src, dst, c->Wc, c->Hc, c->Wcp, c->Hcp, c->cg.pad_x, c->cg.pad_y); break;
-    case JMHIP_YUV444: interp_chroma_kernel<4, 4, 2, 2><<<grid, block, 0, c->stream>>>(src, dst, c->Wc, c->Hc, c->Wcp, c->Hcp, c->cg.pad_x, c->cg.pad_y); break;
+    case JMHIP_YUV420: interp_chroma_kernel<8, 8, 1, 1><<<grid, block, 0, c->stream>>>(src, dst, c->Wc, c->Hc, c->Wcp, c->Hcp, c->cg.pad_x, c->cg.pad_y, g0); break;
+    case JMHIP_YUV422: interp_chroma_kernel<8, 4, 1, 2><<<grid, block, 0, c->stream>>>(src, dst, c->Wc, c->Hc, c->Wcp, c->Hcp, c->cg.pad_x, c->cg.pad_y, g0); break;
+    case JMHIP_YUV444: interp_chroma_kernel<4, 4, 2, 2><<<grid, block, 0, c->stream>>>(src, dst, c->Wc, c->Hc, c->Wcp, c->Hcp, c->cg.pad_x, c->cg.pad_y, g0); break;
     default: return jm_fail(c, JMHIP_ERR_ARG, "interp_chroma: no chroma");
     }
     JM_HIP_CHECK(c, hipGetLastError());

@@ -14,6 +14,8 @@
 // (halo re-reads hit L2); each lane owns 4 adjacent pels and stores one dword per plane per row, a wave
 // store covers 256 contiguous bytes.
 #include "jmhip_internal.h"
+#include <algorithm>
+using std::max; using std::min;
 
 namespace {
 
@@ -32,13 +34,13 @@ __device__ __forceinline__ uint32_t pack4(uint32_t a, uint32_t b, uint32_t c, ui
 __device__ __forceinline__ uint32_t avg4(uint32_t a, uint32_t b) { return __builtin_amdgcn_lerp(a, b, 0x01010101u); }
 
 __global__ __launch_bounds__(256) void interp_luma_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ out,
-                                                         int W, int H, int Wp, int Hp)
+                                                         int W, int H, int Wp, int Hp, int tile_row0)
 {
   __shared__ __attribute__((aligned(16))) uint8_t s00[ROWS][S00_W];
   __shared__ __attribute__((aligned(16))) int16_t stmp[ROWS][TX];
 
   const int tid = threadIdx.y * 64 + threadIdx.x;
-  const int i0 = blockIdx.x * TX, j0 = blockIdx.y * TY;
+  const int i0 = blockIdx.x * TX, j0 = (blockIdx.y + tile_row0) * TY;
 
   // ---- stage the integer tile: padded coords (row j0-2+r, col i0-4+c), clamped to the padded plane, then to the picture
   for (int d = tid; d < ROWS * (S00_W / 4); d += 256) {
@@ -153,13 +155,17 @@ __global__ __launch_bounds__(256) void interp_luma_kernel(const uint8_t *__restr
 
 }  // namespace
 
-int jm_launch_interp_luma(jmhip_ctx *c, int ref)
+// rows [prow0, prow1) of the padded plane, widened to whole tiles; the full plane when prow1 <= prow0
+int jm_launch_interp_luma(jmhip_ctx *c, int ref, int prow0, int prow1)
 {
   // operand shapes the kernel assumes
   if ((c->Wp & 3) || (c->W & 3) || ((size_t)c->Wp * c->Hp) % 4) return jm_fail(c, JMHIP_ERR_ARG, "interp_luma: width must be a multiple of 4");
   RefSlot &r = c->refs[ref];
-  dim3 grid((c->Wp + TX - 1) / TX, (c->Hp + TY - 1) / TY), block(64, 4);
-  interp_luma_kernel<<<grid, block, 0, c->stream>>>(r.y, r.luma_sub, c->W, c->H, c->Wp, c->Hp);
+  int t0 = 0, t1 = (c->Hp + TY - 1) / TY;
+  if (prow1 > prow0) { t0 = max(0, prow0) / TY; t1 = min(t1, (min(c->Hp, prow1) + TY - 1) / TY); }
+  if (t1 <= t0) return JMHIP_OK;
+  dim3 grid((c->Wp + TX - 1) / TX, t1 - t0), block(64, 4);
+  interp_luma_kernel<<<grid, block, 0, c->stream>>>(r.y, r.luma_sub, c->W, c->H, c->Wp, c->Hp, t0);
   JM_HIP_CHECK(c, hipGetLastError());
   return JMHIP_OK;
 }

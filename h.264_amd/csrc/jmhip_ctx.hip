@@ -339,6 +339,32 @@ extern "C" int jmhip_interp_luma(jmhip_ctx *c, int ref)
   return rc;
 }
 
+// Sub-pel planes for the luma rows [row0, row1) of the PICTURE only (plus whatever the tile granularity adds): a rank that
+// searches a band of macroblock rows needs the planes of that band +- (search range + predictor reach + block height) and
+// nothing else. The caller owns that margin; rows outside keep whatever an earlier call left there.
+extern "C" int jmhip_interp_rows(jmhip_ctx *c, int ref, int row0, int row1)
+{
+  if (!c) return JMHIP_ERR_ARG;
+  if (ref < 0 || ref >= (int)c->refs.size()) return jm_fail(c, JMHIP_ERR_ARG, "ref slot out of range");
+  if (!c->refs[ref].has_pic) return jm_fail(c, JMHIP_ERR_ARG, "reference picture not uploaded");
+  if (row1 <= row0) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_interp_rows: empty row range");
+  JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
+  jm_stage_begin(c, JMHIP_STAGE_INTERP_LUMA);
+  int rc = jm_launch_interp_luma(c, ref, row0 + JMHIP_PAD, row1 + JMHIP_PAD);
+  jm_stage_end(c, JMHIP_STAGE_INTERP_LUMA);
+  if (rc) return rc;
+  c->refs[ref].has_luma_sub = true;
+  if (c->Wc) {
+    const int sy = c->cfg.yuv_format == JMHIP_YUV420 ? 1 : 0;       // luma rows -> chroma rows
+    jm_stage_begin(c, JMHIP_STAGE_INTERP_CHROMA);
+    rc = jm_launch_interp_chroma(c, ref, (row0 >> sy) + c->cg.pad_y - 1, ((row1 + sy) >> sy) + c->cg.pad_y + 1);
+    jm_stage_end(c, JMHIP_STAGE_INTERP_CHROMA);
+    if (rc) return rc;
+    c->refs[ref].has_cr_sub = true;
+  }
+  return JMHIP_OK;
+}
+
 extern "C" int jmhip_interp_chroma(jmhip_ctx *c, int ref)
 {
   if (!c) return JMHIP_ERR_ARG;

@@ -80,8 +80,8 @@ void jm_stage_begin(jmhip_ctx *ctx, int stage);
 void jm_stage_end(jmhip_ctx *ctx, int stage);
 
 // kernels (one translation unit each)
-int jm_launch_interp_luma(jmhip_ctx *ctx, int ref);
-int jm_launch_interp_chroma(jmhip_ctx *ctx, int ref);
+int jm_launch_interp_luma(jmhip_ctx *ctx, int ref, int prow0 = 0, int prow1 = 0);
+int jm_launch_interp_chroma(jmhip_ctx *ctx, int ref, int prow0 = 0, int prow1 = 0);
 constexpr int JMHIP_TQ_SELECT = 0x100;   // frame stage: each luma kernel takes only the macroblocks of its transform size
 int jm_launch_tq(jmhip_ctx *ctx, int kind, int yuv_format, const void *jobs, const void *quants, void *results, int n);
 int jm_ensure_ref_table(jmhip_ctx *ctx);

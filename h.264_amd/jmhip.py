@@ -131,6 +131,7 @@ def load_library():
     lib.jmhip_recon_copy_band.argtypes = [vp, vp, vp, vp, ip, ip]
     lib.jmhip_sizeof.argtypes = [ip]
     lib.jmhip_cur_bind.argtypes = [vp, vp, vp, vp]
+    lib.jmhip_interp_rows.argtypes = [vp, ip, ip, ip]
     lib.jmhip_timing_select.argtypes = [vp, C.c_uint]
     for which, dt in ((0, ME_MB_DTYPE), (1, ME_RESULT_DTYPE), (2, QUANT_DTYPE), (3, TQ_JOB_DTYPE), (4, TQ_RESULT_DTYPE),
                       (5, DIST_JOB_DTYPE), (8, MB_MODE_DTYPE), (9, SURFACE_JOB_DTYPE), (10, BIPRED_JOB_DTYPE), (11, BIPRED_RESULT_DTYPE)):
@@ -352,6 +353,9 @@ class Context:
         return Y, U, V
 
     # ---- timing
+    def interp_rows(self, ref, row0, row1):
+        self._chk(self.lib.jmhip_interp_rows(self.h, ref, row0, row1), "jmhip_interp_rows")
+
     def cur_bind(self, y_ptr, u_ptr=None, v_ptr=None):
         """Current picture = the caller's device planes (uint8, tight pitch), no copy."""
         self._chk(self.lib.jmhip_cur_bind(self.h, y_ptr, u_ptr, v_ptr), "jmhip_cur_bind")

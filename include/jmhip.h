@@ -88,6 +88,9 @@ int jmhip_interp_luma(jmhip_ctx *ctx, int ref);
 
 /* getSubImagesChroma (src/img_chroma.c:374, proto inc/img_chroma.h:20): imgUV_sub[2][sy][sx][..][..]. */
 int jmhip_interp_chroma(jmhip_ctx *ctx, int ref);
+/* Luma AND chroma sub-pel planes restricted to the picture's luma rows [row0, row1) (slice-parallel ranks: own band +- search
+ * reach; rows outside keep what an earlier call left). Values inside the range are identical to the full-plane calls'. */
+int jmhip_interp_rows(jmhip_ctx *ctx, int ref, int row0, int row1);
 
 /* Test/diagnostic: copy sub-pel planes back. `out` holds 16 (luma) or sub_y*sub_x (chroma, one component
  * uv = 0/1) planes of padded size, contiguous, pel_bytes per sample. */

@@ -12,7 +12,7 @@ from tests.test_me import lambda_factors, make_mbs
 pytestmark = pytest.mark.gpu
 
 
-def code(pkg, ctx, cur_dev, ref, rows, mbw, quants, lam, R):
+def code(pkg, ctx, cur_dev, ref, rows, mbw, quants, lam, R, band_interp=False):
     from h264_amd.jmhip import ME_MB_DTYPE
     mbs = np.zeros(len(rows) * mbw, dtype=ME_MB_DTYPE)
     k = 0
@@ -27,8 +27,11 @@ def code(pkg, ctx, cur_dev, ref, rows, mbw, quants, lam, R):
     prm.lambda_[0], prm.lambda_[1], prm.lambda_[2] = lam
     prm.subpel, prm.partition_mask = 1, (1 << 41) - 1
     ctx.ref_upload(0, *ref)
-    ctx.interp_luma(0)
-    ctx.interp_chroma(0)
+    if band_interp:      # only the rows this band's search and prediction can reach: own rows +- (range + predictor reach + slack)
+        ctx.interp_rows(0, rows[0] * 16 - (R + 16), (rows[-1] + 1) * 16 + (R + 16))
+    else:
+        ctx.interp_luma(0)
+        ctx.interp_chroma(0)
     ctx.cur_bind(*[t.data_ptr() for t in cur_dev])
     ctx.me_frame_async(prm, mbs)
     ctx.residual_frame(quants)
@@ -37,7 +40,7 @@ def code(pkg, ctx, cur_dev, ref, rows, mbw, quants, lam, R):
 
 def test_two_bands_rebuild_the_reference(pkg):
     rng = np.random.default_rng(17)
-    w, h, R, world = 96, 80, 8, 2
+    w, h, R, world = 96, 160, 8, 2
     mbw, mbh = w // 16, h // 16
     cur, ref = synth(rng, w, h, 1)
     dev = torch.device("cuda", 0)
@@ -59,7 +62,7 @@ def test_two_bands_rebuild_the_reference(pkg):
     for rank in range(world):
         row0, row1, band = pkg.slices.band_rows(mbh, world, rank)
         ctx = pkg.Context(w, h, yuv_format=1, max_refs=1, search_range=R)
-        code(pkg, ctx, cur_dev, ref, list(range(row0, row1)), mbw, quants, lam, R)
+        code(pkg, ctx, cur_dev, ref, list(range(row0, row1)), mbw, quants, lam, R, band_interp=True)
         sY, sU, sV = pkg.slices.send_buffers(torch, band, w, 8, w // 2, dev)
         ctx.recon_copy_band(sY.data_ptr(), sU.data_ptr(), sV.data_ptr(), row0, row1 - row0)
         ctx.sync()
@@ -76,3 +79,23 @@ def test_two_bands_rebuild_the_reference(pkg):
     assert np.array_equal(got_luma, want_luma), "sub-pel planes of the gathered reference differ from the single-context frame"
     assert np.array_equal(got_cb, want_cb)
     assert got_luma[0, 0, 20:20 + h, 20:20 + w].std() > 10      # a real picture, not zeros
+
+
+def test_interp_rows_matches_the_full_planes_inside_the_range(pkg):
+    rng = np.random.default_rng(3)
+    w, h = 64, 96
+    _, ref = synth(rng, w, h, 2)                       # 4:2:2: chroma rows are luma rows
+    full = pkg.Context(w, h, yuv_format=2, max_refs=1, search_range=8)
+    full.ref_upload(0, *ref)
+    full.interp_luma(0)
+    full.interp_chroma(0)
+    fl, fc = full.download_luma_planes(0), full.download_chroma_planes(0, 1)
+    full.close()
+    part = pkg.Context(w, h, yuv_format=2, max_refs=1, search_range=8)
+    part.ref_upload(0, *ref)
+    part.interp_rows(0, 30, 60)
+    pl, pc = part.download_luma_planes(0), part.download_chroma_planes(0, 1)
+    part.close()
+    assert np.array_equal(pl[:, :, 20 + 30:20 + 60], fl[:, :, 20 + 30:20 + 60])
+    assert np.array_equal(pc[:, :, 20 + 30:20 + 60], fc[:, :, 20 + 30:20 + 60])
+    assert not pl[:, :, :20].any() and not pl[:, :, 20 + 80:].any()      # far rows untouched (zero-initialised planes)
