@@ -259,6 +259,8 @@ def main():
     sY, sU, sV = sviews
 
     first = [True]
+    # N > 1: the all-gather is enqueued on the context's own stream (stream-ordered with the kernels round it, no host sync)
+    ext = torch.cuda.ExternalStream(ctx.stream_ptr(), device=dev) if world > 1 else None
 
     def step(k):
         Y, U, V = src[1 + (k % (nframes - 1))]
@@ -281,9 +283,8 @@ def main():
         else:
             if n:
                 ctx.recon_copy_band(sY.data_ptr(), sU.data_ptr(), sV.data_ptr(), row0, row1 - row0)
-            ctx.sync()
-            slices.all_gather_recon(dist, gbufs, sviews)
-            torch.cuda.current_stream().synchronize()
+            with torch.cuda.stream(ext):
+                slices.all_gather_recon(dist, gbufs, sviews)
             ctx.ref_upload_device(0, gY.data_ptr(), gU.data_ptr(), gV.data_ptr(), W, W // 2)
 
     def fence():

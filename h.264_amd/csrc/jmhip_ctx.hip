@@ -162,6 +162,8 @@ extern "C" int jmhip_sync(jmhip_ctx *c)
   return JMHIP_OK;
 }
 
+extern "C" void *jmhip_stream_handle(jmhip_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
 extern "C" int jmhip_timing_enable(jmhip_ctx *c, int on)
 {
   if (!c) return JMHIP_ERR_ARG;

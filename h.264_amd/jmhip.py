@@ -131,6 +131,8 @@ def load_library():
     lib.jmhip_recon_copy_band.argtypes = [vp, vp, vp, vp, ip, ip]
     lib.jmhip_sizeof.argtypes = [ip]
     lib.jmhip_cur_bind.argtypes = [vp, vp, vp, vp]
+    lib.jmhip_stream_handle.argtypes = [vp]
+    lib.jmhip_stream_handle.restype = vp
     lib.jmhip_interp_rows.argtypes = [vp, ip, ip, ip]
     lib.jmhip_timing_select.argtypes = [vp, C.c_uint]
     for which, dt in ((0, ME_MB_DTYPE), (1, ME_RESULT_DTYPE), (2, QUANT_DTYPE), (3, TQ_JOB_DTYPE), (4, TQ_RESULT_DTYPE),
@@ -353,6 +355,10 @@ class Context:
         return Y, U, V
 
     # ---- timing
+    def stream_ptr(self):
+        """hipStream_t of the context as an integer (torch.cuda.ExternalStream(ptr))."""
+        return int(self.lib.jmhip_stream_handle(self.h))
+
     def interp_rows(self, ref, row0, row1):
         self._chk(self.lib.jmhip_interp_rows(self.h, ref, row0, row1), "jmhip_interp_rows")
 

@@ -59,6 +59,9 @@ typedef struct {
 int  jmhip_ctx_create(const jmhip_config *cfg, jmhip_ctx **out);
 void jmhip_ctx_destroy(jmhip_ctx *ctx);
 int  jmhip_sync(jmhip_ctx *ctx);
+/* The context's HIP stream (hipStream_t) for callers that enqueue their own work -- a collective, a copy -- in order with the
+ * context's kernels instead of synchronising the host (bench.py wraps it as torch.cuda.ExternalStream for the RCCL all-gather). */
+void *jmhip_stream_handle(jmhip_ctx *ctx);
 const char *jmhip_last_error(jmhip_ctx *ctx);      /* text of the last failure on this context */
 const char *jmhip_strerror(int code);
 int  jmhip_abi_version(void);

@@ -65,9 +65,11 @@ def test_two_bands_rebuild_the_reference(pkg):
         code(pkg, ctx, cur_dev, ref, list(range(row0, row1)), mbw, quants, lam, R, band_interp=True)
         sY, sU, sV = pkg.slices.send_buffers(torch, band, w, 8, w // 2, dev)
         ctx.recon_copy_band(sY.data_ptr(), sU.data_ptr(), sV.data_ptr(), row0, row1 - row0)
+        # the exchange is enqueued on the context's own stream, as bench.py does with the RCCL all-gather: no host sync between
+        with torch.cuda.stream(torch.cuda.ExternalStream(ctx.stream_ptr(), device=dev)):
+            for g, s, rows_per_mb in zip(gbufs, (sY, sU, sV), (16, 8, 8)):  # what all_gather_into_tensor does with this rank's send buffer
+                g[rank * band * rows_per_mb:(rank + 1) * band * rows_per_mb].copy_(s, non_blocking=True)
         ctx.sync()
-        for g, s, rows_per_mb in zip(gbufs, (sY, sU, sV), (16, 8, 8)):      # what all_gather_into_tensor does with rank `rank`'s send buffer
-            g[rank * band * rows_per_mb:(rank + 1) * band * rows_per_mb] = s
         ctx.close()
     torch.cuda.synchronize()
     chk = pkg.Context(w, h, yuv_format=1, max_refs=1, search_range=R)
