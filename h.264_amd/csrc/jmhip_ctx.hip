@@ -27,6 +27,7 @@ extern "C" int jmhip_sizeof(int which)
   case 10: return (int)sizeof(jmhip_bipred_job);
   case 11: return (int)sizeof(jmhip_bipred_result);
   case 12: return (int)sizeof(jmhip_bipred_params);
+  case 13: return (int)sizeof(jmhip_predcost_job);
   default: return -1;
   }
 }

@@ -2087,6 +2087,117 @@ extern "C" int jmhip_bipred_search(jmhip_ctx *c, const jmhip_bipred_params *prm,
   return JMHIP_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ RD-off mode-decision costs
+
+namespace {
+
+// One wavefront per macroblock: lanes 0..15 fetch their 4x4 prediction block (quarter-pel plane of the block's vector, UMV clamp
+// of the block origin) and form its residual; lanes 0..15 then produce distortion4x4, lanes 0..3 distortion8x8.
+__global__ __launch_bounds__(64) void predcost_kernel(MeDev P, const jmhip_predcost_job *__restrict__ jobs, int n, int metric, int layout,
+                                                     int32_t *__restrict__ out)
+{
+  __shared__ int s_diff[16][16];                     // residual of 4x4 block b (raster y*4+x) as 16 values, row-major inside the block
+  __shared__ int s_c4[16], s_c8[4];
+  const int i = blockIdx.x, tid = threadIdx.x;
+  if (i >= n) return;
+  const jmhip_predcost_job &job = jobs[i];
+  if (tid < 16) {
+    const int x4 = tid & 3, y4 = tid >> 2;
+    const int xq = ((job.mb_x * 16 + 4 * x4 + JMHIP_PAD) << 2) + job.mv[tid][0], yq = ((job.mb_y * 16 + 4 * y4 + JMHIP_PAD) << 2) + job.mv[tid][1];
+    const int xpos = clampi(xq >> 2, 0, P.Wp - 1 - 16), ypos = clampi(yq >> 2, 0, P.Hp - 1 - 16);           // UMVLine4X, refbuf.c:37
+    const uint8_t *src = P.ref_sub[job.ref[tid]] + (size_t)((yq & 3) * 4 + (xq & 3)) * P.Wp * P.Hp + (size_t)ypos * P.Wp + xpos;
+    int d[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      uint32_t pv, hi;
+      fetch_row(src + (size_t)r * P.Wp, 4, &pv, &hi);
+      const uint32_t cv = *reinterpret_cast<const uint32_t *>(P.cur + (size_t)(job.mb_y * 16 + 4 * y4 + r) * P.W + job.mb_x * 16 + 4 * x4);
+#pragma unroll
+      for (int x = 0; x < 4; x++) { d[r][x] = (int)((cv >> (8 * x)) & 255) - (int)((pv >> (8 * x)) & 255); s_diff[tid][r * 4 + x] = d[r][x]; }
+    }
+    int c;
+    if (metric == 2) c = satd4x4(d);
+    else { c = 0; for (int r = 0; r < 4; r++) for (int x = 0; x < 4; x++) c += iabs(d[r][x]); }
+    s_c4[tid] = c;
+  }
+  __syncthreads();
+  if (tid < 4) {
+    const int b8 = tid, bx4 = 2 * (b8 & 1), by4 = 2 * (b8 >> 1);
+    // diff64 as JM builds it: the four 4x4 blocks (raster inside the 8x8) one after the other ...
+    int seq[64];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+      for (int k = 0; k < 16; k++) seq[q * 16 + k] = s_diff[(by4 + (q >> 1)) * 4 + bx4 + (q & 1)][k];
+    int m2[8][8];
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+#pragma unroll
+      for (int x = 0; x < 8; x++)
+        m2[r][x] = layout == JMHIP_DIFF64_RASTER ? s_diff[(by4 + (r >> 2)) * 4 + bx4 + (x >> 2)][(r & 3) * 4 + (x & 3)]   // ... or the true raster
+                                                 : seq[r * 8 + x];
+    int c = 0;
+    if (metric == 2) {
+#pragma unroll
+      for (int r = 0; r < 8; r++) had8(m2[r]);
+#pragma unroll
+      for (int x = 0; x < 8; x++) {
+        int col[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) col[r] = m2[r][x];
+        had8(col);
+#pragma unroll
+        for (int r = 0; r < 8; r++) c += iabs(col[r]);
+      }
+      c = (c + 2) >> 2;
+    } else {
+      for (int r = 0; r < 8; r++) for (int x = 0; x < 8; x++) c += iabs(m2[r][x]);
+    }
+    s_c8[tid] = c;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int c4 = 0;
+    for (int b = 0; b < 16; b++) c4 += s_c4[b];
+    out[2 * i] = c4; out[2 * i + 1] = s_c8[0] + s_c8[1] + s_c8[2] + s_c8[3];
+  }
+}
+
+}  // namespace
+
+extern "C" int jmhip_pred_cost_batch(jmhip_ctx *c, const jmhip_predcost_job *jobs, int n, int metric, int layout, int32_t (*out)[2])
+{
+  if (!c || !jobs || !out || n <= 0) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_pred_cost_batch: NULL/empty arguments") : JMHIP_ERR_ARG;
+  if (metric != 0 && metric != 2) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_pred_cost_batch: metric must be 0 (SAD) or 2 (SATD)");
+  if (layout != JMHIP_DIFF64_SEQUENTIAL && layout != JMHIP_DIFF64_RASTER) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_pred_cost_batch: layout");
+  if (!c->has_cur) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_pred_cost_batch: current picture not uploaded");
+  for (int i = 0; i < n; i++) {
+    const jmhip_predcost_job &j = jobs[i];
+    if (j.mb_x < 0 || j.mb_x >= c->mbw || j.mb_y < 0 || j.mb_y >= c->mbh) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_pred_cost_batch: macroblock outside the picture");
+    for (int b = 0; b < 16; b++) {
+      if (j.ref[b] < 0 || j.ref[b] >= (int)c->refs.size() || !c->refs[j.ref[b]].has_luma_sub) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_pred_cost_batch: sub-pel planes of a reference not built");
+      if (j.mv[b][0] < -8192 || j.mv[b][0] > 8192 || j.mv[b][1] < -8192 || j.mv[b][1] > 8192) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_pred_cost_batch: vector out of range");
+    }
+  }
+  JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
+  int rc = jm_ensure_ref_table(c);
+  if (rc) return rc;
+  void *dj = nullptr, *dout = nullptr;
+  if (hipMalloc(&dj, sizeof(jmhip_predcost_job) * (size_t)n) != hipSuccess || hipMalloc(&dout, sizeof(int32_t) * 2 * (size_t)n) != hipSuccess) {
+    (void)hipFree(dj); return jm_fail(c, JMHIP_ERR_NOMEM, "prediction-cost arrays");
+  }
+  MeDev P{};
+  P.W = c->W; P.H = c->H; P.Wp = c->Wp; P.Hp = c->Hp; P.cur = c->cur_y;
+  P.ref_sub = reinterpret_cast<const uint8_t *const *>(c->ref_ptrs_dev) + 32;
+  hipError_t e = hipMemcpyAsync(dj, jobs, sizeof(jmhip_predcost_job) * (size_t)n, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) { predcost_kernel<<<n, 64, 0, c->stream>>>(P, (const jmhip_predcost_job *)dj, n, metric, layout, (int32_t *)dout); e = hipGetLastError(); }
+  if (e == hipSuccess) e = hipMemcpyAsync(out, dout, sizeof(int32_t) * 2 * (size_t)n, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(dj); (void)hipFree(dout);
+  if (e != hipSuccess) { c->err = std::string("jmhip_pred_cost_batch: ") + hipGetErrorString(e); return JMHIP_ERR_DEVICE; }
+  return JMHIP_OK;
+}
+
 extern "C" int jmhip_me_results_download(jmhip_ctx *c, jmhip_me_result *results, int n)
 {
   if (!c || !results || n <= 0) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_results_download: NULL/empty arguments") : JMHIP_ERR_ARG;

@@ -64,6 +64,7 @@ class BipredParams(C.Structure):
                 ("offset_bi", C.c_int), ("wp_luma_round", C.c_int), ("luma_log_weight_denom", C.c_int)]
 
 
+PREDCOST_JOB_DTYPE = np.dtype([("mb_x", "<i2"), ("mb_y", "<i2"), ("mv", "<i2", (16, 2)), ("ref", "i1", (16,))])
 SURFACE_JOB_DTYPE = np.dtype([("mb_x", "<i2"), ("mb_y", "<i2"), ("ref", "<i2"), ("R", "<i2"), ("cx", "<i2"), ("cy", "<i2"),
                               ("wp", "<i2"), ("weight", "<i2"), ("offset", "<i2"), ("wp_round", "<i2"), ("wp_denom", "<i2"), ("pad", "<i2")])
 DIST_JOB_DTYPE = np.dtype([("pic_x", "<i2"), ("pic_y", "<i2"), ("bsx", "<i2"), ("bsy", "<i2"),
@@ -131,12 +132,13 @@ def load_library():
     lib.jmhip_recon_copy_band.argtypes = [vp, vp, vp, vp, ip, ip]
     lib.jmhip_sizeof.argtypes = [ip]
     lib.jmhip_cur_bind.argtypes = [vp, vp, vp, vp]
+    lib.jmhip_pred_cost_batch.argtypes = [vp, vp, ip, ip, ip, vp]
     lib.jmhip_stream_handle.argtypes = [vp]
     lib.jmhip_stream_handle.restype = vp
     lib.jmhip_interp_rows.argtypes = [vp, ip, ip, ip]
     lib.jmhip_timing_select.argtypes = [vp, C.c_uint]
     for which, dt in ((0, ME_MB_DTYPE), (1, ME_RESULT_DTYPE), (2, QUANT_DTYPE), (3, TQ_JOB_DTYPE), (4, TQ_RESULT_DTYPE),
-                      (5, DIST_JOB_DTYPE), (8, MB_MODE_DTYPE), (9, SURFACE_JOB_DTYPE), (10, BIPRED_JOB_DTYPE), (11, BIPRED_RESULT_DTYPE)):
+                      (5, DIST_JOB_DTYPE), (8, MB_MODE_DTYPE), (9, SURFACE_JOB_DTYPE), (10, BIPRED_JOB_DTYPE), (11, BIPRED_RESULT_DTYPE), (13, PREDCOST_JOB_DTYPE)):
         if lib.jmhip_sizeof(which) != dt.itemsize:
             raise JmhipError("binding layout mismatch for struct %d: C %d vs numpy %d" % (which, lib.jmhip_sizeof(which), dt.itemsize))
     if lib.jmhip_sizeof(6) != C.sizeof(MeParams) or lib.jmhip_sizeof(7) != C.sizeof(Config) or lib.jmhip_sizeof(12) != C.sizeof(BipredParams):
@@ -291,6 +293,13 @@ class Context:
         results = np.ascontiguousarray(results, dtype=ME_RESULT_DTYPE)
         self._chk(self.lib.jmhip_me_subpel(self.h, C.byref(prm), _ptr(mbs), len(mbs), _ptr(results)), "jmhip_me_subpel")
         return results
+
+    def pred_cost_batch(self, jobs, metric=2, layout=0):
+        """-> (n, 2) int32: cost4x4, cost8x8 (layout 0: JM's sequential diff64 of TransformDecision; 1: raster, GetSkipCostMB)."""
+        jobs = np.ascontiguousarray(jobs, dtype=PREDCOST_JOB_DTYPE)
+        out = np.zeros((len(jobs), 2), dtype=np.int32)
+        self._chk(self.lib.jmhip_pred_cost_batch(self.h, _ptr(jobs), len(jobs), metric, layout, _ptr(out)), "jmhip_pred_cost_batch")
+        return out
 
     def bipred_search(self, prm, jobs):
         jobs = np.ascontiguousarray(jobs, dtype=BIPRED_JOB_DTYPE)

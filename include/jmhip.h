@@ -228,6 +228,21 @@ int jmhip_bipred_search(jmhip_ctx *ctx, const jmhip_bipred_params *prm, const jm
  * units, as FullPel/FastFull left it), results[i].mv/cost[p] the output. Same params/jobs as jmhip_me_frame. */
 int jmhip_me_subpel(jmhip_ctx *ctx, const jmhip_me_params *prm, const jmhip_me_mb *mbs, int n, jmhip_me_result *results);
 
+/* ------------------------------------------------------------------ low-complexity (rdopt off) mode-decision costs */
+
+/* The residual distortion of an inter-predicted macroblock, the quantity JM's RD-off decision compares:
+ *   TransformDecision (src/macroblock.c:1458): cost4x4 = sum of distortion4x4 over the sixteen 4x4 blocks, cost8x8 = sum of
+ *     distortion8x8 over the four 8x8 blocks -- with JM's diff64 layout (the 8x8 block's four 4x4 residual blocks stored one after
+ *     the other and read back as 8 rows of 8, :1496-1505): layout = JMHIP_DIFF64_SEQUENTIAL;
+ *   GetSkipCostMB (src/mv-search.c:1136): the same sums on the true 8x8 raster: layout = JMHIP_DIFF64_RASTER.
+ * Prediction per 4x4 block as LumaPrediction(.., 4, 4, ..) (list 0, no weights): its own vector, its own reference slot, UMV origin
+ * clamp per 4x4 block. metric: input->ModeDecisionMetric, 0 = SAD, 2 = SATD (src/me_distortion.c:76, :110). out[i] = {cost4x4, cost8x8}.
+ * (The two layouts yield equal sums: the sequential one permutes the index bits of the 8x8 block and the Hadamard magnitudes' sum is
+ * invariant under that; both are implemented literally and tested.) */
+enum { JMHIP_DIFF64_SEQUENTIAL = 0, JMHIP_DIFF64_RASTER = 1 };
+typedef struct { int16_t mb_x, mb_y; int16_t mv[16][2]; int8_t ref[16]; } jmhip_predcost_job;   /* 4x4 blocks in raster order y*4+x */
+int jmhip_pred_cost_batch(jmhip_ctx *ctx, const jmhip_predcost_job *jobs, int n, int metric, int layout, int32_t (*out)[2]);
+
 /* ------------------------------------------------------------------ transform / quant / recon */
 
 /* Quantiser of one block (JM: levelscale/invlevelscale/leveloffset selected at src/block.c:874-877,
@@ -310,7 +325,7 @@ int jmhip_recon_download(jmhip_ctx *ctx, void *Y, void *U, void *V, int pel_byte
 
 /* sizeof() of the ABI structs, for language bindings to verify their layout: 0 jmhip_me_mb, 1 jmhip_me_result,
  * 2 jmhip_quant, 3 jmhip_tq_job, 4 jmhip_tq_result, 5 jmhip_dist_job, 6 jmhip_me_params, 7 jmhip_config,
- * 8 jmhip_mb_mode, 9 jmhip_surface_job, 10 jmhip_bipred_job, 11 jmhip_bipred_result, 12 jmhip_bipred_params. */
+ * 8 jmhip_mb_mode, 9 jmhip_surface_job, 10 jmhip_bipred_job, 11 jmhip_bipred_result, 12 jmhip_bipred_params, 13 jmhip_predcost_job. */
 int jmhip_sizeof(int which);
 
 /* Flat (no scaling matrix) tables: CalculateQuantParam / CalculateQuant8Param (src/q_matrix.c:451,590) and

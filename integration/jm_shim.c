@@ -9,7 +9,8 @@
  * error()/exit). JMHIP_SHIM_STATS=1 prints, per symbol, how many calls ran on the device and how many were forwarded.
  * JMHIP_SHIM (hex mask, default all): 0x01 sub-pel planes, 0x04 full-pel + sub-pel search, 0x08 fast full search,
  * 0x10 dct_4x4/dct_16x16, 0x20 dct_8x8, 0x40 dct_chroma, 0x100 distortion surfaces for EPZS / UMHexagonS integer walks,
- * 0x200 bi-predictive full-pel + sub-pel search.
+ * 0x200 bi-predictive full-pel + sub-pel search,
+ * 0x400 RD-off mode-decision costs (TransformDecision, GetSkipCostMB).
  *
  * The proof of the drop-in claim is tests/test_jm_shim_gpu.py: the bitstream and the reconstruction this encoder
  * writes are byte-identical to the unmodified encoder's.
@@ -37,12 +38,13 @@ extern void SetMotionVectorPredictor(short pmv[2], char **refPic, short ***tmp_m
                                      int block_x, int block_y, int blockshape_x, int blockshape_y);
 extern const int LEVELMVLIMIT[17][6];
 
-enum { S_LUMA, S_CHROMA, S_FULL, S_SUB, S_FAST, S_D4, S_D8, S_D16, S_DCR, S_WALK, S_SAD, S_SATD, S_BIFULL, S_BISUB, S_COUNT };
+enum { S_LUMA, S_CHROMA, S_FULL, S_SUB, S_FAST, S_D4, S_D8, S_D16, S_DCR, S_WALK, S_SAD, S_SATD, S_BIFULL, S_BISUB, S_TDEC, S_SKIPC, S_COUNT };
 static const char *s_names[S_COUNT] = { "getSubImagesLuma", "getSubImagesChroma", "FullPelBlockMotionSearch",
   "SubPelBlockMotionSearch", "FastFullPelBlockMotionSearch", "dct_4x4", "dct_8x8", "dct_16x16", "dct_chroma",
-  "EPZS_UMHex_integer_walks", "computeSAD", "computeSATD", "FullPelBlockMotionBiPred", "SubPelBlockSearchBiPred" };
+  "EPZS_UMHex_integer_walks", "computeSAD", "computeSATD", "FullPelBlockMotionBiPred", "SubPelBlockSearchBiPred",
+  "TransformDecision", "GetSkipCostMB" };
 static long n_dev[S_COUNT], n_fwd[S_COUNT];
-static unsigned shim_mask = 0x3ff;
+static unsigned shim_mask = 0x7ff;
 static int verify;            /* JMHIP_SHIM_VERIFY=1: run JM's own search beside the device's and report differences */
 static jmhip_ctx *g;
 static int g_w, g_h;
@@ -594,6 +596,80 @@ int EPZSPelBlockMotionSearch(imgpel *cur_pic, short ref, int list, int list_offs
   }
 UMHEX_WALK(UMHEXIntegerPelBlockMotionSearch)
 UMHEX_WALK(smpUMHEXIntegerPelBlockMotionSearch)
+
+/* ------------------------------------------------------------------ RD-off mode-decision costs */
+
+extern void SetModesAndRefframe(Macroblock *currMB, int b8, short *p_dir, int *l0_mode, int *l1_mode, short *l0_ref, short *l1_ref);
+extern void LumaPrediction(Macroblock *currMB, int block_x, int block_y, int block_size_x, int block_size_y, int p_dir, int l0_mode,
+                           int l1_mode, short l0_ref_idx, short l1_ref_idx);
+
+/* one job from JM's state: per 4x4 block the list-0 vector of its mode and the slot of its reference; 0 if the device cannot take it
+ * (bi-pred / list 1 / direct blocks, weighted prediction, field pictures, SSE) */
+static int predcost_job(Macroblock *currMB, jmhip_predcost_job *job, int skip)
+{
+  int b8, bx, by;
+  int weighted = (active_pps->weighted_pred_flag && (img->type == P_SLICE || img->type == SP_SLICE)) || (active_pps->weighted_bipred_idc && img->type == B_SLICE);
+  if (weighted || input->ModeDecisionMetric == ERROR_SSE || !cur_ready() || img->mb_data[img->current_mb_nr].list_offset) return 0;
+  memset(job, 0, sizeof(*job));
+  job->mb_x = img->opix_x >> 4; job->mb_y = img->opix_y >> 4;
+  for (b8 = 0; b8 < 4; b8++) {
+    short p_dir = 0, l0_ref = 0, l1_ref = 0; int l0_mode = 0, l1_mode = 0, slot;
+    if (!skip) {
+      SetModesAndRefframe(currMB, b8, &p_dir, &l0_mode, &l1_mode, &l0_ref, &l1_ref);
+      if (p_dir != 0 || l0_mode < 1 || l0_mode > 7 || l0_ref < 0) return 0;
+    }
+    slot = slot_find(listX[LIST_0][l0_ref]);
+    if (slot < 0) return 0;
+    for (by = (b8 >> 1) * 2; by < (b8 >> 1) * 2 + 2; by++)
+      for (bx = (b8 & 1) * 2; bx < (b8 & 1) * 2 + 2; bx++) {
+        short *mv = img->all_mv[by][bx][LIST_0][l0_ref][l0_mode];      /* LumaPrediction, macroblock.c:851-870 */
+        job->mv[by * 4 + bx][0] = mv[0]; job->mv[by * 4 + bx][1] = mv[1];
+        job->ref[by * 4 + bx] = (int8_t)slot;
+      }
+  }
+  return 1;
+}
+
+int TransformDecision(Macroblock *currMB, int block_check, int *cost)
+{
+  static int (*orig)(Macroblock *, int, int *);
+  jmhip_predcost_job job; int32_t out[1][2];
+  if (!(shim_mask & 0x400) || block_check != -1 || !predcost_job(currMB, &job, 0)) {
+    if (!orig) orig = next_sym("TransformDecision");
+    n_fwd[S_TDEC]++;
+    return orig(currMB, block_check, cost);
+  }
+  OK(jmhip_pred_cost_batch(g, &job, 1, input->ModeDecisionMetric, JMHIP_DIFF64_SEQUENTIAL, out));
+  {
+    /* JM leaves the macroblock's prediction in img->mpr (later code may read it): keep that side effect with JM's own routine */
+    int b8, bx, by, l0_mode, l1_mode; short p_dir, l0_ref, l1_ref;
+    for (b8 = 0; b8 < 4; b8++) {
+      SetModesAndRefframe(currMB, b8, &p_dir, &l0_mode, &l1_mode, &l0_ref, &l1_ref);
+      for (by = (b8 >> 1) << 3; by < ((b8 >> 1) << 3) + 8; by += 4)
+        for (bx = (b8 & 1) << 3; bx < ((b8 & 1) << 3) + 8; bx += 4) LumaPrediction(currMB, bx, by, 4, 4, p_dir, l0_mode, l1_mode, l0_ref, l1_ref);
+    }
+  }
+  n_dev[S_TDEC]++;
+  if (input->Transform8x8Mode == 2) return 1;          /* macroblock.c:1508-1517 */
+  if (out[0][1] < out[0][0]) return 1;
+  *cost = (*cost - out[0][1] + out[0][0]);
+  return 0;
+}
+
+int GetSkipCostMB(Macroblock *currMB)
+{
+  static int (*orig)(Macroblock *);
+  jmhip_predcost_job job; int32_t out[1][2];
+  if (!(shim_mask & 0x400) || !predcost_job(currMB, &job, 1)) {
+    if (!orig) orig = next_sym("GetSkipCostMB");
+    n_fwd[S_SKIPC]++;
+    return orig(currMB);
+  }
+  OK(jmhip_pred_cost_batch(g, &job, 1, input->ModeDecisionMetric, JMHIP_DIFF64_RASTER, out));
+  { int bx, by; for (by = 0; by < 16; by += 4) for (bx = 0; bx < 16; bx += 4) LumaPrediction(currMB, bx, by, 4, 4, 0, 0, 0, 0, 0); }   /* img->mpr side effect */
+  n_dev[S_SKIPC]++;
+  return (input->rdopt == 0 && input->Transform8x8Mode) ? out[0][1] : out[0][0];      /* mv-search.c:1167-1177 */
+}
 
 /* ------------------------------------------------------------------ transform + quantisation + reconstruction */
 

@@ -98,6 +98,10 @@ int jmo_sse    (const jmo_dist *d, const jmo_pel *src, int bsy, int bsx, int min
 int jmo_hadamard_sad4x4(const int *diff);   /* HadamardSAD4x4, me_distortion.c:182 */
 int jmo_hadamard_sad8x8(const int *diff);   /* HadamardSAD8x8, me_distortion.c:272 */
 
+/* Low-complexity mode-decision costs of one macroblock (jmo_frame.c): TransformDecision macroblock.c:1458 (proper8x8 = 0: JM's
+ * sequential 4x4 layout of diff64) and GetSkipCostMB mv-search.c:1136 (proper8x8 = 1). metric: JMO_ERR_SAD / JMO_ERR_SATD. */
+void jmo_pred_costs(const jmo_pel *cur, const jmo_pel *mpr, int metric, int proper8x8, int *cost4x4, int *cost8x8);
+
 /* ------------------------------------------------------------------ bi-predictive distortion + search (jmo_bipred.c) */
 
 /* JM's naming: "1" = the FIXED block (s_mv; picture listX[list][ref]), "2" = the SWEPT candidate (mv; listX[list^1][0]). */

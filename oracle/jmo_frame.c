@@ -114,3 +114,47 @@ long long jmo_hotpath_mbs(const jmo_me_params *p, const jmo_ref *ref, const jmo_
   }
   return sum;
 }
+
+/* ------------------------------------------------------------------ low-complexity mode-decision costs */
+
+/* distortion4x4 / distortion8x8, me_distortion.c:76 / :110 (ModeDecisionMetric: 0 SAD, 2 SATD; SSE not restated) */
+static int dist4(const int *d, int metric)
+{
+  int k, s = 0;
+  if (metric == JMO_ERR_SATD) return jmo_hadamard_sad4x4(d);
+  for (k = 0; k < 16; k++) s += d[k] < 0 ? -d[k] : d[k];
+  return s;
+}
+static int dist8(const int *d, int metric)
+{
+  int k, s = 0;
+  if (metric == JMO_ERR_SATD) return jmo_hadamard_sad8x8(d);
+  for (k = 0; k < 64; k++) s += d[k] < 0 ? -d[k] : d[k];
+  return s;
+}
+
+/* The cost pair of TransformDecision (macroblock.c:1458-1520) for one macroblock whose prediction (per 4x4 block) is `mpr`:
+ * cost4x4 = sum of distortion4x4 over the sixteen 4x4 residual blocks; cost8x8 = sum over the four 8x8 blocks of
+ * distortion8x8(diff64), where diff64 holds the block's four 4x4 residual blocks ONE AFTER THE OTHER (16 values each, :1496-1500)
+ * and is then read as eight rows of eight (:1505) -- not the 8x8 block's raster. `proper8x8` != 0 selects the true raster instead,
+ * which is what GetSkipCostMB builds (curr_diff[8][8] copied row by row, mv-search.c:1161-1176). */
+void jmo_pred_costs(const jmo_pel *cur /*[16][16]*/, const jmo_pel *mpr /*[16][16]*/, int metric, int proper8x8, int *cost4x4, int *cost8x8)
+{
+  int b8, c4 = 0, c8 = 0;
+  for (b8 = 0; b8 < 4; b8++) {
+    const int mb_y = (b8 >> 1) << 3, mb_x = (b8 & 1) << 3;
+    int diff64[64], raster[64], k = 0, by, bx, j, i;
+    for (by = mb_y; by < mb_y + 8; by += 4)
+      for (bx = mb_x; bx < mb_x + 8; bx += 4) {
+        const int *dp = &diff64[k];
+        for (j = by; j < by + 4; j++)
+          for (i = bx; i < bx + 4; i++, k++) {
+            diff64[k] = (int)cur[j * 16 + i] - (int)mpr[j * 16 + i];
+            raster[(j - mb_y) * 8 + (i - mb_x)] = diff64[k];
+          }
+        c4 += dist4(dp, metric);
+      }
+    c8 += dist8(proper8x8 ? raster : diff64, metric);
+  }
+  *cost4x4 = c4; *cost8x8 = c8;
+}

@@ -13,6 +13,7 @@
  *   0x01 interpolation   0x02 SAD/SATD kernels   0x04 full/sub-pel search   0x08 fast full search
  *   0x10 dct_4x4/16x16   0x20 dct_8x8            0x40 dct_chroma            0x80 transform primitives
  *   0x100 bi-predictive full-pel + sub-pel search (FullPelBlockMotionBiPred, SubPelBlockSearchBiPred)
+ *   0x200 low-complexity mode-decision costs (TransformDecision, GetSkipCostMB)
  * JMO_SWAP_STATS=1 prints per-symbol call counts at exit.
  */
 #define _GNU_SOURCE
@@ -38,12 +39,12 @@ extern void SetMotionVectorPredictor(short pmv[2], char **refPic, short ***tmp_m
                                      int block_x, int block_y, int blockshape_x, int blockshape_y);
 extern const int LEVELMVLIMIT[17][6];
 
-static unsigned swap_mask = 0x1ff;
+static unsigned swap_mask = 0x3ff;
 static long n_calls[16];
-enum { C_LUMA, C_CHROMA, C_SAD, C_SATD, C_FULL, C_SUB, C_FAST, C_D4, C_D8, C_D16, C_DCR, C_PRIM, C_BIFULL, C_BISUB };
+enum { C_LUMA, C_CHROMA, C_SAD, C_SATD, C_FULL, C_SUB, C_FAST, C_D4, C_D8, C_D16, C_DCR, C_PRIM, C_BIFULL, C_BISUB, C_TDEC, C_SKIPC };
 static const char *c_names[] = { "getSubImagesLuma", "getSubImagesChroma", "computeSAD*", "computeSATD*",
   "FullPelBlockMotionSearch", "SubPelBlockMotionSearch", "FastFullPelBlockMotionSearch", "dct_4x4",
-  "dct_8x8", "dct_16x16", "dct_chroma", "transform primitives", "FullPelBlockMotionBiPred", "SubPelBlockSearchBiPred" };
+  "dct_8x8", "dct_16x16", "dct_chroma", "transform primitives", "FullPelBlockMotionBiPred", "SubPelBlockSearchBiPred", "TransformDecision", "GetSkipCostMB" };
 
 static void *next_sym(const char *name)
 {
@@ -57,7 +58,7 @@ static void print_stats(void)
   int i;
   if (!getenv("JMO_SWAP_STATS")) return;
   fprintf(stderr, "swap_oracle: mask=0x%x\n", swap_mask);
-  for (i = 0; i <= C_BISUB; i++) fprintf(stderr, "  %-30s %ld\n", c_names[i], n_calls[i]);
+  for (i = 0; i <= C_SKIPC; i++) fprintf(stderr, "  %-30s %ld\n", c_names[i], n_calls[i]);
 }
 
 int main(int argc, char **argv)
@@ -372,6 +373,60 @@ int SubPelBlockSearchBiPred(imgpel *orig_pic, short ref, int list, int pic_pix_x
     }
     return jmo_subpel_bipred(&b, orig_pic, pic_pix_x, pic_pix_y, blocktype, pred_mv_x, pred_mv_y, mv_x, mv_y, s_mv_x, s_mv_y,
                              search_pos2, search_pos4, min_mcost, lambda);
+  }
+}
+
+/* ------------------------------------------------------------------ 0x200 low-complexity mode-decision costs */
+
+extern void SetModesAndRefframe(Macroblock *currMB, int b8, short *p_dir, int *l0_mode, int *l1_mode, short *l0_ref, short *l1_ref);
+extern void LumaPrediction(Macroblock *currMB, int block_x, int block_y, int block_size_x, int block_size_y, int p_dir, int l0_mode,
+                           int l1_mode, short l0_ref_idx, short l1_ref_idx);
+
+static void mb_cur(jmo_pel cur[256]) { int j; for (j = 0; j < 16; j++) memcpy(cur + 16 * j, &pCurImg[img->opix_y + j][img->opix_x], 16 * sizeof(imgpel)); }
+
+int TransformDecision(Macroblock *currMB, int block_check, int *cost)
+{
+  static int (*orig)(Macroblock *, int, int *);
+  n_calls[C_TDEC]++;
+  if (!(swap_mask & 0x200) || block_check != -1 || input->ModeDecisionMetric == ERROR_SSE) {
+    if (!orig) orig = next_sym("TransformDecision");
+    return orig(currMB, block_check, cost);
+  }
+  {
+    int b8, bx, by, l0_mode, l1_mode, c4, c8;
+    short p_dir, l0_ref, l1_ref;
+    jmo_pel cur[256];
+    /* the predictions are JM's own (LumaPrediction per 4x4 block, :1493); img->mpr is also the side effect later code sees */
+    for (b8 = 0; b8 < 4; b8++) {
+      SetModesAndRefframe(currMB, b8, &p_dir, &l0_mode, &l1_mode, &l0_ref, &l1_ref);
+      for (by = (b8 >> 1) << 3; by < ((b8 >> 1) << 3) + 8; by += 4)
+        for (bx = (b8 & 1) << 3; bx < ((b8 & 1) << 3) + 8; bx += 4)
+          LumaPrediction(currMB, bx, by, 4, 4, p_dir, l0_mode, l1_mode, l0_ref, l1_ref);
+    }
+    mb_cur(cur);
+    jmo_pred_costs(cur, &img->mpr[0][0][0], input->ModeDecisionMetric, 0, &c4, &c8);
+    if (input->Transform8x8Mode == 2) return 1;
+    if (c8 < c4) return 1;
+    *cost = (*cost - c8 + c4);
+    return 0;
+  }
+}
+
+int GetSkipCostMB(Macroblock *currMB)
+{
+  static int (*orig)(Macroblock *);
+  n_calls[C_SKIPC]++;
+  if (!(swap_mask & 0x200) || input->ModeDecisionMetric == ERROR_SSE) {
+    if (!orig) orig = next_sym("GetSkipCostMB");
+    return orig(currMB);
+  }
+  {
+    int bx, by, c4, c8;
+    jmo_pel cur[256];
+    for (by = 0; by < 16; by += 4) for (bx = 0; bx < 16; bx += 4) LumaPrediction(currMB, bx, by, 4, 4, 0, 0, 0, 0, 0);
+    mb_cur(cur);
+    jmo_pred_costs(cur, &img->mpr[0][0][0], input->ModeDecisionMetric, 1, &c4, &c8);
+    return (input->rdopt == 0 && input->Transform8x8Mode) ? c8 : c4;      /* mv-search.c:1167-1177 */
   }
 }
 

@@ -75,6 +75,8 @@ CASES = {
     "epzs_satd_high": dict(search=3, profile=100, cabac=1, t8x8=1, bframes=0, refs=1, rdopt=1, adrnd=0, yuv=1, fpel=2),
     # BASELINE config 5 in small: 4:2:2, UMHexagonS, explicit weighted prediction used in ME (computeSADWP surfaces), fading clip
     "umhex_wp_422": dict(search=1, profile=122, cabac=1, t8x8=1, bframes=0, refs=2, rdopt=1, adrnd=0, yuv=2, wp=1, fade=1),
+    # RD-off decision with the 8x8 transform: TransformDecision and GetSkipCostMB costs from the device
+    "lowcplx_t8_decision": dict(search=0, profile=100, cabac=0, t8x8=1, bframes=0, refs=2, rdopt=0, adrnd=0, yuv=1),
     "full_lowcplx_422": dict(search=-1, profile=122, cabac=0, t8x8=1, bframes=0, refs=1, rdopt=0, adrnd=1, yuv=2),  # rdopt off centre rule, 4:2:2 chroma DC
 }
 
@@ -156,6 +158,8 @@ def test_jm_with_hip_hot_path_is_byte_identical(tmp_path, name):
     assert served["dct_4x4"][0] > 1000 and served["dct_chroma"][0] > 100
     if CASES[name]["t8x8"]:
         assert served["dct_8x8"][0] > 100
+    if name == "lowcplx_t8_decision":
+        assert served["TransformDecision"][0] > 100 and served["GetSkipCostMB"][0] > 50
     if CASES[name].get("bipred"):
         assert served["FullPelBlockMotionBiPred"][0] > 100 and served["FullPelBlockMotionBiPred"][1] == 0
         assert served["SubPelBlockSearchBiPred"][0] > 50 and served["SubPelBlockSearchBiPred"][1] == 0

@@ -78,6 +78,8 @@ VARIANTS = {
     "main FS WBP implicit": "-d encoder_main.cfg -p SearchMode=-1 -p WeightedBiprediction=2",
     "main FFS bipred SAD-all R8": "-d encoder_main.cfg -p SearchMode=0 -p MEDistortionHPel=0 -p MEDistortionQPel=0 -p BiPredMESearchRange=8 -p BiPredMERefinements=1",
     "high 8x8 FS bipred subpel1": "-d encoder.cfg -p SearchMode=-1 -p BiPredMESubPel=1",
+    "high rdopt0 8x8 CAVLC": "-d encoder.cfg -p SearchMode=0 -p RDOptimization=0 -p SymbolMode=0 -p Transform8x8Mode=1",
+    "high rdopt0 8x8 SAD-md": "-d encoder.cfg -p SearchMode=-1 -p RDOptimization=0 -p MDDistortion=0 -p Transform8x8Mode=1",
     "main EPZS WP": "-d encoder_main.cfg -p SearchMode=3 -p WeightedPrediction=1 -p UseWeightedReferenceME=1",
     "main FS SATD-fpel": "-d encoder_main.cfg -p SearchMode=-1 -p MEDistortionFPel=2",
     "main FS SAD-all": "-d encoder_main.cfg -p SearchMode=-1 -p MEDistortionHPel=0 -p MEDistortionQPel=0",
