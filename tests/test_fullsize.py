@@ -84,3 +84,53 @@ def test_full_frame_search_1080p(pkg):
                       None, None, mv_out.ctypes.data, cost_out.ctypes.data)
     assert np.array_equal(got["mv"][sel], mv_out), "vectors differ from the oracle on the sampled macroblocks"
     assert np.array_equal(got["cost"][sel], cost_out), "costs differ from the oracle on the sampled macroblocks"
+
+
+def test_full_frame_residual_stage_1080p(pkg):
+    """The frame stage (MC -> residual -> dct_4x4 / dct_chroma -> thresholds -> recon) over all 8160 macroblocks of a 1080p 4:2:0
+    frame; a sample of macroblocks (corners, edges, interior) against the reference assembled from the oracle, and whole-frame
+    properties: recon == prediction wherever the coded block pattern is empty, recon of a second identical run is identical."""
+    from h264_amd.jmhip import ME_MB_DTYPE
+    cur, ref = clip()
+    mk = lambda img, s: np.clip(np.round(128 + s * 0.25 * (img[::2, ::2].astype(float) - 128)), 0, 255).astype(np.uint8)
+    curs, refs = (cur, mk(cur, 1), mk(cur, -1)), (ref, mk(ref, 1), mk(ref, -1))
+    mbw, mbh = W // 16, H // 16
+    n = mbw * mbh
+    rng = np.random.default_rng(9)
+    mbs = np.zeros(n, dtype=ME_MB_DTYPE)
+    mbs["mb_x"], mbs["mb_y"], mbs["ref_is_0"] = np.arange(n) % mbw, np.arange(n) // mbw, 1
+    mbs["pred_mv"] = (np.array([16, -16]) + rng.integers(-8, 9, (n, 1, 2))) + np.zeros((n, 41, 2), int)
+    ctx = pkg.Context(W, H, yuv_format=1, max_refs=1, search_range=R)
+    ctx.ref_upload(0, *refs)
+    ctx.interp_luma(0)
+    ctx.interp_chroma(0)
+    ctx.cur_upload(*curs)
+    lam = lambda_factors(28)
+    prm = pkg.MeParams()
+    prm.search_mode, prm.search_range, prm.rdopt = 0, R, 1
+    prm.level_mv_min, prm.level_mv_max = -511, 511
+    prm.lambda_[0], prm.lambda_[1], prm.lambda_[2] = lam
+    prm.subpel, prm.partition_mask = 1, (1 << 41) - 1
+    me = ctx.me_frame(prm, mbs)
+    quants = np.array([pkg.flat_quant(28 + d, 342, adaptive_rounding=1, adapt_rnd_weight=4, cavlc=1) for d in (0, 0, 3)], dtype=pkg.QUANT_DTYPE)
+    ctx.residual_frame(quants, None)
+    got = ctx.residual_download(n)
+    recon = ctx.recon_download()
+    ctx.residual_frame(quants, None)
+    recon2 = ctx.recon_download()
+    ctx.close()
+    for a, b in zip(recon, recon2):
+        assert np.array_equal(a, b)
+    assert (got["cbp"] & 15).max() > 0 and ((got["cbp"] & 15) == 0).any()       # coded and uncoded macroblocks both occur
+
+    rows = [0, 34, 67]
+    sel = np.concatenate([np.arange(r * mbw, (r + 1) * mbw, 7) for r in rows])
+    rp = oracle.RefPic(refs[0], refs[1], refs[2], yuv_format=1)
+    want = oracle.residual_frame(rp, curs, mbs[sel], me["mv"][sel], got["modes"][sel], quants, pkg.TQ_JOB_DTYPE, yuv_format=1)
+    assert np.array_equal(got["cbp"][sel], want["cbp"])
+    assert np.array_equal(got["cbp_blk"][sel], want["cbp_blk"])
+    for i in sel:
+        x, y = int(mbs[i]["mb_x"]) * 16, int(mbs[i]["mb_y"]) * 16
+        assert np.array_equal(recon[0][y:y + 16, x:x + 16], want["recon"][0][y:y + 16, x:x + 16]), ("luma recon", i)
+        assert np.array_equal(recon[1][y // 2:y // 2 + 8, x // 2:x // 2 + 8], want["recon"][1][y // 2:y // 2 + 8, x // 2:x // 2 + 8]), ("Cb recon", i)
+        assert np.array_equal(recon[2][y // 2:y // 2 + 8, x // 2:x // 2 + 8], want["recon"][2][y // 2:y // 2 + 8, x // 2:x // 2 + 8]), ("Cr recon", i)
