@@ -2103,17 +2103,53 @@ __global__ __launch_bounds__(64) void predcost_kernel(MeDev P, const jmhip_predc
   const jmhip_predcost_job &job = jobs[i];
   if (tid < 16) {
     const int x4 = tid & 3, y4 = tid >> 2;
-    const int xq = ((job.mb_x * 16 + 4 * x4 + JMHIP_PAD) << 2) + job.mv[tid][0], yq = ((job.mb_y * 16 + 4 * y4 + JMHIP_PAD) << 2) + job.mv[tid][1];
-    const int xpos = clampi(xq >> 2, 0, P.Wp - 1 - 16), ypos = clampi(yq >> 2, 0, P.Hp - 1 - 16);           // UMVLine4X, refbuf.c:37
-    const uint8_t *src = P.ref_sub[job.ref[tid]] + (size_t)((yq & 3) * 4 + (xq & 3)) * P.Wp * P.Hp + (size_t)ypos * P.Wp + xpos;
+    // LumaPrediction (macroblock.c:836-945): one or two quarter-pel fetches, each with its own UMV origin clamp, then the mix
+    uint32_t pv[4];
+    {
+      const int xq = ((job.mb_x * 16 + 4 * x4 + JMHIP_PAD) << 2) + job.mv[tid][0], yq = ((job.mb_y * 16 + 4 * y4 + JMHIP_PAD) << 2) + job.mv[tid][1];
+      const int xpos = clampi(xq >> 2, 0, P.Wp - 1 - 16), ypos = clampi(yq >> 2, 0, P.Hp - 1 - 16);           // UMVLine4X, refbuf.c:37
+      const uint8_t *src = P.ref_sub[job.ref[tid]] + (size_t)((yq & 3) * 4 + (xq & 3)) * P.Wp * P.Hp + (size_t)ypos * P.Wp + xpos;
+      uint32_t hi;
+#pragma unroll
+      for (int r = 0; r < 4; r++) fetch_row(src + (size_t)r * P.Wp, 4, &pv[r], &hi);
+    }
+    if (job.bi[tid]) {
+      const int xq = ((job.mb_x * 16 + 4 * x4 + JMHIP_PAD) << 2) + job.mv1[tid][0], yq = ((job.mb_y * 16 + 4 * y4 + JMHIP_PAD) << 2) + job.mv1[tid][1];
+      const int xpos = clampi(xq >> 2, 0, P.Wp - 1 - 16), ypos = clampi(yq >> 2, 0, P.Hp - 1 - 16);
+      const uint8_t *src = P.ref_sub[job.ref1[tid]] + (size_t)((yq & 3) * 4 + (xq & 3)) * P.Wp * P.Hp + (size_t)ypos * P.Wp + xpos;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        uint32_t q, hi;
+        fetch_row(src + (size_t)r * P.Wp, 4, &q, &hi);
+        if (!job.weighted) pv[r] = __builtin_amdgcn_lerp(pv[r], q, 0x01010101u);                              // (a + b + 1) >> 1, :917
+        else {
+          uint32_t v = 0;
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int a = (pv[r] >> (8 * k)) & 255, b = (q >> (8 * k)) & 255;
+            v |= (uint32_t)min(max(((job.w0[tid] * a + job.w1[tid] * b + 2 * job.wp_round) >> (job.wp_denom + 1)) + job.off[tid], 0), 255) << (8 * k);   // :884-890
+          }
+          pv[r] = v;
+        }
+      }
+    } else if (job.weighted) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int a = (pv[r] >> (8 * k)) & 255;
+          v |= (uint32_t)min(max(((job.w0[tid] * a + job.wp_round) >> job.wp_denom) + job.off[tid], 0), 255) << (8 * k);                                     // :892-899
+        }
+        pv[r] = v;
+      }
+    }
     int d[4][4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-      uint32_t pv, hi;
-      fetch_row(src + (size_t)r * P.Wp, 4, &pv, &hi);
       const uint32_t cv = *reinterpret_cast<const uint32_t *>(P.cur + (size_t)(job.mb_y * 16 + 4 * y4 + r) * P.W + job.mb_x * 16 + 4 * x4);
 #pragma unroll
-      for (int x = 0; x < 4; x++) { d[r][x] = (int)((cv >> (8 * x)) & 255) - (int)((pv >> (8 * x)) & 255); s_diff[tid][r * 4 + x] = d[r][x]; }
+      for (int x = 0; x < 4; x++) { d[r][x] = (int)((cv >> (8 * x)) & 255) - (int)((pv[r] >> (8 * x)) & 255); s_diff[tid][r * 4 + x] = d[r][x]; }
     }
     int c;
     if (metric == 2) c = satd4x4(d);
@@ -2157,9 +2193,14 @@ __global__ __launch_bounds__(64) void predcost_kernel(MeDev P, const jmhip_predc
   }
   __syncthreads();
   if (tid == 0) {
-    int c4 = 0;
-    for (int b = 0; b < 16; b++) c4 += s_c4[b];
-    out[2 * i] = c4; out[2 * i + 1] = s_c8[0] + s_c8[1] + s_c8[2] + s_c8[3];
+    int c4 = 0, c8 = 0;
+    for (int b = 0; b < 16; b++) if ((job.blocks >> b) & 1) c4 += s_c4[b];
+    for (int b8 = 0; b8 < 4; b8++) {
+      const int o = 8 * (b8 >> 1) + 2 * (b8 & 1);      // top-left 4x4 of the 8x8
+      const unsigned need = (1u << o) | (1u << (o + 1)) | (1u << (o + 4)) | (1u << (o + 5));
+      if ((job.blocks & need) == need) c8 += s_c8[b8];
+    }
+    out[2 * i] = c4; out[2 * i + 1] = c8;
   }
 }
 
@@ -2174,9 +2215,14 @@ extern "C" int jmhip_pred_cost_batch(jmhip_ctx *c, const jmhip_predcost_job *job
   for (int i = 0; i < n; i++) {
     const jmhip_predcost_job &j = jobs[i];
     if (j.mb_x < 0 || j.mb_x >= c->mbw || j.mb_y < 0 || j.mb_y >= c->mbh) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_pred_cost_batch: macroblock outside the picture");
+    if (j.weighted && (j.wp_denom < 0 || j.wp_denom > 14)) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_pred_cost_batch: weight denominator");
     for (int b = 0; b < 16; b++) {
       if (j.ref[b] < 0 || j.ref[b] >= (int)c->refs.size() || !c->refs[j.ref[b]].has_luma_sub) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_pred_cost_batch: sub-pel planes of a reference not built");
       if (j.mv[b][0] < -8192 || j.mv[b][0] > 8192 || j.mv[b][1] < -8192 || j.mv[b][1] > 8192) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_pred_cost_batch: vector out of range");
+      if (j.bi[b]) {
+        if (j.ref1[b] < 0 || j.ref1[b] >= (int)c->refs.size() || !c->refs[j.ref1[b]].has_luma_sub) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_pred_cost_batch: sub-pel planes of the second reference not built");
+        if (j.mv1[b][0] < -8192 || j.mv1[b][0] > 8192 || j.mv1[b][1] < -8192 || j.mv1[b][1] > 8192) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_pred_cost_batch: second vector out of range");
+      }
     }
   }
   JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));

@@ -64,7 +64,9 @@ class BipredParams(C.Structure):
                 ("offset_bi", C.c_int), ("wp_luma_round", C.c_int), ("luma_log_weight_denom", C.c_int)]
 
 
-PREDCOST_JOB_DTYPE = np.dtype([("mb_x", "<i2"), ("mb_y", "<i2"), ("mv", "<i2", (16, 2)), ("ref", "i1", (16,))])
+PREDCOST_JOB_DTYPE = np.dtype([("mb_x", "<i2"), ("mb_y", "<i2"), ("blocks", "<u2"), ("weighted", "<i2"), ("wp_round", "<i2"), ("wp_denom", "<i2"),
+                               ("mv", "<i2", (16, 2)), ("mv1", "<i2", (16, 2)), ("ref", "i1", (16,)), ("ref1", "i1", (16,)), ("bi", "i1", (16,)),
+                               ("w0", "<i2", (16,)), ("w1", "<i2", (16,)), ("off", "<i2", (16,))])
 SURFACE_JOB_DTYPE = np.dtype([("mb_x", "<i2"), ("mb_y", "<i2"), ("ref", "<i2"), ("R", "<i2"), ("cx", "<i2"), ("cy", "<i2"),
                               ("wp", "<i2"), ("weight", "<i2"), ("offset", "<i2"), ("wp_round", "<i2"), ("wp_denom", "<i2"), ("pad", "<i2")])
 DIST_JOB_DTYPE = np.dtype([("pic_x", "<i2"), ("pic_y", "<i2"), ("bsx", "<i2"), ("bsy", "<i2"),

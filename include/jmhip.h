@@ -235,12 +235,24 @@ int jmhip_me_subpel(jmhip_ctx *ctx, const jmhip_me_params *prm, const jmhip_me_m
  *     distortion8x8 over the four 8x8 blocks -- with JM's diff64 layout (the 8x8 block's four 4x4 residual blocks stored one after
  *     the other and read back as 8 rows of 8, :1496-1505): layout = JMHIP_DIFF64_SEQUENTIAL;
  *   GetSkipCostMB (src/mv-search.c:1136): the same sums on the true 8x8 raster: layout = JMHIP_DIFF64_RASTER.
- * Prediction per 4x4 block as LumaPrediction(.., 4, 4, ..) (list 0, no weights): its own vector, its own reference slot, UMV origin
- * clamp per 4x4 block. metric: input->ModeDecisionMetric, 0 = SAD, 2 = SATD (src/me_distortion.c:76, :110). out[i] = {cost4x4, cost8x8}.
+ * Prediction per 4x4 block as LumaPrediction(.., 4, 4, ..): its own vector(s) and reference slot(s), UMV origin clamp per 4x4 block. metric: input->ModeDecisionMetric, 0 = SAD, 2 = SATD (src/me_distortion.c:76, :110). out[i] = {cost4x4, cost8x8}.
  * (The two layouts yield equal sums: the sequential one permutes the index bits of the 8x8 block and the Hadamard magnitudes' sum is
  * invariant under that; both are implemented literally and tested.) */
 enum { JMHIP_DIFF64_SEQUENTIAL = 0, JMHIP_DIFF64_RASTER = 1 };
-typedef struct { int16_t mb_x, mb_y; int16_t mv[16][2]; int8_t ref[16]; } jmhip_predcost_job;   /* 4x4 blocks in raster order y*4+x */
+/* One macroblock's prediction as LumaPrediction forms it (src/macroblock.c:836-945), 4x4 blocks in raster order y*4+x:
+ *   bi[b] == 0: list-X prediction from (mv[b], ref[b]);  bi[b] != 0: p_dir 2, the second operand is (mv1[b], ref1[b]).
+ *   weighted == 0: the sample or (a + b + 1) >> 1; weighted != 0: clip1(((w0*a + wp_round) >> denom) + off) (uni) or
+ *   clip1(((w0*a + w1*b + 2*wp_round) >> (denom + 1)) + off) (bi), per block (the weights depend on the references).
+ * blocks: bit b set = 4x4 block b counts in cost4x4; an 8x8 block counts in cost8x8 when all four of its 4x4 blocks are set
+ * (BIDPartitionCost src/mv-search.c:1050 evaluates one partition; TransformDecision / GetSkipCostMB the whole macroblock: 0xffff). */
+typedef struct {
+  int16_t mb_x, mb_y;
+  uint16_t blocks;
+  int16_t weighted, wp_round, wp_denom;
+  int16_t mv[16][2], mv1[16][2];
+  int8_t  ref[16], ref1[16], bi[16];
+  int16_t w0[16], w1[16], off[16];
+} jmhip_predcost_job;
 int jmhip_pred_cost_batch(jmhip_ctx *ctx, const jmhip_predcost_job *jobs, int n, int metric, int layout, int32_t (*out)[2]);
 
 /* ------------------------------------------------------------------ transform / quant / recon */

@@ -37,12 +37,13 @@ extern int ****ptLevelOffset4x4;
 extern void SetMotionVectorPredictor(short pmv[2], char **refPic, short ***tmp_mv, short ref_frame, int list,
                                      int block_x, int block_y, int blockshape_x, int blockshape_y);
 extern const int LEVELMVLIMIT[17][6];
+extern int *mvbits;                       /* src/mv-search.c:59 */
 
-enum { S_LUMA, S_CHROMA, S_FULL, S_SUB, S_FAST, S_D4, S_D8, S_D16, S_DCR, S_WALK, S_SAD, S_SATD, S_BIFULL, S_BISUB, S_TDEC, S_SKIPC, S_COUNT };
+enum { S_LUMA, S_CHROMA, S_FULL, S_SUB, S_FAST, S_D4, S_D8, S_D16, S_DCR, S_WALK, S_SAD, S_SATD, S_BIFULL, S_BISUB, S_TDEC, S_SKIPC, S_BIDC, S_COUNT };
 static const char *s_names[S_COUNT] = { "getSubImagesLuma", "getSubImagesChroma", "FullPelBlockMotionSearch",
   "SubPelBlockMotionSearch", "FastFullPelBlockMotionSearch", "dct_4x4", "dct_8x8", "dct_16x16", "dct_chroma",
   "EPZS_UMHex_integer_walks", "computeSAD", "computeSATD", "FullPelBlockMotionBiPred", "SubPelBlockSearchBiPred",
-  "TransformDecision", "GetSkipCostMB" };
+  "TransformDecision", "GetSkipCostMB", "BIDPartitionCost" };
 static long n_dev[S_COUNT], n_fwd[S_COUNT];
 static unsigned shim_mask = 0x7ff;
 static int verify;            /* JMHIP_SHIM_VERIFY=1: run JM's own search beside the device's and report differences */
@@ -611,7 +612,7 @@ static int predcost_job(Macroblock *currMB, jmhip_predcost_job *job, int skip)
   int weighted = (active_pps->weighted_pred_flag && (img->type == P_SLICE || img->type == SP_SLICE)) || (active_pps->weighted_bipred_idc && img->type == B_SLICE);
   if (weighted || input->ModeDecisionMetric == ERROR_SSE || !cur_ready() || img->mb_data[img->current_mb_nr].list_offset) return 0;
   memset(job, 0, sizeof(*job));
-  job->mb_x = img->opix_x >> 4; job->mb_y = img->opix_y >> 4;
+  job->mb_x = img->opix_x >> 4; job->mb_y = img->opix_y >> 4; job->blocks = 0xffff;
   for (b8 = 0; b8 < 4; b8++) {
     short p_dir = 0, l0_ref = 0, l1_ref = 0; int l0_mode = 0, l1_mode = 0, slot;
     if (!skip) {
@@ -669,6 +670,58 @@ int GetSkipCostMB(Macroblock *currMB)
   { int bx, by; for (by = 0; by < 16; by += 4) for (bx = 0; bx < 16; bx += 4) LumaPrediction(currMB, bx, by, 4, 4, 0, 0, 0, 0, 0); }   /* img->mpr side effect */
   n_dev[S_SKIPC]++;
   return (input->rdopt == 0 && input->Transform8x8Mode) ? out[0][1] : out[0][0];      /* mv-search.c:1167-1177 */
+}
+
+/* BIDPartitionCost (src/mv-search.c:1050): mvd bits on the host, the bi-predicted residual distortion of the partition on the device */
+int BIDPartitionCost(Macroblock *currMB, int blocktype, int block8x8, short ref_l0, short ref_l1, int lambda_factor)
+{
+  static int (*orig)(Macroblock *, int, int, short, short, int);
+  static const int bx0[5][4] = {{0,0,0,0}, {0,0,0,0}, {0,0,0,0}, {0,2,0,0}, {0,2,0,2}};
+  static const int by0[5][4] = {{0,0,0,0}, {0,0,0,0}, {0,2,0,0}, {0,0,0,0}, {0,0,2,2}};
+  jmhip_predcost_job job; int32_t out[1][2];
+  int parttype = blocktype < 4 ? blocktype : 4;
+  int step_h0 = input->part_size[parttype][0], step_v0 = input->part_size[parttype][1];
+  int step_h = input->part_size[blocktype][0], step_v = input->part_size[blocktype][1];
+  int bx = bx0[parttype][block8x8], by = by0[parttype][block8x8], v, h, mvd_bits = 0, s0, s1;
+  int weighted = (active_pps->weighted_bipred_idc && img->type == B_SLICE) || (active_pps->weighted_pred_flag && (img->type == P_SLICE || img->type == SP_SLICE));
+  int ok = (shim_mask & 0x400) && input->ModeDecisionMetric != ERROR_SSE && cur_ready() && !img->mb_data[img->current_mb_nr].list_offset &&
+           ref_l0 >= 0 && ref_l1 >= 0;
+  if (ok) { s0 = slot_find(listX[LIST_0][ref_l0]); s1 = slot_find(listX[LIST_1][ref_l1]); ok = s0 >= 0 && s1 >= 0; }
+  if (!ok) {
+    if (!orig) orig = next_sym("BIDPartitionCost");
+    n_fwd[S_BIDC]++;
+    return orig(currMB, blocktype, block8x8, ref_l0, ref_l1, lambda_factor);
+  }
+  memset(&job, 0, sizeof(job));
+  job.mb_x = img->opix_x >> 4; job.mb_y = img->opix_y >> 4;
+  job.weighted = weighted; job.wp_round = wp_luma_round; job.wp_denom = luma_log_weight_denom;
+  for (v = by; v < by + step_v0; v += step_v)
+    for (h = bx; h < bx + step_h0; h += step_h) {
+      mvd_bits += mvbits[img->all_mv[v][h][LIST_0][ref_l0][blocktype][0] - img->pred_mv[v][h][LIST_0][ref_l0][blocktype][0]];
+      mvd_bits += mvbits[img->all_mv[v][h][LIST_0][ref_l0][blocktype][1] - img->pred_mv[v][h][LIST_0][ref_l0][blocktype][1]];
+      mvd_bits += mvbits[img->all_mv[v][h][LIST_1][ref_l1][blocktype][0] - img->pred_mv[v][h][LIST_1][ref_l1][blocktype][0]];
+      mvd_bits += mvbits[img->all_mv[v][h][LIST_1][ref_l1][blocktype][1] - img->pred_mv[v][h][LIST_1][ref_l1][blocktype][1]];
+    }
+  for (v = by; v < by + step_v0; v++)
+    for (h = bx; h < bx + step_h0; h++) {
+      int b = v * 4 + h;
+      short ****mv_array = img->all_mv[v][h];
+      /* the bi-pred ME vectors replace the ordinary ones for the 16x16 / ref 0 pair (LumaPrediction, macroblock.c:862-863) */
+      if (currMB->bi_pred_me && ref_l0 == 0 && ref_l1 == 0 && blocktype == 1) mv_array = currMB->bi_pred_me == 1 ? img->bipred_mv1[v][h] : img->bipred_mv2[v][h];
+      job.blocks |= (uint16_t)(1u << b);
+      job.bi[b] = 1; job.ref[b] = (int8_t)s0; job.ref1[b] = (int8_t)s1;
+      job.mv[b][0] = mv_array[LIST_0][ref_l0][blocktype][0]; job.mv[b][1] = mv_array[LIST_0][ref_l0][blocktype][1];
+      job.mv1[b][0] = mv_array[LIST_1][ref_l1][blocktype][0]; job.mv1[b][1] = mv_array[LIST_1][ref_l1][blocktype][1];
+      if (weighted) {
+        job.w0[b] = wbp_weight[0][ref_l0][ref_l1][0]; job.w1[b] = wbp_weight[1][ref_l0][ref_l1][0];
+        job.off[b] = (wp_offset[0][ref_l0][0] + wp_offset[1][ref_l1][0] + 1) >> 1;
+      }
+    }
+  OK(jmhip_pred_cost_batch(g, &job, 1, input->ModeDecisionMetric, JMHIP_DIFF64_RASTER, out));
+  for (v = by; v < by + step_v0; v++)                   /* img->mpr side effect, with JM's own routine */
+    for (h = bx; h < bx + step_h0; h++) LumaPrediction(currMB, h << 2, v << 2, 4, 4, 2, blocktype, blocktype, ref_l0, ref_l1);
+  n_dev[S_BIDC]++;
+  return WEIGHTED_COST(lambda_factor, mvd_bits) + ((input->Transform8x8Mode && blocktype <= 4) ? out[0][1] : out[0][0]);
 }
 
 /* ------------------------------------------------------------------ transform + quantisation + reconstruction */

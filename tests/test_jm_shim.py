@@ -160,6 +160,8 @@ def test_jm_with_hip_hot_path_is_byte_identical(tmp_path, name):
         assert served["dct_8x8"][0] > 100
     if name == "lowcplx_t8_decision":
         assert served["TransformDecision"][0] > 100 and served["GetSkipCostMB"][0] > 50
+    if CASES[name]["bframes"] and name != "epzs_main":
+        assert served["BIDPartitionCost"][0] > 500, "bi-directional partition costs were not served by the device"
     if CASES[name].get("bipred"):
         assert served["FullPelBlockMotionBiPred"][0] > 100 and served["FullPelBlockMotionBiPred"][1] == 0
         assert served["SubPelBlockSearchBiPred"][0] > 50 and served["SubPelBlockSearchBiPred"][1] == 0
