@@ -17,6 +17,7 @@
 // (4x4: 16 lanes per macroblock), all butterflies are 32-bit integer add/shift in registers -- no MFMA: this is
 // not a dense contraction (the 4x4 "matrix" has entries +-1, +-2 applied as shifts).
 #include "jmhip_internal.h"
+#include <cstddef>
 
 namespace {
 
@@ -149,6 +150,8 @@ __device__ void xf8_tile(int (*m)[16], int py, int px, bool inverse)  // forward
   }
 }
 
+static_assert(offsetof(jmhip_tq_result, fadjust) % 8 == 0 && sizeof(jmhip_tq_result) % 8 == 0, "fadjust rows are written as int2");
+
 // ---------------------------------------------------------------------------------------- dct_4x4: one lane per 4x4 block
 
 // `select`: frame stage -- a job marked as an 8x8-transform macroblock (intra16_unused != 0) belongs to tq_luma8x8_kernel
@@ -177,6 +180,7 @@ __global__ __launch_bounds__(256) void tq_luma4x4_kernel(const jmhip_tq_job *__r
   fwd4(m);
 
   int scan_pos = 0, run = -1, nonzero = 0, cost = 0;
+  int fa[4][4];                                      // fadjust of this block, stored as 8-byte pairs at the end
   int *levels = o.levels[blk], *runs = o.runs[blk];
 #pragma unroll
   for (int k = 0; k < 16; k++) {
@@ -201,11 +205,17 @@ __global__ __launch_bounds__(256) void tq_luma4x4_kernel(const jmhip_tq_job *__r
       deq = rsr((level * q.invlevelscale[idx]) << qp_per, 4);                                             // block.c:907
       run = -1;
     }
-    if (q.adaptive_rounding) o.fadjust[by + (idx >> 2)][bx + (idx & 3)] = fadj;
-    if (q.field_scan) m[j1][i1] = deq; else m[j0][i0] = deq;
+    if (q.field_scan) { m[j1][i1] = deq; fa[j1][i1] = fadj; } else { m[j0][i0] = deq; fa[j0][i0] = fadj; }
   }
   levels[scan_pos] = 0;
   o.coeff_cost[blk] = cost; o.nonzero[blk] = nonzero;
+  if (q.adaptive_rounding) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      int2 *d = reinterpret_cast<int2 *>(&o.fadjust[by + j][bx]);       // the struct keeps this 8-byte aligned
+      d[0] = make_int2(fa[j][0], fa[j][1]); d[1] = make_int2(fa[j][2], fa[j][3]);
+    }
+  }
 
   if (scan_pos) inv4(m);
 #pragma unroll
@@ -564,6 +574,8 @@ __global__ __launch_bounds__(256) void tq_chroma420_kernel(const jmhip_tq_job *_
   // ---- AC of this lane's block (scan positions 1..15)
   int coeff_cost = 0, any = 0;
   scan_pos = 0; run = -1;
+  int fa[4][4];
+  fa[0][0] = 0;                                      // the DC position is not dct_chroma's to write (block.c:1321: AC only); the buffer's own zero stays
   int *levels = o.levels[b4], *runs = o.runs[b4];
 #pragma unroll
   for (int k = 1; k < 16; k++) {
@@ -586,10 +598,16 @@ __global__ __launch_bounds__(256) void tq_chroma420_kernel(const jmhip_tq_job *_
       run = -1;
       deq = rsr((level * q.invlevelscale[idx]) << qp_per, 4);
     }
-    if (live && q.adaptive_rounding) o.fadjust[by + (idx >> 2)][bx + (idx & 3)] = fadj;
-    if (q.field_scan) m[j1][i1] = deq; else m[j0][i0] = deq;
+    if (q.field_scan) { m[j1][i1] = deq; fa[j1][i1] = fadj; } else { m[j0][i0] = deq; fa[j0][i0] = fadj; }
   }
   if (live) levels[scan_pos] = 0;
+  if (live && q.adaptive_rounding) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      int2 *d = reinterpret_cast<int2 *>(&o.fadjust[by + j][bx]);
+      d[0] = make_int2(fa[j][0], fa[j][1]); d[1] = make_int2(fa[j][2], fa[j][3]);
+    }
+  }
   if (any) cbp |= 1LL << (16 + 4 * uv + b4);                           // cbp_blk_chroma[uv][b4], block.h:109 (4:2:0: one 8x8 per component)
 
   // ---- thresholding over the four blocks of the component (_CHROMA_COEFF_COST_ = 4), block.c:1384-1410
