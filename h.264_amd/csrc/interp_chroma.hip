@@ -24,29 +24,34 @@ __global__ __launch_bounds__(256) void interp_chroma_kernel(const uint8_t *__res
   if (gi >= Wcp || gj >= Hcp - 1) return;          // last row keeps its zeros
   const uint8_t *r0 = src + (size_t)clampi(gj - pad_y, 0, Hc - 1) * Wc;
   const uint8_t *r1 = src + (size_t)clampi(gj - pad_y + 1, 0, Hc - 1) * Wc;
-  int a[5], b[5];
+  // five source samples of the two rows as adjacent pairs of 16-bit lanes: all sums stay below 2^15 (8*8*255 + 32), so the
+  // blends run on packed 16-bit lanes (v_pk_mul_lo_u16 / v_pk_mad_u16 / v_pk_lshrrev_b16), two samples per instruction
+  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+  unsigned short a[5], b[5];
 #pragma unroll
   for (int k = 0; k < 5; k++) {
     const int x = clampi(gi + k - pad_x, 0, Wc - 1);
     a[k] = r0[x]; b[k] = r1[x];
   }
+  const us2 a01 = {a[0], a[1]}, a12 = {a[1], a[2]}, a23 = {a[2], a[3]}, a34 = {a[3], a[4]};
+  const us2 b01 = {b[0], b[1]}, b12 = {b[1], b[2]}, b23 = {b[2], b[3]}, b34 = {b[3], b[4]};
   const bool last_group = (gi + 3 == Wcp - 1);     // last padded column keeps its zero
   const size_t plane = (size_t)Wcp * Hcp;
   uint32_t *o = reinterpret_cast<uint32_t *>(out + (size_t)gj * Wcp + gi);
 #pragma unroll
   for (int sx = 0; sx < SUBX; sx++) {
-    const int l = sx * MULX;
-    int h0[4], h1[4];
+    const unsigned short l = (unsigned short)(sx * MULX), l8 = (unsigned short)(8 - sx * MULX);
+    const us2 h0lo = a01 * l8 + a12 * l, h0hi = a23 * l8 + a34 * l;      // samples (0,1) and (2,3) of the upper row
+    const us2 h1lo = b01 * l8 + b12 * l, h1hi = b23 * l8 + b34 * l;
+    uint32_t *p = o + (size_t)sx * (plane / 4);                       // plane (sy, sx): stride SUBX planes per sy
 #pragma unroll
-    for (int x = 0; x < 4; x++) { h0[x] = (8 - l) * a[x] + l * a[x + 1]; h1[x] = (8 - l) * b[x] + l * b[x + 1]; }
-#pragma unroll
-    for (int sy = 0; sy < SUBY; sy++) {
-      const int k = sy * MULY;
-      uint32_t v = 0;
-#pragma unroll
-      for (int x = 0; x < 4; x++) v |= (uint32_t)(((8 - k) * h0[x] + k * h1[x] + 32) >> 6) << (8 * x);
+    for (int sy = 0; sy < SUBY; sy++, p += (size_t)SUBX * (plane / 4)) {
+      const unsigned short k = (unsigned short)(sy * MULY), k8 = (unsigned short)(8 - sy * MULY);
+      const us2 lo = (h0lo * k8 + h1lo * k + (unsigned short)32) >> (unsigned short)6;
+      const us2 hi = (h0hi * k8 + h1hi * k + (unsigned short)32) >> (unsigned short)6;
+      uint32_t v = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi), __builtin_bit_cast(uint32_t, lo), 0x06040200u);   // the four low bytes
       if (last_group) v &= 0x00ffffffu;
-      o[(size_t)(sy * SUBX + sx) * (plane / 4)] = v;
+      *p = v;
     }
   }
 }
