@@ -1386,8 +1386,8 @@ constexpr int FAST_MAX_CENTRES = 8;
 // JMHIP_ME_KERNEL=single selects the one-lane-per-candidate kernel (2R+1 >= 64 only); default: the pair-lane kernel (2R+1 >= 32)
 static int me_use_pair_kernel()
 {
-  static const int v = [] { const char *e = getenv("JMHIP_ME_KERNEL"); return e && !strcmp(e, "single") ? 0 : 1; }();
-  return v;
+  const char *e = getenv("JMHIP_ME_KERNEL");         // read per call: tests switch it
+  return e && !strcmp(e, "single") ? 0 : 1;
 }
 
 static void host_center(const jmhip_me_params *prm, int pmx, int pmy, int *cx, int *cy)

@@ -128,6 +128,14 @@ def test_me_pair_kernel_other_ranges(pkg, R, mode, rdopt, per_partition, spread)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode,rdopt,per_partition,spread", [(0, 1, True, 8), (-1, 0, False, 8), (-1, 1, True, 5), (0, 0, True, 4)])
+def test_me_single_lane_kernel_still_agrees(pkg, mode, rdopt, per_partition, spread, monkeypatch):
+    """JMHIP_ME_KERNEL=single: the one-lane-per-candidate kernel the pair-lane kernel replaced stays selectable and exact."""
+    monkeypatch.setenv("JMHIP_ME_KERNEL", "single")
+    run_case(pkg, 96, 64, "shift", mode, 32, rdopt, spread, per_partition=per_partition, seed=77 + spread)
+
+
+@pytest.mark.gpu
 def test_me_mixed_fast_and_generic_macroblocks(pkg):
     """FullSearch where some MBs have one predictor (fast kernel) and others per-partition predictors (generic)."""
     rng = np.random.default_rng(5)
