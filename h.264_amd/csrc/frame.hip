@@ -26,7 +26,7 @@ struct FrameDev {
 
 __device__ __forceinline__ int clampi(int x, int lo, int hi) { return min(max(x, lo), hi); }
 
-// partition index (me_search.hip table order) that covers luma 4x4 block (x4,y4) for a macroblock mode
+// partition index (me_common.h table order) that covers luma 4x4 block (x4,y4) for a macroblock mode
 __device__ __forceinline__ int covering_partition(const jmhip_mb_mode &m, int x4, int y4)
 {
   const int b8 = 2 * (y4 >> 1) + (x4 >> 1);

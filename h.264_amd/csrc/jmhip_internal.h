@@ -85,6 +85,9 @@ int jm_launch_interp_chroma(jmhip_ctx *ctx, int ref, int prow0 = 0, int prow1 = 
 constexpr int JMHIP_TQ_SELECT = 0x100;   // frame stage: each luma kernel takes only the macroblocks of its transform size
 int jm_launch_tq(jmhip_ctx *ctx, int kind, int yuv_format, const void *jobs, const void *quants, void *results, int n);
 int jm_ensure_ref_table(jmhip_ctx *ctx);
+struct MeDev;
+int jm_me_sub_tables(jmhip_ctx *ctx);                                                   // me_sub.hip
+void jm_launch_me_sub(jmhip_ctx *ctx, const MeDev &P, const jmhip_me_mb *jobs_dev, jmhip_me_result *res_dev, int n);
 
 // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8) and every XCD has its own L2. Kernels whose neighbouring
 // work items share data (adjacent macroblocks: overlapping reference windows) take their item through this mapping, which
