@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 W, H, R = 1920, 1088, 32
 
 
-def clip():
+def clip(W=W, H=H):
     rng = np.random.default_rng(20260410)
     B = rng.integers(0, 256, (H // 8 + 16, W // 8 + 16)).astype(np.float64)
     B = np.kron(B, np.ones((8, 8)))
@@ -27,9 +27,10 @@ def clip():
     return cur, ref
 
 
-def test_full_frame_search_1080p(pkg):
+@pytest.mark.parametrize("W,H", [(1920, 1088), (3840, 2160)])          # BASELINE configs 2 and 4
+def test_full_frame_search(pkg, W, H):
     from h264_amd.jmhip import ME_MB_DTYPE
-    cur, ref = clip()
+    cur, ref = clip(W, H)
     mbw, mbh = W // 16, H // 16
     n = mbw * mbh
     rng = np.random.default_rng(5)
@@ -65,8 +66,8 @@ def test_full_frame_search_1080p(pkg):
     assert hit > 0.9, hit
 
     # ---- oracle on a sample: corners/edges (UMV windows) and interior rows
-    rows = [0, 1, 33, 34, 66, 67]
-    sel = np.concatenate([np.arange(r * mbw, (r + 1) * mbw, 3) for r in rows])
+    rows = [0, 1, mbh // 2 - 1, mbh // 2, mbh - 2, mbh - 1]
+    sel = np.concatenate([np.arange(r * mbw, (r + 1) * mbw, 3 * (W // 1920)) for r in rows])
     L = oracle.lib()
     p = oracle.me_params(rdopt=1)
     rp = oracle.RefPic(ref, yuv_format=0)
