@@ -225,10 +225,15 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
     dist = None
+    # JMHIP_BENCH_REHEARSAL=1: rehearse the N > 1 control flow on ONE GPU (every rank on cuda:0, gloo instead of RCCL, the band
+    # exchange staged through host memory). For testing the multi-process path where no multi-GPU node is at hand; the numbers mean nothing.
+    rehearsal = os.environ.get("JMHIP_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if rehearsal else "nccl", rank=rank, world_size=world)
     dev = torch.device("cuda", local_rank)
 
     # ---- slice of this rank: whole macroblock rows, B = ceil(MBH / world) rows per rank
@@ -283,8 +288,16 @@ def main():
         else:
             if n:
                 ctx.recon_copy_band(sY.data_ptr(), sU.data_ptr(), sV.data_ptr(), row0, row1 - row0)
-            with torch.cuda.stream(ext):
-                slices.all_gather_recon(dist, gbufs, sviews)
+            if rehearsal:
+                ctx.sync()
+                for g, s in zip(gbufs, sviews):
+                    gc, sc = torch.empty(g.shape, dtype=g.dtype), s.cpu()
+                    dist.all_gather_into_tensor(gc, sc)
+                    g.copy_(gc)
+                torch.cuda.synchronize()
+            else:
+                with torch.cuda.stream(ext):
+                    slices.all_gather_recon(dist, gbufs, sviews)
             ctx.ref_upload_device(0, gY.data_ptr(), gU.data_ptr(), gV.data_ptr(), W, W // 2)
 
     def fence():
@@ -317,9 +330,19 @@ def main():
     ctx.timing_enable(False)
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # checksum of the reference picture the last step produced: the same for every N (strong scaling: the same frames are coded,
+    # only sharded differently) -- tests/test_bench_ranks.py compares N = 1 with a rehearsed N = 2
+    ctx.sync()
+    ry, ru, rv, _, _ = ctx.ref_device_planes_ro(0)
+    ref_sum = 0
+    for ptr, rows, cols in ((ry, H, W), (ru, H // 2, W // 2), (rv, H // 2, W // 2)):
+        host = np.zeros((rows, cols), np.uint8)
+        ctx.copy_from_device(ptr, host)
+        ref_sum = (ref_sum * 1000003 + int(host.astype(np.int64).sum()) + int((host.astype(np.int64) * (np.arange(cols) % 251 + 1)).sum())) % (1 << 61)
 
     if rank == 0:
         total_mbs = MBW * MBH * args.steps
@@ -352,6 +375,7 @@ def main():
                                   "ns_per_wave_candidate_row": round(VALU_NS_PER_WAVE_CANDIDATE, 1), "simds": N_SIMD,
                                   "abs_diffs_per_s": round(sad_ops, 1)}},
             "stages_ms_per_launch": {k: round(v[0] / max(1, v[1]), 4) for k, v in stage.items()},
+            "ref_checksum": ref_sum,
         }
         if world == 1 and args.cpu_mbs > 0:
             ref = cpu_baseline_reference(frames)

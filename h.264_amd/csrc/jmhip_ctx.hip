@@ -272,6 +272,28 @@ extern "C" int jmhip_cur_upload(jmhip_ctx *c, const void *Y, const void *U, cons
   return JMHIP_OK;
 }
 
+extern "C" int jmhip_ref_planes_peek(jmhip_ctx *c, int ref, void **Y, void **U, void **V, int *pitch_y, int *pitch_c)
+{
+  if (!c) return JMHIP_ERR_ARG;
+  if (ref < 0 || ref >= (int)c->refs.size()) return jm_fail(c, JMHIP_ERR_ARG, "ref slot out of range");
+  const RefSlot &r = c->refs[ref];
+  if (Y) *Y = r.y;
+  if (U) *U = r.u;
+  if (V) *V = r.v;
+  if (pitch_y) *pitch_y = c->W;
+  if (pitch_c) *pitch_c = c->Wc;
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_copy_from_device(jmhip_ctx *c, const void *device_src, void *host_dst, size_t bytes)
+{
+  if (!c || !device_src || !host_dst) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_copy_from_device: NULL") : JMHIP_ERR_ARG;
+  JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
+  JM_HIP_CHECK(c, hipMemcpyAsync(host_dst, device_src, bytes, hipMemcpyDeviceToHost, c->stream));
+  JM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+  return JMHIP_OK;
+}
+
 extern "C" int jmhip_cur_bind(jmhip_ctx *c, const void *Y, const void *U, const void *V)
 {
   if (!c || !Y || (c->Wc && (!U || !V))) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_cur_bind: NULL plane") : JMHIP_ERR_ARG;

@@ -134,6 +134,8 @@ def load_library():
     lib.jmhip_recon_copy_band.argtypes = [vp, vp, vp, vp, ip, ip]
     lib.jmhip_sizeof.argtypes = [ip]
     lib.jmhip_cur_bind.argtypes = [vp, vp, vp, vp]
+    lib.jmhip_ref_planes_peek.argtypes = [vp, ip, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(ip), C.POINTER(ip)]
+    lib.jmhip_copy_from_device.argtypes = [vp, vp, vp, C.c_size_t]
     lib.jmhip_pred_cost_batch.argtypes = [vp, vp, ip, ip, ip, vp]
     lib.jmhip_stream_handle.argtypes = [vp]
     lib.jmhip_stream_handle.restype = vp
@@ -244,6 +246,18 @@ class Context:
 
     def cur_upload_device(self, y_ptr, u_ptr, v_ptr, stride_y, stride_c):
         self._chk(self.lib.jmhip_cur_upload(self.h, y_ptr, u_ptr, v_ptr, 1, stride_y, stride_c, 1), "jmhip_cur_upload(device)")
+
+    def ref_device_planes_ro(self, ref):
+        """Device pointers of the slot's picture planes for READING (does not invalidate the slot's sub-pel planes)."""
+        s = self.lib.jmhip_ref_planes_peek
+        y, u, v = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        py, pc = C.c_int(), C.c_int()
+        self._chk(s(self.h, ref, C.byref(y), C.byref(u), C.byref(v), C.byref(py), C.byref(pc)), "jmhip_ref_planes_peek")
+        return y.value, u.value, v.value, py.value, pc.value
+
+    def copy_from_device(self, ptr, host):
+        """Stream-ordered device-to-host copy of a tight uint8 plane (test / checksum helper)."""
+        self._chk(self.lib.jmhip_copy_from_device(self.h, ptr, _ptr(host), host.nbytes), "jmhip_copy_from_device")
 
     def ref_device_planes(self, ref):
         y, u, v = C.c_void_p(), C.c_void_p(), C.c_void_p()

@@ -22,6 +22,7 @@
 #ifndef JMHIP_H
 #define JMHIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -103,6 +104,11 @@ int jmhip_ref_download_chroma(jmhip_ctx *ctx, int ref, int uv, void *out, int pe
 /* Device addresses of a slot's integer-pel picture (for device-to-device exchange, e.g. the RCCL
  * all-gather of reconstructed slice bands): pitch in bytes. */
 int jmhip_ref_device_planes(jmhip_ctx *ctx, int ref, void **Y, void **U, void **V, int *pitch_y, int *pitch_c);
+
+/* Read-only view of a slot's picture planes (does not touch the slot's state), and a stream-ordered device-to-host copy: for
+ * checks and checksums (bench.py's ref_checksum). */
+int jmhip_ref_planes_peek(jmhip_ctx *ctx, int ref, void **Y, void **U, void **V, int *pitch_y, int *pitch_c);
+int jmhip_copy_from_device(jmhip_ctx *ctx, const void *device_src, void *host_dst, size_t bytes);
 
 /* Upload the current (source) picture: pCurImg / imgUV_org (inc/global.h). */
 int jmhip_cur_upload(jmhip_ctx *ctx, const void *Y, const void *U, const void *V,

@@ -1,0 +1,34 @@
+"""bench.py's N > 1 control flow, rehearsed on ONE GPU (JMHIP_BENCH_REHEARSAL=1: every rank on cuda:0, gloo, exchange through host
+memory): torch.distributed.run launches two ranks, each codes its band of macroblock rows, the bands are gathered every frame.
+The reference picture after the last step must be the one a single process produces -- same frames, only sharded -- and only
+rank 0 may print the JSON line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(cmd, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_two_ranks_rebuild_the_same_reference_as_one():
+    one = run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--cpu-mbs", "0"])
+    two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29541", "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--cpu-mbs", "0"],
+              {"JMHIP_BENCH_REHEARSAL": "1"})
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["config"]["slices"] == 2
+    assert one["ref_checksum"] == two["ref_checksum"], "the sharded run did not reproduce the single-process reference picture"
+    for d in (one, two):
+        for key in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+            assert key in d
