@@ -57,8 +57,16 @@ def pmc_traffic(kernel, n_units):
         return None
 
 
-def synth_frames(nframes):
-    """SURVEY 8(d) recipe: blurred random field translated by (+4,-4)/frame + N(0,2) noise; chroma from luma."""
+def synth_frames(nframes, noise_clip=False):
+    """SURVEY 8(d) recipe: blurred random field translated by (+4,-4)/frame + N(0,2) noise; chroma from luma.
+    noise_clip: the recipe's adversarial second clip, i.i.d. uniform samples (every partition finds its own vector)."""
+    if noise_clip:
+        frames = []
+        for f in range(nframes):
+            r = np.random.default_rng(1000 + f)
+            Y = r.integers(0, 256, (H, W), dtype=np.uint8)
+            frames.append((Y, r.integers(0, 256, (H // 2, W // 2), dtype=np.uint8), r.integers(0, 256, (H // 2, W // 2), dtype=np.uint8)))
+        return frames
     rng = np.random.default_rng(20260410)
     B = rng.integers(0, 256, (H // 8 + 16, W // 8 + 16)).astype(np.float64)
     B = np.kron(B, np.ones((8, 8)))
@@ -206,6 +214,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu-mbs", type=int, default=4 * MBW, help="macroblocks in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--clip", choices=["translation", "noise"], default="translation",
+                    help="translation = SURVEY 8(d)'s clip (default, the metric's workload); noise = its adversarial i.i.d. clip, for information only")
     ap.add_argument("--size", choices=["1080p", "2160p"], default="1080p",
                     help="1080p = BASELINE config 2, the metric's workload (default); 2160p = config 4's picture size, for information only")
     args = ap.parse_args()
@@ -242,7 +252,9 @@ def main():
     rows = list(range(row0, row1))
 
     nframes = 4
-    frames = synth_frames(nframes)
+    frames = synth_frames(nframes, args.clip == "noise")
+    if args.clip == "noise":
+        args.cpu_mbs = 0
     ctx = pkg.Context(W, H, yuv_format=1, max_refs=1, search_range=R, device=local_rank)
     src = [[torch.from_numpy(p).to(dev) for p in f] for f in frames]      # source frames resident in HBM
     ctx.ref_upload(0, *frames[0])
@@ -359,7 +371,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": ("1920x1080 (coded 1920x1088, 8160 MBs)" if args.size == "1080p" else "3840x2160 (32400 MBs)") + " YUV420 P-frames, baseline tools, FullSearch +-32, "
                                    "41 partitions, SAD full-pel + SATD sub-pel, dct_4x4 + dct_chroma, QP %d, 1 reference; "
-                                   "predictor field (16,-16)+U{-8..8} qpel per MB" % QP,
+                                   "predictor field (16,-16)+U{-8..8} qpel per MB%s" % (QP, "" if args.clip == "translation" else "; ADVERSARIAL i.i.d. noise clip"),
                        "slices": world, "parallelism": "slice%d" % world},
             "roofline": {"kernel": "me_int_pair_kernel (integer full search, all 41 partitions)", "bound": "hbm",
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
