@@ -31,6 +31,10 @@ extern "C" {
 
 #define JMHIP_ABI_VERSION 1
 
+/* One context per GPU and per encoder instance. A context is NOT thread-safe (JM is single-threaded and non-reentrant; every
+ * call is issued from the thread that owns the encoder); different contexts may be used from different threads or processes.
+ * Calls are asynchronous on the context's stream unless they return data to the host; errors are returned, never hidden:
+ * there is no CPU fallback anywhere behind this interface. */
 typedef struct jmhip_ctx jmhip_ctx;
 
 enum {
