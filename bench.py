@@ -269,11 +269,10 @@ def main():
     quants = np.array([pkg.flat_quant(QP, 342, adaptive_rounding=1, adapt_rnd_weight=4, cavlc=1),
                        pkg.flat_quant(QP, 342, adaptive_rounding=1, adapt_rnd_weight=4, cavlc=1),
                        pkg.flat_quant(QP + 3, 342, adaptive_rounding=1, adapt_rnd_weight=4, cavlc=1)], dtype=pkg.QUANT_DTYPE)
-    # gather buffers: [world * band rows] so that rank r's band lands at its picture position
-    gbufs = slices.gather_buffers(torch, world, band, W, 8, W // 2, dev)
-    gY, gU, gV = gbufs
-    sviews = slices.send_buffers(torch, band, W, 8, W // 2, dev)
-    sY, sU, sV = sviews
+    # N > 1: one exchange buffer per rank -- its band as a single chunk [Y | U | V] -- and one gather buffer of `world` chunks
+    chunk = ctx.band_chunk_bytes(band) if world > 1 else 0
+    sbuf = torch.zeros(max(chunk, 4), dtype=torch.uint8, device=dev)
+    gbuf = torch.zeros(max(chunk * world, 4), dtype=torch.uint8, device=dev)
 
     first = [True]
     # N > 1: the all-gather is enqueued on the context's own stream (stream-ordered with the kernels round it, no host sync)
@@ -298,19 +297,17 @@ def main():
         if world == 1:
             ctx.recon_to_ref(0)
         else:
-            if n:
-                ctx.recon_copy_band(sY.data_ptr(), sU.data_ptr(), sV.data_ptr(), row0, row1 - row0)
+            ctx.recon_pack_band(sbuf.data_ptr(), rank, band)
             if rehearsal:
                 ctx.sync()
-                for g, s in zip(gbufs, sviews):
-                    gc, sc = torch.empty(g.shape, dtype=g.dtype), s.cpu()
-                    dist.all_gather_into_tensor(gc, sc)
-                    g.copy_(gc)
+                gc = torch.empty(gbuf.shape, dtype=gbuf.dtype)
+                dist.all_gather_into_tensor(gc, sbuf.cpu())
+                gbuf.copy_(gc)
                 torch.cuda.synchronize()
             else:
                 with torch.cuda.stream(ext):
-                    slices.all_gather_recon(dist, gbufs, sviews)
-            ctx.ref_upload_device(0, gY.data_ptr(), gU.data_ptr(), gV.data_ptr(), W, W // 2)
+                    dist.all_gather_into_tensor(gbuf, sbuf)
+            ctx.ref_unpack_bands(0, gbuf.data_ptr(), world, band)
 
     def fence():
         ctx.sync()

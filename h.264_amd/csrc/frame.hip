@@ -374,6 +374,77 @@ extern "C" int jmhip_recon_copy_band(jmhip_ctx *c, void *Y, void *U, void *V, in
   return JMHIP_OK;
 }
 
+// ---- one-buffer band exchange for slice-parallel ranks: a rank's reconstructed band travels as ONE chunk [Y rows | U rows | V rows]
+//      (band_rows macroblock rows, the same for every rank; the last rank's missing rows are padding), so the per-frame exchange
+//      is a single all-gather and a single scatter kernel instead of three of each.
+namespace {
+
+// chunk geometry in bytes for `band` macroblock rows
+struct BandGeom { int W, Wc, H, Hc, mb_h, band; size_t ybytes, cbytes, chunk; };
+
+__host__ __device__ inline BandGeom band_geom(int W, int Wc, int H, int Hc, int mb_h, int band)
+{
+  BandGeom g;
+  g.W = W; g.Wc = Wc; g.H = H; g.Hc = Hc; g.mb_h = mb_h; g.band = band;
+  g.ybytes = (size_t)band * 16 * W; g.cbytes = (size_t)band * mb_h * Wc; g.chunk = g.ybytes + 2 * g.cbytes;
+  return g;
+}
+
+// dir 0: picture planes (rank's rows) -> chunk; dir 1: `world` chunks -> picture planes. One dword per thread iteration.
+__global__ __launch_bounds__(256) void band_copy_kernel(BandGeom g, uint8_t *py, uint8_t *pu, uint8_t *pv, uint8_t *chunks, int first_rank, int nranks, int dir)
+{
+  const size_t chunk_dw = g.chunk / 4, total = chunk_dw * (size_t)nranks;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int r = (int)(i / chunk_dw) + first_rank;
+    size_t off = (i - (size_t)(r - first_rank) * chunk_dw) * 4;           // byte offset inside the chunk
+    uint8_t *plane; int pw, ph, rows_per_mb;
+    if (off < g.ybytes) { plane = py; pw = g.W; ph = g.H; rows_per_mb = 16; }
+    else if (off < g.ybytes + g.cbytes) { off -= g.ybytes; plane = pu; pw = g.Wc; ph = g.Hc; rows_per_mb = g.mb_h; }
+    else { off -= g.ybytes + g.cbytes; plane = pv; pw = g.Wc; ph = g.Hc; rows_per_mb = g.mb_h; }
+    const int row = (int)(off / pw), col = (int)(off - (size_t)row * pw);
+    const int prow = r * g.band * rows_per_mb + row;                       // picture row of this chunk row
+    if (prow >= ph) continue;                                              // padding rows of the last band
+    uint32_t *c = reinterpret_cast<uint32_t *>(chunks + (size_t)(r - first_rank) * g.chunk) + (i - (size_t)(r - first_rank) * chunk_dw);
+    uint32_t *p = reinterpret_cast<uint32_t *>(plane + (size_t)prow * pw + col);
+    if (dir == 0) *c = *p; else *p = *c;
+  }
+}
+
+}  // namespace
+
+extern "C" size_t jmhip_band_chunk_bytes(jmhip_ctx *c, int band_rows)
+{
+  if (!c || band_rows <= 0) return 0;
+  return band_geom(c->W, c->Wc, c->H, c->Hc, c->Wc ? c->cg.mb_h : 0, band_rows).chunk;
+}
+
+extern "C" int jmhip_recon_pack_band(jmhip_ctx *c, void *chunk, int rank, int band_rows)
+{
+  if (!c || !chunk || rank < 0 || band_rows <= 0) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_recon_pack_band: arguments") : JMHIP_ERR_ARG;
+  if (!c->rec_y || c->fr_n <= 0) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_recon_pack_band: no recon picture yet");
+  if ((c->W & 3) || (c->Wc & 3)) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_recon_pack_band: plane widths must be multiples of 4");
+  JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
+  const BandGeom g = band_geom(c->W, c->Wc, c->H, c->Hc, c->Wc ? c->cg.mb_h : 0, band_rows);
+  band_copy_kernel<<<256, 256, 0, c->stream>>>(g, c->rec_y, c->rec_u, c->rec_v, (uint8_t *)chunk, rank, 1, 0);
+  JM_HIP_CHECK(c, hipGetLastError());
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_ref_unpack_bands(jmhip_ctx *c, int ref, const void *chunks, int world, int band_rows)
+{
+  if (!c || !chunks || world <= 0 || band_rows <= 0) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_ref_unpack_bands: arguments") : JMHIP_ERR_ARG;
+  if (ref < 0 || ref >= (int)c->refs.size()) return jm_fail(c, JMHIP_ERR_ARG, "ref slot out of range");
+  if (world * band_rows < c->mbh) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_ref_unpack_bands: the bands do not cover the picture");
+  if ((c->W & 3) || (c->Wc & 3)) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_ref_unpack_bands: plane widths must be multiples of 4");
+  JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
+  RefSlot &r = c->refs[ref];
+  const BandGeom g = band_geom(c->W, c->Wc, c->H, c->Hc, c->Wc ? c->cg.mb_h : 0, band_rows);
+  band_copy_kernel<<<512, 256, 0, c->stream>>>(g, r.y, r.u, r.v, (uint8_t *)chunks, 0, world, 1);
+  JM_HIP_CHECK(c, hipGetLastError());
+  r.has_pic = true; r.has_luma_sub = false; r.has_cr_sub = false;
+  return JMHIP_OK;
+}
+
 extern "C" int jmhip_recon_download(jmhip_ctx *c, void *Y, void *U, void *V, int pel_bytes)
 {
   if (!c || !Y) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_recon_download: NULL output") : JMHIP_ERR_ARG;

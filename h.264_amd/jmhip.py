@@ -134,6 +134,10 @@ def load_library():
     lib.jmhip_recon_copy_band.argtypes = [vp, vp, vp, vp, ip, ip]
     lib.jmhip_sizeof.argtypes = [ip]
     lib.jmhip_cur_bind.argtypes = [vp, vp, vp, vp]
+    lib.jmhip_band_chunk_bytes.argtypes = [vp, ip]
+    lib.jmhip_band_chunk_bytes.restype = C.c_size_t
+    lib.jmhip_recon_pack_band.argtypes = [vp, vp, ip, ip]
+    lib.jmhip_ref_unpack_bands.argtypes = [vp, ip, vp, ip, ip]
     lib.jmhip_ref_planes_peek.argtypes = [vp, ip, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(ip), C.POINTER(ip)]
     lib.jmhip_copy_from_device.argtypes = [vp, vp, vp, C.c_size_t]
     lib.jmhip_pred_cost_batch.argtypes = [vp, vp, ip, ip, ip, vp]
@@ -368,6 +372,15 @@ class Context:
 
     def recon_to_ref(self, ref):
         self._chk(self.lib.jmhip_recon_to_ref(self.h, ref), "jmhip_recon_to_ref")
+
+    def band_chunk_bytes(self, band_rows):
+        return int(self.lib.jmhip_band_chunk_bytes(self.h, band_rows))
+
+    def recon_pack_band(self, chunk_ptr, rank, band_rows):
+        self._chk(self.lib.jmhip_recon_pack_band(self.h, chunk_ptr, rank, band_rows), "jmhip_recon_pack_band")
+
+    def ref_unpack_bands(self, ref, chunks_ptr, world, band_rows):
+        self._chk(self.lib.jmhip_ref_unpack_bands(self.h, ref, chunks_ptr, world, band_rows), "jmhip_ref_unpack_bands")
 
     def recon_copy_band(self, y_ptr, u_ptr, v_ptr, mb_row0, mb_rows):
         self._chk(self.lib.jmhip_recon_copy_band(self.h, y_ptr, u_ptr, v_ptr, mb_row0, mb_rows), "jmhip_recon_copy_band")

@@ -344,6 +344,12 @@ int jmhip_recon_to_ref(jmhip_ctx *ctx, int ref);
 int jmhip_recon_copy_band(jmhip_ctx *ctx, void *Y, void *U, void *V, int mb_row0, int mb_rows);
 /* Copy the recon picture to the host (8-bit samples). */
 int jmhip_recon_download(jmhip_ctx *ctx, void *Y, void *U, void *V, int pel_bytes);
+/* One-buffer band exchange (slice-parallel ranks): rank `rank`'s reconstructed band of `band_rows` macroblock rows
+ * as ONE device chunk [Y rows | U rows | V rows] (jmhip_band_chunk_bytes), so that one all-gather moves the frame;
+ * jmhip_ref_unpack_bands scatters the `world` gathered chunks into reference slot `ref` (rows below the picture are padding). */
+size_t jmhip_band_chunk_bytes(jmhip_ctx *ctx, int band_rows);
+int jmhip_recon_pack_band(jmhip_ctx *ctx, void *chunk_device, int rank, int band_rows);
+int jmhip_ref_unpack_bands(jmhip_ctx *ctx, int ref, const void *chunks_device, int world, int band_rows);
 
 /* sizeof() of the ABI structs, for language bindings to verify their layout: 0 jmhip_me_mb, 1 jmhip_me_result,
  * 2 jmhip_quant, 3 jmhip_tq_job, 4 jmhip_tq_result, 5 jmhip_dist_job, 6 jmhip_me_params, 7 jmhip_config,

@@ -101,3 +101,41 @@ def test_interp_rows_matches_the_full_planes_inside_the_range(pkg):
     assert np.array_equal(pl[:, :, 20 + 30:20 + 60], fl[:, :, 20 + 30:20 + 60])
     assert np.array_equal(pc[:, :, 20 + 30:20 + 60], fc[:, :, 20 + 30:20 + 60])
     assert not pl[:, :, :20].any() and not pl[:, :, 20 + 80:].any()      # far rows untouched (zero-initialised planes)
+
+
+def test_one_buffer_band_exchange(pkg):
+    """jmhip_recon_pack_band / jmhip_ref_unpack_bands: each rank's band as one chunk, `world` chunks scattered into the reference --
+    three emulated ranks (the last band partly padding) against the single-context frame."""
+    rng = np.random.default_rng(23)
+    w, h, R, world = 96, 112, 8, 3                      # 7 macroblock rows: bands of 3, 3, 1 (+2 padding)
+    mbw, mbh = w // 16, h // 16
+    cur, ref = synth(rng, w, h, 1)
+    dev = torch.device("cuda", 0)
+    cur_dev = [torch.from_numpy(p).to(dev) for p in cur]
+    lam = lambda_factors(28)
+    quants = np.array([pkg.flat_quant(28 + d, 342, adaptive_rounding=1, adapt_rnd_weight=4, cavlc=1) for d in (0, 0, 3)], dtype=pkg.QUANT_DTYPE)
+    one = pkg.Context(w, h, yuv_format=1, max_refs=1, search_range=R)
+    code(pkg, one, cur_dev, ref, list(range(mbh)), mbw, quants, lam, R)
+    want = one.recon_download()
+    one.close()
+    band = -(-mbh // world)
+    gbuf = None
+    for rank in range(world):
+        row0, row1, b = pkg.slices.band_rows(mbh, world, rank)
+        ctx = pkg.Context(w, h, yuv_format=1, max_refs=1, search_range=R)
+        code(pkg, ctx, cur_dev, ref, list(range(row0, row1)), mbw, quants, lam, R, band_interp=True)
+        chunk = ctx.band_chunk_bytes(band)
+        assert chunk == band * (16 * w + 2 * 8 * (w // 2))
+        if gbuf is None:
+            gbuf = torch.full((world * chunk,), 0xAB, dtype=torch.uint8, device=dev)
+        ctx.recon_pack_band(gbuf[rank * chunk:(rank + 1) * chunk].data_ptr(), rank, band)      # where the all-gather would put it
+        ctx.sync()
+        ctx.close()
+    chk = pkg.Context(w, h, yuv_format=1, max_refs=1, search_range=R)
+    chk.ref_unpack_bands(0, gbuf.data_ptr(), world, band)
+    y, u, v, _, _ = chk.ref_device_planes_ro(0)
+    for ptr, wantp in zip((y, u, v), want):
+        got = np.zeros_like(wantp)
+        chk.copy_from_device(ptr, got)
+        assert np.array_equal(got, wantp)
+    chk.close()
