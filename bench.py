@@ -297,7 +297,8 @@ def main():
         if world == 1:
             ctx.recon_to_ref(0)
         else:
-            ctx.recon_pack_band(sbuf.data_ptr(), rank, band)
+            if n:                                           # a rank without rows (world > picture rows / band) only receives
+                ctx.recon_pack_band(sbuf.data_ptr(), rank, band)
             if rehearsal:
                 ctx.sync()
                 gc = torch.empty(gbuf.shape, dtype=gbuf.dtype)
