@@ -40,7 +40,7 @@ def make_mbs(pkg, rng, mbw, mbh, spread, per_partition=True):
     return mbs
 
 
-def run_case(pkg, w, h, kind, mode, R, rdopt, spread, t8x8=0, per_partition=True, subpel=1, seed=0, mask=(1 << 41) - 1):
+def run_case(pkg, w, h, kind, mode, R, rdopt, spread, t8x8=0, per_partition=True, subpel=1, seed=0, mask=(1 << 41) - 1, is_b=0):
     rng = np.random.default_rng(seed)
     cur, ref = make_pair(rng, w, h, kind)
     ctx = pkg.Context(w, h, yuv_format=0, max_refs=1, search_range=R)
@@ -50,14 +50,14 @@ def run_case(pkg, w, h, kind, mode, R, rdopt, spread, t8x8=0, per_partition=True
     mbs = make_mbs(pkg, rng, w // 16, h // 16, spread, per_partition)
     lam = lambda_factors(28)
     prm = pkg.MeParams()
-    prm.search_mode, prm.search_range, prm.rdopt, prm.is_b_slice = mode, R, rdopt, 0
+    prm.search_mode, prm.search_range, prm.rdopt, prm.is_b_slice = mode, R, rdopt, is_b
     prm.level_mv_min, prm.level_mv_max = -511, 511
     prm.lambda_[0], prm.lambda_[1], prm.lambda_[2] = lam
     prm.transform8x8_mode, prm.subpel, prm.partition_mask = t8x8, subpel, mask
     got = ctx.me_frame(prm, mbs)
     ctx.close()
 
-    p = oracle.me_params(rdopt=rdopt, transform8x8_mode=t8x8)
+    p = oracle.me_params(rdopt=rdopt, is_b_slice=is_b, transform8x8_mode=t8x8)
     want = oracle.me_frame(p, [oracle.RefPic(ref, yuv_format=0)], cur, mbs, mode, R, lam, subpel=bool(subpel), mask=mask)
     for key in ("mv_int", "cost_int", "mv", "cost"):
         g, wv = got[key], want[key]
@@ -81,6 +81,13 @@ def run_case(pkg, w, h, kind, mode, R, rdopt, spread, t8x8=0, per_partition=True
 ])
 def test_me_frame_small(pkg, kind, mode, R, rdopt, spread, t8x8):
     run_case(pkg, 64, 48, kind, mode, R, rdopt, spread, t8x8, seed=R * 7 + spread)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,R,spread", [(-1, 8, 0), (-1, 32, 2), (0, 32, 3)])
+def test_b_slices_switch_the_zero_vector_bonuses_off(pkg, mode, R, spread):
+    """img->type == B_SLICE: check_for_00 (me_fullsearch.c:75) and check_position0 (:361) do not apply even with rdopt off."""
+    run_case(pkg, 96, 64, "shift", mode, R, 0, spread, per_partition=False, seed=5 + R, is_b=1)
 
 
 @pytest.mark.gpu
