@@ -231,6 +231,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # JMHIP_BENCH_SOLO="r/w": run rank r of w ALONE (no process group; the all-gather replaced by a local copy of the own chunk) to time
+    # one rank's share of an N-GPU step on a single GPU. A diagnostic: the line it prints is not a bench result.
+    solo = os.environ.get("JMHIP_BENCH_SOLO")
+    if solo:
+        rank, world = (int(v) for v in solo.split("/"))
+        args.gpus = world
+        args.cpu_mbs = 0
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
@@ -240,7 +247,7 @@ def main():
     rehearsal = os.environ.get("JMHIP_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
-    if world > 1:
+    if world > 1 and not solo:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("gloo" if rehearsal else "nccl", rank=rank, world_size=world)
@@ -299,7 +306,10 @@ def main():
         else:
             if n:                                           # a rank without rows (world > picture rows / band) only receives
                 ctx.recon_pack_band(sbuf.data_ptr(), rank, band)
-            if rehearsal:
+            if solo:
+                with torch.cuda.stream(ext):
+                    gbuf[rank * chunk:(rank + 1) * chunk].copy_(sbuf)
+            elif rehearsal:
                 ctx.sync()
                 gc = torch.empty(gbuf.shape, dtype=gbuf.dtype)
                 dist.all_gather_into_tensor(gc, sbuf.cpu())
@@ -354,7 +364,7 @@ def main():
         ctx.copy_from_device(ptr, host)
         ref_sum = (ref_sum * 1000003 + int(host.astype(np.int64).sum()) + int((host.astype(np.int64) * (np.arange(cols) % 251 + 1)).sum())) % (1 << 61)
 
-    if rank == 0:
+    if rank == 0 or solo:
         total_mbs = MBW * MBH * args.steps
         ms_step = elapsed / args.steps * 1e3
         me_ms, me_launches = stage["me_int"]
@@ -393,6 +403,8 @@ def main():
             out["cpu_baseline"] = ref if ref is not None else port
             out["cpu_baseline_port"] = port
             out["speedup_vs_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        if solo:
+            out = {"DIAGNOSTIC_solo_rank": solo, "ms_per_step_of_this_rank": out["ms_per_step"], "stages_ms_per_launch": out.get("stages_ms_per_launch")}
         print(json.dumps(out))
     ctx.close()
     if dist is not None:

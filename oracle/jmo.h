@@ -252,6 +252,25 @@ int jmo_dct_chroma(const jmo_quant *q, const jmo_quant *qdc, int yuv_format, int
                    int (*ac_levels)[16], int (*ac_runs)[16] /* [8][16] indexed b8*4+b4 within comp */,
                    jmo_pel (*recon)[16], int (*fadjust)[16], long long *cbp_blk);
 
+/* ------------------------------------------------------------------ in-loop deblocking filter (jmo_deblock.c) */
+
+/* What DeblockMb / GetStrengthNormal read of one macroblock (img->mb_data[], global.h Macroblock), raster order */
+typedef struct {
+  unsigned char intra;                 /* mb_type is I4MB, I8MB, I16MB or IPCM                                     */
+  unsigned char qp, qpc[2];            /* IPCM: 0 (DeblockFrame, loopFilter.c:107-112)                             */
+  unsigned char disable_idc;           /* LFDisableIdc                                                             */
+  signed char alpha_c0_offset, beta_offset;
+  unsigned char transform_8x8;         /* luma_transform_size_8x8_flag                                             */
+  unsigned char avail_a, avail_b;      /* mbAvailA / mbAvailB as the encoder left them (slice-aware): read for idc 2 */
+  unsigned short cbp_blk;              /* the 16 luma bits of cbp_blk                                              */
+} jmo_deblock_mb;
+/* ... and of one 4x4 block (enc_picture->mv, ->ref_pic_id with INT64_MIN where ref_idx < 0), raster order over the picture */
+typedef struct { short mv[2][2]; long long ref_id[2]; } jmo_deblock_blk;
+
+/* DeblockFrame (loopFilter.c:87) on a frame picture, in place. U = V = NULL: luma only (the decs->decY_best call, image.c:319). */
+void jmo_deblock_frame(jmo_pel *Y, jmo_pel *U, jmo_pel *V, int W, int H, int yuv_format, int bit_depth,
+                       const jmo_deblock_mb *mbs, const jmo_deblock_blk *blks, int mvlimit);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,6 +14,7 @@
  *   0x10 dct_4x4/16x16   0x20 dct_8x8            0x40 dct_chroma            0x80 transform primitives
  *   0x100 bi-predictive full-pel + sub-pel search (FullPelBlockMotionBiPred, SubPelBlockSearchBiPred)
  *   0x200 low-complexity mode-decision costs (TransformDecision, GetSkipCostMB)
+ *   0x400 in-loop deblocking filter (DeblockFrame)
  * JMO_SWAP_STATS=1 prints per-symbol call counts at exit.
  */
 #define _GNU_SOURCE
@@ -39,12 +40,12 @@ extern void SetMotionVectorPredictor(short pmv[2], char **refPic, short ***tmp_m
                                      int block_x, int block_y, int blockshape_x, int blockshape_y);
 extern const int LEVELMVLIMIT[17][6];
 
-static unsigned swap_mask = 0x3ff;
-static long n_calls[16];
-enum { C_LUMA, C_CHROMA, C_SAD, C_SATD, C_FULL, C_SUB, C_FAST, C_D4, C_D8, C_D16, C_DCR, C_PRIM, C_BIFULL, C_BISUB, C_TDEC, C_SKIPC };
+static unsigned swap_mask = 0x7ff;
+static long n_calls[17];
+enum { C_LUMA, C_CHROMA, C_SAD, C_SATD, C_FULL, C_SUB, C_FAST, C_D4, C_D8, C_D16, C_DCR, C_PRIM, C_BIFULL, C_BISUB, C_TDEC, C_SKIPC, C_DEBLOCK };
 static const char *c_names[] = { "getSubImagesLuma", "getSubImagesChroma", "computeSAD*", "computeSATD*",
   "FullPelBlockMotionSearch", "SubPelBlockMotionSearch", "FastFullPelBlockMotionSearch", "dct_4x4",
-  "dct_8x8", "dct_16x16", "dct_chroma", "transform primitives", "FullPelBlockMotionBiPred", "SubPelBlockSearchBiPred", "TransformDecision", "GetSkipCostMB" };
+  "dct_8x8", "dct_16x16", "dct_chroma", "transform primitives", "FullPelBlockMotionBiPred", "SubPelBlockSearchBiPred", "TransformDecision", "GetSkipCostMB", "DeblockFrame" };
 
 static void *next_sym(const char *name)
 {
@@ -58,7 +59,7 @@ static void print_stats(void)
   int i;
   if (!getenv("JMO_SWAP_STATS")) return;
   fprintf(stderr, "swap_oracle: mask=0x%x\n", swap_mask);
-  for (i = 0; i <= C_SKIPC; i++) fprintf(stderr, "  %-30s %ld\n", c_names[i], n_calls[i]);
+  for (i = 0; i <= C_DEBLOCK; i++) fprintf(stderr, "  %-30s %ld\n", c_names[i], n_calls[i]);
 }
 
 int main(int argc, char **argv)
@@ -427,6 +428,50 @@ int GetSkipCostMB(Macroblock *currMB)
     mb_cur(cur);
     jmo_pred_costs(cur, &img->mpr[0][0][0], input->ModeDecisionMetric, 1, &c4, &c8);
     return (input->rdopt == 0 && input->Transform8x8Mode) ? c8 : c4;      /* mv-search.c:1167-1177 */
+  }
+}
+
+/* ------------------------------------------------------------------ 0x400 in-loop deblocking filter */
+
+void DeblockFrame(ImageParameters *im, imgpel **imgY, imgpel ***imgUV)
+{
+  static void (*orig)(ImageParameters *, imgpel **, imgpel ***);
+  const int W = im->width, H = im->height, mbw = W / 16, nmb = (int)im->PicSizeInMbs, w4 = W / 4, h4 = H / 4;
+  int i, l, x, y;
+  n_calls[C_DEBLOCK]++;
+  if (!(swap_mask & 0x400) || im->MbaffFrameFlag || im->structure != FRAME || im->type == SP_SLICE || im->type == SI_SLICE ||
+      (imgUV && im->yuv_format != YUV400 && im->bitdepth_chroma != im->bitdepth_luma) || (im->yuv_format == YUV444 && IS_INDEPENDENT(input)) ||
+      imgY[1] != imgY[0] + W) {
+    if (!orig) orig = next_sym("DeblockFrame");
+    orig(im, imgY, imgUV);
+    return;
+  }
+  {
+    jmo_deblock_mb *mbs = calloc(nmb, sizeof(*mbs));
+    jmo_deblock_blk *blks = calloc((size_t)w4 * h4, sizeof(*blks));
+    for (i = 0; i < nmb; i++) {
+      Macroblock *m = &im->mb_data[i];
+      if (m->mb_type == IPCM) { m->qp = 0; m->qpc[0] = 0; m->qpc[1] = 0; }        /* loopFilter.c:105-113, a side effect that stays */
+      mbs[i].intra = m->mb_type == I4MB || m->mb_type == I8MB || m->mb_type == I16MB || m->mb_type == IPCM;
+      mbs[i].qp = (unsigned char)m->qp; mbs[i].qpc[0] = (unsigned char)m->qpc[0]; mbs[i].qpc[1] = (unsigned char)m->qpc[1];
+      mbs[i].disable_idc = (unsigned char)m->LFDisableIdc;
+      mbs[i].alpha_c0_offset = (signed char)m->LFAlphaC0Offset; mbs[i].beta_offset = (signed char)m->LFBetaOffset;
+      mbs[i].transform_8x8 = (unsigned char)m->luma_transform_size_8x8_flag;
+      mbs[i].avail_a = (unsigned char)m->mbAvailA; mbs[i].avail_b = (unsigned char)m->mbAvailB;
+      mbs[i].cbp_blk = (unsigned short)(m->cbp_blk & 0xffff);
+    }
+    for (y = 0; y < h4; y++) for (x = 0; x < w4; x++) {
+      jmo_deblock_blk *b = &blks[y * w4 + x];
+      for (l = 0; l < 2; l++) {
+        b->mv[l][0] = enc_picture->mv[l][y][x][0]; b->mv[l][1] = enc_picture->mv[l][y][x][1];
+        b->ref_id[l] = enc_picture->ref_idx[l][y][x] < 0 ? INT64_MIN : enc_picture->ref_pic_id[l][y][x];
+      }
+    }
+    jmo_deblock_frame(imgY[0], imgUV && im->yuv_format != YUV400 ? imgUV[0][0] : NULL, imgUV && im->yuv_format != YUV400 ? imgUV[1][0] : NULL,
+                      W, H, im->yuv_format, im->bitdepth_luma, mbs, blks, 4);
+    free(mbs); free(blks);
+    im->current_mb_nr = nmb - 1;            /* where DeblockMb :178 leaves it */
+    (void)mbw;
   }
 }
 

@@ -89,6 +89,10 @@ VARIANTS = {
     "main qp45": "-d encoder_main.cfg -p QPISlice=45 -p QPPSlice=45 -p QPBSlice=46",
     "main field": "-d encoder_main.cfg -p PicInterlace=1 -p ReferenceReorder=0 -p PocMemoryManagement=0",
     "main mbaff": "-d encoder_main.cfg -p MbInterlace=1 -p ReferenceReorder=0 -p PocMemoryManagement=0",
+    "main slices deblock idc2 offsets": "-d encoder_main.cfg -p SearchMode=0 -p SliceMode=1 -p SliceArgument=27 -p LoopFilterParametersFlag=1 -p LoopFilterDisable=2 -p LoopFilterAlphaC0Offset=3 -p LoopFilterBetaOffset=-2",
+    "baseline slices deblock across": "-d encoder_baseline.cfg -p SearchMode=0 -p SliceMode=1 -p SliceArgument=40 -p LoopFilterParametersFlag=1 -p LoopFilterAlphaC0Offset=-3 -p LoopFilterBetaOffset=4",
+    "high 8x8 deblock qp40": "-d encoder.cfg -p SearchMode=0 -p Transform8x8Mode=1 -p QPISlice=40 -p QPPSlice=40 -p QPBSlice=41",
+    "422 deblock qp38 8x8": "-d encoder_yuv422.cfg -p SearchMode=0 -p Transform8x8Mode=1 -p QPISlice=38 -p QPPSlice=38 -p QPBSlice=39",
     "444": "-d encoder_yuv422.cfg -p YUVFormat=3 -p ProfileIDC=244 -p InputFile=foreman_part_qcif_444.yuv",
 }
 
