@@ -346,7 +346,7 @@ extern "C" int jmhip_recon_to_ref(jmhip_ctx *c, int ref)
 {
   if (!c) return JMHIP_ERR_ARG;
   if (ref < 0 || ref >= (int)c->refs.size()) return jm_fail(c, JMHIP_ERR_ARG, "ref slot out of range");
-  if (!c->rec_y || c->fr_n <= 0) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_recon_to_ref: no recon picture yet");
+  if (!c->rec_y || !(c->fr_n > 0 || c->rec_has_pic)) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_recon_to_ref: no recon picture yet");
   RefSlot &r = c->refs[ref];
   JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
   std::swap(r.y, c->rec_y);
@@ -362,7 +362,7 @@ extern "C" int jmhip_recon_to_ref(jmhip_ctx *c, int ref)
 extern "C" int jmhip_recon_copy_band(jmhip_ctx *c, void *Y, void *U, void *V, int mb_row0, int mb_rows)
 {
   if (!c || !Y) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_recon_copy_band: NULL destination") : JMHIP_ERR_ARG;
-  if (!c->rec_y || c->fr_n <= 0) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_recon_copy_band: no recon picture yet");
+  if (!c->rec_y || !(c->fr_n > 0 || c->rec_has_pic)) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_recon_copy_band: no recon picture yet");
   if (mb_row0 < 0 || mb_rows <= 0 || mb_row0 + mb_rows > c->mbh) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_recon_copy_band: band outside the picture");
   const size_t y0 = (size_t)mb_row0 * 16 * c->W, yn = (size_t)mb_rows * 16 * c->W;
   JM_HIP_CHECK(c, hipMemcpyAsync(Y, c->rec_y + y0, yn, hipMemcpyDeviceToDevice, c->stream));
@@ -421,7 +421,7 @@ extern "C" size_t jmhip_band_chunk_bytes(jmhip_ctx *c, int band_rows)
 extern "C" int jmhip_recon_pack_band(jmhip_ctx *c, void *chunk, int rank, int band_rows)
 {
   if (!c || !chunk || rank < 0 || band_rows <= 0) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_recon_pack_band: arguments") : JMHIP_ERR_ARG;
-  if (!c->rec_y || c->fr_n <= 0) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_recon_pack_band: no recon picture yet");
+  if (!c->rec_y || !(c->fr_n > 0 || c->rec_has_pic)) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_recon_pack_band: no recon picture yet");
   if ((c->W & 3) || (c->Wc & 3)) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_recon_pack_band: plane widths must be multiples of 4");
   JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
   const BandGeom g = band_geom(c->W, c->Wc, c->H, c->Hc, c->Wc ? c->cg.mb_h : 0, band_rows);
@@ -448,13 +448,12 @@ extern "C" int jmhip_ref_unpack_bands(jmhip_ctx *c, int ref, const void *chunks,
 extern "C" int jmhip_recon_download(jmhip_ctx *c, void *Y, void *U, void *V, int pel_bytes)
 {
   if (!c || !Y) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_recon_download: NULL output") : JMHIP_ERR_ARG;
-  if (!c->rec_y || c->fr_n <= 0) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_recon_download: no recon picture yet");
-  if (pel_bytes != 1) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_recon_download: 8-bit samples only");
-  JM_HIP_CHECK(c, hipMemcpyAsync(Y, c->rec_y, (size_t)c->W * c->H, hipMemcpyDeviceToHost, c->stream));
+  if (!c->rec_y || !(c->fr_n > 0 || c->rec_has_pic)) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_recon_download: no recon picture yet");
+  int rc = jm_download_planes(c, c->rec_y, (size_t)c->W * c->H, Y, pel_bytes);
+  if (rc) return rc;
   if (c->Wc && U && V) {
-    JM_HIP_CHECK(c, hipMemcpyAsync(U, c->rec_u, (size_t)c->Wc * c->Hc, hipMemcpyDeviceToHost, c->stream));
-    JM_HIP_CHECK(c, hipMemcpyAsync(V, c->rec_v, (size_t)c->Wc * c->Hc, hipMemcpyDeviceToHost, c->stream));
+    if ((rc = jm_download_planes(c, c->rec_u, (size_t)c->Wc * c->Hc, U, pel_bytes))) return rc;
+    if ((rc = jm_download_planes(c, c->rec_v, (size_t)c->Wc * c->Hc, V, pel_bytes))) return rc;
   }
-  JM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
   return JMHIP_OK;
 }

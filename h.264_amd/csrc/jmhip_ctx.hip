@@ -28,6 +28,8 @@ extern "C" int jmhip_sizeof(int which)
   case 11: return (int)sizeof(jmhip_bipred_result);
   case 12: return (int)sizeof(jmhip_bipred_params);
   case 13: return (int)sizeof(jmhip_predcost_job);
+  case 14: return (int)sizeof(jmhip_deblock_mb);
+  case 15: return (int)sizeof(jmhip_deblock_blk);
   default: return -1;
   }
 }
@@ -111,7 +113,7 @@ extern "C" void jmhip_ctx_destroy(jmhip_ctx *c)
   (void)hipFree(c->stage_dev); (void)hipFree(c->me_jobs_dev); (void)hipFree(c->me_res_dev); (void)hipFree(c->ref_ptrs_dev); (void)hipFree(c->me_idx_dev); (void)hipFree(c->surf_dev); (void)hipFree(c->surf_jobs_dev);
   (void)hipFree(c->tq_jobs_dev); (void)hipFree(c->tq_res_dev); (void)hipFree(c->tq_quant_dev);
   (void)hipFree(c->fr_jobs_y); (void)hipFree(c->fr_jobs_c); (void)hipFree(c->fr_res_y); (void)hipFree(c->fr_res_c);
-  (void)hipFree(c->fr_quant); (void)hipFree(c->fr_modes); (void)hipFree(c->rec_y); (void)hipFree(c->rec_u); (void)hipFree(c->rec_v);
+  (void)hipFree(c->dbk_dev); (void)hipFree(c->fr_quant); (void)hipFree(c->fr_modes); (void)hipFree(c->rec_y); (void)hipFree(c->rec_u); (void)hipFree(c->rec_v);
   for (auto &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto e : c->evt_pool) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -216,7 +218,7 @@ static int ensure_stage(jmhip_ctx *c, size_t bytes)
 }
 
 // copy one plane (w x h samples) into a tightly packed 8-bit device plane
-static int upload_plane(jmhip_ctx *c, uint8_t *dst, const void *src, int w, int h, int pel_bytes, int stride, int device_ptrs)
+int jm_upload_plane(jmhip_ctx *c, uint8_t *dst, const void *src, int w, int h, int pel_bytes, int stride, int device_ptrs)
 {
   if (!src) return jm_fail(c, JMHIP_ERR_ARG, "NULL plane");
   if (stride < w) return jm_fail(c, JMHIP_ERR_ARG, "stride < width");
@@ -246,11 +248,11 @@ extern "C" int jmhip_ref_upload(jmhip_ctx *c, int ref, const void *Y, const void
   if (ref < 0 || ref >= (int)c->refs.size()) return jm_fail(c, JMHIP_ERR_ARG, "ref slot out of range");
   JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
   RefSlot &r = c->refs[ref];
-  int rc = upload_plane(c, r.y, Y, c->W, c->H, pel_bytes, stride_y, device_ptrs);
+  int rc = jm_upload_plane(c, r.y, Y, c->W, c->H, pel_bytes, stride_y, device_ptrs);
   if (rc) return rc;
   if (c->Wc) {
-    if ((rc = upload_plane(c, r.u, U, c->Wc, c->Hc, pel_bytes, stride_c, device_ptrs))) return rc;
-    if ((rc = upload_plane(c, r.v, V, c->Wc, c->Hc, pel_bytes, stride_c, device_ptrs))) return rc;
+    if ((rc = jm_upload_plane(c, r.u, U, c->Wc, c->Hc, pel_bytes, stride_c, device_ptrs))) return rc;
+    if ((rc = jm_upload_plane(c, r.v, V, c->Wc, c->Hc, pel_bytes, stride_c, device_ptrs))) return rc;
   }
   r.has_pic = true; r.has_luma_sub = false; r.has_cr_sub = false;
   return JMHIP_OK;
@@ -262,11 +264,11 @@ extern "C" int jmhip_cur_upload(jmhip_ctx *c, const void *Y, const void *U, cons
   if (!c) return JMHIP_ERR_ARG;
   JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
   c->cur_y = c->cur_own[0]; c->cur_u = c->cur_own[1]; c->cur_v = c->cur_own[2];
-  int rc = upload_plane(c, c->cur_y, Y, c->W, c->H, pel_bytes, stride_y, device_ptrs);
+  int rc = jm_upload_plane(c, c->cur_y, Y, c->W, c->H, pel_bytes, stride_y, device_ptrs);
   if (rc) return rc;
   if (c->Wc && U && V) {
-    if ((rc = upload_plane(c, c->cur_u, U, c->Wc, c->Hc, pel_bytes, stride_c, device_ptrs))) return rc;
-    if ((rc = upload_plane(c, c->cur_v, V, c->Wc, c->Hc, pel_bytes, stride_c, device_ptrs))) return rc;
+    if ((rc = jm_upload_plane(c, c->cur_u, U, c->Wc, c->Hc, pel_bytes, stride_c, device_ptrs))) return rc;
+    if ((rc = jm_upload_plane(c, c->cur_v, V, c->Wc, c->Hc, pel_bytes, stride_c, device_ptrs))) return rc;
   }
   c->has_cur = true;
   return JMHIP_OK;
@@ -318,7 +320,7 @@ extern "C" int jmhip_ref_device_planes(jmhip_ctx *c, int ref, void **Y, void **U
   return JMHIP_OK;
 }
 
-static int download_planes(jmhip_ctx *c, const uint8_t *src, size_t n, void *out, int pel_bytes)
+int jm_download_planes(jmhip_ctx *c, const uint8_t *src, size_t n, void *out, int pel_bytes)
 {
   if (!out) return jm_fail(c, JMHIP_ERR_ARG, "NULL output");
   if (pel_bytes == 1) {
@@ -339,7 +341,7 @@ extern "C" int jmhip_ref_download_luma(jmhip_ctx *c, int ref, void *out, int pel
   if (!c) return JMHIP_ERR_ARG;
   if (ref < 0 || ref >= (int)c->refs.size()) return jm_fail(c, JMHIP_ERR_ARG, "ref slot out of range");
   if (!c->refs[ref].has_luma_sub) return jm_fail(c, JMHIP_ERR_ARG, "luma sub-pel planes not built (call jmhip_interp_luma)");
-  return download_planes(c, c->refs[ref].luma_sub, 16 * (size_t)c->Wp * c->Hp, out, pel_bytes);
+  return jm_download_planes(c, c->refs[ref].luma_sub, 16 * (size_t)c->Wp * c->Hp, out, pel_bytes);
 }
 
 extern "C" int jmhip_ref_download_chroma(jmhip_ctx *c, int ref, int uv, void *out, int pel_bytes)
@@ -348,7 +350,7 @@ extern "C" int jmhip_ref_download_chroma(jmhip_ctx *c, int ref, int uv, void *ou
   if (ref < 0 || ref >= (int)c->refs.size() || uv < 0 || uv > 1) return jm_fail(c, JMHIP_ERR_ARG, "ref/uv out of range");
   if (!c->Wc) return jm_fail(c, JMHIP_ERR_ARG, "4:0:0 has no chroma");
   if (!c->refs[ref].has_cr_sub) return jm_fail(c, JMHIP_ERR_ARG, "chroma sub-pel planes not built (call jmhip_interp_chroma)");
-  return download_planes(c, c->refs[ref].cr_sub[uv], (size_t)c->cg.sub_x * c->cg.sub_y * c->Wcp * c->Hcp, out, pel_bytes);
+  return jm_download_planes(c, c->refs[ref].cr_sub[uv], (size_t)c->cg.sub_x * c->cg.sub_y * c->Wcp * c->Hcp, out, pel_bytes);
 }
 
 extern "C" int jmhip_interp_luma(jmhip_ctx *c, int ref)

@@ -47,6 +47,8 @@ struct jmhip_ctx {
   int fr_capacity = 0, fr_n = 0;
   jmhip_quant fr_quant_host[4];
   uint8_t *rec_y = nullptr, *rec_u = nullptr, *rec_v = nullptr;
+  bool rec_has_pic = false;                           // recon planes loaded by jmhip_recon_upload
+  void *dbk_dev = nullptr; size_t dbk_cap = 0;        // deblocking: macroblock / block / edge arrays
   // TQ arrays
   void *tq_jobs_dev = nullptr, *tq_res_dev = nullptr, *tq_quant_dev = nullptr; int tq_capacity = 0, tq_qcap = 0;
   // timing
@@ -78,6 +80,9 @@ static inline int jm_fail(jmhip_ctx *ctx, int code, const char *msg)
 // RAII-less stage timer: call begin before the launches of a stage and end after them.
 void jm_stage_begin(jmhip_ctx *ctx, int stage);
 void jm_stage_end(jmhip_ctx *ctx, int stage);
+
+int jm_upload_plane(jmhip_ctx *c, uint8_t *dst, const void *src, int w, int h, int pel_bytes, int stride, int device_ptrs);
+int jm_download_planes(jmhip_ctx *c, const uint8_t *src, size_t n, void *out, int pel_bytes);
 
 // kernels (one translation unit each)
 int jm_launch_interp_luma(jmhip_ctx *ctx, int ref, int prow0 = 0, int prow1 = 0);

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 NPART = 41
 PAD = 20
-STAGES = ("interp_luma", "interp_chroma", "me_int", "me_sub", "mc", "tq")
+STAGES = ("interp_luma", "interp_chroma", "me_int", "me_sub", "mc", "tq", "deblock")
 
 _lib = None
 
@@ -69,6 +69,9 @@ PREDCOST_JOB_DTYPE = np.dtype([("mb_x", "<i2"), ("mb_y", "<i2"), ("blocks", "<u2
                                ("w0", "<i2", (16,)), ("w1", "<i2", (16,)), ("off", "<i2", (16,))])
 SURFACE_JOB_DTYPE = np.dtype([("mb_x", "<i2"), ("mb_y", "<i2"), ("ref", "<i2"), ("R", "<i2"), ("cx", "<i2"), ("cy", "<i2"),
                               ("wp", "<i2"), ("weight", "<i2"), ("offset", "<i2"), ("wp_round", "<i2"), ("wp_denom", "<i2"), ("pad", "<i2")])
+DEBLOCK_MB_DTYPE = np.dtype([("intra", "u1"), ("qp", "u1"), ("qpc", "u1", (2,)), ("disable_idc", "u1"), ("alpha_c0_offset", "i1"), ("beta_offset", "i1"),
+                             ("transform_8x8", "u1"), ("avail_a", "u1"), ("avail_b", "u1"), ("cbp_blk", "<u2")])
+DEBLOCK_BLK_DTYPE = np.dtype([("mv", "<i2", (2, 2)), ("ref_id", "<i8", (2,))])
 DIST_JOB_DTYPE = np.dtype([("pic_x", "<i2"), ("pic_y", "<i2"), ("bsx", "<i2"), ("bsy", "<i2"),
                            ("cand_x", "<i4"), ("cand_y", "<i4"), ("ref", "<i2"), ("use_satd", "<i2"),
                            ("umv", "<i2"), ("wp", "<i2"), ("weight", "<i2"), ("offset", "<i2"), ("wp_round", "<i2"), ("wp_denom", "<i2")])
@@ -108,6 +111,8 @@ def load_library():
     lib.jmhip_timing_enable.argtypes = [vp, ip]
     lib.jmhip_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(ip)]
     lib.jmhip_ref_upload.argtypes = [vp, ip, vp, vp, vp, ip, ip, ip, ip]
+    lib.jmhip_recon_upload.argtypes = [vp, vp, vp, vp, ip]
+    lib.jmhip_deblock_frame.argtypes = [vp, vp, vp, ip, ip, ip]
     lib.jmhip_cur_upload.argtypes = [vp, vp, vp, vp, ip, ip, ip, ip]
     lib.jmhip_interp_luma.argtypes = [vp, ip]
     lib.jmhip_interp_chroma.argtypes = [vp, ip]
@@ -146,7 +151,8 @@ def load_library():
     lib.jmhip_interp_rows.argtypes = [vp, ip, ip, ip]
     lib.jmhip_timing_select.argtypes = [vp, C.c_uint]
     for which, dt in ((0, ME_MB_DTYPE), (1, ME_RESULT_DTYPE), (2, QUANT_DTYPE), (3, TQ_JOB_DTYPE), (4, TQ_RESULT_DTYPE),
-                      (5, DIST_JOB_DTYPE), (8, MB_MODE_DTYPE), (9, SURFACE_JOB_DTYPE), (10, BIPRED_JOB_DTYPE), (11, BIPRED_RESULT_DTYPE), (13, PREDCOST_JOB_DTYPE)):
+                      (5, DIST_JOB_DTYPE), (8, MB_MODE_DTYPE), (9, SURFACE_JOB_DTYPE), (10, BIPRED_JOB_DTYPE), (11, BIPRED_RESULT_DTYPE), (13, PREDCOST_JOB_DTYPE),
+                      (14, DEBLOCK_MB_DTYPE), (15, DEBLOCK_BLK_DTYPE)):
         if lib.jmhip_sizeof(which) != dt.itemsize:
             raise JmhipError("binding layout mismatch for struct %d: C %d vs numpy %d" % (which, lib.jmhip_sizeof(which), dt.itemsize))
     if lib.jmhip_sizeof(6) != C.sizeof(MeParams) or lib.jmhip_sizeof(7) != C.sizeof(Config) or lib.jmhip_sizeof(12) != C.sizeof(BipredParams):
@@ -391,6 +397,21 @@ class Context:
         V = np.zeros((self.Hc, self.Wc), np.uint8) if self.Wc else None
         self._chk(self.lib.jmhip_recon_download(self.h, _ptr(Y), _ptr(U), _ptr(V), 1), "jmhip_recon_download")
         return Y, U, V
+
+    def recon_upload(self, Y, U=None, V=None):
+        Y = np.ascontiguousarray(Y, np.uint8)
+        U = np.ascontiguousarray(U, np.uint8) if U is not None else None
+        V = np.ascontiguousarray(V, np.uint8) if V is not None else None
+        self._chk(self.lib.jmhip_recon_upload(self.h, _ptr(Y), _ptr(U), _ptr(V), 1), "jmhip_recon_upload")
+
+    def deblock_frame(self, mbs, blks, mvlimit=4, mb_row0=0, mb_rows=0):
+        """DeblockFrame on the recon picture, in place. mbs: DEBLOCK_MB_DTYPE[mbw*mbh], blks: DEBLOCK_BLK_DTYPE[16*mbw*mbh] (raster)."""
+        mbs = np.ascontiguousarray(mbs, DEBLOCK_MB_DTYPE)
+        blks = np.ascontiguousarray(blks, DEBLOCK_BLK_DTYPE)
+        nmb = (self.W // 16) * (self.H // 16)
+        if mbs.size != nmb or blks.size != 16 * nmb:
+            raise ValueError("deblock_frame: need %d macroblock and %d block entries" % (nmb, 16 * nmb))
+        self._chk(self.lib.jmhip_deblock_frame(self.h, _ptr(mbs), _ptr(blks), mvlimit, mb_row0, mb_rows), "jmhip_deblock_frame")
 
     # ---- timing
     def stream_ptr(self):

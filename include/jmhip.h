@@ -75,7 +75,7 @@ int  jmhip_abi_version(void);
  * jmhip_timing_enable(ctx,1) makes every stage call record start/stop events; jmhip_timing_read returns
  * the accumulated milliseconds and launch count per stage since the last reset and resets them. */
 enum { JMHIP_STAGE_INTERP_LUMA = 0, JMHIP_STAGE_INTERP_CHROMA, JMHIP_STAGE_ME_INT, JMHIP_STAGE_ME_SUB,
-       JMHIP_STAGE_MC, JMHIP_STAGE_TQ, JMHIP_STAGE_COUNT };
+       JMHIP_STAGE_MC, JMHIP_STAGE_TQ, JMHIP_STAGE_DEBLOCK, JMHIP_STAGE_COUNT };
 int jmhip_timing_enable(jmhip_ctx *ctx, int on);
 int jmhip_timing_read(jmhip_ctx *ctx, double ms[JMHIP_STAGE_COUNT], int launches[JMHIP_STAGE_COUNT]);
 /* Only the stages whose bit (1 << JMHIP_STAGE_x) is set record events while timing is on (default: all). */
@@ -342,8 +342,32 @@ int jmhip_recon_to_ref(jmhip_ctx *ctx, int ref);
 /* Copy the band of macroblock rows [mb_row0, mb_row0+mb_rows) of the recon picture into caller-provided DEVICE buffers
  * (tightly packed rows): the send buffer of the per-frame all-gather of reconstructed slice bands. */
 int jmhip_recon_copy_band(jmhip_ctx *ctx, void *Y, void *U, void *V, int mb_row0, int mb_rows);
-/* Copy the recon picture to the host (8-bit samples). */
+/* Copy the recon picture to the host (pel_bytes 1, or 2 for JM's `imgpel` rows). */
 int jmhip_recon_download(jmhip_ctx *ctx, void *Y, void *U, void *V, int pel_bytes);
+/* Load the recon picture from the host (tightly packed rows; pel_bytes 1 or 2): for callers that reconstruct elsewhere
+ * (the JM binding) and only want jmhip_deblock_frame. */
+int jmhip_recon_upload(jmhip_ctx *ctx, const void *Y, const void *U, const void *V, int pel_bytes);
+
+/* ---- in-loop deblocking filter: DeblockFrame, lencod/src/loopFilter.c:87 (DeblockMb :128, GetStrengthNormal :263,
+ * EdgeLoopLumaNormal :529, EdgeLoopChromaNormal :815). Frame pictures without MBAFF; not for SP/SI slices. */
+typedef struct jmhip_deblock_mb {      /* what the filter reads of img->mb_data[i], raster order */
+  uint8_t intra;                       /* mb_type is I4MB, I8MB, I16MB or IPCM (ANY_INTRA, loopFilter.c:261) */
+  uint8_t qp, qpc[2];                  /* IPCM: 0 (DeblockFrame :105-113) */
+  uint8_t disable_idc;                 /* LFDisableIdc: 0 filter, 1 off, 2 not across slice borders */
+  int8_t alpha_c0_offset, beta_offset; /* LFAlphaC0Offset, LFBetaOffset */
+  uint8_t transform_8x8;               /* luma_transform_size_8x8_flag: luma edges 1 and 3 are skipped (:153) */
+  uint8_t avail_a, avail_b;            /* mbAvailA / mbAvailB as the encoder left them (slice-aware); read when disable_idc == 2 (:163-169) */
+  uint16_t cbp_blk;                    /* the 16 luma bits of cbp_blk */
+} jmhip_deblock_mb;
+typedef struct jmhip_deblock_blk {     /* one 4x4 block, raster order over the picture (width/4 per row) */
+  int16_t mv[2][2];                    /* enc_picture->mv[list][by][bx][0..1] */
+  int64_t ref_id[2];                   /* enc_picture->ref_pic_id[list][by][bx], INT64_MIN where ref_idx[list] < 0 (:334-337) */
+} jmhip_deblock_blk;
+/* Filters the recon picture in place, macroblock rows [mb_row0, mb_row0 + mb_rows) (mb_rows <= 0: the whole picture; a band is only
+ * self-contained when its first row's top edge is not filtered, i.e. slices with disable_idc 2). mbs: mbw*mbh entries, blks:
+ * 16*mbw*mbh entries, HOST arrays borrowed for the call. mvlimit: 4 (frame pictures). Results are identical to JM's macroblock-
+ * order filter: the kernel keeps that order through a 2:1 wavefront (deblock.hip). */
+int jmhip_deblock_frame(jmhip_ctx *ctx, const jmhip_deblock_mb *mbs, const jmhip_deblock_blk *blks, int mvlimit, int mb_row0, int mb_rows);
 /* One-buffer band exchange (slice-parallel ranks): rank `rank`'s reconstructed band of `band_rows` macroblock rows
  * as ONE device chunk [Y rows | U rows | V rows] (jmhip_band_chunk_bytes), so that one all-gather moves the frame;
  * jmhip_ref_unpack_bands scatters the `world` gathered chunks into reference slot `ref` (rows below the picture are padding). */
@@ -353,7 +377,8 @@ int jmhip_ref_unpack_bands(jmhip_ctx *ctx, int ref, const void *chunks_device, i
 
 /* sizeof() of the ABI structs, for language bindings to verify their layout: 0 jmhip_me_mb, 1 jmhip_me_result,
  * 2 jmhip_quant, 3 jmhip_tq_job, 4 jmhip_tq_result, 5 jmhip_dist_job, 6 jmhip_me_params, 7 jmhip_config,
- * 8 jmhip_mb_mode, 9 jmhip_surface_job, 10 jmhip_bipred_job, 11 jmhip_bipred_result, 12 jmhip_bipred_params, 13 jmhip_predcost_job. */
+ * 8 jmhip_mb_mode, 9 jmhip_surface_job, 10 jmhip_bipred_job, 11 jmhip_bipred_result, 12 jmhip_bipred_params, 13 jmhip_predcost_job,
+ * 14 jmhip_deblock_mb, 15 jmhip_deblock_blk. */
 int jmhip_sizeof(int which);
 
 /* Flat (no scaling matrix) tables: CalculateQuantParam / CalculateQuant8Param (src/q_matrix.c:451,590) and

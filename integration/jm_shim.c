@@ -10,7 +10,8 @@
  * JMHIP_SHIM (hex mask, default all): 0x01 sub-pel planes, 0x04 full-pel + sub-pel search, 0x08 fast full search,
  * 0x10 dct_4x4/dct_16x16, 0x20 dct_8x8, 0x40 dct_chroma, 0x100 distortion surfaces for EPZS / UMHexagonS integer walks,
  * 0x200 bi-predictive full-pel + sub-pel search,
- * 0x400 RD-off mode-decision costs (TransformDecision, GetSkipCostMB).
+ * 0x400 RD-off mode-decision costs (TransformDecision, GetSkipCostMB),
+ * 0x800 in-loop deblocking filter (DeblockFrame).
  *
  * The proof of the drop-in claim is tests/test_jm_shim_gpu.py: the bitstream and the reconstruction this encoder
  * writes are byte-identical to the unmodified encoder's.
@@ -39,13 +40,13 @@ extern void SetMotionVectorPredictor(short pmv[2], char **refPic, short ***tmp_m
 extern const int LEVELMVLIMIT[17][6];
 extern int *mvbits;                       /* src/mv-search.c:59 */
 
-enum { S_LUMA, S_CHROMA, S_FULL, S_SUB, S_FAST, S_D4, S_D8, S_D16, S_DCR, S_WALK, S_SAD, S_SATD, S_BIFULL, S_BISUB, S_TDEC, S_SKIPC, S_BIDC, S_COUNT };
+enum { S_LUMA, S_CHROMA, S_FULL, S_SUB, S_FAST, S_D4, S_D8, S_D16, S_DCR, S_WALK, S_SAD, S_SATD, S_BIFULL, S_BISUB, S_TDEC, S_SKIPC, S_BIDC, S_DEBLOCK, S_COUNT };
 static const char *s_names[S_COUNT] = { "getSubImagesLuma", "getSubImagesChroma", "FullPelBlockMotionSearch",
   "SubPelBlockMotionSearch", "FastFullPelBlockMotionSearch", "dct_4x4", "dct_8x8", "dct_16x16", "dct_chroma",
   "EPZS_UMHex_integer_walks", "computeSAD", "computeSATD", "FullPelBlockMotionBiPred", "SubPelBlockSearchBiPred",
-  "TransformDecision", "GetSkipCostMB", "BIDPartitionCost" };
+  "TransformDecision", "GetSkipCostMB", "BIDPartitionCost", "DeblockFrame" };
 static long n_dev[S_COUNT], n_fwd[S_COUNT];
-static unsigned shim_mask = 0x7ff;
+static unsigned shim_mask = 0xfff;
 static int verify;            /* JMHIP_SHIM_VERIFY=1: run JM's own search beside the device's and report differences */
 static jmhip_ctx *g;
 static int g_w, g_h;
@@ -902,4 +903,55 @@ int dct_chroma(Macroblock *currMB, int uv, int cr_cbp)
     n_dev[S_DCR]++;
     return res.ret;
   }
+}
+
+/* ------------------------------------------------------------------ 0x800 in-loop deblocking filter */
+
+/* DeblockFrame (src/loopFilter.c:87): the picture goes up, jmhip_deblock_frame filters it in JM's macroblock order, it comes back.
+ * MBAFF, field pictures and SP/SI slices stay in JM. */
+void DeblockFrame(ImageParameters *im, imgpel **imgY, imgpel ***imgUV)
+{
+  static void (*orig)(ImageParameters *, imgpel **, imgpel ***);
+  static jmhip_deblock_mb *mbs;
+  static jmhip_deblock_blk *blks;
+  const int W = im->width, H = im->height, nmb = (int)im->PicSizeInMbs, w4 = W / 4, h4 = H / 4;
+  const int chroma = imgUV && im->yuv_format != YUV400;
+  int i, l, x, y;
+  int ok = (shim_mask & 0x800) && !im->MbaffFrameFlag && im->structure == FRAME && im->type != SP_SLICE && im->type != SI_SLICE &&
+           imgUV && !(im->yuv_format == YUV444 && IS_INDEPENDENT(input)) && ctx_ready() && W == g_w && H == g_h &&
+           imgY[1] == imgY[0] + W && (!chroma || imgUV[0][1] == imgUV[0][0] + im->width_cr);
+  if (!ok) {
+    n_fwd[S_DEBLOCK]++;
+    if (!orig) orig = next_sym("DeblockFrame");
+    orig(im, imgY, imgUV);
+    return;
+  }
+  n_dev[S_DEBLOCK]++;
+  if (!mbs) {
+    mbs = malloc(sizeof(*mbs) * (size_t)nmb);
+    blks = malloc(sizeof(*blks) * (size_t)w4 * h4);
+    if (!mbs || !blks) { fprintf(stderr, "jm_shim: out of memory\n"); exit(96); }
+  }
+  for (i = 0; i < nmb; i++) {
+    Macroblock *m = &im->mb_data[i];
+    if (m->mb_type == IPCM) { m->qp = 0; m->qpc[0] = 0; m->qpc[1] = 0; }          /* loopFilter.c:105-113: a side effect JM keeps */
+    mbs[i].intra = m->mb_type == I4MB || m->mb_type == I8MB || m->mb_type == I16MB || m->mb_type == IPCM;
+    mbs[i].qp = (uint8_t)m->qp; mbs[i].qpc[0] = (uint8_t)m->qpc[0]; mbs[i].qpc[1] = (uint8_t)m->qpc[1];
+    mbs[i].disable_idc = (uint8_t)m->LFDisableIdc;
+    mbs[i].alpha_c0_offset = (int8_t)m->LFAlphaC0Offset; mbs[i].beta_offset = (int8_t)m->LFBetaOffset;
+    mbs[i].transform_8x8 = (uint8_t)m->luma_transform_size_8x8_flag;
+    mbs[i].avail_a = (uint8_t)m->mbAvailA; mbs[i].avail_b = (uint8_t)m->mbAvailB;
+    mbs[i].cbp_blk = (uint16_t)(m->cbp_blk & 0xffff);
+  }
+  for (y = 0; y < h4; y++) for (x = 0; x < w4; x++) {
+    jmhip_deblock_blk *b = &blks[y * w4 + x];
+    for (l = 0; l < 2; l++) {
+      b->mv[l][0] = enc_picture->mv[l][y][x][0]; b->mv[l][1] = enc_picture->mv[l][y][x][1];
+      b->ref_id[l] = enc_picture->ref_idx[l][y][x] < 0 ? INT64_MIN : enc_picture->ref_pic_id[l][y][x];
+    }
+  }
+  OK(jmhip_recon_upload(g, imgY[0], chroma ? imgUV[0][0] : NULL, chroma ? imgUV[1][0] : NULL, 2));
+  OK(jmhip_deblock_frame(g, mbs, blks, 4, 0, 0));
+  OK(jmhip_recon_download(g, imgY[0], chroma ? imgUV[0][0] : NULL, chroma ? imgUV[1][0] : NULL, 2));
+  im->current_mb_nr = nmb - 1;                                                     /* where DeblockMb :178 leaves it */
 }

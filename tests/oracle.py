@@ -452,3 +452,18 @@ def residual_frame(refpic, cur, mbs, mv, modes, quants3, job_dtype, yuv_format=1
         recU[mby * mch:mby * mch + mch, mbx * mcw:mbx * mcw + mcw] = rc["recon"][2 * i][:mch, :mcw]
         recV[mby * mch:mby * mch + mch, mbx * mcw:mbx * mcw + mcw] = rc["recon"][2 * i + 1][:mch, :mcw]
     return {"luma": ry, "chroma": rc, "cbp": cbp, "cbp_blk": cbp_blk, "recon": (recY, recU, recV), "jobs_y": jobs_y, "jobs_c": jobs_c}
+
+
+def deblock_frame(Y, U, V, yuv_format, mbs, blks, mvlimit=4):
+    """jmo_deblock_frame (loopFilter.c:87) on 8-bit planes; mbs / blks use the ABI's dtypes (same layout as jmo_deblock_mb / _blk)."""
+    L = lib()
+    L.jmo_deblock_frame.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p] * 2 + [C.c_int]
+    L.jmo_deblock_frame.restype = None
+    H, W = Y.shape
+    planes = [np.ascontiguousarray(p, np.uint16) if p is not None else None for p in (Y, U, V)]
+    mbs = np.ascontiguousarray(mbs)
+    blks = np.ascontiguousarray(blks)
+    assert mbs.dtype.itemsize == 12 and blks.dtype.itemsize == 24
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+    L.jmo_deblock_frame(ptr(planes[0]), ptr(planes[1]), ptr(planes[2]), W, H, yuv_format, 8, ptr(mbs), ptr(blks), mvlimit)
+    return [p.astype(np.uint8) if p is not None else None for p in planes]

@@ -58,7 +58,12 @@ RestrictSearchRange = 2
 AdaptiveRounding = {adrnd}
 Transform8x8Mode = {t8x8}
 YUVFormat = {yuv}
-LoopFilterDisable = 0
+LoopFilterParametersFlag = {lfflag}
+LoopFilterDisable = {lfidc}
+LoopFilterAlphaC0Offset = {lfa}
+LoopFilterBetaOffset = {lfb}
+SliceMode = {slicemode}
+SliceArgument = 33
 """
 
 CASES = {
@@ -77,6 +82,9 @@ CASES = {
     "umhex_wp_422": dict(search=1, profile=122, cabac=1, t8x8=1, bframes=0, refs=2, rdopt=1, adrnd=0, yuv=2, wp=1, fade=1),
     # RD-off decision with the 8x8 transform: TransformDecision and GetSkipCostMB costs from the device
     "lowcplx_t8_decision": dict(search=0, profile=100, cabac=0, t8x8=1, bframes=0, refs=2, rdopt=0, adrnd=0, yuv=1),
+    # in-loop deblocking: three slices per picture, filter kept inside slices (idc 2), non-zero alpha / beta offsets, coarse quantiser
+    "slices_deblock_idc2": dict(search=0, profile=100, cabac=1, t8x8=1, bframes=1, refs=2, rdopt=1, adrnd=0, yuv=1, qp=38, lfflag=1, lfidc=2, lfa=2, lfb=-1, slicemode=1),
+    "slices_deblock_across_422": dict(search=0, profile=122, cabac=0, t8x8=1, bframes=0, refs=1, rdopt=1, adrnd=0, yuv=2, qp=36, lfflag=1, lfidc=0, lfa=-2, lfb=3, slicemode=1),
     "full_lowcplx_422": dict(search=-1, profile=122, cabac=0, t8x8=1, bframes=0, refs=1, rdopt=0, adrnd=1, yuv=2),  # rdopt off centre rule, 4:2:2 chroma DC
 }
 
@@ -110,8 +118,7 @@ def run(exe, d, env=None):
 
 
 def prepare(tmp_path, name, w=176, h=144, frames=3, R=16, qp=28):
-    v = dict(CASES[name], w=w, h=h, frames=frames, R=R, qp=qp)
-    v = {k: x for k, x in v.items()}
+    v = dict(dict(w=w, h=h, frames=frames, R=R, qp=qp, lfflag=0, lfidc=0, lfa=0, lfb=0, slicemode=0), **CASES[name])
     v.setdefault("fpel", 0)
     v.setdefault("bipred", 0)
     v.setdefault("wbp", 0)
@@ -156,6 +163,7 @@ def test_jm_with_hip_hot_path_is_byte_identical(tmp_path, name):
         kernel = "computeSATD" if CASES[name].get("fpel") == 2 else "computeSAD"
         assert served[kernel][0] > 10000, "integer-pel distortions were not served from the device surface"
     assert served["dct_4x4"][0] > 1000 and served["dct_chroma"][0] > 100
+    assert served["DeblockFrame"][0] >= 2 and served["DeblockFrame"][1] == 0, "the in-loop filter did not run on the device"
     if CASES[name]["t8x8"]:
         assert served["dct_8x8"][0] > 100
     if name == "lowcplx_t8_decision":

@@ -1,0 +1,22 @@
+"""Times jmhip_deblock_frame (strength + wavefront kernels) with the context's own HIP events. Usage: python tools/time_deblock.py [w h]"""
+import sys, os
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as ge
+pkg = ge._load_pkg()
+from tests.test_deblock import make_case
+
+w, h = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1920, 1088)
+rng = np.random.default_rng(0)
+planes, mbs, blks = make_case(pkg, rng, w, h, 1, idc_mode="zero")
+ctx = pkg.Context(w, h, yuv_format=1, max_refs=1, search_range=8)
+ctx.recon_upload(*planes)
+ctx.deblock_frame(mbs, blks)
+ctx.timing_enable(True)
+ctx.timing_read()
+for _ in range(10):
+    ctx.deblock_frame(mbs, blks)
+ctx.sync()
+ms, n = ctx.timing_read()["deblock"]
+print("%dx%d: deblock %.3f ms per picture (%d launches), %d diagonals" % (w, h, ms / n, n, w // 16 + 2 * (h // 16 - 1)))
+ctx.close()
