@@ -14,6 +14,8 @@
 //    and between diagonals. mbw + 2(mbh-1) serial steps per picture: latency-bound by construction (254 steps at 1080p).
 //    No inter-workgroup waiting anywhere: every wave runs the same number of barriers and leaves.
 #include "jmhip_internal.h"
+#include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -27,14 +29,12 @@ __constant__ uint8_t c_tc0[3][52] = {
   {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5, 5, 6, 7, 8, 8, 10, 11, 12, 13, 15, 17},
   {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 4, 5, 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 23, 25}};
 
-struct PlaneParams { uint8_t alpha, beta, tc[3]; };          // tc[bS-1]; bS 4 never reads it for luma and uses tc[2] nowhere
-struct EdgeInfo {                                            // 24 bytes per (macroblock, direction, edge)
-  uint8_t bs[4];
-  PlaneParams pl[3];
-  uint8_t on;                                                // bit 0: some strength is non-zero and the edge is filtered; bit 1: luma samples too
-  uint8_t pad[4];
-};
-static_assert(sizeof(EdgeInfo) == 24, "EdgeInfo layout");
+// 16 bytes per (macroblock, direction, edge), fetched whole and picked apart with shifts (no dependent byte loads on the serial path):
+//   bs    = bS of the four sample groups, one byte each
+//   pl[p] = alpha | beta << 8 | tc0(bS 1) << 13 | tc0(bS 2) << 18 | tc0(bS 3) << 23 | on << 28      (alpha <= 255, beta <= 18, tc0 <= 25)
+// on: bit 0 = the edge is filtered and some strength is non-zero; bit 1 = its luma samples too (not an inner edge of an 8x8-transform macroblock)
+struct EdgeInfo { uint32_t bs; uint32_t pl[3]; };
+static_assert(sizeof(EdgeInfo) == 16, "EdgeInfo layout");
 
 __device__ __forceinline__ int iabs_(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int clip3(int lo, int hi, int v) { return min(max(v, lo), hi); }
@@ -48,9 +48,8 @@ __global__ __launch_bounds__(256) void deblock_strength_kernel(const jmhip_deblo
   const int dir = (t >> 2) & 1, edge = t & 3, mbx = mb % mbw, mby = mb / mbw;
   const jmhip_deblock_mb q = mbs[mb];
   EdgeInfo e;
-  e.on = 0;
-  for (int i = 0; i < 4; i++) { e.bs[i] = 0; e.pad[i] = 0; }
-  for (int p = 0; p < 3; p++) { e.pl[p].alpha = e.pl[p].beta = 0; e.pl[p].tc[0] = e.pl[p].tc[1] = e.pl[p].tc[2] = 0; }
+  e.bs = e.pl[0] = e.pl[1] = e.pl[2] = 0;
+  uint32_t bs[4] = {0, 0, 0, 0};
   bool filtered = q.disable_idc != 1;
   if (edge == 0) {
     // loopFilter.c:139-140 (picture border) and :163-169 (idc 2: slice border, from the availability the encoder left)
@@ -64,7 +63,7 @@ __global__ __launch_bounds__(256) void deblock_strength_kernel(const jmhip_deblo
     const int pmbx = pmb % mbw, pmby = pmb / mbw;
     int any = 0;
     if (p.intra || q.intra) {
-      for (int i = 0; i < 4; i++) e.bs[i] = (uint8_t)(edge == 0 ? 4 : 3);           // :399
+      for (int i = 0; i < 4; i++) bs[i] = edge == 0 ? 4 : 3;                       // :399
       any = 1;
     } else {
       const int w4 = mbw * 4;
@@ -83,19 +82,19 @@ __global__ __launch_bounds__(256) void deblock_strength_kernel(const jmhip_deblo
             else v = (far(0, 0) | far(1, 1)) && (far(0, 1) | far(1, 0));                              // :369-379
           } else v = 1;
         }
-        e.bs[g] = (uint8_t)v;
+        bs[g] = (uint32_t)v;
         any |= v;
       }
     }
     if (any) {
-      e.on = (uint8_t)(1 | ((q.transform_8x8 && (edge & 1)) ? 0 : 2));              // filterNon8x8LumaEdgesFlag :153
+      const uint32_t on = 1u | ((q.transform_8x8 && (edge & 1)) ? 0u : 2u);           // filterNon8x8LumaEdgesFlag :153
       for (int pl = 0; pl < 3; pl++) {
         const int qp = pl ? (p.qpc[pl - 1] + q.qpc[pl - 1] + 1) >> 1 : (p.qp + q.qp + 1) >> 1;        // :566 / :851
         const int ia = clip3(0, 51, qp + q.alpha_c0_offset), ib = clip3(0, 51, qp + q.beta_offset);
-        e.pl[pl].alpha = c_alpha[ia];
-        e.pl[pl].beta = c_beta[ib];
-        for (int k = 0; k < 3; k++) e.pl[pl].tc[k] = c_tc0[k][ia];
+        e.pl[pl] = (uint32_t)c_alpha[ia] | ((uint32_t)c_beta[ib] << 8) | ((uint32_t)c_tc0[0][ia] << 13) | ((uint32_t)c_tc0[1][ia] << 18) |
+                   ((uint32_t)c_tc0[2][ia] << 23) | (on << 28);
       }
+      e.bs = bs[0] | (bs[1] << 8) | (bs[2] << 16) | (bs[3] << 24);
     }
   }
   out[t] = e;
@@ -146,12 +145,58 @@ __device__ __forceinline__ void chroma_line(int *s, int bS, int alpha, int beta,
   }
 }
 
-__device__ __forceinline__ int tc_of(const PlaneParams &p, int bS) { return bS ? p.tc[bS > 3 ? 2 : bS - 1] : 0; }
+// the four edges of one (macroblock, direction) in registers
+struct Edges4 { uint32_t u[4][4]; };
+__device__ __forceinline__ Edges4 load_edges(const EdgeInfo *ei)       // global or LDS, 16-byte aligned
+{
+  Edges4 E;
+  const uint4 *p = reinterpret_cast<const uint4 *>(ei);
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint4 v = p[k];
+    E.u[k][0] = v.x; E.u[k][1] = v.y; E.u[k][2] = v.z; E.u[k][3] = v.w;
+  }
+  return E;
+}
+__device__ __forceinline__ uint32_t e_plane(const uint32_t *u, int pl) { return pl == 0 ? u[1] : pl == 1 ? u[2] : u[3]; }
+__device__ __forceinline__ int e_on(const uint32_t *u) { return u[1] >> 28; }
+__device__ __forceinline__ int e_bs(const uint32_t *u, int g) { return (u[0] >> (8 * g)) & 255; }
+__device__ __forceinline__ int e_alpha(uint32_t w) { return w & 255; }
+__device__ __forceinline__ int e_beta(uint32_t w) { return (w >> 8) & 31; }
+__device__ __forceinline__ int e_tc(uint32_t w, int bS) { return bS ? (w >> (13 + 5 * (min(bS, 3) - 1))) & 31 : 0; }
+
+// the four edges of a direction on one line of samples in registers: s[0..3] belong to the neighbour, s[4..] to this macroblock
+__device__ __forceinline__ void luma_edges(int *s, const Edges4 &ei, int pl, int g)
+{
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const uint32_t *E = ei.u[e];
+    if (e_on(E) == 3) {
+      const int bS = e_bs(E, g);
+      const uint32_t w = e_plane(E, pl);
+      luma_line(&s[4 + 4 * e], bS, e_alpha(w), e_beta(w), e_tc(w, bS));
+    }
+  }
+}
+__device__ __forceinline__ void chroma_edges(int *s, const Edges4 &ei, int pl, int g, int off0, int off1, int off2, int off3)
+{
+  const int off[4] = {off0, off1, off2, off3};      // luma edge e -> chroma sample offset, < 0: no chroma edge
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    if (off[e] < 0) continue;
+    const uint32_t *E = ei.u[e];
+    if (e_on(E) & 1) {
+      const int bS = e_bs(E, g);
+      const uint32_t w = e_plane(E, pl);
+      chroma_line(&s[4 + off[e]], bS, e_alpha(w), e_beta(w), e_tc(w, bS));
+    }
+  }
+}
 
 // a luma-type line of 16 samples of this macroblock + the 4 before it; `step` = distance in bytes between samples of the line
 // (1: a row, vertical edges; pitch: a column, horizontal edges). g = the line's strength group (line >> 2).
 template <bool ROW>
-__device__ __forceinline__ void luma_type_line(uint8_t *base, int pitch, bool has_before, const EdgeInfo *ei, int pl, int g)
+__device__ __forceinline__ void luma_type_line(uint8_t *base, int pitch, bool has_before, const Edges4 &ei, int pl, int g)
 {
   int s[20];
   if (ROW) {
@@ -165,14 +210,7 @@ __device__ __forceinline__ void luma_type_line(uint8_t *base, int pitch, bool ha
 #pragma unroll
     for (int k = 0; k < 20; k++) s[k] = (k >= 4 || has_before) ? base[(ptrdiff_t)(k - 4) * pitch] : 0;
   }
-#pragma unroll
-  for (int e = 0; e < 4; e++) {
-    const EdgeInfo &E = ei[e];
-    if ((E.on & 3) == 3) {
-      const int bS = E.bs[g];
-      luma_line(&s[4 + 4 * e], bS, E.pl[pl].alpha, E.pl[pl].beta, tc_of(E.pl[pl], bS));
-    }
-  }
+  luma_edges(s, ei, pl, g);
   if (ROW) {
     uint32_t *w = reinterpret_cast<uint32_t *>(base - 4);
 #pragma unroll
@@ -187,7 +225,7 @@ __device__ __forceinline__ void luma_type_line(uint8_t *base, int pitch, bool ha
 
 // a chroma line of N (8 or 16) samples + the ones before it; edges: luma edge e maps to chroma sample offset off[e] (< 0: none)
 template <bool ROW, int N>
-__device__ __forceinline__ void chroma_type_line(uint8_t *base, int pitch, bool has_before, const EdgeInfo *ei, int pl, int g,
+__device__ __forceinline__ void chroma_type_line(uint8_t *base, int pitch, bool has_before, const Edges4 &ei, int pl, int g,
                                                  int off0, int off1, int off2, int off3)
 {
   int s[4 + N];
@@ -203,16 +241,7 @@ __device__ __forceinline__ void chroma_type_line(uint8_t *base, int pitch, bool 
     for (int k = 2; k < 4 + N; k++) s[k] = (k >= 4 || has_before) ? base[(ptrdiff_t)(k - 4) * pitch] : 0;
     s[0] = s[1] = 0;
   }
-  const int off[4] = {off0, off1, off2, off3};
-#pragma unroll
-  for (int e = 0; e < 4; e++) {
-    if (off[e] < 0) continue;
-    const EdgeInfo &E = ei[e];
-    if (E.on & 1) {
-      const int bS = E.bs[g];
-      chroma_line(&s[4 + off[e]], bS, E.pl[pl].alpha, E.pl[pl].beta, tc_of(E.pl[pl], bS));
-    }
-  }
+  chroma_edges(s, ei, pl, g, off0, off1, off2, off3);
   if (ROW) {
     uint32_t *w = reinterpret_cast<uint32_t *>(base - 4);
 #pragma unroll
@@ -243,7 +272,7 @@ __global__ __launch_bounds__(1024) void deblock_filter_kernel(DeblockDev D)
     for (int dir = 0; dir < 2; dir++) {
       for (int k = slot; k < count; k += 64) {
         const int mby = D.row0 + y_lo + k, mbx = d - 2 * (y_lo + k);
-        const EdgeInfo *ei = D.edges + ((size_t)(mby * D.mbw + mbx) * 2 + dir) * 4;
+        const Edges4 ei = load_edges(D.edges + ((size_t)(mby * D.mbw + mbx) * 2 + dir) * 4);
         const bool before = dir ? mby != 0 : mbx != 0;
         if (dir == 0) {
           // vertical edges: lane = row
@@ -280,6 +309,167 @@ __global__ __launch_bounds__(1024) void deblock_filter_kernel(DeblockDev D)
         }
       }
       __syncthreads();
+    }
+  }
+}
+
+// ---- the same walk with the three live diagonals held in LDS (4:2:0 and 4:0:0).
+// A macroblock of diagonal d is still changed on d+1 (its right neighbour's vertical pass: columns 13..15) and on d+2 (the
+// macroblock below: rows 13..15), then it is final. So the kernel keeps a ring of three diagonals of 384-byte tiles
+// [Y 16x16 | U 8x8 | V 8x8] in LDS: a diagonal is fetched from HBM once (16-byte row loads, prefetched one diagonal ahead into
+// registers), filtered twice in LDS, touched by its neighbours there, and written back once two diagonals later. The serial path
+// then only sees LDS latency; one CU's vector-memory path, which the global-memory kernel above saturates with byte accesses,
+// carries 24 wide loads and stores per macroblock. Tile k of a ring slot is always filled, filtered and written back by the same
+// 16 lanes, so the only barriers are the two per diagonal the data flow needs.
+constexpr int DBK_TILE = 384, DBK_ETILE = 128;
+
+struct Diag { int y_lo, count; };
+__device__ __forceinline__ Diag diag_of(int d, int mbw, int rows, int last_d)
+{
+  Diag g;
+  g.y_lo = max(0, (d - mbw + 2) >> 1);
+  g.count = (d < 0 || d > last_d) ? 0 : min(rows - 1, d >> 1) - g.y_lo + 1;
+  return g;
+}
+__device__ __forceinline__ void unpack4(int *s, uint32_t v) { s[0] = v & 255; s[1] = (v >> 8) & 255; s[2] = (v >> 16) & 255; s[3] = v >> 24; }
+__device__ __forceinline__ uint32_t pack4(const int *s) { return (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16) | ((uint32_t)s[3] << 24); }
+
+// HBM -> registers: this lane's share of macroblock k of diagonal d (one luma row, one chroma row, 8 bytes of the edge records)
+struct DbkFetch { uint4 y; uint2 c, e; };
+template <bool CHROMA>
+__device__ __forceinline__ void dbk_prefetch(const DeblockDev &D, int d, const Diag &g, int k, int l, int cpl, int cl, DbkFetch &f)
+{
+  if (k < g.count) {
+    const int y = g.y_lo + k, mby = D.row0 + y, mbx = d - 2 * y;
+    f.y = *reinterpret_cast<const uint4 *>(D.y + (size_t)(mby * 16 + l) * D.W + mbx * 16);
+    if (CHROMA) f.c = *reinterpret_cast<const uint2 *>((cpl ? D.v : D.u) + (size_t)(mby * 8 + cl) * D.Wc + mbx * 8);
+    f.e = reinterpret_cast<const uint2 *>(D.edges + (size_t)(mby * D.mbw + mbx) * 8)[l];
+  }
+}
+template <bool CHROMA>
+__device__ __forceinline__ void dbk_fill(uint8_t *slot, uint8_t *etiles, const Diag &g, int k, int l, int cpl, int cl, const DbkFetch &f)
+{
+  if (k < g.count) {
+    uint8_t *tile = slot + (size_t)k * DBK_TILE;
+    *reinterpret_cast<uint4 *>(tile + l * 16) = f.y;
+    if (CHROMA) *reinterpret_cast<uint2 *>(tile + 256 + cpl * 64 + cl * 8) = f.c;
+    reinterpret_cast<uint2 *>(etiles + (size_t)k * DBK_ETILE)[l] = f.e;
+  }
+}
+
+template <int NP, bool CHROMA>
+__global__ __launch_bounds__(1024) void deblock_lds_kernel(DeblockDev D, int S)
+{
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  uint8_t *const etiles = lds + (size_t)3 * S * DBK_TILE;
+  const int grp = threadIdx.x >> 4, l = threadIdx.x & 15;
+  const int cpl = l >> 3, cl = l & 7;                       // chroma: lanes 0..7 own U lines, 8..15 V lines
+  const int last_d = D.mbw - 1 + 2 * (D.rows - 1);
+  DbkFetch pf0, pf1;
+  pf0.y = pf1.y = make_uint4(0, 0, 0, 0); pf0.c = pf0.e = pf1.c = pf1.e = make_uint2(0, 0);
+
+  {
+    const Diag g0 = diag_of(0, D.mbw, D.rows, last_d);
+    dbk_prefetch<CHROMA>(D, 0, g0, grp, l, cpl, cl, pf0);
+    if (NP > 1) dbk_prefetch<CHROMA>(D, 0, g0, grp + 64, l, cpl, cl, pf1);
+  }
+  for (int d = 0; d <= last_d + 2; d++) {
+    const Diag g = diag_of(d, D.mbw, D.rows, last_d), gl = diag_of(d - 1, D.mbw, D.rows, last_d), gt = diag_of(d - 2, D.mbw, D.rows, last_d);
+    uint8_t *const slot = lds + (size_t)(d % 3) * S * DBK_TILE;
+    uint8_t *const slot_l = lds + (size_t)((d + 2) % 3) * S * DBK_TILE;      // diagonal d-1
+    uint8_t *const slot_t = lds + (size_t)((d + 1) % 3) * S * DBK_TILE;      // diagonal d-2
+    // ---- fill: the registers fetched during the previous diagonal; then start fetching the next one
+    dbk_fill<CHROMA>(slot, etiles, g, grp, l, cpl, cl, pf0);
+    if (NP > 1) dbk_fill<CHROMA>(slot, etiles, g, grp + 64, l, cpl, cl, pf1);
+    {
+      const Diag gn = diag_of(d + 1, D.mbw, D.rows, last_d);
+      dbk_prefetch<CHROMA>(D, d + 1, gn, grp, l, cpl, cl, pf0);
+      if (NP > 1) dbk_prefetch<CHROMA>(D, d + 1, gn, grp + 64, l, cpl, cl, pf1);
+    }
+    // ---- vertical edges: lane = row
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+      const int k = grp + 64 * p;
+      if (k < g.count) {
+        const int y = g.y_lo + k, mbx = d - 2 * y;
+        uint8_t *tile = slot + (size_t)k * DBK_TILE;
+        uint8_t *left = slot_l + (size_t)(y - gl.y_lo) * DBK_TILE;          // (mbx-1, y) lies on diagonal d-1
+        const bool before = mbx != 0;
+        const Edges4 ei = load_edges(reinterpret_cast<const EdgeInfo *>(etiles + (size_t)k * DBK_ETILE));
+        {
+          int s[20];
+          const uint4 row = *reinterpret_cast<const uint4 *>(tile + l * 16);
+          unpack4(s, before ? *reinterpret_cast<const uint32_t *>(left + l * 16 + 12) : 0u);
+          unpack4(s + 4, row.x); unpack4(s + 8, row.y); unpack4(s + 12, row.z); unpack4(s + 16, row.w);
+          luma_edges(s, ei, 0, l >> 2);
+          if (before) *reinterpret_cast<uint32_t *>(left + l * 16 + 12) = pack4(s);
+          *reinterpret_cast<uint4 *>(tile + l * 16) = make_uint4(pack4(s + 4), pack4(s + 8), pack4(s + 12), pack4(s + 16));
+        }
+        if (CHROMA) {
+          int s[12];
+          const int o = 256 + cpl * 64 + cl * 8;
+          const uint2 row = *reinterpret_cast<const uint2 *>(tile + o);
+          unpack4(s, before ? *reinterpret_cast<const uint32_t *>(left + o + 4) : 0u);
+          unpack4(s + 4, row.x); unpack4(s + 8, row.y);
+          chroma_edges(s, ei, 1 + cpl, cl >> 1, 0, -1, 4, -1);
+          if (before) *reinterpret_cast<uint32_t *>(left + o + 4) = pack4(s);
+          *reinterpret_cast<uint2 *>(tile + o) = make_uint2(pack4(s + 4), pack4(s + 8));
+        }
+      }
+    }
+    __syncthreads();
+    // ---- horizontal edges: lane = column
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+      const int k = grp + 64 * p;
+      if (k < g.count) {
+        const int y = g.y_lo + k, mby = D.row0 + y, mbx = d - 2 * y;
+        uint8_t *tile = slot + (size_t)k * DBK_TILE;
+        uint8_t *top = slot_t + (size_t)(y - 1 - gt.y_lo) * DBK_TILE;       // (mbx, y-1) lies on diagonal d-2
+        const bool before = mby != 0, top_lds = y > 0;                       // first row of a band: the rows above live in HBM only
+        const Edges4 ei = load_edges(reinterpret_cast<const EdgeInfo *>(etiles + (size_t)k * DBK_ETILE + 64));
+        {
+          int s[20];
+          uint8_t *gtop = D.y + (size_t)(mby * 16 - 4) * D.W + mbx * 16 + l;
+#pragma unroll
+          for (int r = 0; r < 4; r++) s[r] = !before ? 0 : top_lds ? top[(12 + r) * 16 + l] : gtop[(size_t)r * D.W];
+#pragma unroll
+          for (int r = 0; r < 16; r++) s[4 + r] = tile[r * 16 + l];
+          luma_edges(s, ei, 0, l >> 2);
+          if (before) {
+#pragma unroll
+            for (int r = 1; r < 4; r++) { if (top_lds) top[(12 + r) * 16 + l] = (uint8_t)s[r]; else gtop[(size_t)r * D.W] = (uint8_t)s[r]; }
+          }
+#pragma unroll
+          for (int r = 0; r < 15; r++) tile[r * 16 + l] = (uint8_t)s[4 + r];
+        }
+        if (CHROMA) {
+          int s[12];
+          const int o = 256 + cpl * 64 + cl;
+          uint8_t *gtop = (cpl ? D.v : D.u) + (size_t)(mby * 8 - 2) * D.Wc + mbx * 8 + cl;
+          s[0] = s[1] = 0;
+#pragma unroll
+          for (int r = 0; r < 2; r++) s[2 + r] = !before ? 0 : top_lds ? top[o + (6 + r) * 8] : gtop[(size_t)r * D.Wc];
+#pragma unroll
+          for (int r = 0; r < 8; r++) s[4 + r] = tile[o + r * 8];
+          chroma_edges(s, ei, 1 + cpl, cl >> 1, 0, -1, 4, -1);
+          if (before) { if (top_lds) top[o + 7 * 8] = (uint8_t)s[3]; else gtop[D.Wc] = (uint8_t)s[3]; }
+#pragma unroll
+          for (int r = 0; r < 8; r++) tile[o + r * 8] = (uint8_t)s[4 + r];
+        }
+      }
+    }
+    __syncthreads();
+    // ---- diagonal d-2 is final: back to HBM
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+      const int k = grp + 64 * p;
+      if (k < gt.count) {
+        const int y = gt.y_lo + k, mby = D.row0 + y, mbx = d - 2 - 2 * y;
+        const uint8_t *tile = slot_t + (size_t)k * DBK_TILE;
+        *reinterpret_cast<uint4 *>(D.y + (size_t)(mby * 16 + l) * D.W + mbx * 16) = *reinterpret_cast<const uint4 *>(tile + l * 16);
+        if (CHROMA) *reinterpret_cast<uint2 *>((cpl ? D.v : D.u) + (size_t)(mby * 8 + cl) * D.Wc + mbx * 8) = *reinterpret_cast<const uint2 *>(tile + 256 + cpl * 64 + cl * 8);
+      }
     }
   }
 }
@@ -340,6 +530,29 @@ extern "C" int jmhip_deblock_frame(jmhip_ctx *c, const jmhip_deblock_mb *mbs, co
   D.y = c->rec_y; D.u = c->rec_u; D.v = c->rec_v;
   D.edges = (const EdgeInfo *)(base + edge_off);
   D.W = c->W; D.Wc = c->Wc; D.mbw = c->mbw; D.row0 = mb_row0; D.rows = mb_rows;
+  // LDS ring (4:2:0 / 4:0:0) when three diagonals + one diagonal of edge records fit into 160 KB; JMHIP_DEBLOCK_KERNEL=global forces the
+  // global-memory kernel (kept for 4:2:2 / 4:4:4, larger pictures, and as a cross-check in the tests)
+  int S = 0;
+  for (int d = 0; d <= c->mbw - 1 + 2 * (mb_rows - 1); d++) {
+    const int y_lo = std::max(0, (d - c->mbw + 2) >> 1), y_hi = std::min(mb_rows - 1, d >> 1);
+    S = std::max(S, y_hi - y_lo + 1);
+  }
+  const size_t lds = (size_t)S * (3 * DBK_TILE + DBK_ETILE);
+  const char *force = getenv("JMHIP_DEBLOCK_KERNEL");
+  const bool use_lds = (c->cfg.yuv_format == JMHIP_YUV420 || c->cfg.yuv_format == JMHIP_YUV400) && S <= 128 && lds <= 160 * 1024 &&
+                       !(force && !strcmp(force, "global"));
+  if (use_lds) {
+    const bool chroma = c->cfg.yuv_format == JMHIP_YUV420;
+    auto launch = [&](auto kernel) -> hipError_t {
+      hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      kernel<<<1, 1024, lds, c->stream>>>(D, S);
+      return hipGetLastError();
+    };
+    hipError_t e = S <= 64 ? (chroma ? launch(deblock_lds_kernel<1, true>) : launch(deblock_lds_kernel<1, false>))
+                           : (chroma ? launch(deblock_lds_kernel<2, true>) : launch(deblock_lds_kernel<2, false>));
+    JM_HIP_CHECK(c, e);
+  } else
   switch (c->cfg.yuv_format) {
   case JMHIP_YUV400: deblock_filter_kernel<JMHIP_YUV400><<<1, 1024, 0, c->stream>>>(D); break;
   case JMHIP_YUV420: deblock_filter_kernel<JMHIP_YUV420><<<1, 1024, 0, c->stream>>>(D); break;

@@ -132,3 +132,29 @@ def test_deblock_band_of_a_slice(pkg):
     ctx.close()
     for g, wv in zip(got, want):
         assert np.array_equal(g, wv)
+
+
+@pytest.mark.gpu
+def test_deblock_bands_in_sequence_cross_their_borders(pkg):
+    """Bands filtered one after the other (top to bottom) give the whole-picture result even when the filter crosses the band
+    borders (idc 0): the first row of a band then changes rows that only live in HBM."""
+    rng = np.random.default_rng(9)
+    w, h = 192, 160
+    planes, mbs, blks = make_case(pkg, rng, w, h, 1, idc_mode="zero")
+    want = oracle.deblock_frame(planes[0], planes[1], planes[2], 1, mbs, blks)
+    ctx = pkg.Context(w, h, yuv_format=1, max_refs=1, search_range=8)
+    ctx.recon_upload(*planes)
+    for r0, n in ((0, 3), (3, 1), (4, 6)):
+        ctx.deblock_frame(mbs, blks, 4, r0, n)
+    got = ctx.recon_download()
+    ctx.close()
+    for g, wv in zip(got, want):
+        assert np.array_equal(g, wv)
+
+
+@pytest.mark.gpu
+def test_deblock_global_memory_kernel_on_420(pkg, monkeypatch):
+    """4:2:0 normally takes the LDS-ring kernel; the global-memory wavefront kernel (4:2:2 / 4:4:4 / oversized pictures) must agree."""
+    monkeypatch.setenv("JMHIP_DEBLOCK_KERNEL", "global")
+    run(pkg, 176, 144, 1, seed=21)
+    run(pkg, 320, 64, 0, seed=22)
