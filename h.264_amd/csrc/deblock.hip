@@ -258,6 +258,7 @@ struct DeblockDev {
   uint8_t *y, *u, *v;
   const EdgeInfo *edges;        // [mb][dir][edge]
   int W, Wc, mbw, row0, rows;
+  int dbg;                      // JMHIP_DBK_DEBUG (timing experiments only): 1 skip the vertical pass, 2 skip the horizontal pass, 4 skip fetch / write-back
 };
 
 // FMT: JMHIP_YUV400 / 420 / 422 / 444
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(1024) void deblock_lds_kernel(DeblockDev D, int S)
 #pragma unroll
     for (int p = 0; p < NP; p++) {
       const int k = grp + 64 * p;
-      if (k < g.count) {
+      if (k < g.count && !(D.dbg & 1)) {
         const int y = g.y_lo + k, mbx = d - 2 * y;
         uint8_t *tile = slot + (size_t)k * DBK_TILE;
         uint8_t *left = slot_l + (size_t)(y - gl.y_lo) * DBK_TILE;          // (mbx-1, y) lies on diagonal d-1
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(1024) void deblock_lds_kernel(DeblockDev D, int S)
 #pragma unroll
     for (int p = 0; p < NP; p++) {
       const int k = grp + 64 * p;
-      if (k < g.count) {
+      if (k < g.count && !(D.dbg & 2)) {
         const int y = g.y_lo + k, mby = D.row0 + y, mbx = d - 2 * y;
         uint8_t *tile = slot + (size_t)k * DBK_TILE;
         uint8_t *top = slot_t + (size_t)(y - 1 - gt.y_lo) * DBK_TILE;       // (mbx, y-1) lies on diagonal d-2
@@ -464,7 +465,7 @@ __global__ __launch_bounds__(1024) void deblock_lds_kernel(DeblockDev D, int S)
 #pragma unroll
     for (int p = 0; p < NP; p++) {
       const int k = grp + 64 * p;
-      if (k < gt.count) {
+      if (k < gt.count && !(D.dbg & 4)) {
         const int y = gt.y_lo + k, mby = D.row0 + y, mbx = d - 2 - 2 * y;
         const uint8_t *tile = slot_t + (size_t)k * DBK_TILE;
         *reinterpret_cast<uint4 *>(D.y + (size_t)(mby * 16 + l) * D.W + mbx * 16) = *reinterpret_cast<const uint4 *>(tile + l * 16);
@@ -530,6 +531,7 @@ extern "C" int jmhip_deblock_frame(jmhip_ctx *c, const jmhip_deblock_mb *mbs, co
   D.y = c->rec_y; D.u = c->rec_u; D.v = c->rec_v;
   D.edges = (const EdgeInfo *)(base + edge_off);
   D.W = c->W; D.Wc = c->Wc; D.mbw = c->mbw; D.row0 = mb_row0; D.rows = mb_rows;
+  D.dbg = getenv("JMHIP_DBK_DEBUG") ? atoi(getenv("JMHIP_DBK_DEBUG")) : 0;
   // LDS ring (4:2:0 / 4:0:0) when three diagonals + one diagonal of edge records fit into 160 KB; JMHIP_DEBLOCK_KERNEL=global forces the
   // global-memory kernel (kept for 4:2:2 / 4:4:4, larger pictures, and as a cross-check in the tests)
   int S = 0;
