@@ -352,10 +352,19 @@ extern "C" int jmhip_recon_to_ref(jmhip_ctx *c, int ref)
   std::swap(r.y, c->rec_y);
   if (c->Wc) { std::swap(r.u, c->rec_u); std::swap(r.v, c->rec_v); }
   if (c->ref_ptrs_dev) {
-    set_plane_pointer<<<1, 1, 0, c->stream>>>(reinterpret_cast<const uint8_t **>(c->ref_ptrs_dev), ref, r.y);
-    JM_HIP_CHECK(c, hipGetLastError());
+    if (c->table_fix.idx >= 0 && c->table_fix.idx != ref) { int rc = jm_flush_table_fix(c); if (rc) return rc; }
+    c->table_fix.idx = ref; c->table_fix.ptr = r.y;
   }
   r.has_pic = true; r.has_luma_sub = false; r.has_cr_sub = false;
+  return JMHIP_OK;
+}
+
+int jm_flush_table_fix(jmhip_ctx *c)
+{
+  if (c->table_fix.idx < 0 || !c->ref_ptrs_dev) { c->table_fix.idx = -1; return JMHIP_OK; }
+  set_plane_pointer<<<1, 1, 0, c->stream>>>(reinterpret_cast<const uint8_t **>(c->ref_ptrs_dev), c->table_fix.idx, c->table_fix.ptr);
+  c->table_fix.idx = -1;
+  JM_HIP_CHECK(c, hipGetLastError());
   return JMHIP_OK;
 }
 

@@ -16,9 +16,12 @@ namespace {
 __device__ __forceinline__ int clampi(int x, int lo, int hi) { return min(max(x, lo), hi); }
 
 template <int SUBX, int SUBY, int MULX, int MULY>
-__global__ __launch_bounds__(256) void interp_chroma_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ out,
+__global__ __launch_bounds__(256) void interp_chroma_kernel(const uint8_t *__restrict__ src_u, uint8_t *__restrict__ out_u,
+                                                           const uint8_t *__restrict__ src_v, uint8_t *__restrict__ out_v,
                                                            int Wc, int Hc, int Wcp, int Hcp, int pad_x, int pad_y, int row4_0)
 {
+  const uint8_t *__restrict__ src = blockIdx.z ? src_v : src_u;      // both components in one launch
+  uint8_t *__restrict__ out = blockIdx.z ? out_v : out_u;
   const int gi = (blockIdx.x * 64 + threadIdx.x) * 4;
   const int gj = (blockIdx.y + row4_0) * 4 + threadIdx.y;
   if (gi >= Wcp || gj >= Hcp - 1) return;          // last row keeps its zeros
@@ -66,17 +69,13 @@ int jm_launch_interp_chroma(jmhip_ctx *c, int ref, int prow0, int prow1)
   int g0 = 0, g1 = (c->Hcp + 3) / 4;
   if (prow1 > prow0) { g0 = (prow0 < 0 ? 0 : prow0) / 4; const int e = ((prow1 > c->Hcp ? c->Hcp : prow1) + 3) / 4; g1 = e < g1 ? e : g1; }
   if (g1 <= g0) return JMHIP_OK;
-  dim3 grid((c->Wcp / 4 + 63) / 64, g1 - g0), block(64, 4);
-  for (int uv = 0; uv < 2; uv++) {
-    const uint8_t *src = uv ? r.v : r.u;
-    uint8_t *dst = r.cr_sub[uv];
-    switch (c->cfg.yuv_format) {
-    case JMHIP_YUV420: interp_chroma_kernel<8, 8, 1, 1><<<grid, block, 0, c->stream>>>(src, dst, c->Wc, c->Hc, c->Wcp, c->Hcp, c->cg.pad_x, c->cg.pad_y, g0); break;
-    case JMHIP_YUV422: interp_chroma_kernel<8, 4, 1, 2><<<grid, block, 0, c->stream>>>(src, dst, c->Wc, c->Hc, c->Wcp, c->Hcp, c->cg.pad_x, c->cg.pad_y, g0); break;
-    case JMHIP_YUV444: interp_chroma_kernel<4, 4, 2, 2><<<grid, block, 0, c->stream>>>(src, dst, c->Wc, c->Hc, c->Wcp, c->Hcp, c->cg.pad_x, c->cg.pad_y, g0); break;
-    default: return jm_fail(c, JMHIP_ERR_ARG, "interp_chroma: no chroma");
-    }
-    JM_HIP_CHECK(c, hipGetLastError());
+  dim3 grid((c->Wcp / 4 + 63) / 64, g1 - g0, 2), block(64, 4);
+  switch (c->cfg.yuv_format) {
+  case JMHIP_YUV420: interp_chroma_kernel<8, 8, 1, 1><<<grid, block, 0, c->stream>>>(r.u, r.cr_sub[0], r.v, r.cr_sub[1], c->Wc, c->Hc, c->Wcp, c->Hcp, c->cg.pad_x, c->cg.pad_y, g0); break;
+  case JMHIP_YUV422: interp_chroma_kernel<8, 4, 1, 2><<<grid, block, 0, c->stream>>>(r.u, r.cr_sub[0], r.v, r.cr_sub[1], c->Wc, c->Hc, c->Wcp, c->Hcp, c->cg.pad_x, c->cg.pad_y, g0); break;
+  case JMHIP_YUV444: interp_chroma_kernel<4, 4, 2, 2><<<grid, block, 0, c->stream>>>(r.u, r.cr_sub[0], r.v, r.cr_sub[1], c->Wc, c->Hc, c->Wcp, c->Hcp, c->cg.pad_x, c->cg.pad_y, g0); break;
+  default: return jm_fail(c, JMHIP_ERR_ARG, "interp_chroma: no chroma");
   }
+  JM_HIP_CHECK(c, hipGetLastError());
   return JMHIP_OK;
 }

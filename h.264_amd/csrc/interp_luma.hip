@@ -34,8 +34,11 @@ __device__ __forceinline__ uint32_t pack4(uint32_t a, uint32_t b, uint32_t c, ui
 __device__ __forceinline__ uint32_t avg4(uint32_t a, uint32_t b) { return __builtin_amdgcn_lerp(a, b, 0x01010101u); }
 
 __global__ __launch_bounds__(256) void interp_luma_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ out,
-                                                         int W, int H, int Wp, int Hp, int tile_row0)
+                                                         int W, int H, int Wp, int Hp, int tile_row0,
+                                                         const uint8_t **fix_table, int fix_idx, const uint8_t *fix_ptr)
 {
+  // a pending entry of the reference pointer table (jmhip_recon_to_ref) rides along: later kernels of the stream read the table
+  if (fix_table && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && threadIdx.y == 0) fix_table[fix_idx] = fix_ptr;
   __shared__ __attribute__((aligned(16))) uint8_t s00[ROWS][S00_W];
   __shared__ __attribute__((aligned(16))) int16_t stmp[ROWS][TX];
 
@@ -165,7 +168,10 @@ int jm_launch_interp_luma(jmhip_ctx *c, int ref, int prow0, int prow1)
   if (prow1 > prow0) { t0 = max(0, prow0) / TY; t1 = min(t1, (min(c->Hp, prow1) + TY - 1) / TY); }
   if (t1 <= t0) return JMHIP_OK;
   dim3 grid((c->Wp + TX - 1) / TX, t1 - t0), block(64, 4);
-  interp_luma_kernel<<<grid, block, 0, c->stream>>>(r.y, r.luma_sub, c->W, c->H, c->Wp, c->Hp, t0);
+  const bool fix = c->table_fix.idx >= 0 && c->ref_ptrs_dev;
+  interp_luma_kernel<<<grid, block, 0, c->stream>>>(r.y, r.luma_sub, c->W, c->H, c->Wp, c->Hp, t0,
+                                                   fix ? reinterpret_cast<const uint8_t **>(c->ref_ptrs_dev) : nullptr, c->table_fix.idx, c->table_fix.ptr);
+  c->table_fix.idx = -1;
   JM_HIP_CHECK(c, hipGetLastError());
   return JMHIP_OK;
 }

@@ -42,6 +42,9 @@ struct jmhip_ctx {
   std::vector<int> me_fast_idx, me_gen_idx;                           // reference slots used by the last ME call
   void *surf_dev = nullptr, *surf_jobs_dev = nullptr; size_t surf_cap = 0, surf_jobs_cap = 0;   // jmhip_distortion_surface
   void *ref_ptrs_dev = nullptr;                       // [0..31] integer recon, [32..63] quarter-pel plane stacks
+  // jmhip_recon_to_ref swaps plane pointers; the one table entry that changes is written by the next kernel that can carry it
+  // (interp_luma, which every pipeline launches next) instead of a launch of its own; jm_ensure_ref_table flushes it otherwise
+  struct TableFix { int idx = -1; const uint8_t *ptr = nullptr; } table_fix;
   // frame pipeline (MC -> residual -> TQ -> recon): per-MB luma job/result, 2 chroma jobs/results, recon picture
   void *fr_jobs_y = nullptr, *fr_jobs_c = nullptr, *fr_res_y = nullptr, *fr_res_c = nullptr, *fr_quant = nullptr, *fr_modes = nullptr;
   int fr_capacity = 0, fr_n = 0;
@@ -90,6 +93,7 @@ int jm_launch_interp_chroma(jmhip_ctx *ctx, int ref, int prow0 = 0, int prow1 = 
 constexpr int JMHIP_TQ_SELECT = 0x100;   // frame stage: each luma kernel takes only the macroblocks of its transform size
 int jm_launch_tq(jmhip_ctx *ctx, int kind, int yuv_format, const void *jobs, const void *quants, void *results, int n);
 int jm_ensure_ref_table(jmhip_ctx *ctx);
+int jm_flush_table_fix(jmhip_ctx *ctx);                                                    // frame.hip
 struct MeDev;
 int jm_me_sub_tables(jmhip_ctx *ctx);                                                   // me_sub.hip
 void jm_launch_me_sub(jmhip_ctx *ctx, const MeDev &P, const jmhip_me_mb *jobs_dev, jmhip_me_result *res_dev, int n);

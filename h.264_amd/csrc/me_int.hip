@@ -964,7 +964,7 @@ int ensure_tables(jmhip_ctx *c)
 // [64..95] Cb eighth-pel stacks, [96..127] Cr
 int jm_ensure_ref_table(jmhip_ctx *c)
 {
-  if (c->ref_ptrs_dev) return JMHIP_OK;
+  if (c->ref_ptrs_dev) return jm_flush_table_fix(c);
   std::vector<const uint8_t *> tab(128, nullptr);
   for (size_t i = 0; i < c->refs.size(); i++) {
     tab[i] = c->refs[i].y; tab[32 + i] = c->refs[i].luma_sub; tab[64 + i] = c->refs[i].cr_sub[0]; tab[96 + i] = c->refs[i].cr_sub[1];
