@@ -799,7 +799,13 @@ __global__ __launch_bounds__(256, 3) void me_int_pair_kernel(MeDev P, const jmhi
   unsigned mvc[PAIR_NK];                             // cached (mv cost << 16); [21] (16x16) unshifted + bias
 
   // one half candidate: sads of the 8 leaves (tie seeded), tree, partner exchange, 21 + 1 keys
-  auto evaluate = [&](const uint32_t (&w)[16][2], int base, unsigned tie, bool zero_bonus) __attribute__((always_inline)) {
+  // mode 0: keep the keys in hold[] (even step of the row walk); 1: best = min3(best, hold, key) (odd step: one v_min3_u32 per two
+  // candidates instead of two v_min_u32, both quarter-rate); 2: plain minimum (candidates outside the walk)
+  unsigned hold[PAIR_NK];
+#pragma unroll
+  for (int j = 0; j < PAIR_NK; j++) hold[j] = KEY_INVALID;
+  auto evaluate = [&](auto modec, const uint32_t (&w)[16][2], int base, unsigned tie, bool zero_bonus) __attribute__((always_inline)) {
+    constexpr int mode = decltype(modec)::value;
     unsigned sad[8];
 #pragma unroll
     for (int r = 0; r < 16; r++) {
@@ -817,11 +823,18 @@ __global__ __launch_bounds__(256, 3) void me_int_pair_kernel(MeDev P, const jmhi
     ps[16] = ps[8] + ps[9]; ps[17] = ps[10] + ps[11];
     ps[18] = ps[16] + ps[17];
     ps[19] = quad_swap_add(ps[16]); ps[20] = quad_swap_add(ps[17]);
-#pragma unroll
-    for (int j = 0; j < PAIR_NK - 1; j++) best[j] = min(best[j], ps[j] + mvc[j]);
     unsigned c0 = ((ps[19] >> 16) + (ps[20] >> 16)) + mvc[21];
     if (zero_bonus) c0 -= (unsigned)w16;
-    best[21] = min(best[21], (c0 << TIE_BITS) + tie);
+    unsigned key[PAIR_NK];
+#pragma unroll
+    for (int j = 0; j < PAIR_NK - 1; j++) key[j] = ps[j] + mvc[j];
+    key[21] = (c0 << TIE_BITS) + tie;
+#pragma unroll
+    for (int j = 0; j < PAIR_NK; j++) {
+      if (mode == 0) hold[j] = key[j];
+      else if (mode == 1) best[j] = min(min(best[j], hold[j]), key[j]);
+      else best[j] = min(best[j], key[j]);
+    }
   };
   auto load_mvc = [&](int colx, int row) __attribute__((always_inline)) {
     const uint2 *bt = reinterpret_cast<const uint2 *>(&S.bytab[row][half * 24]), *bxq = reinterpret_cast<const uint2 *>(&S.bxtab[colx][half * 24]);
@@ -870,7 +883,7 @@ __global__ __launch_bounds__(256, 3) void me_int_pair_kernel(MeDev P, const jmhi
       const int ady = iabs(dy);
       unsigned tie = (ady > adx) ? (unsigned)(spiral_base_A(dy) + 1 + twodx) : (unsigned)(tieB + 2 * dy);
       if (ff00 && mvx == 0 && mvy == 0) tie = 0;
-      evaluate(win, tt, tie, qx && 4 * (mby * 16 + mvy) == mby * 16);
+      evaluate(std::integral_constant<int, tt & 1>{}, win, tt, tie, qx && 4 * (mby * 16 + mvy) == mby * 16);
     };
     for (int t0 = 0; t0 < nrows; t0 += 16) {
       step(std::integral_constant<int, 0>{}, t0);  step(std::integral_constant<int, 1>{}, t0);
@@ -881,6 +894,10 @@ __global__ __launch_bounds__(256, 3) void me_int_pair_kernel(MeDev P, const jmhi
       step(std::integral_constant<int, 10>{}, t0); step(std::integral_constant<int, 11>{}, t0);
       step(std::integral_constant<int, 12>{}, t0); step(std::integral_constant<int, 13>{}, t0);
       step(std::integral_constant<int, 14>{}, t0); step(std::integral_constant<int, 15>{}, t0);
+    }
+    if (nrows & 1) {                                  // the last row of an odd band is still on hold
+#pragma unroll
+      for (int j = 0; j < PAIR_NK; j++) best[j] = min(best[j], hold[j]);
     }
   }
 
@@ -897,7 +914,7 @@ __global__ __launch_bounds__(256, 3) void me_int_pair_kernel(MeDev P, const jmhi
 #pragma unroll
       for (int r = 0; r < 16; r++) { w[r][0] = wrow[r * PITCH]; w[r][1] = wrow[r * PITCH + 1]; }
       load_mvc(ax, ay);
-      evaluate(w, 0, tie, quirk00 && 4 * (mbx * 16 + cmx) == mbx * 16 && 4 * (mby * 16 + cmy) == mby * 16);
+      evaluate(std::integral_constant<int, 2>{}, w, 0, tie, quirk00 && 4 * (mbx * 16 + cmx) == mbx * 16 && 4 * (mby * 16 + cmy) == mby * 16);
     }
   }
 
