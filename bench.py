@@ -37,9 +37,10 @@ ME_BYTES_PER_MB = 1352          # cur 512 + ref 512 + out 41*8 (u16
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 # Integer-VALU model of the search kernel (the bound that actually binds): per candidate and lane the algorithm
 # needs 64 v_sad_u8-class ops (16 rows x 4 dwords), 25 adds for the SetupLargerBlocks tree, and per partition one add
-# (mv cost) and one min. Issue times per wave-instruction per SIMD measured on MI355X with tools/ubench/valu_rate2.hip
-# (profiles/r01_valu_issue_rates.txt): v_sad_u8 / v_min_u32 1.89 ns, v_add_u32 1.04 ns. 1024 SIMDs.
-VALU_NS_PER_WAVE_CANDIDATE = 64 * 1.89 + 25 * 1.04 + 40 * 1.04 + 41 * 1.89
+# (mv cost) and half a v_min3_u32 (one min3 folds the keys of two candidates). Issue times per wave-instruction per SIMD measured
+# on MI355X with tools/ubench/valu_rate2.hip (profiles/r01_valu_issue_rates.txt): v_sad_u8 / v_min3_u32 1.89 ns, v_add_u32 1.04 ns.
+# 1024 SIMDs. (Until the min3 pairing was built the model charged one v_min_u32 per partition: 266 ns.)
+VALU_NS_PER_WAVE_CANDIDATE = 64 * 1.89 + 25 * 1.04 + 40 * 1.04 + 20.5 * 1.89
 N_SIMD = 1024
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_final_summary.json")
 
