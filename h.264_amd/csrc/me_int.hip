@@ -699,6 +699,7 @@ __global__ __launch_bounds__(256, 3) void me_int_pair_kernel(MeDev P, const jmhi
   if (item < 0) return;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  STAMP(0);
   const int mbi = job_index[item] & 0xffffff, rep = (job_index[item] >> 24) & 63;
   const jmhip_me_mb &job = jobs[mbi];
   const int mbx = job.mb_x, mby = job.mb_y;
@@ -779,6 +780,7 @@ __global__ __launch_bounds__(256, 3) void me_int_pair_kernel(MeDev P, const jmhi
     S.chg[tid] = m;
   }
   __syncthreads();
+  STAMP(1);
 
   // ---- per-lane constants
   const int half = lane & 1;
@@ -854,6 +856,7 @@ __global__ __launch_bounds__(256, 3) void me_int_pair_kernel(MeDev P, const jmhi
     }
   };
 
+  STAMP(2);
   // ---- main grid: 64 columns (two groups of 32 lane pairs) x all rows (two halves)
   {
     const int col = (wave % NG) * 32 + (lane >> 1);
@@ -901,6 +904,7 @@ __global__ __launch_bounds__(256, 3) void me_int_pair_kernel(MeDev P, const jmhi
     }
   }
 
+  STAMP(3);
   // ---- columns beyond 64: one candidate per lane pair, fresh window rows, mv costs straight from the tables
   {
     const int nrc = UW - 32 * NG, nrest = nrc * UH;
@@ -918,6 +922,7 @@ __global__ __launch_bounds__(256, 3) void me_int_pair_kernel(MeDev P, const jmhi
     }
   }
 
+  STAMP(4);
   // ---- reduce: keys to LDS as red[slot = local * 2 + half][pair index], 64-bit key as two slot rows (42+half hi, 44+half lo)
   __syncthreads();
   {
@@ -936,6 +941,7 @@ __global__ __launch_bounds__(256, 3) void me_int_pair_kernel(MeDev P, const jmhi
     S.part[s][hq] = mm;
   }
   __syncthreads();
+  STAMP(5);
   if (tid < JMHIP_NPART) {
     const int p = tid, s = c_pair_slot[p];
     jmhip_me_result &o = res[mbi];
@@ -959,6 +965,7 @@ __global__ __launch_bounds__(256, 3) void me_int_pair_kernel(MeDev P, const jmhi
       if (!P.subpel) { o.mv[p][0] = (int16_t)(rx << 2); o.mv[p][1] = (int16_t)(ry << 2); o.cost[p] = cost; }
     }
   }
+  STAMP(6);
 }
 
 int ensure_tables(jmhip_ctx *c)
