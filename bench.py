@@ -217,6 +217,9 @@ def main():
     ap.add_argument("--cpu-mbs", type=int, default=4 * MBW, help="macroblocks in the CPU baseline sample (0 = skip)")
     ap.add_argument("--clip", choices=["translation", "noise"], default="translation",
                     help="translation = SURVEY 8(d)'s clip (default, the metric's workload); noise = its adversarial i.i.d. clip, for information only")
+    ap.add_argument("--deblock", action="store_true",
+                    help="for information: also run the in-loop deblocking filter on the device each frame (jmhip_deblock_recon; idc 0 on one GPU, "
+                         "idc 2 with one slice per rank on N GPUs). Not part of the metric; the filter is a serial wavefront (DESIGN.md section 3)")
     ap.add_argument("--size", choices=["1080p", "2160p"], default="1080p",
                     help="1080p = BASELINE config 2, the metric's workload (default); 2160p = config 4's picture size, for information only")
     args = ap.parse_args()
@@ -302,6 +305,11 @@ def main():
             else:
                 ctx.me_frame_async(prm, None, n)
             ctx.residual_frame(quants)
+            if args.deblock:
+                if world == 1:
+                    ctx.deblock_recon(QP, (QP, QP))
+                else:
+                    ctx.deblock_recon(QP, (QP, QP), disable_idc=2, slice_rows=band, mb_row0=row0, mb_rows=row1 - row0)
         if world == 1:
             ctx.recon_to_ref(0)
         else:
@@ -380,7 +388,8 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": ("1920x1080 (coded 1920x1088, 8160 MBs)" if args.size == "1080p" else "3840x2160 (32400 MBs)") + " YUV420 P-frames, baseline tools, FullSearch +-32, "
                                    "41 partitions, SAD full-pel + SATD sub-pel, dct_4x4 + dct_chroma, QP %d, 1 reference; "
-                                   "predictor field (16,-16)+U{-8..8} qpel per MB%s" % (QP, "" if args.clip == "translation" else "; ADVERSARIAL i.i.d. noise clip"),
+                                   "predictor field (16,-16)+U{-8..8} qpel per MB%s%s" % (QP, "" if args.clip == "translation" else "; ADVERSARIAL i.i.d. noise clip",
+                                                                                      "; + in-loop deblocking (NOT the metric's path)" if args.deblock else ""),
                        "slices": world, "parallelism": "slice%d" % world},
             "roofline": {"kernel": "me_int_pair_kernel (integer full search, all 41 partitions)", "bound": "hbm",
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),

@@ -501,14 +501,12 @@ extern "C" int jmhip_recon_upload(jmhip_ctx *c, const void *Y, const void *U, co
   return JMHIP_OK;
 }
 
-extern "C" int jmhip_deblock_frame(jmhip_ctx *c, const jmhip_deblock_mb *mbs, const jmhip_deblock_blk *blks, int mvlimit, int mb_row0, int mb_rows)
+namespace {
+
+struct DbkArrays { uint8_t *mbs, *blks, *edges; };
+
+int dbk_arrays(jmhip_ctx *c, DbkArrays *a)
 {
-  if (!c || !mbs || !blks) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_deblock_frame: NULL argument") : JMHIP_ERR_ARG;
-  if (!c->rec_y || !(c->fr_n > 0 || c->rec_has_pic)) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_deblock_frame: no recon picture yet");
-  if (mb_rows <= 0) { mb_row0 = 0; mb_rows = c->mbh; }
-  if (mb_row0 < 0 || mb_row0 + mb_rows > c->mbh) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_deblock_frame: row band outside the picture");
-  if (mvlimit != 4 && mvlimit != 2) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_deblock_frame: mvlimit is 4 (frame) or 2 (field)");
-  JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
   const int nmb = c->mbw * c->mbh;
   const size_t mb_bytes = sizeof(jmhip_deblock_mb) * (size_t)nmb, blk_bytes = sizeof(jmhip_deblock_blk) * (size_t)nmb * 16;
   const size_t blk_off = (mb_bytes + 255) & ~(size_t)255, edge_off = (blk_off + blk_bytes + 255) & ~(size_t)255;
@@ -519,17 +517,20 @@ extern "C" int jmhip_deblock_frame(jmhip_ctx *c, const jmhip_deblock_mb *mbs, co
     if (hipMalloc(&c->dbk_dev, total) != hipSuccess) return jm_fail(c, JMHIP_ERR_NOMEM, "deblocking arrays");
     c->dbk_cap = total;
   }
-  uint8_t *base = (uint8_t *)c->dbk_dev;
-  JM_HIP_CHECK(c, hipMemcpyAsync(base, mbs, mb_bytes, hipMemcpyHostToDevice, c->stream));
-  JM_HIP_CHECK(c, hipMemcpyAsync(base + blk_off, blks, blk_bytes, hipMemcpyHostToDevice, c->stream));
-  JM_HIP_CHECK(c, hipStreamSynchronize(c->stream));             // the caller's arrays are only borrowed for the call
-  jm_stage_begin(c, JMHIP_STAGE_DEBLOCK);
-  deblock_strength_kernel<<<(nmb * 8 + 255) / 256, 256, 0, c->stream>>>((const jmhip_deblock_mb *)base, (const jmhip_deblock_blk *)(base + blk_off),
-                                                                         (EdgeInfo *)(base + edge_off), c->mbw, c->mbh, mvlimit);
+  a->mbs = (uint8_t *)c->dbk_dev; a->blks = a->mbs + blk_off; a->edges = a->mbs + edge_off;
+  return JMHIP_OK;
+}
+
+// strengths + the wavefront walk over macroblock rows [mb_row0, mb_row0 + mb_rows); the side arrays are on the device
+int dbk_run(jmhip_ctx *c, const DbkArrays &a, int mvlimit, int mb_row0, int mb_rows)
+{
+  const int nmb = c->mbw * c->mbh;
+  deblock_strength_kernel<<<(nmb * 8 + 255) / 256, 256, 0, c->stream>>>((const jmhip_deblock_mb *)a.mbs, (const jmhip_deblock_blk *)a.blks,
+                                                                         (EdgeInfo *)a.edges, c->mbw, c->mbh, mvlimit);
   JM_HIP_CHECK(c, hipGetLastError());
   DeblockDev D;
   D.y = c->rec_y; D.u = c->rec_u; D.v = c->rec_v;
-  D.edges = (const EdgeInfo *)(base + edge_off);
+  D.edges = (const EdgeInfo *)a.edges;
   D.W = c->W; D.Wc = c->Wc; D.mbw = c->mbw; D.row0 = mb_row0; D.rows = mb_rows;
   D.dbg = getenv("JMHIP_DBK_DEBUG") ? atoi(getenv("JMHIP_DBK_DEBUG")) : 0;
   // LDS ring (4:2:0 / 4:0:0) when three diagonals + one diagonal of edge records fit into 160 KB; JMHIP_DEBLOCK_KERNEL=global forces the
@@ -560,9 +561,109 @@ extern "C" int jmhip_deblock_frame(jmhip_ctx *c, const jmhip_deblock_mb *mbs, co
   case JMHIP_YUV420: deblock_filter_kernel<JMHIP_YUV420><<<1, 1024, 0, c->stream>>>(D); break;
   case JMHIP_YUV422: deblock_filter_kernel<JMHIP_YUV422><<<1, 1024, 0, c->stream>>>(D); break;
   case JMHIP_YUV444: deblock_filter_kernel<JMHIP_YUV444><<<1, 1024, 0, c->stream>>>(D); break;
-  default: return jm_fail(c, JMHIP_ERR_ARG, "jmhip_deblock_frame: chroma format");
+  default: return jm_fail(c, JMHIP_ERR_ARG, "deblocking: chroma format");
   }
   JM_HIP_CHECK(c, hipGetLastError());
-  jm_stage_end(c, JMHIP_STAGE_DEBLOCK);
   return JMHIP_OK;
+}
+
+// The filter's side information straight from what the frame stage left on the device (P macroblocks: jmhip_me_frame's vectors,
+// the modes and coded-block bits of jmhip_residual_frame): what DeblockFrame would read from img->mb_data[] / enc_picture after JM
+// had stored the same decisions. 16 lanes per listed macroblock, one per 4x4 block.
+__device__ __forceinline__ int dbk_covering_partition(const jmhip_mb_mode &m, int x4, int y4)
+{
+  const int b8 = 2 * (y4 >> 1) + (x4 >> 1);
+  if (m.mode == 1) return 0;
+  if (m.mode == 2) return 1 + (y4 >> 1);
+  if (m.mode == 3) return 3 + (x4 >> 1);
+  const int bm = m.b8mode[b8];
+  if (bm == 4) return 5 + b8;
+  if (bm == 5) return 9 + 2 * b8 + (y4 & 1);
+  if (bm == 6) return 17 + 2 * b8 + (x4 & 1);
+  return 25 + 4 * b8 + 2 * (y4 & 1) + (x4 & 1);
+}
+
+__global__ __launch_bounds__(256) void deblock_inputs_kernel(const jmhip_me_mb *__restrict__ jobs, const jmhip_me_result *__restrict__ res,
+                                                             const jmhip_mb_mode *__restrict__ modes, const JmMbCoded *__restrict__ coded, int n,
+                                                             jmhip_deblock_params prm, int mbw, jmhip_deblock_mb *__restrict__ mbs,
+                                                             jmhip_deblock_blk *__restrict__ blks)
+{
+  const int i = blockIdx.x * 16 + (threadIdx.x >> 4), t = threadIdx.x & 15;
+  if (i >= n) return;
+  const jmhip_me_mb &job = jobs[i];
+  const jmhip_mb_mode m = modes[i];
+  const int mbx = job.mb_x, mby = job.mb_y, x4 = t & 3, y4 = t >> 2;
+  const int p = dbk_covering_partition(m, x4, y4);
+  jmhip_deblock_blk b;
+  b.mv[0][0] = res[i].mv[p][0]; b.mv[0][1] = res[i].mv[p][1];
+  b.mv[1][0] = 0; b.mv[1][1] = 0;
+  b.ref_id[0] = job.ref;                                   // one picture per reference slot: slot equality is picture equality
+  b.ref_id[1] = INT64_MIN;
+  blks[(size_t)(mby * 4 + y4) * (mbw * 4) + mbx * 4 + x4] = b;
+  if (t == 0) {
+    jmhip_deblock_mb o;
+    o.intra = 0;
+    o.qp = (uint8_t)prm.qp; o.qpc[0] = (uint8_t)prm.qpc[0]; o.qpc[1] = (uint8_t)prm.qpc[1];
+    o.disable_idc = (uint8_t)prm.disable_idc;
+    o.alpha_c0_offset = (int8_t)prm.alpha_c0_offset; o.beta_offset = (int8_t)prm.beta_offset;
+    o.transform_8x8 = (uint8_t)(m.pad[0] != 0);
+    o.avail_a = (uint8_t)(mbx != 0);
+    o.avail_b = (uint8_t)(mby != 0 && (prm.slice_rows <= 0 || (mby % prm.slice_rows) != 0));
+    o.cbp_blk = (uint16_t)(coded[i].cbp_blk & 0xffff);
+    mbs[mby * mbw + mbx] = o;
+  }
+}
+
+}  // namespace
+
+extern "C" int jmhip_deblock_frame(jmhip_ctx *c, const jmhip_deblock_mb *mbs, const jmhip_deblock_blk *blks, int mvlimit, int mb_row0, int mb_rows)
+{
+  if (!c || !mbs || !blks) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_deblock_frame: NULL argument") : JMHIP_ERR_ARG;
+  if (!c->rec_y || !(c->fr_n > 0 || c->rec_has_pic)) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_deblock_frame: no recon picture yet");
+  if (mb_rows <= 0) { mb_row0 = 0; mb_rows = c->mbh; }
+  if (mb_row0 < 0 || mb_row0 + mb_rows > c->mbh) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_deblock_frame: row band outside the picture");
+  if (mvlimit != 4 && mvlimit != 2) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_deblock_frame: mvlimit is 4 (frame) or 2 (field)");
+  JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
+  DbkArrays a;
+  int rc = dbk_arrays(c, &a);
+  if (rc) return rc;
+  const int nmb = c->mbw * c->mbh;
+  JM_HIP_CHECK(c, hipMemcpyAsync(a.mbs, mbs, sizeof(jmhip_deblock_mb) * (size_t)nmb, hipMemcpyHostToDevice, c->stream));
+  JM_HIP_CHECK(c, hipMemcpyAsync(a.blks, blks, sizeof(jmhip_deblock_blk) * (size_t)nmb * 16, hipMemcpyHostToDevice, c->stream));
+  JM_HIP_CHECK(c, hipStreamSynchronize(c->stream));             // the caller's arrays are only borrowed for the call
+  jm_stage_begin(c, JMHIP_STAGE_DEBLOCK);
+  rc = dbk_run(c, a, mvlimit, mb_row0, mb_rows);
+  jm_stage_end(c, JMHIP_STAGE_DEBLOCK);
+  return rc;
+}
+
+extern "C" int jmhip_deblock_recon(jmhip_ctx *c, const jmhip_deblock_params *prm)
+{
+  if (!c || !prm) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_deblock_recon: NULL argument") : JMHIP_ERR_ARG;
+  if (!c->rec_y || c->fr_n <= 0 || c->fr_n != c->me_n) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_deblock_recon: needs the macroblock list of the last jmhip_me_frame + jmhip_residual_frame");
+  int row0 = prm->mb_row0, rows = prm->mb_rows;
+  if (rows <= 0) { row0 = 0; rows = c->mbh; }
+  if (row0 < 0 || row0 + rows > c->mbh) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_deblock_recon: row band outside the picture");
+  const int mvlimit = prm->mvlimit ? prm->mvlimit : 4;
+  if (mvlimit != 4 && mvlimit != 2) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_deblock_recon: mvlimit is 4 (frame) or 2 (field)");
+  if (prm->qp < 0 || prm->qp > 51 || prm->qpc[0] < 0 || prm->qpc[0] > 51 || prm->qpc[1] < 0 || prm->qpc[1] > 51 || prm->disable_idc < 0 || prm->disable_idc > 2)
+    return jm_fail(c, JMHIP_ERR_ARG, "jmhip_deblock_recon: quantiser / idc out of range");
+  JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
+  DbkArrays a;
+  int rc = dbk_arrays(c, &a);
+  if (rc) return rc;
+  const int nmb = c->mbw * c->mbh, n = c->fr_n;
+  jm_stage_begin(c, JMHIP_STAGE_DEBLOCK);
+  // macroblocks outside the list (other ranks' rows) read as "P, nothing coded, zero vectors": a band is only self-contained when
+  // its first row's top edge is off (idc 2 with slice_rows), exactly as for jmhip_deblock_frame
+  JM_HIP_CHECK(c, hipMemsetAsync(a.mbs, 0, (size_t)(a.edges - a.mbs), c->stream));
+  (void)nmb;
+  const jmhip_mb_mode *modes = (const jmhip_mb_mode *)c->fr_modes;
+  const JmMbCoded *coded = reinterpret_cast<const JmMbCoded *>(modes + 2 * (size_t)n);       // layout of jmhip_residual_frame
+  deblock_inputs_kernel<<<(n + 15) / 16, 256, 0, c->stream>>>((const jmhip_me_mb *)c->me_jobs_dev, (const jmhip_me_result *)c->me_res_dev, modes, coded, n,
+                                                              *prm, c->mbw, (jmhip_deblock_mb *)a.mbs, (jmhip_deblock_blk *)a.blks);
+  JM_HIP_CHECK(c, hipGetLastError());
+  rc = dbk_run(c, a, mvlimit, row0, rows);
+  jm_stage_end(c, JMHIP_STAGE_DEBLOCK);
+  return rc;
 }

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(64) void mc_kernel(FrameDev F, const jmhip_me_mb *_
   }
 }
 
-struct MbCoded { int32_t cbp; int32_t pad; int64_t cbp_blk; };
+using MbCoded = JmMbCoded;
 
 __global__ __launch_bounds__(64) void finalize_kernel(FrameDev F, const jmhip_me_mb *__restrict__ mbs, const jmhip_tq_job *__restrict__ jobs_y,
                                                      const jmhip_tq_result *__restrict__ res_y, const jmhip_tq_job *__restrict__ jobs_c,

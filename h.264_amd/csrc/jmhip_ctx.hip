@@ -30,6 +30,7 @@ extern "C" int jmhip_sizeof(int which)
   case 13: return (int)sizeof(jmhip_predcost_job);
   case 14: return (int)sizeof(jmhip_deblock_mb);
   case 15: return (int)sizeof(jmhip_deblock_blk);
+  case 16: return (int)sizeof(jmhip_deblock_params);
   default: return -1;
   }
 }

@@ -13,6 +13,9 @@ struct ChromaGeom {           // chroma_mc_setup, lencod/src/lencod.c:2851-2884
   int sub_x, sub_y, pad_x, pad_y, shift_x, shift_y, mask_x, mask_y, mul_x, mul_y, mb_w, mb_h;
 };
 
+// what the frame stage keeps per macroblock after thresholding (frame.hip finalize_kernel); read by deblock.hip
+struct JmMbCoded { int32_t cbp; int32_t pad; int64_t cbp_blk; };
+
 struct RefSlot {
   uint8_t *y = nullptr, *u = nullptr, *v = nullptr;   // integer-pel recon, pitch = W / Wc
   uint8_t *luma_sub = nullptr;                        // [16][Hp][Wp]

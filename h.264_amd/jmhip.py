@@ -39,6 +39,11 @@ def declared_symbols():
     return sorted(set(re.findall(r"\b(jmhip_[a-z0-9_]+)\s*\(", txt)))
 
 
+class DeblockParams(C.Structure):
+    _fields_ = [("qp", C.c_int32), ("qpc", C.c_int32 * 2), ("disable_idc", C.c_int32), ("alpha_c0_offset", C.c_int32), ("beta_offset", C.c_int32),
+                ("slice_rows", C.c_int32), ("mvlimit", C.c_int32), ("mb_row0", C.c_int32), ("mb_rows", C.c_int32)]
+
+
 class Config(C.Structure):
     _fields_ = [("device", C.c_int), ("width", C.c_int), ("height", C.c_int), ("yuv_format", C.c_int),
                 ("bit_depth", C.c_int), ("max_refs", C.c_int), ("search_range", C.c_int)]
@@ -113,6 +118,7 @@ def load_library():
     lib.jmhip_ref_upload.argtypes = [vp, ip, vp, vp, vp, ip, ip, ip, ip]
     lib.jmhip_recon_upload.argtypes = [vp, vp, vp, vp, ip]
     lib.jmhip_deblock_frame.argtypes = [vp, vp, vp, ip, ip, ip]
+    lib.jmhip_deblock_recon.argtypes = [vp, C.POINTER(DeblockParams)]
     lib.jmhip_cur_upload.argtypes = [vp, vp, vp, vp, ip, ip, ip, ip]
     lib.jmhip_interp_luma.argtypes = [vp, ip]
     lib.jmhip_interp_chroma.argtypes = [vp, ip]
@@ -155,7 +161,8 @@ def load_library():
                       (14, DEBLOCK_MB_DTYPE), (15, DEBLOCK_BLK_DTYPE)):
         if lib.jmhip_sizeof(which) != dt.itemsize:
             raise JmhipError("binding layout mismatch for struct %d: C %d vs numpy %d" % (which, lib.jmhip_sizeof(which), dt.itemsize))
-    if lib.jmhip_sizeof(6) != C.sizeof(MeParams) or lib.jmhip_sizeof(7) != C.sizeof(Config) or lib.jmhip_sizeof(12) != C.sizeof(BipredParams):
+    if lib.jmhip_sizeof(6) != C.sizeof(MeParams) or lib.jmhip_sizeof(7) != C.sizeof(Config) or lib.jmhip_sizeof(12) != C.sizeof(BipredParams) or \
+            lib.jmhip_sizeof(16) != C.sizeof(DeblockParams):
         raise JmhipError("binding layout mismatch for jmhip_me_params / jmhip_config")
     _lib = lib
     return lib
@@ -412,6 +419,15 @@ class Context:
         if mbs.size != nmb or blks.size != 16 * nmb:
             raise ValueError("deblock_frame: need %d macroblock and %d block entries" % (nmb, 16 * nmb))
         self._chk(self.lib.jmhip_deblock_frame(self.h, _ptr(mbs), _ptr(blks), mvlimit, mb_row0, mb_rows), "jmhip_deblock_frame")
+
+    def deblock_recon(self, qp, qpc=None, disable_idc=0, alpha_c0_offset=0, beta_offset=0, slice_rows=0, mb_row0=0, mb_rows=0):
+        """DeblockFrame on the recon picture from the device-resident results of me_frame + residual_frame (nothing crosses PCIe)."""
+        p = DeblockParams()
+        p.qp = qp
+        p.qpc[0], p.qpc[1] = qpc if qpc is not None else (qp, qp)
+        p.disable_idc, p.alpha_c0_offset, p.beta_offset, p.slice_rows, p.mvlimit = disable_idc, alpha_c0_offset, beta_offset, slice_rows, 4
+        p.mb_row0, p.mb_rows = mb_row0, mb_rows
+        self._chk(self.lib.jmhip_deblock_recon(self.h, C.byref(p)), "jmhip_deblock_recon")
 
     # ---- timing
     def stream_ptr(self):

@@ -368,6 +368,21 @@ typedef struct jmhip_deblock_blk {     /* one 4x4 block, raster order over the p
  * 16*mbw*mbh entries, HOST arrays borrowed for the call. mvlimit: 4 (frame pictures). Results are identical to JM's macroblock-
  * order filter: the kernel keeps that order through a 2:1 wavefront (deblock.hip). */
 int jmhip_deblock_frame(jmhip_ctx *ctx, const jmhip_deblock_mb *mbs, const jmhip_deblock_blk *blks, int mvlimit, int mb_row0, int mb_rows);
+
+/* The same filter fed from what the frame stage left on the device: the vectors of the last jmhip_me_frame, the modes and coded-block
+ * bits of the last jmhip_residual_frame (same macroblock list; P macroblocks, one reference slot per macroblock) -- the state JM
+ * would have stored in img->mb_data[] / enc_picture before image.c:331 calls DeblockFrame. Nothing crosses PCIe. The picture-level
+ * values come from the caller: the (uniform) quantisers as MbQ->qp / qpc[0..1], the slice header's filter fields, and the slice
+ * height in macroblock rows (0 = one slice) from which mbAvailB follows for disable_idc 2. Rows outside the list (other ranks' bands)
+ * are not known: restrict [mb_row0, mb_row0 + mb_rows) to listed rows whose top edge is off. */
+typedef struct jmhip_deblock_params {
+  int32_t qp, qpc[2];
+  int32_t disable_idc, alpha_c0_offset, beta_offset;
+  int32_t slice_rows;
+  int32_t mvlimit;               /* 0 or 4: frame pictures */
+  int32_t mb_row0, mb_rows;      /* mb_rows <= 0: the whole picture */
+} jmhip_deblock_params;
+int jmhip_deblock_recon(jmhip_ctx *ctx, const jmhip_deblock_params *prm);
 /* One-buffer band exchange (slice-parallel ranks): rank `rank`'s reconstructed band of `band_rows` macroblock rows
  * as ONE device chunk [Y rows | U rows | V rows] (jmhip_band_chunk_bytes), so that one all-gather moves the frame;
  * jmhip_ref_unpack_bands scatters the `world` gathered chunks into reference slot `ref` (rows below the picture are padding). */
@@ -378,7 +393,7 @@ int jmhip_ref_unpack_bands(jmhip_ctx *ctx, int ref, const void *chunks_device, i
 /* sizeof() of the ABI structs, for language bindings to verify their layout: 0 jmhip_me_mb, 1 jmhip_me_result,
  * 2 jmhip_quant, 3 jmhip_tq_job, 4 jmhip_tq_result, 5 jmhip_dist_job, 6 jmhip_me_params, 7 jmhip_config,
  * 8 jmhip_mb_mode, 9 jmhip_surface_job, 10 jmhip_bipred_job, 11 jmhip_bipred_result, 12 jmhip_bipred_params, 13 jmhip_predcost_job,
- * 14 jmhip_deblock_mb, 15 jmhip_deblock_blk. */
+ * 14 jmhip_deblock_mb, 15 jmhip_deblock_blk, 16 jmhip_deblock_params. */
 int jmhip_sizeof(int which);
 
 /* Flat (no scaling matrix) tables: CalculateQuantParam / CalculateQuant8Param (src/q_matrix.c:451,590) and

@@ -158,3 +158,57 @@ def test_deblock_global_memory_kernel_on_420(pkg, monkeypatch):
     monkeypatch.setenv("JMHIP_DEBLOCK_KERNEL", "global")
     run(pkg, 176, 144, 1, seed=21)
     run(pkg, 320, 64, 0, seed=22)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("idc,slice_rows", [(0, 0), (2, 2)])
+def test_deblock_recon_from_the_frame_stage(pkg, idc, slice_rows):
+    """jmhip_deblock_recon builds the filter's side information on the device from the results of me_frame + residual_frame.
+    Expected: the oracle's filter on the downloaded (unfiltered) reconstruction with the same information assembled on the host."""
+    from tests.test_frame import synth
+    from tests.test_me import lambda_factors, make_mbs
+    rng = np.random.default_rng(12)
+    w, h, R, qp = 96, 64, 8, 38
+    cur, ref = synth(rng, w, h, 1)
+    ctx = pkg.Context(w, h, yuv_format=1, max_refs=1, search_range=R)
+    ctx.ref_upload(0, *ref)
+    ctx.interp_luma(0)
+    ctx.interp_chroma(0)
+    ctx.cur_upload(*cur)
+    mbw, mbh = w // 16, h // 16
+    mbs_me = make_mbs(pkg, rng, mbw, mbh, 6)
+    prm = pkg.MeParams()
+    prm.search_mode, prm.search_range, prm.rdopt = -1, R, 1
+    prm.level_mv_min, prm.level_mv_max = -511, 511
+    prm.lambda_[0], prm.lambda_[1], prm.lambda_[2] = lambda_factors(qp)
+    prm.subpel, prm.partition_mask = 1, (1 << 41) - 1
+    me = ctx.me_frame(prm, mbs_me)
+    quants = np.array([pkg.flat_quant(qp + d, 342, adaptive_rounding=0, adapt_rnd_weight=4, cavlc=1) for d in (0, 0, 3)], dtype=pkg.QUANT_DTYPE)
+    ctx.residual_frame(quants, None)
+    got = ctx.residual_download(len(mbs_me))
+    before = ctx.recon_download()
+    # the same information, assembled on the host
+    mbs = np.zeros(mbw * mbh, pkg.DEBLOCK_MB_DTYPE)
+    blks = np.zeros(16 * mbw * mbh, pkg.DEBLOCK_BLK_DTYPE)
+    blks["ref_id"][:, 1] = INT64_MIN
+    for i, job in enumerate(mbs_me):
+        x, y = int(job["mb_x"]), int(job["mb_y"])
+        a = y * mbw + x
+        mbs["qp"][a], mbs["qpc"][a] = qp, (qp - 2, qp - 3)
+        mbs["disable_idc"][a], mbs["alpha_c0_offset"][a], mbs["beta_offset"][a] = idc, 2, -2
+        mbs["transform_8x8"][a] = int(got["modes"][i]["pad"][0]) != 0
+        mbs["avail_a"][a] = x != 0
+        mbs["avail_b"][a] = y != 0 and (slice_rows == 0 or y % slice_rows != 0)
+        mbs["cbp_blk"][a] = int(got["cbp_blk"][i]) & 0xffff
+        for t in range(16):
+            p = oracle.covering_partition(got["modes"][i], t & 3, t >> 2)
+            k = (y * 4 + (t >> 2)) * (mbw * 4) + x * 4 + (t & 3)
+            blks["mv"][k, 0] = me["mv"][i, p]
+            blks["ref_id"][k, 0] = int(job["ref"])
+    want = oracle.deblock_frame(before[0], before[1], before[2], 1, mbs, blks)
+    assert int((want[0] != before[0]).sum()) > 0
+    ctx.deblock_recon(qp, (qp - 2, qp - 3), disable_idc=idc, alpha_c0_offset=2, beta_offset=-2, slice_rows=slice_rows)
+    after = ctx.recon_download()
+    ctx.close()
+    for g, wv, name in zip(after, want, "YUV"):
+        assert np.array_equal(g, wv), name
