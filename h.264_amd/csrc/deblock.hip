@@ -321,7 +321,7 @@ __global__ __launch_bounds__(1024) void deblock_filter_kernel(DeblockDev D)
 // registers), filtered twice in LDS, touched by its neighbours there, and written back once two diagonals later. The serial path
 // then only sees LDS latency; one CU's vector-memory path, which the global-memory kernel above saturates with byte accesses,
 // carries 24 wide loads and stores per macroblock. Tile k of a ring slot is always filled, filtered and written back by the same
-// 16 lanes, so the only barriers are the two per diagonal the data flow needs.
+// 16 lanes, and a macroblock's two passes run in one wave, so ONE workgroup barrier per diagonal is all the data flow needs.
 constexpr int DBK_TILE = 384, DBK_ETILE = 128;
 
 struct Diag { int y_lo, count; };
@@ -418,7 +418,8 @@ __global__ __launch_bounds__(1024) void deblock_lds_kernel(DeblockDev D, int S)
         }
       }
     }
-    __syncthreads();
+    // No workgroup barrier here: the horizontal pass of a macroblock reads its own tile -- written just above by the 16 lanes of the
+    // same wave, and a wave's LDS operations complete in order -- and the tile above it, last touched one diagonal ago.
     // ---- horizontal edges: lane = column
 #pragma unroll
     for (int p = 0; p < NP; p++) {
