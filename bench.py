@@ -407,6 +407,16 @@ def main():
             "stages_ms_per_launch": {k: round(v[0] / max(1, v[1]), 4) for k, v in stage.items()},
             "ref_checksum": ref_sum,
         }
+        if world == 1:
+            # the HBM-bound stages against the same 8 TB/s, from SURVEY 8(d)'s algorithmic bytes at this build's 8-bit samples:
+            # luma planes (1 read + 16 written) x padded plane; chroma 2 x (1 + 64) x padded plane; transform/quant/recon per macroblock
+            # cur + pred 768 B in, levels 384 x 4 B + recon 384 B out
+            ms = out["stages_ms_per_launch"]
+            alg = {"interp_luma": (W + 40) * (H + 40) * 17, "interp_chroma": 2 * (W // 2 + 20) * (H // 2 + 20) * 65,
+                   "mc+tq": n * (768 + 384 * 4 + 384)}
+            t_ms = {"interp_luma": ms["interp_luma"], "interp_chroma": ms["interp_chroma"], "mc+tq": ms["mc"] + ms["tq"]}
+            out["hbm_bound_stages"] = {k: {"algorithmic_bytes": alg[k], "ms": round(t_ms[k], 4), "achieved_GBs": round(alg[k] / (t_ms[k] * 1e-3) / 1e9, 1),
+                                           "frac_of_8TBs": round(alg[k] / (t_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)} for k in alg if t_ms[k] > 0}
         if world == 1 and args.cpu_mbs > 0:
             ref = cpu_baseline_reference(frames)
             port = cpu_baseline(pkg, frames, args.cpu_mbs)

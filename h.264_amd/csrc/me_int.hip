@@ -676,8 +676,10 @@ void build_pair_tables()
   for (int h = 1; h >= 0; h--) for (int j = 0; j < PAIR_NK; j++) h_pair_slot[h_pair_g[h][j]] = (int8_t)(j * 2 + h);    // half 0 wins for the spanning ones
 }
 
+constexpr int SLOT_UNUSED = 0x7fffffff;
 struct PairShared {                                   // 2R+1 <= 81 on this path (host check)
   int px[JMHIP_NPART], py[JMHIP_NPART];
+  int spx[48], spy[48];                               // predictor of table slot half * 24 + local (SLOT_UNUSED: none)
   unsigned chg[96];
   uint8_t bytab[96][48] __attribute__((aligned(16)));    // [row][half * 24 + local]: vertical mv bits
   uint8_t bxtab[84][48] __attribute__((aligned(16)));    // [column][half * 24 + local]: horizontal mv bits
@@ -710,6 +712,12 @@ __global__ __launch_bounds__(256, 3) void me_int_pair_kernel(MeDev P, const jmhi
   search_center(P, job.pred_mv[rep][0], job.pred_mv[rep][1], &ucx, &ucy);
   const int umin_x = ucx - R, umin_y = ucy - R;
   if (tid < JMHIP_NPART) { S.px[tid] = job.pred_mv[tid][0]; S.py[tid] = job.pred_mv[tid][1]; }
+  if (tid >= 64 && tid < 112) {                       // predictors in table-slot order, for the table build below
+    const int s = tid - 64, g = c_pair_g[s / 24][s % 24];
+    S.spx[s] = g >= 0 ? job.pred_mv[g][0] : SLOT_UNUSED;
+    S.spy[s] = g >= 0 ? job.pred_mv[g][1] : SLOT_UNUSED;
+  }
+  __syncthreads();                                    // before the window loads are issued: every lane waits for the job anyway
   if (tid < 64) S.cur[tid] = *reinterpret_cast<const uint32_t *>(P.cur + (size_t)(mby * 16 + (tid >> 2)) * P.W + mbx * 16 + (tid & 3) * 4);
 
   // ---- reference window (as me_int_fast_kernel): loads first, tables while they fly, four copies from registers
@@ -728,14 +736,20 @@ __global__ __launch_bounds__(256, 3) void me_int_pair_kernel(MeDev P, const jmhi
       q0[u] = q[0]; q1[u] = q[1]; q2[u] = q[2];
     }
   }
-  {
-    const int s = tid & 63, i0 = tid >> 6;             // table slot = half * 24 + local
-    if (s < 48) {
-      const int g = c_pair_g[s / 24][s % 24];
-      const int py = g >= 0 ? job.pred_mv[g][1] : 0, px = g >= 0 ? job.pred_mv[g][0] : 0;
-      for (int row = i0; row < UH; row += 4) S.bytab[row][s] = g >= 0 ? (uint8_t)mvbits(4 * (umin_y + row) - py) : 0;
-      for (int c = i0; c < UW; c += 4) S.bxtab[c][s] = g >= 0 ? (uint8_t)mvbits(4 * (umin_x + c) - px) : 0;
+  // mv-bit tables, four slots (one dword) per item so that all 256 lanes work and a line of 48 slots is 12 stores:
+  // 12 x (UH + UW) items; slot = half * 24 + local, unused slots hold 0
+  for (int e = tid; e < 12 * (UH + UW); e += 256) {
+    const bool isx = e >= 12 * UH;
+    const int e2 = isx ? e - 12 * UH : e, line = e2 / 12, q = e2 - line * 12;
+    const int v4 = 4 * ((isx ? umin_x : umin_y) + line);
+    const int *sp = isx ? S.spx : S.spy;
+    uint32_t w = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int p = sp[4 * q + k];
+      w |= (p == SLOT_UNUSED ? 0u : (uint32_t)mvbits(v4 - p)) << (8 * k);
     }
+    reinterpret_cast<uint32_t *>(isx ? S.bxtab[line] : S.bytab[line])[q] = w;
   }
   if (xw < PITCH) {
     if (inside) {
