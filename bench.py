@@ -228,6 +228,7 @@ def main():
         MBW, MBH = W // 16, H // 16
         args.cpu_mbs = 0                              # the CPU baseline is quoted on the metric's own workload only
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL across processes)
     import torch
     import __graft_entry__ as ge
     pkg = ge._load_pkg()

@@ -294,7 +294,8 @@ typedef struct {
 } jmhip_tq_job;
 
 typedef struct {
-  int32_t  levels[16][17];       /* (level) lists per 4x4 block in JM block order b8*4+b4, 0-terminated;
+  int32_t  levels[16][17];       /* (level) lists per 4x4 block in JM block order b8*4+b4, 0-terminated; entries after the
+                                    terminator are not written (JM never clears img->cofAC either);
                                     LUMA8x8: rows 4*b8 .. 4*b8+3 hold cofAC[b8][0..3] (17 entries each
                                     for CAVLC interleave) -- see levels8 for the 64-entry CABAC list  */
   int32_t  runs[16][17];
