@@ -142,10 +142,11 @@ using MbCoded = JmMbCoded;
 
 __global__ __launch_bounds__(64) void finalize_kernel(FrameDev F, const jmhip_me_mb *__restrict__ mbs, const jmhip_tq_job *__restrict__ jobs_y,
                                                      const jmhip_tq_result *__restrict__ res_y, const jmhip_tq_job *__restrict__ jobs_c,
-                                                     const jmhip_tq_result *__restrict__ res_c, MbCoded *__restrict__ coded)
+                                                     const jmhip_tq_result *__restrict__ res_c, MbCoded *__restrict__ coded, int n)
 {
   __shared__ int s_keep[4], s_mbkeep;
-  const int i = blockIdx.x, tid = threadIdx.x;
+  const int i = jm_xcd_item(n), tid = threadIdx.x;
+  if (i < 0) return;
   const jmhip_me_mb &mb = mbs[i];
   const jmhip_tq_result &ry = res_y[i];
   if (tid == 0) {
@@ -306,8 +307,8 @@ extern "C" int jmhip_residual_frame_q(jmhip_ctx *c, const jmhip_mb_mode *modes, 
   if (!rc && any_t8) rc = jm_launch_tq(c, JMHIP_TQ_LUMA8x8 | JMHIP_TQ_SELECT, F.yuv, c->fr_jobs_y, c->fr_quant, c->fr_res_y, n);
   if (!rc && F.yuv != JMHIP_YUV400) rc = jm_launch_tq(c, JMHIP_TQ_CHROMA, F.yuv, c->fr_jobs_c, c->fr_quant, c->fr_res_c, 2 * n);
   if (!rc) {
-    finalize_kernel<<<n, 64, 0, c->stream>>>(F, (const jmhip_me_mb *)c->me_jobs_dev, (const jmhip_tq_job *)c->fr_jobs_y, (const jmhip_tq_result *)c->fr_res_y,
-                                             (const jmhip_tq_job *)c->fr_jobs_c, (const jmhip_tq_result *)c->fr_res_c, coded_dev);
+    finalize_kernel<<<jm_xcd_grid(n), 64, 0, c->stream>>>(F, (const jmhip_me_mb *)c->me_jobs_dev, (const jmhip_tq_job *)c->fr_jobs_y, (const jmhip_tq_result *)c->fr_res_y,
+                                                          (const jmhip_tq_job *)c->fr_jobs_c, (const jmhip_tq_result *)c->fr_res_c, coded_dev, n);
     if (hipGetLastError() != hipSuccess) rc = jm_fail(c, JMHIP_ERR_DEVICE, "finalize_kernel launch");
   }
   jm_stage_end(c, JMHIP_STAGE_TQ);

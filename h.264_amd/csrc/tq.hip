@@ -158,7 +158,10 @@ static_assert(offsetof(jmhip_tq_result, fadjust) % 8 == 0 && sizeof(jmhip_tq_res
 __global__ __launch_bounds__(256) void tq_luma4x4_kernel(const jmhip_tq_job *__restrict__ jobs, const jmhip_quant *__restrict__ quants,
                                                         jmhip_tq_result *__restrict__ res, int n, int select)
 {
-  const int gid = blockIdx.x * 256 + threadIdx.x;
+  // XCD-contiguous block order (as mc_kernel and finalize_kernel): a job tile is read from the L2 it was written into
+  const int vb = jm_xcd_item((n * 16 + 255) / 256);
+  if (vb < 0) return;
+  const int gid = vb * 256 + threadIdx.x;
   const int jobi = gid >> 4, blk = gid & 15;                 // blk = b8*4 + b4 (JM block order)
   if (jobi >= n) return;
   const jmhip_tq_job &job = jobs[jobi];
@@ -524,7 +527,9 @@ __device__ __forceinline__ int quad_bcast(int v, int src)      // value of lane 
 __global__ __launch_bounds__(256) void tq_chroma420_kernel(const jmhip_tq_job *__restrict__ jobs, const jmhip_quant *__restrict__ quants,
                                                           jmhip_tq_result *__restrict__ res, int n)
 {
-  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int vb = jm_xcd_item((n * 4 + 255) / 256);             // XCD-contiguous block order, see tq_luma4x4_kernel
+  if (vb < 0) return;
+  const int gid = vb * 256 + threadIdx.x;
   const int jobi = min(gid >> 2, n - 1), b4 = gid & 3;          // b4: 0 (0,0)  1 (4,0)  2 (0,4)  3 (4,4)  (hor/ver_offset[1][0])
   const bool live = (gid >> 2) < n;                             // whole quads are live or dead together
   const jmhip_tq_job &job = jobs[jobi];
@@ -694,11 +699,11 @@ int jm_launch_tq(jmhip_ctx *c, int kind, int yuv_format, const void *jobs, const
   const int select = (kind & JMHIP_TQ_SELECT) ? 1 : 0;
   kind &= ~JMHIP_TQ_SELECT;
   switch (kind) {
-  case JMHIP_TQ_LUMA4x4:   tq_luma4x4_kernel<<<(n * 16 + 255) / 256, 256, 0, c->stream>>>(dj, dq, dr, n, select); break;
+  case JMHIP_TQ_LUMA4x4:   tq_luma4x4_kernel<<<jm_xcd_grid((n * 16 + 255) / 256), 256, 0, c->stream>>>(dj, dq, dr, n, select); break;
   case JMHIP_TQ_LUMA8x8:   tq_luma8x8_kernel<<<(n * 4 + 63) / 64, 64, 0, c->stream>>>(dj, dq, dr, n, select); break;
   case JMHIP_TQ_LUMA16x16: tq_luma16x16_kernel<<<(n + 63) / 64, 64, 0, c->stream>>>(dj, dq, dr, n); break;
   default:
-    if (yuv_format == JMHIP_YUV420) tq_chroma420_kernel<<<(n * 4 + 255) / 256, 256, 0, c->stream>>>(dj, dq, dr, n);
+    if (yuv_format == JMHIP_YUV420) tq_chroma420_kernel<<<jm_xcd_grid((n * 4 + 255) / 256), 256, 0, c->stream>>>(dj, dq, dr, n);
     else tq_chroma_kernel<<<(n + 63) / 64, 64, 0, c->stream>>>(dj, dq, dr, n, yuv_format);
     break;
   }
