@@ -1,5 +1,5 @@
 """bench.py's N > 1 control flow, rehearsed on ONE GPU (JMHIP_BENCH_REHEARSAL=1: every rank on cuda:0, gloo, exchange through host
-memory): torch.distributed.run launches two ranks, each codes its band of macroblock rows, the bands are gathered every frame.
+memory): torch.distributed.run launches two (and three) ranks, each codes its band of macroblock rows, the bands are gathered every frame.
 The reference picture after the last step must be the one a single process produces -- same frames, only sharded -- and only
 rank 0 may print the JSON line."""
 import json
@@ -22,12 +22,13 @@ def run(cmd, env=None):
 
 
 @pytest.mark.gpu
-def test_two_ranks_rebuild_the_same_reference_as_one():
+@pytest.mark.parametrize("ranks", [2, 3])          # 3: uneven bands (23 + 23 + 22 macroblock rows), padded exchange chunks
+def test_ranks_rebuild_the_same_reference_as_one(ranks):
     one = run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--cpu-mbs", "0"])
-    two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-               "--master-port", "29541", "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--cpu-mbs", "0"],
+    two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+               "--master-port", str(29539 + ranks), "bench.py", "--gpus", str(ranks), "--steps", "3", "--warmup", "1", "--cpu-mbs", "0"],
               {"JMHIP_BENCH_REHEARSAL": "1"})
-    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["config"]["slices"] == 2
+    assert one["n_gpus"] == 1 and two["n_gpus"] == ranks and two["config"]["slices"] == ranks
     assert one["ref_checksum"] == two["ref_checksum"], "the sharded run did not reproduce the single-process reference picture"
     for d in (one, two):
         for key in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
