@@ -220,6 +220,9 @@ def main():
     ap.add_argument("--deblock", action="store_true",
                     help="for information: also run the in-loop deblocking filter on the device each frame (jmhip_deblock_recon; idc 0 on one GPU, "
                          "idc 2 with one slice per rank on N GPUs). Not part of the metric; the filter is a serial wavefront (DESIGN.md section 3)")
+    ap.add_argument("--deblock-slices", type=int, default=0,
+                    help="with --deblock on ONE GPU: filter as if the picture were cut into this many row slices with idc 2 "
+                         "(what an N-GPU run does), to compare reference checksums")
     ap.add_argument("--size", choices=["1080p", "2160p"], default="1080p",
                     help="1080p = BASELINE config 2, the metric's workload (default); 2160p = config 4's picture size, for information only")
     args = ap.parse_args()
@@ -307,7 +310,9 @@ def main():
                 ctx.me_frame_async(prm, None, n)
             ctx.residual_frame(quants)
             if args.deblock:
-                if world == 1:
+                if world == 1 and args.deblock_slices > 1:
+                    ctx.deblock_recon(QP, (QP, QP), disable_idc=2, slice_rows=(MBH + args.deblock_slices - 1) // args.deblock_slices)
+                elif world == 1:
                     ctx.deblock_recon(QP, (QP, QP))
                 else:
                     ctx.deblock_recon(QP, (QP, QP), disable_idc=2, slice_rows=band, mb_row0=row0, mb_rows=row1 - row0)

@@ -33,3 +33,15 @@ def test_ranks_rebuild_the_same_reference_as_one(ranks):
     for d in (one, two):
         for key in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
             assert key in d
+
+
+@pytest.mark.gpu
+def test_two_ranks_with_the_loop_filter_inside_their_slices():
+    """--deblock: every rank filters its own slice (idc 2) before the exchange; one GPU filtering the same two slices must agree."""
+    one = run([sys.executable, "bench.py", "--deblock", "--deblock-slices", "2", "--steps", "2", "--warmup", "1", "--cpu-mbs", "0"])
+    two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29547", "bench.py", "--gpus", "2", "--deblock", "--steps", "2", "--warmup", "1", "--cpu-mbs", "0"],
+              {"JMHIP_BENCH_REHEARSAL": "1"})
+    plain = run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--cpu-mbs", "0"])
+    assert one["ref_checksum"] == two["ref_checksum"]
+    assert one["ref_checksum"] != plain["ref_checksum"], "the filter changed nothing"
