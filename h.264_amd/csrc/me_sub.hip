@@ -152,8 +152,11 @@ __global__ __launch_bounds__(NT) void me_sub_kernel(MeDev P, const jmhip_me_mb *
     SSTAMP(2 + 5 * phase);
 
     const int K = s_nlead, total = K * ncand;
+    // idx / K without the integer-division sequence: idx + 0.5 is never a multiple of K, so the float quotient stays at least 0.5 / K
+    // (>= 0.0045) away from an integer while its error is below 1e-4 for idx < 1008
+    const float rK = __builtin_amdgcn_rcpf((float)K);
     for (int idx = tid; idx < total; idx += NT) {
-      const int ci = idx / K, it = s_list[idx - ci * K], cand = first + ci;     // adjacent lanes: adjacent sub-blocks, same plane
+      const int ci = (int)(((float)idx + 0.5f) * rK), it = s_list[idx - ci * K], cand = first + ci;     // adjacent lanes: adjacent sub-blocks, same plane
       const SubItem si = items[it];
       const int p = si.p;
       // quarter-pel coordinate of the sub-block origin incl. the pad offset (me_fullsearch.c:364-365, me_distortion.c:678)
