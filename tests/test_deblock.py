@@ -114,6 +114,8 @@ def test_deblock_1080p_and_wide_diagonals(pkg):
     the kernel's multi-pass case)."""
     run(pkg, 1920, 1088, 1, seed=5)
     run(pkg, 3840, 1088, 1, seed=6, idc_mode="zero")
+    # the global-memory kernel (4:2:2) with more than 64 macroblocks on a diagonal (136 x 66 macroblocks: 66)
+    run(pkg, 2176, 1056, 2, seed=7, idc_mode="zero")
 
 
 @pytest.mark.gpu
