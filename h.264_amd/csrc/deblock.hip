@@ -314,7 +314,7 @@ __global__ __launch_bounds__(1024) void deblock_filter_kernel(DeblockDev D)
   }
 }
 
-// ---- the same walk with the three live diagonals held in LDS (4:2:0 and 4:0:0).
+// ---- the same walk with the three live diagonals held in LDS (4:0:0, 4:2:0, 4:2:2).
 // A macroblock of diagonal d is still changed on d+1 (its right neighbour's vertical pass: columns 13..15) and on d+2 (the
 // macroblock below: rows 13..15), then it is final. So the kernel keeps a ring of three diagonals of 384-byte tiles
 // [Y 16x16 | U 8x8 | V 8x8] in LDS: a diagonal is fetched from HBM once (16-byte row loads, prefetched one diagonal ahead into
@@ -322,7 +322,9 @@ __global__ __launch_bounds__(1024) void deblock_filter_kernel(DeblockDev D)
 // then only sees LDS latency; one CU's vector-memory path, which the global-memory kernel above saturates with byte accesses,
 // carries 24 wide loads and stores per macroblock. Tile k of a ring slot is always filled, filtered and written back by the same
 // 16 lanes, and a macroblock's two passes run in one wave, so ONE workgroup barrier per diagonal is all the data flow needs.
-constexpr int DBK_TILE = 384, DBK_ETILE = 128;
+constexpr int DBK_ETILE = 128;
+// CF: 0 = no chroma (4:0:0), 1 = 4:2:0 (two 8x8 planes), 2 = 4:2:2 (two 8-wide x 16-high planes); tile = [Y 16x16 | U | V]
+__host__ __device__ constexpr int dbk_tile(int cf) { return cf == 2 ? 512 : 384; }
 
 struct Diag { int y_lo, count; };
 __device__ __forceinline__ Diag diag_of(int d, int mbw, int rows, int last_d)
@@ -336,43 +338,49 @@ __device__ __forceinline__ void unpack4(int *s, uint32_t v) { s[0] = v & 255; s[
 __device__ __forceinline__ uint32_t pack4(const int *s) { return (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16) | ((uint32_t)s[3] << 24); }
 
 // HBM -> registers: this lane's share of macroblock k of diagonal d (one luma row, one chroma row, 8 bytes of the edge records)
-struct DbkFetch { uint4 y; uint2 c, e; };
-template <bool CHROMA>
+struct DbkFetch { uint4 y; uint2 c, c2, e; };
+template <int CF>
 __device__ __forceinline__ void dbk_prefetch(const DeblockDev &D, int d, const Diag &g, int k, int l, int cpl, int cl, DbkFetch &f)
 {
   if (k < g.count) {
     const int y = g.y_lo + k, mby = D.row0 + y, mbx = d - 2 * y;
     f.y = *reinterpret_cast<const uint4 *>(D.y + (size_t)(mby * 16 + l) * D.W + mbx * 16);
-    if (CHROMA) f.c = *reinterpret_cast<const uint2 *>((cpl ? D.v : D.u) + (size_t)(mby * 8 + cl) * D.Wc + mbx * 8);
+    if (CF == 1) f.c = *reinterpret_cast<const uint2 *>((cpl ? D.v : D.u) + (size_t)(mby * 8 + cl) * D.Wc + mbx * 8);
+    if (CF == 2) {                                   // row l of both planes
+      f.c = *reinterpret_cast<const uint2 *>(D.u + (size_t)(mby * 16 + l) * D.Wc + mbx * 8);
+      f.c2 = *reinterpret_cast<const uint2 *>(D.v + (size_t)(mby * 16 + l) * D.Wc + mbx * 8);
+    }
     f.e = reinterpret_cast<const uint2 *>(D.edges + (size_t)(mby * D.mbw + mbx) * 8)[l];
   }
 }
-template <bool CHROMA>
+template <int CF>
 __device__ __forceinline__ void dbk_fill(uint8_t *slot, uint8_t *etiles, const Diag &g, int k, int l, int cpl, int cl, const DbkFetch &f)
 {
   if (k < g.count) {
-    uint8_t *tile = slot + (size_t)k * DBK_TILE;
+    uint8_t *tile = slot + (size_t)k * dbk_tile(CF);
     *reinterpret_cast<uint4 *>(tile + l * 16) = f.y;
-    if (CHROMA) *reinterpret_cast<uint2 *>(tile + 256 + cpl * 64 + cl * 8) = f.c;
+    if (CF == 1) *reinterpret_cast<uint2 *>(tile + 256 + cpl * 64 + cl * 8) = f.c;
+    if (CF == 2) { *reinterpret_cast<uint2 *>(tile + 256 + l * 8) = f.c; *reinterpret_cast<uint2 *>(tile + 384 + l * 8) = f.c2; }
     reinterpret_cast<uint2 *>(etiles + (size_t)k * DBK_ETILE)[l] = f.e;
   }
 }
 
-template <int NP, bool CHROMA>
+template <int NP, int CF>
 __global__ __launch_bounds__(1024) void deblock_lds_kernel(DeblockDev D, int S)
 {
+  constexpr int DBK_TILE = dbk_tile(CF);
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   uint8_t *const etiles = lds + (size_t)3 * S * DBK_TILE;
   const int grp = threadIdx.x >> 4, l = threadIdx.x & 15;
   const int cpl = l >> 3, cl = l & 7;                       // chroma: lanes 0..7 own U lines, 8..15 V lines
   const int last_d = D.mbw - 1 + 2 * (D.rows - 1);
   DbkFetch pf0, pf1;
-  pf0.y = pf1.y = make_uint4(0, 0, 0, 0); pf0.c = pf0.e = pf1.c = pf1.e = make_uint2(0, 0);
+  pf0.y = pf1.y = make_uint4(0, 0, 0, 0); pf0.c = pf0.c2 = pf0.e = pf1.c = pf1.c2 = pf1.e = make_uint2(0, 0);
 
   {
     const Diag g0 = diag_of(0, D.mbw, D.rows, last_d);
-    dbk_prefetch<CHROMA>(D, 0, g0, grp, l, cpl, cl, pf0);
-    if (NP > 1) dbk_prefetch<CHROMA>(D, 0, g0, grp + 64, l, cpl, cl, pf1);
+    dbk_prefetch<CF>(D, 0, g0, grp, l, cpl, cl, pf0);
+    if (NP > 1) dbk_prefetch<CF>(D, 0, g0, grp + 64, l, cpl, cl, pf1);
   }
   for (int d = 0; d <= last_d + 2; d++) {
     const Diag g = diag_of(d, D.mbw, D.rows, last_d), gl = diag_of(d - 1, D.mbw, D.rows, last_d), gt = diag_of(d - 2, D.mbw, D.rows, last_d);
@@ -380,12 +388,12 @@ __global__ __launch_bounds__(1024) void deblock_lds_kernel(DeblockDev D, int S)
     uint8_t *const slot_l = lds + (size_t)((d + 2) % 3) * S * DBK_TILE;      // diagonal d-1
     uint8_t *const slot_t = lds + (size_t)((d + 1) % 3) * S * DBK_TILE;      // diagonal d-2
     // ---- fill: the registers fetched during the previous diagonal; then start fetching the next one
-    dbk_fill<CHROMA>(slot, etiles, g, grp, l, cpl, cl, pf0);
-    if (NP > 1) dbk_fill<CHROMA>(slot, etiles, g, grp + 64, l, cpl, cl, pf1);
+    dbk_fill<CF>(slot, etiles, g, grp, l, cpl, cl, pf0);
+    if (NP > 1) dbk_fill<CF>(slot, etiles, g, grp + 64, l, cpl, cl, pf1);
     {
       const Diag gn = diag_of(d + 1, D.mbw, D.rows, last_d);
-      dbk_prefetch<CHROMA>(D, d + 1, gn, grp, l, cpl, cl, pf0);
-      if (NP > 1) dbk_prefetch<CHROMA>(D, d + 1, gn, grp + 64, l, cpl, cl, pf1);
+      dbk_prefetch<CF>(D, d + 1, gn, grp, l, cpl, cl, pf0);
+      if (NP > 1) dbk_prefetch<CF>(D, d + 1, gn, grp + 64, l, cpl, cl, pf1);
     }
     // ---- vertical edges: lane = row
 #pragma unroll
@@ -406,13 +414,15 @@ __global__ __launch_bounds__(1024) void deblock_lds_kernel(DeblockDev D, int S)
           if (before) *reinterpret_cast<uint32_t *>(left + l * 16 + 12) = pack4(s);
           *reinterpret_cast<uint4 *>(tile + l * 16) = make_uint4(pack4(s + 4), pack4(s + 8), pack4(s + 12), pack4(s + 16));
         }
-        if (CHROMA) {
+        // 4:2:0: 8 rows x 2 planes over the 16 lanes (strength group row >> 1); 4:2:2: 16 rows, a lane takes row l of both planes (row >> 2)
+#pragma unroll
+        for (int pass = 0; pass < (CF == 2 ? 2 : CF); pass++) {
           int s[12];
-          const int o = 256 + cpl * 64 + cl * 8;
+          const int pl = CF == 2 ? pass : cpl, o = CF == 2 ? 256 + pass * 128 + l * 8 : 256 + cpl * 64 + cl * 8;
           const uint2 row = *reinterpret_cast<const uint2 *>(tile + o);
           unpack4(s, before ? *reinterpret_cast<const uint32_t *>(left + o + 4) : 0u);
           unpack4(s + 4, row.x); unpack4(s + 8, row.y);
-          chroma_edges(s, ei, 1 + cpl, cl >> 1, 0, -1, 4, -1);
+          chroma_edges(s, ei, 1 + pl, CF == 2 ? l >> 2 : cl >> 1, 0, -1, 4, -1);
           if (before) *reinterpret_cast<uint32_t *>(left + o + 4) = pack4(s);
           *reinterpret_cast<uint2 *>(tile + o) = make_uint2(pack4(s + 4), pack4(s + 8));
         }
@@ -445,19 +455,21 @@ __global__ __launch_bounds__(1024) void deblock_lds_kernel(DeblockDev D, int S)
 #pragma unroll
           for (int r = 0; r < 15; r++) tile[r * 16 + l] = (uint8_t)s[4 + r];
         }
-        if (CHROMA) {
-          int s[12];
-          const int o = 256 + cpl * 64 + cl;
-          uint8_t *gtop = (cpl ? D.v : D.u) + (size_t)(mby * 8 - 2) * D.Wc + mbx * 8 + cl;
+        if (CF) {                                       // lane = (plane, column); 4:2:2 has a chroma edge under every luma edge (rows 0, 4, 8, 12)
+          constexpr int CH = CF == 2 ? 16 : 8, CP = 8 * CH;
+          int s[4 + CH];
+          const int o = 256 + cpl * CP + cl;
+          uint8_t *gtop = (cpl ? D.v : D.u) + (size_t)(mby * CH - 2) * D.Wc + mbx * 8 + cl;
           s[0] = s[1] = 0;
 #pragma unroll
-          for (int r = 0; r < 2; r++) s[2 + r] = !before ? 0 : top_lds ? top[o + (6 + r) * 8] : gtop[(size_t)r * D.Wc];
+          for (int r = 0; r < 2; r++) s[2 + r] = !before ? 0 : top_lds ? top[o + (CH - 2 + r) * 8] : gtop[(size_t)r * D.Wc];
 #pragma unroll
-          for (int r = 0; r < 8; r++) s[4 + r] = tile[o + r * 8];
-          chroma_edges(s, ei, 1 + cpl, cl >> 1, 0, -1, 4, -1);
-          if (before) { if (top_lds) top[o + 7 * 8] = (uint8_t)s[3]; else gtop[D.Wc] = (uint8_t)s[3]; }
+          for (int r = 0; r < CH; r++) s[4 + r] = tile[o + r * 8];
+          if (CF == 2) chroma_edges(s, ei, 1 + cpl, cl >> 1, 0, 4, 8, 12);
+          else chroma_edges(s, ei, 1 + cpl, cl >> 1, 0, -1, 4, -1);
+          if (before) { if (top_lds) top[o + (CH - 1) * 8] = (uint8_t)s[3]; else gtop[D.Wc] = (uint8_t)s[3]; }
 #pragma unroll
-          for (int r = 0; r < 8; r++) tile[o + r * 8] = (uint8_t)s[4 + r];
+          for (int r = 0; r < CH; r++) tile[o + r * 8] = (uint8_t)s[4 + r];
         }
       }
     }
@@ -470,7 +482,11 @@ __global__ __launch_bounds__(1024) void deblock_lds_kernel(DeblockDev D, int S)
         const int y = gt.y_lo + k, mby = D.row0 + y, mbx = d - 2 - 2 * y;
         const uint8_t *tile = slot_t + (size_t)k * DBK_TILE;
         *reinterpret_cast<uint4 *>(D.y + (size_t)(mby * 16 + l) * D.W + mbx * 16) = *reinterpret_cast<const uint4 *>(tile + l * 16);
-        if (CHROMA) *reinterpret_cast<uint2 *>((cpl ? D.v : D.u) + (size_t)(mby * 8 + cl) * D.Wc + mbx * 8) = *reinterpret_cast<const uint2 *>(tile + 256 + cpl * 64 + cl * 8);
+        if (CF == 1) *reinterpret_cast<uint2 *>((cpl ? D.v : D.u) + (size_t)(mby * 8 + cl) * D.Wc + mbx * 8) = *reinterpret_cast<const uint2 *>(tile + 256 + cpl * 64 + cl * 8);
+        if (CF == 2) {
+          *reinterpret_cast<uint2 *>(D.u + (size_t)(mby * 16 + l) * D.Wc + mbx * 8) = *reinterpret_cast<const uint2 *>(tile + 256 + l * 8);
+          *reinterpret_cast<uint2 *>(D.v + (size_t)(mby * 16 + l) * D.Wc + mbx * 8) = *reinterpret_cast<const uint2 *>(tile + 384 + l * 8);
+        }
       }
     }
   }
@@ -534,27 +550,27 @@ int dbk_run(jmhip_ctx *c, const DbkArrays &a, int mvlimit, int mb_row0, int mb_r
   D.edges = (const EdgeInfo *)a.edges;
   D.W = c->W; D.Wc = c->Wc; D.mbw = c->mbw; D.row0 = mb_row0; D.rows = mb_rows;
   D.dbg = getenv("JMHIP_DBK_DEBUG") ? atoi(getenv("JMHIP_DBK_DEBUG")) : 0;
-  // LDS ring (4:2:0 / 4:0:0) when three diagonals + one diagonal of edge records fit into 160 KB; JMHIP_DEBLOCK_KERNEL=global forces the
-  // global-memory kernel (kept for 4:2:2 / 4:4:4, larger pictures, and as a cross-check in the tests)
+  // LDS ring (4:0:0 / 4:2:0 / 4:2:2) when three diagonals + one diagonal of edge records fit into 160 KB; JMHIP_DEBLOCK_KERNEL=global forces
+  // the global-memory kernel (kept for 4:4:4, larger pictures, and as a cross-check in the tests)
   int S = 0;
   for (int d = 0; d <= c->mbw - 1 + 2 * (mb_rows - 1); d++) {
     const int y_lo = std::max(0, (d - c->mbw + 2) >> 1), y_hi = std::min(mb_rows - 1, d >> 1);
     S = std::max(S, y_hi - y_lo + 1);
   }
-  const size_t lds = (size_t)S * (3 * DBK_TILE + DBK_ETILE);
+  const int cf = c->cfg.yuv_format == JMHIP_YUV420 ? 1 : c->cfg.yuv_format == JMHIP_YUV422 ? 2 : 0;
+  const size_t lds = (size_t)S * (3 * dbk_tile(cf) + DBK_ETILE);
   const char *force = getenv("JMHIP_DEBLOCK_KERNEL");
-  const bool use_lds = (c->cfg.yuv_format == JMHIP_YUV420 || c->cfg.yuv_format == JMHIP_YUV400) && S <= 128 && lds <= 160 * 1024 &&
-                       !(force && !strcmp(force, "global"));
+  const bool use_lds = c->cfg.yuv_format != JMHIP_YUV444 && S <= 128 && lds <= 160 * 1024 && !(force && !strcmp(force, "global"));
   if (use_lds) {
-    const bool chroma = c->cfg.yuv_format == JMHIP_YUV420;
     auto launch = [&](auto kernel) -> hipError_t {
       hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
       kernel<<<1, 1024, lds, c->stream>>>(D, S);
       return hipGetLastError();
     };
-    hipError_t e = S <= 64 ? (chroma ? launch(deblock_lds_kernel<1, true>) : launch(deblock_lds_kernel<1, false>))
-                           : (chroma ? launch(deblock_lds_kernel<2, true>) : launch(deblock_lds_kernel<2, false>));
+    hipError_t e;
+    if (S <= 64) e = cf == 2 ? launch(deblock_lds_kernel<1, 2>) : cf == 1 ? launch(deblock_lds_kernel<1, 1>) : launch(deblock_lds_kernel<1, 0>);
+    else e = cf == 2 ? launch(deblock_lds_kernel<2, 2>) : cf == 1 ? launch(deblock_lds_kernel<2, 1>) : launch(deblock_lds_kernel<2, 0>);
     JM_HIP_CHECK(c, e);
   } else
   switch (c->cfg.yuv_format) {

@@ -109,12 +109,14 @@ def test_deblock_variants(pkg, kw):
 
 
 @pytest.mark.gpu
-def test_deblock_1080p_and_wide_diagonals(pkg):
+def test_deblock_1080p_and_wide_diagonals(pkg, monkeypatch):
     """1080p (120 macroblocks per row, 60 per diagonal) and a 4K-wide strip (240 per row: more than 64 macroblocks on a diagonal,
     the kernel's multi-pass case)."""
     run(pkg, 1920, 1088, 1, seed=5)
     run(pkg, 3840, 1088, 1, seed=6, idc_mode="zero")
-    # the global-memory kernel (4:2:2) with more than 64 macroblocks on a diagonal (136 x 66 macroblocks: 66)
+    # 4:2:2 with more than 64 macroblocks on a diagonal (136 x 66 macroblocks: 66): LDS ring in two passes, then the global-memory kernel
+    run(pkg, 2176, 1056, 2, seed=7, idc_mode="zero")
+    monkeypatch.setenv("JMHIP_DEBLOCK_KERNEL", "global")
     run(pkg, 2176, 1056, 2, seed=7, idc_mode="zero")
 
 
@@ -156,10 +158,11 @@ def test_deblock_bands_in_sequence_cross_their_borders(pkg):
 
 @pytest.mark.gpu
 def test_deblock_global_memory_kernel_on_420(pkg, monkeypatch):
-    """4:2:0 normally takes the LDS-ring kernel; the global-memory wavefront kernel (4:2:2 / 4:4:4 / oversized pictures) must agree."""
+    """4:0:0 / 4:2:0 / 4:2:2 normally take the LDS-ring kernel; the global-memory wavefront kernel (4:4:4 / oversized pictures) must agree."""
     monkeypatch.setenv("JMHIP_DEBLOCK_KERNEL", "global")
     run(pkg, 176, 144, 1, seed=21)
     run(pkg, 320, 64, 0, seed=22)
+    run(pkg, 176, 144, 2, seed=23)
 
 
 @pytest.mark.gpu
