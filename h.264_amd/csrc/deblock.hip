@@ -16,6 +16,7 @@
 #include "jmhip_internal.h"
 #include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 namespace {
 
@@ -254,10 +255,12 @@ __device__ __forceinline__ void chroma_type_line(uint8_t *base, int pitch, bool 
   }
 }
 
+constexpr int DBK_MAXB = 64;
 struct DeblockDev {
   uint8_t *y, *u, *v;
   const EdgeInfo *edges;        // [mb][dir][edge]
-  int W, Wc, mbw, row0, rows;
+  int W, Wc, mbw;
+  int nbands, band_row[DBK_MAXB + 1];   // workgroup b filters macroblock rows [band_row[b], band_row[b + 1]): bands whose first row has no filtered top edge are independent
   int dbg;                      // JMHIP_DBK_DEBUG (timing experiments only): 1 skip the vertical pass, 2 skip the horizontal pass, 4 skip fetch / write-back
 };
 
@@ -266,15 +269,17 @@ template <int FMT>
 __global__ __launch_bounds__(1024) void deblock_filter_kernel(DeblockDev D)
 {
   const int slot = threadIdx.x >> 4, l = threadIdx.x & 15;
-  const int last_d = D.mbw - 1 + 2 * (D.rows - 1);
+  const int row0 = D.band_row[blockIdx.x], rows = D.band_row[blockIdx.x + 1] - row0;
+  const int last_d = D.mbw - 1 + 2 * (rows - 1);
   for (int d = 0; d <= last_d; d++) {
-    const int y_lo = max(0, (d - D.mbw + 2) >> 1), y_hi = min(D.rows - 1, d >> 1);
+    const int y_lo = max(0, (d - D.mbw + 2) >> 1), y_hi = min(rows - 1, d >> 1);
     const int count = y_hi - y_lo + 1;
     for (int dir = 0; dir < 2; dir++) {
       for (int k = slot; k < count; k += 64) {
-        const int mby = D.row0 + y_lo + k, mbx = d - 2 * (y_lo + k);
+        const int mby = row0 + y_lo + k, mbx = d - 2 * (y_lo + k);
         const Edges4 ei = load_edges(D.edges + ((size_t)(mby * D.mbw + mbx) * 2 + dir) * 4);
-        const bool before = dir ? mby != 0 : mbx != 0;
+        // the first row of a later band has its top edges off by construction and must not touch the rows above: another workgroup owns them
+        const bool before = dir ? (mby != 0 && !(blockIdx.x > 0 && y_lo + k == 0)) : mbx != 0;
         if (dir == 0) {
           // vertical edges: lane = row
           luma_type_line<true>(D.y + (size_t)(mby * 16 + l) * D.W + mbx * 16, D.W, before, ei, 0, l >> 2);
@@ -340,10 +345,10 @@ __device__ __forceinline__ uint32_t pack4(const int *s) { return (uint32_t)s[0] 
 // HBM -> registers: this lane's share of macroblock k of diagonal d (one luma row, one chroma row, 8 bytes of the edge records)
 struct DbkFetch { uint4 y; uint2 c, c2, e; };
 template <int CF>
-__device__ __forceinline__ void dbk_prefetch(const DeblockDev &D, int d, const Diag &g, int k, int l, int cpl, int cl, DbkFetch &f)
+__device__ __forceinline__ void dbk_prefetch(const DeblockDev &D, int row0, int d, const Diag &g, int k, int l, int cpl, int cl, DbkFetch &f)
 {
   if (k < g.count) {
-    const int y = g.y_lo + k, mby = D.row0 + y, mbx = d - 2 * y;
+    const int y = g.y_lo + k, mby = row0 + y, mbx = d - 2 * y;
     f.y = *reinterpret_cast<const uint4 *>(D.y + (size_t)(mby * 16 + l) * D.W + mbx * 16);
     if (CF == 1) f.c = *reinterpret_cast<const uint2 *>((cpl ? D.v : D.u) + (size_t)(mby * 8 + cl) * D.Wc + mbx * 8);
     if (CF == 2) {                                   // row l of both planes
@@ -373,17 +378,18 @@ __global__ __launch_bounds__(1024) void deblock_lds_kernel(DeblockDev D, int S)
   uint8_t *const etiles = lds + (size_t)3 * S * DBK_TILE;
   const int grp = threadIdx.x >> 4, l = threadIdx.x & 15;
   const int cpl = l >> 3, cl = l & 7;                       // chroma: lanes 0..7 own U lines, 8..15 V lines
-  const int last_d = D.mbw - 1 + 2 * (D.rows - 1);
+  const int row0 = D.band_row[blockIdx.x], rows = D.band_row[blockIdx.x + 1] - row0;
+  const int last_d = D.mbw - 1 + 2 * (rows - 1);
   DbkFetch pf0, pf1;
   pf0.y = pf1.y = make_uint4(0, 0, 0, 0); pf0.c = pf0.c2 = pf0.e = pf1.c = pf1.c2 = pf1.e = make_uint2(0, 0);
 
   {
-    const Diag g0 = diag_of(0, D.mbw, D.rows, last_d);
-    dbk_prefetch<CF>(D, 0, g0, grp, l, cpl, cl, pf0);
-    if (NP > 1) dbk_prefetch<CF>(D, 0, g0, grp + 64, l, cpl, cl, pf1);
+    const Diag g0 = diag_of(0, D.mbw, rows, last_d);
+    dbk_prefetch<CF>(D, row0, 0, g0, grp, l, cpl, cl, pf0);
+    if (NP > 1) dbk_prefetch<CF>(D, row0, 0, g0, grp + 64, l, cpl, cl, pf1);
   }
   for (int d = 0; d <= last_d + 2; d++) {
-    const Diag g = diag_of(d, D.mbw, D.rows, last_d), gl = diag_of(d - 1, D.mbw, D.rows, last_d), gt = diag_of(d - 2, D.mbw, D.rows, last_d);
+    const Diag g = diag_of(d, D.mbw, rows, last_d), gl = diag_of(d - 1, D.mbw, rows, last_d), gt = diag_of(d - 2, D.mbw, rows, last_d);
     uint8_t *const slot = lds + (size_t)(d % 3) * S * DBK_TILE;
     uint8_t *const slot_l = lds + (size_t)((d + 2) % 3) * S * DBK_TILE;      // diagonal d-1
     uint8_t *const slot_t = lds + (size_t)((d + 1) % 3) * S * DBK_TILE;      // diagonal d-2
@@ -391,9 +397,9 @@ __global__ __launch_bounds__(1024) void deblock_lds_kernel(DeblockDev D, int S)
     dbk_fill<CF>(slot, etiles, g, grp, l, cpl, cl, pf0);
     if (NP > 1) dbk_fill<CF>(slot, etiles, g, grp + 64, l, cpl, cl, pf1);
     {
-      const Diag gn = diag_of(d + 1, D.mbw, D.rows, last_d);
-      dbk_prefetch<CF>(D, d + 1, gn, grp, l, cpl, cl, pf0);
-      if (NP > 1) dbk_prefetch<CF>(D, d + 1, gn, grp + 64, l, cpl, cl, pf1);
+      const Diag gn = diag_of(d + 1, D.mbw, rows, last_d);
+      dbk_prefetch<CF>(D, row0, d + 1, gn, grp, l, cpl, cl, pf0);
+      if (NP > 1) dbk_prefetch<CF>(D, row0, d + 1, gn, grp + 64, l, cpl, cl, pf1);
     }
     // ---- vertical edges: lane = row
 #pragma unroll
@@ -435,10 +441,12 @@ __global__ __launch_bounds__(1024) void deblock_lds_kernel(DeblockDev D, int S)
     for (int p = 0; p < NP; p++) {
       const int k = grp + 64 * p;
       if (k < g.count && !(D.dbg & 2)) {
-        const int y = g.y_lo + k, mby = D.row0 + y, mbx = d - 2 * y;
+        const int y = g.y_lo + k, mby = row0 + y, mbx = d - 2 * y;
         uint8_t *tile = slot + (size_t)k * DBK_TILE;
         uint8_t *top = slot_t + (size_t)(y - 1 - gt.y_lo) * DBK_TILE;       // (mbx, y-1) lies on diagonal d-2
-        const bool before = mby != 0, top_lds = y > 0;                       // first row of a band: the rows above live in HBM only
+        // first row of a band: the rows above live in HBM only -- and belong to another workgroup unless this is the call's first band
+        // (a later band's first row has its top edges off by construction: it must neither read nor write back those rows)
+        const bool before = mby != 0 && !(blockIdx.x > 0 && y == 0), top_lds = y > 0;
         const Edges4 ei = load_edges(reinterpret_cast<const EdgeInfo *>(etiles + (size_t)k * DBK_ETILE + 64));
         {
           int s[20];
@@ -479,7 +487,7 @@ __global__ __launch_bounds__(1024) void deblock_lds_kernel(DeblockDev D, int S)
     for (int p = 0; p < NP; p++) {
       const int k = grp + 64 * p;
       if (k < gt.count && !(D.dbg & 4)) {
-        const int y = gt.y_lo + k, mby = D.row0 + y, mbx = d - 2 - 2 * y;
+        const int y = gt.y_lo + k, mby = row0 + y, mbx = d - 2 - 2 * y;
         const uint8_t *tile = slot_t + (size_t)k * DBK_TILE;
         *reinterpret_cast<uint4 *>(D.y + (size_t)(mby * 16 + l) * D.W + mbx * 16) = *reinterpret_cast<const uint4 *>(tile + l * 16);
         if (CF == 1) *reinterpret_cast<uint2 *>((cpl ? D.v : D.u) + (size_t)(mby * 8 + cl) * D.Wc + mbx * 8) = *reinterpret_cast<const uint2 *>(tile + 256 + cpl * 64 + cl * 8);
@@ -539,7 +547,8 @@ int dbk_arrays(jmhip_ctx *c, DbkArrays *a)
 }
 
 // strengths + the wavefront walk over macroblock rows [mb_row0, mb_row0 + mb_rows); the side arrays are on the device
-int dbk_run(jmhip_ctx *c, const DbkArrays &a, int mvlimit, int mb_row0, int mb_rows)
+// `starts`: rows inside (mb_row0, mb_row0 + mb_rows) at which an independent band begins (no macroblock of that row filters its top edge)
+int dbk_run(jmhip_ctx *c, const DbkArrays &a, int mvlimit, int mb_row0, int mb_rows, std::vector<int> starts = {})
 {
   const int nmb = c->mbw * c->mbh;
   deblock_strength_kernel<<<(nmb * 8 + 255) / 256, 256, 0, c->stream>>>((const jmhip_deblock_mb *)a.mbs, (const jmhip_deblock_blk *)a.blks,
@@ -548,14 +557,32 @@ int dbk_run(jmhip_ctx *c, const DbkArrays &a, int mvlimit, int mb_row0, int mb_r
   DeblockDev D;
   D.y = c->rec_y; D.u = c->rec_u; D.v = c->rec_v;
   D.edges = (const EdgeInfo *)a.edges;
-  D.W = c->W; D.Wc = c->Wc; D.mbw = c->mbw; D.row0 = mb_row0; D.rows = mb_rows;
+  D.W = c->W; D.Wc = c->Wc; D.mbw = c->mbw;
+  {
+    // one workgroup per independent band (slices with disable_idc 2): the bands' wavefronts run side by side on different CUs.
+    // JMHIP_DEBLOCK_BANDS=0 keeps one workgroup. More boundaries than workgroups allowed: keep an even subset (any subset is valid).
+    const char *nb = getenv("JMHIP_DEBLOCK_BANDS");
+    if (nb && atoi(nb) == 0) starts.clear();
+    std::vector<int> rows{mb_row0};
+    const int ns = (int)starts.size(), keep = std::min(ns, DBK_MAXB - 1);
+    for (int i = 0; i < keep; i++) {
+      const int r = starts[(size_t)((long long)i * ns / keep)];
+      if (r > rows.back() && r < mb_row0 + mb_rows) rows.push_back(r);
+    }
+    rows.push_back(mb_row0 + mb_rows);
+    D.nbands = (int)rows.size() - 1;
+    for (int i = 0; i <= DBK_MAXB; i++) D.band_row[i] = rows[std::min<size_t>((size_t)i, rows.size() - 1)];
+  }
   D.dbg = getenv("JMHIP_DBK_DEBUG") ? atoi(getenv("JMHIP_DBK_DEBUG")) : 0;
   // LDS ring (4:0:0 / 4:2:0 / 4:2:2) when three diagonals + one diagonal of edge records fit into 160 KB; JMHIP_DEBLOCK_KERNEL=global forces
   // the global-memory kernel (kept for 4:4:4, larger pictures, and as a cross-check in the tests)
   int S = 0;
-  for (int d = 0; d <= c->mbw - 1 + 2 * (mb_rows - 1); d++) {
-    const int y_lo = std::max(0, (d - c->mbw + 2) >> 1), y_hi = std::min(mb_rows - 1, d >> 1);
-    S = std::max(S, y_hi - y_lo + 1);
+  for (int b = 0; b < D.nbands; b++) {
+    const int br = D.band_row[b + 1] - D.band_row[b];
+    for (int d = 0; d <= c->mbw - 1 + 2 * (br - 1); d++) {
+      const int y_lo = std::max(0, (d - c->mbw + 2) >> 1), y_hi = std::min(br - 1, d >> 1);
+      S = std::max(S, y_hi - y_lo + 1);
+    }
   }
   const int cf = c->cfg.yuv_format == JMHIP_YUV420 ? 1 : c->cfg.yuv_format == JMHIP_YUV422 ? 2 : 0;
   const size_t lds = (size_t)S * (3 * dbk_tile(cf) + DBK_ETILE);
@@ -565,7 +592,7 @@ int dbk_run(jmhip_ctx *c, const DbkArrays &a, int mvlimit, int mb_row0, int mb_r
     auto launch = [&](auto kernel) -> hipError_t {
       hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
-      kernel<<<1, 1024, lds, c->stream>>>(D, S);
+      kernel<<<D.nbands, 1024, lds, c->stream>>>(D, S);
       return hipGetLastError();
     };
     hipError_t e;
@@ -574,10 +601,10 @@ int dbk_run(jmhip_ctx *c, const DbkArrays &a, int mvlimit, int mb_row0, int mb_r
     JM_HIP_CHECK(c, e);
   } else
   switch (c->cfg.yuv_format) {
-  case JMHIP_YUV400: deblock_filter_kernel<JMHIP_YUV400><<<1, 1024, 0, c->stream>>>(D); break;
-  case JMHIP_YUV420: deblock_filter_kernel<JMHIP_YUV420><<<1, 1024, 0, c->stream>>>(D); break;
-  case JMHIP_YUV422: deblock_filter_kernel<JMHIP_YUV422><<<1, 1024, 0, c->stream>>>(D); break;
-  case JMHIP_YUV444: deblock_filter_kernel<JMHIP_YUV444><<<1, 1024, 0, c->stream>>>(D); break;
+  case JMHIP_YUV400: deblock_filter_kernel<JMHIP_YUV400><<<D.nbands, 1024, 0, c->stream>>>(D); break;
+  case JMHIP_YUV420: deblock_filter_kernel<JMHIP_YUV420><<<D.nbands, 1024, 0, c->stream>>>(D); break;
+  case JMHIP_YUV422: deblock_filter_kernel<JMHIP_YUV422><<<D.nbands, 1024, 0, c->stream>>>(D); break;
+  case JMHIP_YUV444: deblock_filter_kernel<JMHIP_YUV444><<<D.nbands, 1024, 0, c->stream>>>(D); break;
   default: return jm_fail(c, JMHIP_ERR_ARG, "deblocking: chroma format");
   }
   JM_HIP_CHECK(c, hipGetLastError());
@@ -648,8 +675,18 @@ extern "C" int jmhip_deblock_frame(jmhip_ctx *c, const jmhip_deblock_mb *mbs, co
   JM_HIP_CHECK(c, hipMemcpyAsync(a.mbs, mbs, sizeof(jmhip_deblock_mb) * (size_t)nmb, hipMemcpyHostToDevice, c->stream));
   JM_HIP_CHECK(c, hipMemcpyAsync(a.blks, blks, sizeof(jmhip_deblock_blk) * (size_t)nmb * 16, hipMemcpyHostToDevice, c->stream));
   JM_HIP_CHECK(c, hipStreamSynchronize(c->stream));             // the caller's arrays are only borrowed for the call
+  // rows none of whose macroblocks filter the top edge start an independent band
+  std::vector<int> starts;
+  for (int r = mb_row0 + 1; r < mb_row0 + mb_rows; r++) {
+    bool free_top = true;
+    for (int x = 0; x < c->mbw && free_top; x++) {
+      const jmhip_deblock_mb &m = mbs[r * c->mbw + x];
+      free_top = m.disable_idc == 1 || (m.disable_idc == 2 && !m.avail_b);
+    }
+    if (free_top) starts.push_back(r);
+  }
   jm_stage_begin(c, JMHIP_STAGE_DEBLOCK);
-  rc = dbk_run(c, a, mvlimit, mb_row0, mb_rows);
+  rc = dbk_run(c, a, mvlimit, mb_row0, mb_rows, starts);
   jm_stage_end(c, JMHIP_STAGE_DEBLOCK);
   return rc;
 }
@@ -680,7 +717,10 @@ extern "C" int jmhip_deblock_recon(jmhip_ctx *c, const jmhip_deblock_params *prm
   deblock_inputs_kernel<<<(n + 15) / 16, 256, 0, c->stream>>>((const jmhip_me_mb *)c->me_jobs_dev, (const jmhip_me_result *)c->me_res_dev, modes, coded, n,
                                                               *prm, c->mbw, (jmhip_deblock_mb *)a.mbs, (jmhip_deblock_blk *)a.blks);
   JM_HIP_CHECK(c, hipGetLastError());
-  rc = dbk_run(c, a, mvlimit, row0, rows);
+  std::vector<int> starts;
+  if (prm->disable_idc == 2 && prm->slice_rows > 0)
+    for (int r = (row0 / prm->slice_rows + 1) * prm->slice_rows; r < row0 + rows; r += prm->slice_rows) starts.push_back(r);
+  rc = dbk_run(c, a, mvlimit, row0, rows, starts);
   jm_stage_end(c, JMHIP_STAGE_DEBLOCK);
   return rc;
 }

@@ -8,7 +8,7 @@ from tests import oracle
 INT64_MIN = -(1 << 63)
 
 
-def make_case(pkg, rng, w, h, fmt, intra_frac=0.15, t8_frac=0.3, idc_mode="mixed", qp_lo=20, qp_hi=46, smooth=True, bslice=False):
+def make_case(pkg, rng, w, h, fmt, intra_frac=0.15, t8_frac=0.3, idc_mode="mixed", qp_lo=20, qp_hi=46, smooth=True, bslice=False, nslices=3):
     """A picture with blocking artefacts and the per-macroblock / per-block side information the filter reads."""
     mbw, mbh = w // 16, h // 16
     cw, ch = {0: (0, 0), 1: (w // 2, h // 2), 2: (w // 2, h), 3: (w, h)}[fmt]
@@ -35,7 +35,7 @@ def make_case(pkg, rng, w, h, fmt, intra_frac=0.15, t8_frac=0.3, idc_mode="mixed
     mbs["transform_8x8"] = rng.random(mbw * mbh) < t8_frac
     mbs["cbp_blk"] = rng.integers(0, 1 << 16, mbw * mbh) & rng.integers(0, 1 << 16, mbw * mbh)
     # slices of whole rows: availability as the encoder leaves it (same slice and inside the picture)
-    slice_rows = max(1, mbh // 3)
+    slice_rows = max(1, -(-mbh // nslices))
     for i in range(mbw * mbh):
         x, y = i % mbw, i // mbw
         mbs["avail_a"][i] = x != 0
@@ -217,3 +217,15 @@ def test_deblock_recon_from_the_frame_stage(pkg, idc, slice_rows):
     ctx.close()
     for g, wv, name in zip(after, want, "YUV"):
         assert np.array_equal(g, wv), name
+
+
+@pytest.mark.gpu
+def test_deblock_one_workgroup_per_slice_equals_one_workgroup(pkg, monkeypatch):
+    """Slices whose first row filters no top edge (idc 2, or idc 1) are independent bands: the library gives each its own workgroup.
+    Same result as the single-workgroup walk (JMHIP_DEBLOCK_BANDS=0) and as the oracle, 1080p with 8 slices and a mixed-idc picture."""
+    for kw in (dict(idc_mode="two", nslices=8), dict(idc_mode="mixed", nslices=5)):
+        run(pkg, 1920, 1088, 1, seed=31, **kw)
+        monkeypatch.setenv("JMHIP_DEBLOCK_BANDS", "0")
+        run(pkg, 1920, 1088, 1, seed=31, **kw)
+        monkeypatch.delenv("JMHIP_DEBLOCK_BANDS")
+    run(pkg, 320, 1088, 2, seed=32, idc_mode="two", nslices=68)     # one slice per macroblock row: more bands than workgroups (64)
