@@ -592,7 +592,9 @@ int dbk_run(jmhip_ctx *c, const DbkArrays &a, int mvlimit, int mb_row0, int mb_r
     auto launch = [&](auto kernel) -> hipError_t {
       hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
-      kernel<<<D.nbands, 1024, lds, c->stream>>>(D, S);
+      // 16 lanes per macroblock of the longest diagonal, in whole waves: short bands (slices) synchronise 2-3 waves per barrier, not 16
+      const int threads = S <= 64 ? std::max(64, (S * 16 + 63) / 64 * 64) : 1024;
+      kernel<<<D.nbands, threads, lds, c->stream>>>(D, S);
       return hipGetLastError();
     };
     hipError_t e;
