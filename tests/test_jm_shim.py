@@ -63,7 +63,7 @@ LoopFilterDisable = {lfidc}
 LoopFilterAlphaC0Offset = {lfa}
 LoopFilterBetaOffset = {lfb}
 SliceMode = {slicemode}
-SliceArgument = 33
+SliceArgument = {slicearg}
 """
 
 CASES = {
@@ -84,6 +84,8 @@ CASES = {
     "lowcplx_t8_decision": dict(search=0, profile=100, cabac=0, t8x8=1, bframes=0, refs=2, rdopt=0, adrnd=0, yuv=1),
     # in-loop deblocking: three slices per picture, filter kept inside slices (idc 2), non-zero alpha / beta offsets, coarse quantiser
     "slices_deblock_idc2": dict(search=0, profile=100, cabac=1, t8x8=1, bframes=1, refs=2, rdopt=1, adrnd=0, yuv=1, qp=38, lfflag=1, lfidc=2, lfa=2, lfb=-1, slicemode=1),
+    # slices that begin in the middle of a macroblock row (27 macroblocks, 11 per row): left / top availability differs inside a row
+    "slices_midrow_idc2": dict(search=0, profile=77, cabac=1, t8x8=0, bframes=0, refs=1, rdopt=1, adrnd=0, yuv=1, qp=36, lfflag=1, lfidc=2, lfa=0, lfb=0, slicemode=1, slicearg=27),
     "slices_deblock_across_422": dict(search=0, profile=122, cabac=0, t8x8=1, bframes=0, refs=1, rdopt=1, adrnd=0, yuv=2, qp=36, lfflag=1, lfidc=0, lfa=-2, lfb=3, slicemode=1),
     # 4:4:4 (High 4:4:4 Predictive): chroma planes take the luma filter in the loop filter, quarter-pel chroma planes, dct_4x4 on all three planes
     "fastfull_444": dict(search=0, profile=244, cabac=1, t8x8=1, bframes=0, refs=1, rdopt=1, adrnd=0, yuv=3, qp=34),
@@ -120,7 +122,7 @@ def run(exe, d, env=None):
 
 
 def prepare(tmp_path, name, w=176, h=144, frames=3, R=16, qp=28):
-    v = dict(dict(w=w, h=h, frames=frames, R=R, qp=qp, lfflag=0, lfidc=0, lfa=0, lfb=0, slicemode=0), **CASES[name])
+    v = dict(dict(w=w, h=h, frames=frames, R=R, qp=qp, lfflag=0, lfidc=0, lfa=0, lfb=0, slicemode=0, slicearg=33), **CASES[name])
     v.setdefault("fpel", 0)
     v.setdefault("bipred", 0)
     v.setdefault("wbp", 0)
