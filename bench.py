@@ -217,6 +217,9 @@ def main():
     ap.add_argument("--cpu-mbs", type=int, default=4 * MBW, help="macroblocks in the CPU baseline sample (0 = skip)")
     ap.add_argument("--clip", choices=["translation", "noise"], default="translation",
                     help="translation = SURVEY 8(d)'s clip (default, the metric's workload); noise = its adversarial i.i.d. clip, for information only")
+    ap.add_argument("--chroma-planes", action="store_true",
+                    help="materialise the 2 x 64 eighth-pel chroma planes per reference (getSubImagesChroma, JM's ChromaMCBuffer = 1) instead of "
+                         "computing the chroma prediction samples in the frame stage; same results, +0.019 ms per 1080p frame")
     ap.add_argument("--deblock", action="store_true",
                     help="for information: also run the in-loop deblocking filter on the device each frame (jmhip_deblock_recon; idc 0 on one GPU, "
                          "idc 2 with one slice per rank on N GPUs). Not part of the metric; the filter is a serial wavefront (DESIGN.md section 3)")
@@ -296,12 +299,16 @@ def main():
     def step(k):
         Y, U, V = src[1 + (k % (nframes - 1))]
         ctx.cur_bind(Y.data_ptr(), U.data_ptr(), V.data_ptr())          # the source frame is resident: no copy
+        # luma: the 16 quarter-pel planes (search + sub-pel refinement + MC read them all over). Chroma: MC is their only reader and takes
+        # 2 x 64 samples per macroblock, so the frame stage computes those eighth-pel samples itself (jmhip_residual_frame) instead of
+        # materialising 64 planes per component -- --chroma-planes builds them as JM's ChromaMCBuffer = 1 does (identical results)
         if world == 1:
             ctx.interp_luma(0)
-            ctx.interp_chroma(0)
+            if args.chroma_planes:
+                ctx.interp_chroma(0)
         elif n:
             # a rank only needs the sub-pel planes its band can reach: own rows +- (range + predictor reach 6 + slack)
-            ctx.interp_rows(0, row0 * 16 - (R + 16), row1 * 16 + (R + 16))
+            ctx.interp_rows(0, row0 * 16 - (R + 16), row1 * 16 + (R + 16), chroma=args.chroma_planes)
         if n:
             if first[0]:
                 ctx.me_frame_async(prm, mbs)
@@ -387,15 +394,17 @@ def main():
         achieved = ME_BYTES_PER_MB * n / (me_avg_ms * 1e-3) / 1e9 if me_launches else 0.0
         sad_ops = (2 * R + 1) ** 2 * 256 * n / (me_avg_ms * 1e-3) if me_launches else 0.0
         valu_floor_ms = n * ((2 * R + 1) ** 2 / 64.0) * VALU_NS_PER_WAVE_CANDIDATE / N_SIMD * 1e-6
+        workload = ("1920x1080 (coded 1920x1088, 8160 MBs)" if args.size == "1080p" else "3840x2160 (32400 MBs)") + \
+            " YUV420 P-frames, baseline tools, FullSearch +-32, 41 partitions, SAD full-pel + SATD sub-pel, dct_4x4 + dct_chroma, QP %d, 1 reference; " % QP + \
+            "16 luma quarter-pel planes per reference, chroma eighth-pel samples " + ("from 2 x 64 planes; " if args.chroma_planes else "computed in MC; ") + \
+            "predictor field (16,-16)+U{-8..8} qpel per MB" + ("" if args.clip == "translation" else "; ADVERSARIAL i.i.d. noise clip") + \
+            ("; + in-loop deblocking (NOT the metric's path)" if args.deblock else "")
         out = {
             "metric": "macroblocks/sec (full-search ME + DCT/quant), 1080p; bit-exact MV+coeff vs JM",
             "value": round(total_mbs / elapsed, 1), "unit": "macroblocks/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": ("1920x1080 (coded 1920x1088, 8160 MBs)" if args.size == "1080p" else "3840x2160 (32400 MBs)") + " YUV420 P-frames, baseline tools, FullSearch +-32, "
-                                   "41 partitions, SAD full-pel + SATD sub-pel, dct_4x4 + dct_chroma, QP %d, 1 reference; "
-                                   "predictor field (16,-16)+U{-8..8} qpel per MB%s%s" % (QP, "" if args.clip == "translation" else "; ADVERSARIAL i.i.d. noise clip",
-                                                                                      "; + in-loop deblocking (NOT the metric's path)" if args.deblock else ""),
+            "config": {"workload": workload,
                        "slices": world, "parallelism": "slice%d" % world},
             "roofline": {"kernel": "me_int_pair_kernel (integer full search, all 41 partitions)", "bound": "hbm",
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),

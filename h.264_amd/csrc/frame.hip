@@ -22,6 +22,10 @@ struct FrameDev {
   const uint8_t *cur_y, *cur_u, *cur_v;
   const uint8_t *const *ref_sub, *const *ref_cb, *const *ref_cr;
   uint8_t *rec_y, *rec_u, *rec_v;
+  // chroma prediction without the eighth-pel planes: the sample a plane WOULD hold, computed from the integer chroma picture
+  // (reference slots 0..3; see mc_kernel)
+  int fly, mul_x, mul_y, pad_cx, pad_cy;
+  const uint8_t *ref_u[4], *ref_v[4];
 };
 
 __device__ __forceinline__ int clampi(int x, int lo, int hi) { return min(max(x, lo), hi); }
@@ -127,10 +131,26 @@ __global__ __launch_bounds__(64) void mc_kernel(FrameDev F, const jmhip_me_mb *_
       const int jj = ((j + mby * F.mb_ch) << F.shift_y) + 4 * JMHIP_PAD + mv[1];
       const int width_pad_cr = F.Wcp - 1 - F.mb_cw, height_pad_cr = F.Hcp - 1 - F.mb_ch;      // mbuffer.c:425-426
       const int xpos = clampi(ii >> F.shift_x, 0, width_pad_cr), ypos = clampi(jj >> F.shift_y, 0, height_pad_cr);
-      const uint8_t *planes = (uv ? F.ref_cr : F.ref_cb)[mb.ref];
-      const uint8_t *src = planes + (size_t)((jj & F.mask_y) * F.sub_x + (ii & F.mask_x)) * F.Wcp * F.Hcp + (size_t)ypos * F.Wcp + xpos;
       jmhip_tq_job &jc = jobs_c[2 * i + uv];
-      jc.pred[j][ic] = src[0]; jc.pred[j][ic + 1] = src[1];
+      if (F.fly) {
+        // The value plane (jj & mask_y, ii & mask_x) of getSubImagesChroma holds at padded position (ypos, xpos) and (ypos, xpos + 1)
+        // (img_chroma.c:412-420, interp_chroma.hip): weights (8-k)(8-l), (8-k)l, k(8-l), kl on the four neighbours with the source
+        // coordinates clamped to the picture. The clamp above keeps xpos + 1 and ypos off the plane's never-written last column / row,
+        // so the planes' zero cells cannot be asked for. Same integers as the planes, no 64x copy of the chroma picture in HBM.
+        const uint8_t *pic = uv ? F.ref_v[mb.ref] : F.ref_u[mb.ref];
+        const int k = (jj & F.mask_y) * F.mul_y, l = (ii & F.mask_x) * F.mul_x;
+        const uint8_t *r0 = pic + (size_t)clampi(ypos - F.pad_cy, 0, F.Hc - 1) * F.Wc;
+        const uint8_t *r1 = pic + (size_t)clampi(ypos - F.pad_cy + 1, 0, F.Hc - 1) * F.Wc;
+        const int xa = clampi(xpos - F.pad_cx, 0, F.Wc - 1), xb = clampi(xpos - F.pad_cx + 1, 0, F.Wc - 1), xc = clampi(xpos - F.pad_cx + 2, 0, F.Wc - 1);
+        const int a0 = r0[xa], a1 = r0[xb], a2 = r0[xc], b0 = r1[xa], b1 = r1[xb], b2 = r1[xc];
+        const int h00 = a0 * (8 - l) + a1 * l, h01 = a1 * (8 - l) + a2 * l, h10 = b0 * (8 - l) + b1 * l, h11 = b1 * (8 - l) + b2 * l;
+        jc.pred[j][ic] = (uint8_t)((h00 * (8 - k) + h10 * k + 32) >> 6);
+        jc.pred[j][ic + 1] = (uint8_t)((h01 * (8 - k) + h11 * k + 32) >> 6);
+      } else {
+        const uint8_t *planes = (uv ? F.ref_cr : F.ref_cb)[mb.ref];
+        const uint8_t *src = planes + (size_t)((jj & F.mask_y) * F.sub_x + (ii & F.mask_x)) * F.Wcp * F.Hcp + (size_t)ypos * F.Wcp + xpos;
+        jc.pred[j][ic] = src[0]; jc.pred[j][ic + 1] = src[1];
+      }
       const uint8_t *cs = (uv ? F.cur_v : F.cur_u) + (size_t)(mby * F.mb_ch + j) * F.Wc + mbx * F.mb_cw + ic;
       jc.src[j][ic] = cs[0]; jc.src[j][ic + 1] = cs[1];
       if (q == 0) { jc.quant = 1; jc.quant_dc = 2; jc.uv = uv; jc.cr_cbp_in = 0; jc.intra16_unused = 0; }
@@ -271,10 +291,16 @@ extern "C" int jmhip_residual_frame_q(jmhip_ctx *c, const jmhip_mb_mode *modes, 
   int rc = ensure_frame_buffers(c, n);
   if (rc) return rc;
   if ((rc = jm_ensure_ref_table(c))) return rc;
+  // chroma prediction reads the eighth-pel planes when every used reference has them (JM's ChromaMCBuffer = 1 layout); otherwise the
+  // same sample values are computed in mc_kernel from the integer chroma pictures (reference slots 0..3)
+  bool chroma_fly = false;
   for (size_t k = 0; k < c->refs.size(); k++)
     if ((c->me_ref_mask >> k) & 1) {
       if (!c->refs[k].has_luma_sub) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_residual_frame: quarter-pel planes of a used reference not built (jmhip_interp_luma)");
-      if (c->Wc && !c->refs[k].has_cr_sub) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_residual_frame: chroma planes of a used reference not built (jmhip_interp_chroma)");
+      if (c->Wc && !c->refs[k].has_cr_sub) {
+        if (k >= 4 || !c->refs[k].has_pic) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_residual_frame: chroma planes of a used reference not built (jmhip_interp_chroma)");
+        chroma_fly = true;
+      }
     }
 
   jmhip_mb_mode *modes_in_dev = nullptr, *modes_out_dev = (jmhip_mb_mode *)c->fr_modes;
@@ -296,6 +322,8 @@ extern "C" int jmhip_residual_frame_q(jmhip_ctx *c, const jmhip_mb_mode *modes, 
   const uint8_t *const *tab = reinterpret_cast<const uint8_t *const *>(c->ref_ptrs_dev);
   F.ref_sub = tab + 32; F.ref_cb = tab + 64; F.ref_cr = tab + 96;
   F.rec_y = c->rec_y; F.rec_u = c->rec_u; F.rec_v = c->rec_v;
+  F.fly = chroma_fly ? 1 : 0; F.mul_x = c->cg.mul_x; F.mul_y = c->cg.mul_y; F.pad_cx = c->cg.pad_x; F.pad_cy = c->cg.pad_y;
+  for (int k = 0; k < 4; k++) { F.ref_u[k] = k < (int)c->refs.size() ? c->refs[k].u : nullptr; F.ref_v[k] = k < (int)c->refs.size() ? c->refs[k].v : nullptr; }
 
   jm_stage_begin(c, JMHIP_STAGE_MC);
   mc_kernel<<<jm_xcd_grid(n), 64, 0, c->stream>>>(F, (const jmhip_me_mb *)c->me_jobs_dev, (const jmhip_me_result *)c->me_res_dev, modes_in_dev, modes_out_dev,

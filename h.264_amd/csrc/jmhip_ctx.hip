@@ -370,9 +370,12 @@ extern "C" int jmhip_interp_luma(jmhip_ctx *c, int ref)
 // Sub-pel planes for the luma rows [row0, row1) of the PICTURE only (plus whatever the tile granularity adds): a rank that
 // searches a band of macroblock rows needs the planes of that band +- (search range + predictor reach + block height) and
 // nothing else. The caller owns that margin; rows outside keep whatever an earlier call left there.
-extern "C" int jmhip_interp_rows(jmhip_ctx *c, int ref, int row0, int row1)
+static int interp_rows(jmhip_ctx *c, int ref, int row0, int row1, bool chroma);
+extern "C" int jmhip_interp_rows(jmhip_ctx *c, int ref, int row0, int row1) { return c ? interp_rows(c, ref, row0, row1, true) : JMHIP_ERR_ARG; }
+extern "C" int jmhip_interp_luma_rows(jmhip_ctx *c, int ref, int row0, int row1) { return c ? interp_rows(c, ref, row0, row1, false) : JMHIP_ERR_ARG; }
+
+static int interp_rows(jmhip_ctx *c, int ref, int row0, int row1, bool chroma)
 {
-  if (!c) return JMHIP_ERR_ARG;
   if (ref < 0 || ref >= (int)c->refs.size()) return jm_fail(c, JMHIP_ERR_ARG, "ref slot out of range");
   if (!c->refs[ref].has_pic) return jm_fail(c, JMHIP_ERR_ARG, "reference picture not uploaded");
   if (row1 <= row0) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_interp_rows: empty row range");
@@ -382,7 +385,7 @@ extern "C" int jmhip_interp_rows(jmhip_ctx *c, int ref, int row0, int row1)
   jm_stage_end(c, JMHIP_STAGE_INTERP_LUMA);
   if (rc) return rc;
   c->refs[ref].has_luma_sub = true;
-  if (c->Wc) {
+  if (c->Wc && chroma) {
     const int sy = c->cfg.yuv_format == JMHIP_YUV420 ? 1 : 0;       // luma rows -> chroma rows
     jm_stage_begin(c, JMHIP_STAGE_INTERP_CHROMA);
     rc = jm_launch_interp_chroma(c, ref, (row0 >> sy) + c->cg.pad_y - 1, ((row1 + sy) >> sy) + c->cg.pad_y + 1);

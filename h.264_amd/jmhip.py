@@ -155,6 +155,7 @@ def load_library():
     lib.jmhip_stream_handle.argtypes = [vp]
     lib.jmhip_stream_handle.restype = vp
     lib.jmhip_interp_rows.argtypes = [vp, ip, ip, ip]
+    lib.jmhip_interp_luma_rows.argtypes = [vp, ip, ip, ip]
     lib.jmhip_timing_select.argtypes = [vp, C.c_uint]
     for which, dt in ((0, ME_MB_DTYPE), (1, ME_RESULT_DTYPE), (2, QUANT_DTYPE), (3, TQ_JOB_DTYPE), (4, TQ_RESULT_DTYPE),
                       (5, DIST_JOB_DTYPE), (8, MB_MODE_DTYPE), (9, SURFACE_JOB_DTYPE), (10, BIPRED_JOB_DTYPE), (11, BIPRED_RESULT_DTYPE), (13, PREDCOST_JOB_DTYPE),
@@ -434,8 +435,11 @@ class Context:
         """hipStream_t of the context as an integer (torch.cuda.ExternalStream(ptr))."""
         return int(self.lib.jmhip_stream_handle(self.h))
 
-    def interp_rows(self, ref, row0, row1):
-        self._chk(self.lib.jmhip_interp_rows(self.h, ref, row0, row1), "jmhip_interp_rows")
+    def interp_rows(self, ref, row0, row1, chroma=True):
+        if chroma:
+            self._chk(self.lib.jmhip_interp_rows(self.h, ref, row0, row1), "jmhip_interp_rows")
+        else:
+            self._chk(self.lib.jmhip_interp_luma_rows(self.h, ref, row0, row1), "jmhip_interp_luma_rows")
 
     def cur_bind(self, y_ptr, u_ptr=None, v_ptr=None):
         """Current picture = the caller's device planes (uint8, tight pitch), no copy."""

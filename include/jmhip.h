@@ -99,6 +99,9 @@ int jmhip_interp_chroma(jmhip_ctx *ctx, int ref);
 /* Luma AND chroma sub-pel planes restricted to the picture's luma rows [row0, row1) (slice-parallel ranks: own band +- search
  * reach; rows outside keep what an earlier call left). Values inside the range are identical to the full-plane calls'. */
 int jmhip_interp_rows(jmhip_ctx *ctx, int ref, int row0, int row1);
+/* The luma part of jmhip_interp_rows alone: the frame stage predicts chroma without the eighth-pel planes when they are not
+ * built (jmhip_residual_frame). */
+int jmhip_interp_luma_rows(jmhip_ctx *ctx, int ref, int row0, int row1);
 
 /* Test/diagnostic: copy sub-pel planes back. `out` holds 16 (luma) or sub_y*sub_x (chroma, one component
  * uv = 0/1) planes of padded size, contiguous, pel_bytes per sample. */
@@ -328,6 +331,9 @@ typedef struct { int8_t mode; int8_t b8mode[4]; int8_t pad[3]; } jmhip_mb_mode; 
  *   motion cost (ties to the lower mode number) -- a stand-in for the host's mode decision used by bench.py.
  *   quants[0] = luma inter quantiser, quants[1] = chroma quantiser, quants[2] = 4:2:2 chroma DC (qp+3) quantiser.
  * Results stay on the device until downloaded: luma[n], chroma[2n] (index 2*i+uv), modes_out[n], cbp[n], cbp_blk[n]. */
+/* Chroma prediction (src/macroblock.c:1593 ..._retrieve) reads the eighth-pel planes of jmhip_interp_chroma when every used
+ * reference has them; when they were not built (reference slots 0..3) the kernel computes the very samples those planes would
+ * hold from the integer chroma picture -- identical results, no 64x chroma planes in HBM. */
 int jmhip_residual_frame(jmhip_ctx *ctx, const jmhip_mb_mode *modes, const jmhip_quant quants[3]);
 /* Same with nquants = 4: quants[3] is the 8x8 luma quantiser (transform8x8_flag = 1, 64-entry tables). Macroblocks whose mode has
  * pad[0] = 1 (JM's TransformDecision outcome, src/macroblock.c:1458; only legal without partitions below 8x8) take the dct_8x8

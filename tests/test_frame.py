@@ -20,15 +20,19 @@ def synth(rng, w, h, fmt):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fmt,qp,given_modes", [(1, 28, False), (1, 40, True), (2, 24, False), (1, 12, False)])
-def test_residual_frame(pkg, fmt, qp, given_modes):
+@pytest.mark.parametrize("fmt,qp,given_modes,chroma_planes", [(1, 28, False, True), (1, 40, True, True), (2, 24, False, True), (1, 12, False, True),
+                                                              (1, 28, False, False), (1, 40, True, False), (2, 24, False, False)])
+def test_residual_frame(pkg, fmt, qp, given_modes, chroma_planes):
+    """chroma_planes False: jmhip_interp_chroma is not called and the frame stage computes the eighth-pel chroma samples itself;
+    the expectation (the oracle's planes) is the same."""
     rng = np.random.default_rng(qp + fmt)
     w, h, R = 64, 48, 8
     cur, ref = synth(rng, w, h, fmt)
     ctx = pkg.Context(w, h, yuv_format=fmt, max_refs=1, search_range=R)
     ctx.ref_upload(0, *ref)
     ctx.interp_luma(0)
-    ctx.interp_chroma(0)
+    if chroma_planes:
+        ctx.interp_chroma(0)
     ctx.cur_upload(*cur)
     mbs = make_mbs(pkg, rng, w // 16, h // 16, 6)
     lam = lambda_factors(qp)
@@ -72,8 +76,8 @@ def test_residual_frame(pkg, fmt, qp, given_modes):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cavlc,qp,far", [(1, 28, 6), (0, 22, 6), (1, 34, 45)])
-def test_residual_frame_with_8x8_transform_macroblocks(pkg, cavlc, qp, far):
+@pytest.mark.parametrize("cavlc,qp,far,chroma_planes", [(1, 28, 6, True), (0, 22, 6, True), (1, 34, 45, True), (1, 34, 45, False), (0, 26, 90, False)])
+def test_residual_frame_with_8x8_transform_macroblocks(pkg, cavlc, qp, far, chroma_planes):
     """A mix of 4x4- and 8x8-transform macroblocks (luma_transform_size_8x8_flag per mode): dct_8x8 branch of
     LumaResidualCoding8x8, 8x8-granular prediction clamp (far = vectors beyond the padded plane), CAVLC interleave / CABAC lists."""
     rng = np.random.default_rng(qp + cavlc)
@@ -82,7 +86,8 @@ def test_residual_frame_with_8x8_transform_macroblocks(pkg, cavlc, qp, far):
     ctx = pkg.Context(w, h, yuv_format=1, max_refs=1, search_range=R)
     ctx.ref_upload(0, *ref)
     ctx.interp_luma(0)
-    ctx.interp_chroma(0)
+    if chroma_planes:
+        ctx.interp_chroma(0)                           # without them: vectors far beyond the picture exercise the on-the-fly clamps
     ctx.cur_upload(*cur)
     mbs = make_mbs(pkg, rng, w // 16, h // 16, 4 * far)
     lam = lambda_factors(qp)
