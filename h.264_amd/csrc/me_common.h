@@ -18,6 +18,8 @@ struct MeDev {
   const uint8_t *cur;
   const uint8_t *const *ref_y;        // [slot] integer recon
   const uint8_t *const *ref_sub;      // [slot] 16 quarter-pel planes
+  int wp_on, wp_round, wp_denom;       // weighted reference ME: sample -> clip255(((w * p + round) >> denom) + o), per reference slot
+  short wp_w[16], wp_o[16];
 };
 
 namespace {
@@ -113,6 +115,18 @@ __device__ __forceinline__ void had8(int v[8])
 }
 
 // fetch `n` (4 or 8) samples of one row at byte address p (any alignment) from a quarter-pel plane
+// four packed reference samples through the explicit-weight formula (computeSADWP, me_distortion.c:431)
+__device__ __forceinline__ uint32_t wp_apply4(uint32_t v, int w, int o, int rnd, int den)
+{
+  uint32_t r = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int q = (((w * (int)((v >> (8 * k)) & 255u)) + rnd) >> den) + o;
+    r |= (uint32_t)min(max(q, 0), 255) << (8 * k);
+  }
+  return r;
+}
+
 __device__ __forceinline__ void fetch_row(const uint8_t *p, int n, uint32_t *lo, uint32_t *hi)
 {
   const uintptr_t a = reinterpret_cast<uintptr_t>(p);

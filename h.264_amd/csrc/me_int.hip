@@ -104,6 +104,7 @@ __global__ __launch_bounds__(256) void me_int_kernel(MeDev P, const jmhip_me_mb 
       uint32_t v = 0;
 #pragma unroll
       for (int k = 0; k < 4; k++) v |= (uint32_t)row[clampi(bx + xw * 4 + k, 0, P.W - 1)] << (8 * k);
+      if (P.wp_on) v = wp_apply4(v, P.wp_w[job.ref], P.wp_o[job.ref], P.wp_round, P.wp_denom);      // the weighted window: every SAD below sees weighted samples
       *reinterpret_cast<uint32_t *>(smem + (size_t)y * pitch + xw * 4) = v;
     }
   }
@@ -331,6 +332,7 @@ __global__ __launch_bounds__(256, 2) void me_int_fast_kernel(MeDev P, const jmhi
   //      edge the lane fetches three aligned dwords per slot and builds all four copies in registers; the loads are issued
   //      first and the mv-bits tables are computed while they are in flight.
   const uint8_t *ref = P.ref_y[job.ref];
+  const int wpw = P.wp_w[job.ref], wpo = P.wp_o[job.ref];      // weighted reference ME (P.wp_on)
   const int bx = mbx * 16 + umin_x, by = mby * 16 + umin_y;
   const int xw = tid & 31, y0 = tid >> 5;
   const bool inside = bx >= 4 && bx + PITCH * 4 + 8 <= P.W;       // no horizontal clamping anywhere in the window (+ the third dword)
@@ -360,7 +362,8 @@ __global__ __launch_bounds__(256, 2) void me_int_fast_kernel(MeDev P, const jmhi
 #pragma unroll
       for (int u = 0; u < NB; u++)
         if (y0 + 8 * u < WROWS) {
-          const uint32_t a = __builtin_amdgcn_alignbyte(q1[u], q0[u], sh), b = __builtin_amdgcn_alignbyte(q2[u], q1[u], sh);
+          uint32_t a = __builtin_amdgcn_alignbyte(q1[u], q0[u], sh), b = __builtin_amdgcn_alignbyte(q2[u], q1[u], sh);
+          if (P.wp_on) { a = wp_apply4(a, wpw, wpo, P.wp_round, P.wp_denom); b = wp_apply4(b, wpw, wpo, P.wp_round, P.wp_denom); }
           uint32_t *w = swin + (y0 + 8 * u) * PITCH + xw;
           w[0] = a;
           w[1 * CS] = __builtin_amdgcn_alignbyte(b, a, 1u);
@@ -375,6 +378,7 @@ __global__ __launch_bounds__(256, 2) void me_int_fast_kernel(MeDev P, const jmhi
           uint32_t v = 0;
 #pragma unroll
           for (int k = 0; k < 4; k++) v |= (uint32_t)row[clampi(bx + xw * 4 + k, 0, P.W - 1)] << (8 * k);
+          if (P.wp_on) v = wp_apply4(v, wpw, wpo, P.wp_round, P.wp_denom);
           swin[(y0 + 8 * u) * PITCH + xw] = v;
         }
     }
@@ -722,6 +726,7 @@ __global__ __launch_bounds__(256, 3) void me_int_pair_kernel(MeDev P, const jmhi
 
   // ---- reference window (as me_int_fast_kernel): loads first, tables while they fly, four copies from registers
   const uint8_t *ref = P.ref_y[job.ref];
+  const int wpw = P.wp_w[job.ref], wpo = P.wp_o[job.ref];      // weighted reference ME (P.wp_on)
   const int bx = mbx * 16 + umin_x, by = mby * 16 + umin_y;
   const int xw = tid & 31, y0 = tid >> 5;
   const bool inside = bx >= 4 && bx + PITCH * 4 + 8 <= P.W;
@@ -757,7 +762,8 @@ __global__ __launch_bounds__(256, 3) void me_int_pair_kernel(MeDev P, const jmhi
 #pragma unroll
       for (int u = 0; u < NB; u++)
         if (y0 + 8 * u < WROWS) {
-          const uint32_t a = __builtin_amdgcn_alignbyte(q1[u], q0[u], sh), b = __builtin_amdgcn_alignbyte(q2[u], q1[u], sh);
+          uint32_t a = __builtin_amdgcn_alignbyte(q1[u], q0[u], sh), b = __builtin_amdgcn_alignbyte(q2[u], q1[u], sh);
+          if (P.wp_on) { a = wp_apply4(a, wpw, wpo, P.wp_round, P.wp_denom); b = wp_apply4(b, wpw, wpo, P.wp_round, P.wp_denom); }
           uint32_t *w = swin + (y0 + 8 * u) * PITCH + xw;
           w[0] = a;
           w[1 * CS] = __builtin_amdgcn_alignbyte(b, a, 1u);
@@ -772,6 +778,7 @@ __global__ __launch_bounds__(256, 3) void me_int_pair_kernel(MeDev P, const jmhi
           uint32_t v = 0;
 #pragma unroll
           for (int k = 0; k < 4; k++) v |= (uint32_t)row[clampi(bx + xw * 4 + k, 0, P.W - 1)] << (8 * k);
+          if (P.wp_on) v = wp_apply4(v, wpw, wpo, P.wp_round, P.wp_denom);
           swin[(y0 + 8 * u) * PITCH + xw] = v;
         }
     }
@@ -1059,6 +1066,7 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
     if (prm->lambda[k] < 0 || prm->lambda[k] > 30000000) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_me_frame: lambda factor out of the 32-bit cost range");
   if (!c->has_cur) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_frame: current picture not uploaded");
   if (!(prm->partition_mask & ((1ull << JMHIP_NPART) - 1))) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_frame: empty partition mask");
+  if (prm->wp_enable && (prm->wp_denom < 0 || prm->wp_denom > 7 || prm->wp_round < 0 || prm->wp_round > 64)) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_frame: weighted-prediction denominator / rounding out of range");
   JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
   int rc = ensure_tables(c);
   if (rc) return rc;
@@ -1150,6 +1158,8 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
   P.lvl_min = prm->level_mv_min; P.lvl_max = prm->level_mv_max;
   P.lam_f = prm->lambda[0]; P.lam_h = prm->lambda[1]; P.lam_q = prm->lambda[2];
   P.t8x8 = prm->transform8x8_mode ? 1 : 0; P.subpel = prm->subpel ? 1 : 0;
+  P.wp_on = prm->wp_enable ? 1 : 0; P.wp_round = prm->wp_round; P.wp_denom = prm->wp_denom;
+  for (int k = 0; k < 16; k++) { P.wp_w[k] = prm->wp_weight[k]; P.wp_o[k] = prm->wp_offset[k]; }
   P.mask = prm->partition_mask & ((1ull << JMHIP_NPART) - 1);
   P.W = c->W; P.H = c->H; P.Wp = c->Wp; P.Hp = c->Hp;
   P.win_pitch = pitch; P.win_rows = rows;

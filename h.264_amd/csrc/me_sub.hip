@@ -62,7 +62,7 @@ void build_sub_tables()
 // all partitions are then costed in parallel and JM's sequential strict-< scan becomes an atomic min on (cost, position).
 // The kernel is latency-bound (dependent LDS/global reads between barriers), hence the small register footprint
 // (T8 = false drops the 8x8 Hadamard path) for many resident workgroups.
-template <bool T8, int NT>
+template <bool T8, int NT, bool WP>
 __global__ __launch_bounds__(NT) void me_sub_kernel(MeDev P, const jmhip_me_mb *__restrict__ jobs, jmhip_me_result *__restrict__ res, int n_items)
 {
   const int item = jm_xcd_item(n_items);
@@ -84,6 +84,7 @@ __global__ __launch_bounds__(NT) void me_sub_kernel(MeDev P, const jmhip_me_mb *
   const int mbx = job.mb_x, mby = job.mb_y;
   const unsigned long long mask = P.mask;
   const uint8_t *sub = P.ref_sub[job.ref];
+  const int wpw = WP ? P.wp_w[job.ref] : 0, wpo = WP ? P.wp_o[job.ref] : 0;       // WP: weighted reference ME, a separate instantiation
   const size_t plane = (size_t)P.Wp * P.Hp;
   const int width_pad = P.Wp - 1 - 16, height_pad = P.Hp - 1 - 16;      // size_x_pad / size_y_pad, mbuffer.c:421-422
   const SubItem *items = reinterpret_cast<const SubItem *>(s_tab);
@@ -172,6 +173,7 @@ __global__ __launch_bounds__(NT) void me_sub_kernel(MeDev P, const jmhip_me_mb *
         for (int r = 0; r < 4; r++) {
           uint32_t hi;
           fetch_row(rp + (size_t)r * P.Wp, 4, &ref[r], &hi);
+          if (WP) ref[r] = wp_apply4(ref[r], wpw, wpo, P.wp_round, P.wp_denom);             // computeSATDWP, me_distortion.c:734
           const uint2 c = *reinterpret_cast<const uint2 *>(&s_c16[si.by + r][si.bx >> 1]);
           c01[r] = c.x; c23[r] = c.y;
         }
@@ -182,6 +184,7 @@ __global__ __launch_bounds__(NT) void me_sub_kernel(MeDev P, const jmhip_me_mb *
         for (int r = 0; r < 8; r++) {
           uint32_t lo, hi;
           fetch_row(rp + (size_t)r * P.Wp, 8, &lo, &hi);
+          if (WP) { lo = wp_apply4(lo, wpw, wpo, P.wp_round, P.wp_denom); hi = wp_apply4(hi, wpw, wpo, P.wp_round, P.wp_denom); }
           const uint32_t c0 = *reinterpret_cast<const uint32_t *>(&s_cur[si.by + r][si.bx]);
           const uint32_t c1 = *reinterpret_cast<const uint32_t *>(&s_cur[si.by + r][si.bx + 4]);
           int row[8];
@@ -257,8 +260,11 @@ int jm_me_sub_tables(jmhip_ctx *c)
 
 void jm_launch_me_sub(jmhip_ctx *c, const MeDev &P, const jmhip_me_mb *jobs_dev, jmhip_me_result *res_dev, int n)
 {
-  if (P.t8x8) me_sub_kernel<true, 128><<<jm_xcd_grid(n), 128, 0, c->stream>>>(P, jobs_dev, res_dev, n);
-  else me_sub_kernel<false, SUB_NT><<<jm_xcd_grid(n), SUB_NT, 0, c->stream>>>(P, jobs_dev, res_dev, n);
+  if (P.wp_on) {
+    if (P.t8x8) me_sub_kernel<true, 128, true><<<jm_xcd_grid(n), 128, 0, c->stream>>>(P, jobs_dev, res_dev, n);
+    else me_sub_kernel<false, SUB_NT, true><<<jm_xcd_grid(n), SUB_NT, 0, c->stream>>>(P, jobs_dev, res_dev, n);
+  } else if (P.t8x8) me_sub_kernel<true, 128, false><<<jm_xcd_grid(n), 128, 0, c->stream>>>(P, jobs_dev, res_dev, n);
+  else me_sub_kernel<false, SUB_NT, false><<<jm_xcd_grid(n), SUB_NT, 0, c->stream>>>(P, jobs_dev, res_dev, n);
 }
 
 extern "C" int jmhip_me_subpel(jmhip_ctx *c, const jmhip_me_params *prm, const jmhip_me_mb *mbs, int n, jmhip_me_result *results)
@@ -289,6 +295,8 @@ extern "C" int jmhip_me_subpel(jmhip_ctx *c, const jmhip_me_params *prm, const j
   P.mode = prm->search_mode; P.R = prm->search_range; P.rdopt = prm->rdopt; P.is_b = prm->is_b_slice;
   P.lam_f = prm->lambda[0]; P.lam_h = prm->lambda[1]; P.lam_q = prm->lambda[2];
   P.t8x8 = prm->transform8x8_mode ? 1 : 0; P.subpel = 1;
+  P.wp_on = prm->wp_enable ? 1 : 0; P.wp_round = prm->wp_round; P.wp_denom = prm->wp_denom;
+  for (int k = 0; k < 16; k++) { P.wp_w[k] = prm->wp_weight[k]; P.wp_o[k] = prm->wp_offset[k]; }
   P.mask = prm->partition_mask & ((1ull << JMHIP_NPART) - 1);
   P.W = c->W; P.H = c->H; P.Wp = c->Wp; P.Hp = c->Hp; P.cur = c->cur_y;
   P.ref_y = reinterpret_cast<const uint8_t *const *>(c->ref_ptrs_dev);

@@ -149,6 +149,12 @@ typedef struct {
   int transform8x8_mode;   /* input->Transform8x8Mode: SATD uses the 8x8 Hadamard for block types <= 4 */
   int subpel;              /* !input->DisableSubpelME                                                 */
   uint64_t partition_mask; /* bit p set: partition p is searched (all 41: (1<<41)-1)                  */
+  /* Weighted reference ME (input->UseWeightedReferenceME with explicit / implicit weights, src/mv-search.c:640-668): every reference
+   * sample becomes iClip1(255, ((weight * p + wp_round) >> wp_denom) + offset) before SAD / SATD (computeSADWP src/me_distortion.c:413,
+   * computeSATDWP :734, the weighted line of SetupFastFullPelSearch src/me_fullfast.c:600-640). Per reference SLOT: wp_weight[0] /
+   * wp_offset[0] of JM's [list][ref][0] entry for the picture in that slot. wp_enable = 0: plain search. */
+  int32_t wp_enable, wp_round, wp_denom;
+  int16_t wp_weight[16], wp_offset[16];
 } jmhip_me_params;
 
 /* Per-macroblock inputs. pred_mv: motion-vector predictor per partition in quarter-pel units, what

@@ -227,14 +227,18 @@ static int partition_of(int blocktype, int x, int y)     /* (x, y): block origin
   return tab[blocktype][(y >> 2) * 4 + (x >> 2)];
 }
 
-/* what the device search covers: luma-only SAD (integer) / SATD (sub-pel), no weighted ME, frame pictures */
+/* what the device search covers: luma-only SAD (integer) / SATD (sub-pel), plain or weighted reference, frame pictures */
+/* weighted reference ME of the search just admitted by me_ok(): wp_weight / wp_offset [list][ref][0] (src/me_fullsearch.c:76-91) */
+static struct { int on, weight, offset; } me_wp;
+
 static int me_ok_metric(short ref, int list, StorablePicture **rp, int *slot, int fixed_metrics)
 {
-  const int allow_weights = !fixed_metrics;        /* the walks' weighted kernels have their own surfaces */
   int list_offset = img->mb_data[img->current_mb_nr].list_offset;
   int weighted = ((active_pps->weighted_pred_flag && (img->type == P_SLICE || img->type == SP_SLICE)) ||
                   (active_pps->weighted_bipred_idc && (img->type == B_SLICE))) && input->UseWeightedReferenceME;
-  if ((weighted && !allow_weights) || input->ChromaMEEnable || list_offset) return 0;
+  if (input->ChromaMEEnable || list_offset) return 0;
+  me_wp.on = weighted;
+  if (weighted) { me_wp.weight = wp_weight[list + list_offset][ref][0]; me_wp.offset = wp_offset[list + list_offset][ref][0]; }
   if (fixed_metrics && (input->MEErrorMetric[F_PEL] != ERROR_SAD || input->MEErrorMetric[H_PEL] != ERROR_SATD || input->MEErrorMetric[Q_PEL] != ERROR_SATD)) return 0;
   if (!cur_ready()) return 0;
   *rp = listX[list][ref];
@@ -246,7 +250,12 @@ static int me_ok(short ref, int list, StorablePicture **rp, int *slot) { return 
 
 static void me_params(jmhip_me_params *prm, int mode, int range, int lam_f, int lam_h, int lam_q, int p)
 {
+  int k;
   memset(prm, 0, sizeof(*prm));
+  if (me_wp.on) {                                   /* one search = one reference: the same weights for every slot is exact */
+    prm->wp_enable = 1; prm->wp_round = wp_luma_round; prm->wp_denom = luma_log_weight_denom;
+    for (k = 0; k < 16; k++) { prm->wp_weight[k] = (int16_t)me_wp.weight; prm->wp_offset[k] = (int16_t)me_wp.offset; }
+  }
   prm->search_mode = mode; prm->search_range = range; prm->rdopt = input->rdopt; prm->is_b_slice = (img->type == B_SLICE);
   prm->level_mv_min = LEVELMVLIMIT[img->LevelIndex][0]; prm->level_mv_max = LEVELMVLIMIT[img->LevelIndex][1];
   prm->lambda[0] = lam_f; prm->lambda[1] = lam_h; prm->lambda[2] = lam_q;

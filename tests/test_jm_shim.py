@@ -80,6 +80,10 @@ CASES = {
     "epzs_satd_high": dict(search=3, profile=100, cabac=1, t8x8=1, bframes=0, refs=1, rdopt=1, adrnd=0, yuv=1, fpel=2),
     # BASELINE config 5 in small: 4:2:2, UMHexagonS, explicit weighted prediction used in ME (computeSADWP surfaces), fading clip
     "umhex_wp_422": dict(search=1, profile=122, cabac=1, t8x8=1, bframes=0, refs=2, rdopt=1, adrnd=0, yuv=2, wp=1, fade=1),
+    # explicit weighted prediction used in ME on a fading clip with the exhaustive searches: the device weights the reference window /
+    # the sub-pel rows (computeSADWP / computeSATDWP); P only, and B slices with explicit bi-prediction weights
+    "full_wp": dict(search=-1, profile=77, cabac=1, t8x8=0, bframes=0, refs=2, rdopt=1, adrnd=0, yuv=1, wp=1, fade=1),
+    "fastfull_wp_b": dict(search=0, profile=100, cabac=1, t8x8=1, bframes=1, refs=2, rdopt=1, adrnd=0, yuv=1, wp=1, wbp=1, fade=1),
     # RD-off decision with the 8x8 transform: TransformDecision and GetSkipCostMB costs from the device
     "lowcplx_t8_decision": dict(search=0, profile=100, cabac=0, t8x8=1, bframes=0, refs=2, rdopt=0, adrnd=0, yuv=1),
     # in-loop deblocking: three slices per picture, filter kept inside slices (idc 2), non-zero alpha / beta offsets, coarse quantiser

@@ -40,7 +40,7 @@ def make_mbs(pkg, rng, mbw, mbh, spread, per_partition=True):
     return mbs
 
 
-def run_case(pkg, w, h, kind, mode, R, rdopt, spread, t8x8=0, per_partition=True, subpel=1, seed=0, mask=(1 << 41) - 1, is_b=0):
+def run_case(pkg, w, h, kind, mode, R, rdopt, spread, t8x8=0, per_partition=True, subpel=1, seed=0, mask=(1 << 41) - 1, is_b=0, wp=None):
     rng = np.random.default_rng(seed)
     cur, ref = make_pair(rng, w, h, kind)
     ctx = pkg.Context(w, h, yuv_format=0, max_refs=1, search_range=R)
@@ -54,10 +54,16 @@ def run_case(pkg, w, h, kind, mode, R, rdopt, spread, t8x8=0, per_partition=True
     prm.level_mv_min, prm.level_mv_max = -511, 511
     prm.lambda_[0], prm.lambda_[1], prm.lambda_[2] = lam
     prm.transform8x8_mode, prm.subpel, prm.partition_mask = t8x8, subpel, mask
+    if wp:                                           # (weight, offset, denominator) of the one reference slot
+        prm.wp_enable, prm.wp_denom, prm.wp_round = 1, wp[2], (1 << (wp[2] - 1)) if wp[2] else 0
+        prm.wp_weight[0], prm.wp_offset[0] = wp[0], wp[1]
     got = ctx.me_frame(prm, mbs)
     ctx.close()
 
     p = oracle.me_params(rdopt=rdopt, is_b_slice=is_b, transform8x8_mode=t8x8)
+    if wp:
+        p.apply_weights, p.weight_luma, p.offset_luma = 1, wp[0], wp[1]
+        p.luma_log_weight_denom, p.wp_luma_round = wp[2], (1 << (wp[2] - 1)) if wp[2] else 0
     want = oracle.me_frame(p, [oracle.RefPic(ref, yuv_format=0)], cur, mbs, mode, R, lam, subpel=bool(subpel), mask=mask)
     for key in ("mv_int", "cost_int", "mv", "cost"):
         g, wv = got[key], want[key]
@@ -88,6 +94,16 @@ def test_me_frame_small(pkg, kind, mode, R, rdopt, spread, t8x8):
 def test_b_slices_switch_the_zero_vector_bonuses_off(pkg, mode, R, spread):
     """img->type == B_SLICE: check_for_00 (me_fullsearch.c:75) and check_position0 (:361) do not apply even with rdopt off."""
     run_case(pkg, 96, 64, "shift", mode, R, 0, spread, per_partition=False, seed=5 + R, is_b=1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,R,spread,wp,t8x8", [(-1, 8, 6, (48, -9, 5), 0), (0, 8, 6, (23, 12, 5), 0), (-1, 32, 2, (70, -20, 6), 0), (0, 32, 3, (29, 5, 5), 1),
+                                                   (0, 16, 3, (-12, 200, 4), 0), (-1, 8, 40, (40, 3, 5), 0)])
+def test_weighted_reference_search(pkg, mode, R, spread, wp, t8x8):
+    """UseWeightedReferenceME: every reference sample goes through clip(((w * p + round) >> denom) + o) before SAD (integer) and SATD
+    (sub-pel) -- computeSADWP / computeSATDWP, the weighted line of the fast full search. All three integer kernels (generic for far
+    predictors / R = 8, pair-lane for 2R+1 >= 32) and the 4x4 / 8x8 Hadamard paths; a negative weight; offsets that saturate."""
+    run_case(pkg, 96, 64, "shift", mode, R, 1, spread, t8x8=t8x8, per_partition=(mode == -1), seed=R + wp[0], wp=wp)
 
 
 @pytest.mark.gpu
