@@ -319,7 +319,7 @@ __global__ __launch_bounds__(1024) void deblock_filter_kernel(DeblockDev D)
   }
 }
 
-// ---- the same walk with the three live diagonals held in LDS (4:0:0, 4:2:0, 4:2:2).
+// ---- the same walk with the three live diagonals held in LDS (all four chroma formats).
 // A macroblock of diagonal d is still changed on d+1 (its right neighbour's vertical pass: columns 13..15) and on d+2 (the
 // macroblock below: rows 13..15), then it is final. So the kernel keeps a ring of three diagonals of 384-byte tiles
 // [Y 16x16 | U 8x8 | V 8x8] in LDS: a diagonal is fetched from HBM once (16-byte row loads, prefetched one diagonal ahead into
@@ -328,8 +328,9 @@ __global__ __launch_bounds__(1024) void deblock_filter_kernel(DeblockDev D)
 // carries 24 wide loads and stores per macroblock. Tile k of a ring slot is always filled, filtered and written back by the same
 // 16 lanes, and a macroblock's two passes run in one wave, so ONE workgroup barrier per diagonal is all the data flow needs.
 constexpr int DBK_ETILE = 128;
-// CF: 0 = no chroma (4:0:0), 1 = 4:2:0 (two 8x8 planes), 2 = 4:2:2 (two 8-wide x 16-high planes); tile = [Y 16x16 | U | V]
-__host__ __device__ constexpr int dbk_tile(int cf) { return cf == 2 ? 512 : 384; }
+// CF: 0 = no chroma (4:0:0), 1 = 4:2:0 (two 8x8 planes), 2 = 4:2:2 (two 8-wide x 16-high planes), 3 = 4:4:4 (three 16x16 planes that all
+// take the luma filter); tile = [Y 16x16 | U | V]
+__host__ __device__ constexpr int dbk_tile(int cf) { return cf == 3 ? 768 : cf == 2 ? 512 : 384; }
 
 struct Diag { int y_lo, count; };
 __device__ __forceinline__ Diag diag_of(int d, int mbw, int rows, int last_d)
@@ -343,7 +344,7 @@ __device__ __forceinline__ void unpack4(int *s, uint32_t v) { s[0] = v & 255; s[
 __device__ __forceinline__ uint32_t pack4(const int *s) { return (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16) | ((uint32_t)s[3] << 24); }
 
 // HBM -> registers: this lane's share of macroblock k of diagonal d (one luma row, one chroma row, 8 bytes of the edge records)
-struct DbkFetch { uint4 y; uint2 c, c2, e; };
+struct DbkFetch { uint4 y, u4, v4; uint2 c, c2, e; };
 template <int CF>
 __device__ __forceinline__ void dbk_prefetch(const DeblockDev &D, int row0, int d, const Diag &g, int k, int l, int cpl, int cl, DbkFetch &f)
 {
@@ -354,6 +355,10 @@ __device__ __forceinline__ void dbk_prefetch(const DeblockDev &D, int row0, int 
     if (CF == 2) {                                   // row l of both planes
       f.c = *reinterpret_cast<const uint2 *>(D.u + (size_t)(mby * 16 + l) * D.Wc + mbx * 8);
       f.c2 = *reinterpret_cast<const uint2 *>(D.v + (size_t)(mby * 16 + l) * D.Wc + mbx * 8);
+    }
+    if (CF == 3) {
+      f.u4 = *reinterpret_cast<const uint4 *>(D.u + (size_t)(mby * 16 + l) * D.W + mbx * 16);
+      f.v4 = *reinterpret_cast<const uint4 *>(D.v + (size_t)(mby * 16 + l) * D.W + mbx * 16);
     }
     f.e = reinterpret_cast<const uint2 *>(D.edges + (size_t)(mby * D.mbw + mbx) * 8)[l];
   }
@@ -366,6 +371,7 @@ __device__ __forceinline__ void dbk_fill(uint8_t *slot, uint8_t *etiles, const D
     *reinterpret_cast<uint4 *>(tile + l * 16) = f.y;
     if (CF == 1) *reinterpret_cast<uint2 *>(tile + 256 + cpl * 64 + cl * 8) = f.c;
     if (CF == 2) { *reinterpret_cast<uint2 *>(tile + 256 + l * 8) = f.c; *reinterpret_cast<uint2 *>(tile + 384 + l * 8) = f.c2; }
+    if (CF == 3) { *reinterpret_cast<uint4 *>(tile + 256 + l * 16) = f.u4; *reinterpret_cast<uint4 *>(tile + 512 + l * 16) = f.v4; }
     reinterpret_cast<uint2 *>(etiles + (size_t)k * DBK_ETILE)[l] = f.e;
   }
 }
@@ -381,7 +387,7 @@ __global__ __launch_bounds__(1024) void deblock_lds_kernel(DeblockDev D, int S)
   const int row0 = D.band_row[blockIdx.x], rows = D.band_row[blockIdx.x + 1] - row0;
   const int last_d = D.mbw - 1 + 2 * (rows - 1);
   DbkFetch pf0, pf1;
-  pf0.y = pf1.y = make_uint4(0, 0, 0, 0); pf0.c = pf0.c2 = pf0.e = pf1.c = pf1.c2 = pf1.e = make_uint2(0, 0);
+  pf0.y = pf1.y = pf0.u4 = pf0.v4 = pf1.u4 = pf1.v4 = make_uint4(0, 0, 0, 0); pf0.c = pf0.c2 = pf0.e = pf1.c = pf1.c2 = pf1.e = make_uint2(0, 0);
 
   {
     const Diag g0 = diag_of(0, D.mbw, rows, last_d);
@@ -411,18 +417,20 @@ __global__ __launch_bounds__(1024) void deblock_lds_kernel(DeblockDev D, int S)
         uint8_t *left = slot_l + (size_t)(y - gl.y_lo) * DBK_TILE;          // (mbx-1, y) lies on diagonal d-1
         const bool before = mbx != 0;
         const Edges4 ei = load_edges(reinterpret_cast<const EdgeInfo *>(etiles + (size_t)k * DBK_ETILE));
-        {
+#pragma unroll
+        for (int lp = 0; lp < (CF == 3 ? 3 : 1); lp++) {           // 4:4:4: the luma filter on U and V too (plane parameters 1, 2)
           int s[20];
-          const uint4 row = *reinterpret_cast<const uint4 *>(tile + l * 16);
-          unpack4(s, before ? *reinterpret_cast<const uint32_t *>(left + l * 16 + 12) : 0u);
+          const int o = lp * 256 + l * 16;
+          const uint4 row = *reinterpret_cast<const uint4 *>(tile + o);
+          unpack4(s, before ? *reinterpret_cast<const uint32_t *>(left + o + 12) : 0u);
           unpack4(s + 4, row.x); unpack4(s + 8, row.y); unpack4(s + 12, row.z); unpack4(s + 16, row.w);
-          luma_edges(s, ei, 0, l >> 2);
-          if (before) *reinterpret_cast<uint32_t *>(left + l * 16 + 12) = pack4(s);
-          *reinterpret_cast<uint4 *>(tile + l * 16) = make_uint4(pack4(s + 4), pack4(s + 8), pack4(s + 12), pack4(s + 16));
+          luma_edges(s, ei, lp, l >> 2);
+          if (before) *reinterpret_cast<uint32_t *>(left + o + 12) = pack4(s);
+          *reinterpret_cast<uint4 *>(tile + o) = make_uint4(pack4(s + 4), pack4(s + 8), pack4(s + 12), pack4(s + 16));
         }
         // 4:2:0: 8 rows x 2 planes over the 16 lanes (strength group row >> 1); 4:2:2: 16 rows, a lane takes row l of both planes (row >> 2)
 #pragma unroll
-        for (int pass = 0; pass < (CF == 2 ? 2 : CF); pass++) {
+        for (int pass = 0; pass < (CF == 2 ? 2 : CF == 1 ? 1 : 0); pass++) {
           int s[12];
           const int pl = CF == 2 ? pass : cpl, o = CF == 2 ? 256 + pass * 128 + l * 8 : 256 + cpl * 64 + cl * 8;
           const uint2 row = *reinterpret_cast<const uint2 *>(tile + o);
@@ -448,22 +456,24 @@ __global__ __launch_bounds__(1024) void deblock_lds_kernel(DeblockDev D, int S)
         // (a later band's first row has its top edges off by construction: it must neither read nor write back those rows)
         const bool before = mby != 0 && !(blockIdx.x > 0 && y == 0), top_lds = y > 0;
         const Edges4 ei = load_edges(reinterpret_cast<const EdgeInfo *>(etiles + (size_t)k * DBK_ETILE + 64));
-        {
+#pragma unroll
+        for (int lp = 0; lp < (CF == 3 ? 3 : 1); lp++) {
           int s[20];
-          uint8_t *gtop = D.y + (size_t)(mby * 16 - 4) * D.W + mbx * 16 + l;
+          const int o = lp * 256 + l;
+          uint8_t *gtop = (lp == 0 ? D.y : lp == 1 ? D.u : D.v) + (size_t)(mby * 16 - 4) * D.W + mbx * 16 + l;
 #pragma unroll
-          for (int r = 0; r < 4; r++) s[r] = !before ? 0 : top_lds ? top[(12 + r) * 16 + l] : gtop[(size_t)r * D.W];
+          for (int r = 0; r < 4; r++) s[r] = !before ? 0 : top_lds ? top[o + (12 + r) * 16] : gtop[(size_t)r * D.W];
 #pragma unroll
-          for (int r = 0; r < 16; r++) s[4 + r] = tile[r * 16 + l];
-          luma_edges(s, ei, 0, l >> 2);
+          for (int r = 0; r < 16; r++) s[4 + r] = tile[o + r * 16];
+          luma_edges(s, ei, lp, l >> 2);
           if (before) {
 #pragma unroll
-            for (int r = 1; r < 4; r++) { if (top_lds) top[(12 + r) * 16 + l] = (uint8_t)s[r]; else gtop[(size_t)r * D.W] = (uint8_t)s[r]; }
+            for (int r = 1; r < 4; r++) { if (top_lds) top[o + (12 + r) * 16] = (uint8_t)s[r]; else gtop[(size_t)r * D.W] = (uint8_t)s[r]; }
           }
 #pragma unroll
-          for (int r = 0; r < 15; r++) tile[r * 16 + l] = (uint8_t)s[4 + r];
+          for (int r = 0; r < 15; r++) tile[o + r * 16] = (uint8_t)s[4 + r];
         }
-        if (CF) {                                       // lane = (plane, column); 4:2:2 has a chroma edge under every luma edge (rows 0, 4, 8, 12)
+        if (CF == 1 || CF == 2) {                       // lane = (plane, column); 4:2:2 has a chroma edge under every luma edge (rows 0, 4, 8, 12)
           constexpr int CH = CF == 2 ? 16 : 8, CP = 8 * CH;
           int s[4 + CH];
           const int o = 256 + cpl * CP + cl;
@@ -494,6 +504,10 @@ __global__ __launch_bounds__(1024) void deblock_lds_kernel(DeblockDev D, int S)
         if (CF == 2) {
           *reinterpret_cast<uint2 *>(D.u + (size_t)(mby * 16 + l) * D.Wc + mbx * 8) = *reinterpret_cast<const uint2 *>(tile + 256 + l * 8);
           *reinterpret_cast<uint2 *>(D.v + (size_t)(mby * 16 + l) * D.Wc + mbx * 8) = *reinterpret_cast<const uint2 *>(tile + 384 + l * 8);
+        }
+        if (CF == 3) {
+          *reinterpret_cast<uint4 *>(D.u + (size_t)(mby * 16 + l) * D.W + mbx * 16) = *reinterpret_cast<const uint4 *>(tile + 256 + l * 16);
+          *reinterpret_cast<uint4 *>(D.v + (size_t)(mby * 16 + l) * D.W + mbx * 16) = *reinterpret_cast<const uint4 *>(tile + 512 + l * 16);
         }
       }
     }
@@ -574,8 +588,8 @@ int dbk_run(jmhip_ctx *c, const DbkArrays &a, int mvlimit, int mb_row0, int mb_r
     for (int i = 0; i <= DBK_MAXB; i++) D.band_row[i] = rows[std::min<size_t>((size_t)i, rows.size() - 1)];
   }
   D.dbg = getenv("JMHIP_DBK_DEBUG") ? atoi(getenv("JMHIP_DBK_DEBUG")) : 0;
-  // LDS ring (4:0:0 / 4:2:0 / 4:2:2) when three diagonals + one diagonal of edge records fit into 160 KB; JMHIP_DEBLOCK_KERNEL=global forces
-  // the global-memory kernel (kept for 4:4:4, larger pictures, and as a cross-check in the tests)
+  // LDS ring when three diagonals + one diagonal of edge records fit into 160 KB; JMHIP_DEBLOCK_KERNEL=global forces the global-memory kernel
+  // (kept for larger pictures and as a cross-check in the tests)
   int S = 0;
   for (int b = 0; b < D.nbands; b++) {
     const int br = D.band_row[b + 1] - D.band_row[b];
@@ -584,10 +598,10 @@ int dbk_run(jmhip_ctx *c, const DbkArrays &a, int mvlimit, int mb_row0, int mb_r
       S = std::max(S, y_hi - y_lo + 1);
     }
   }
-  const int cf = c->cfg.yuv_format == JMHIP_YUV420 ? 1 : c->cfg.yuv_format == JMHIP_YUV422 ? 2 : 0;
+  const int cf = c->cfg.yuv_format == JMHIP_YUV420 ? 1 : c->cfg.yuv_format == JMHIP_YUV422 ? 2 : c->cfg.yuv_format == JMHIP_YUV444 ? 3 : 0;
   const size_t lds = (size_t)S * (3 * dbk_tile(cf) + DBK_ETILE);
   const char *force = getenv("JMHIP_DEBLOCK_KERNEL");
-  const bool use_lds = c->cfg.yuv_format != JMHIP_YUV444 && S <= 128 && lds <= 160 * 1024 && !(force && !strcmp(force, "global"));
+  const bool use_lds = S <= (cf == 3 ? 64 : 128) && lds <= 160 * 1024 && !(force && !strcmp(force, "global"));
   if (use_lds) {
     auto launch = [&](auto kernel) -> hipError_t {
       hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -598,7 +612,7 @@ int dbk_run(jmhip_ctx *c, const DbkArrays &a, int mvlimit, int mb_row0, int mb_r
       return hipGetLastError();
     };
     hipError_t e;
-    if (S <= 64) e = cf == 2 ? launch(deblock_lds_kernel<1, 2>) : cf == 1 ? launch(deblock_lds_kernel<1, 1>) : launch(deblock_lds_kernel<1, 0>);
+    if (S <= 64) e = cf == 3 ? launch(deblock_lds_kernel<1, 3>) : cf == 2 ? launch(deblock_lds_kernel<1, 2>) : cf == 1 ? launch(deblock_lds_kernel<1, 1>) : launch(deblock_lds_kernel<1, 0>);
     else e = cf == 2 ? launch(deblock_lds_kernel<2, 2>) : cf == 1 ? launch(deblock_lds_kernel<2, 1>) : launch(deblock_lds_kernel<2, 0>);
     JM_HIP_CHECK(c, e);
   } else

@@ -163,6 +163,7 @@ def test_deblock_global_memory_kernel_on_420(pkg, monkeypatch):
     run(pkg, 176, 144, 1, seed=21)
     run(pkg, 320, 64, 0, seed=22)
     run(pkg, 176, 144, 2, seed=23)
+    run(pkg, 176, 144, 3, seed=24, idc_mode="zero")
 
 
 @pytest.mark.gpu
