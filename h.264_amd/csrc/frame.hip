@@ -144,15 +144,15 @@ __global__ __launch_bounds__(64) void mc_kernel(FrameDev F, const jmhip_me_mb *_
         const int xa = clampi(xpos - F.pad_cx, 0, F.Wc - 1), xb = clampi(xpos - F.pad_cx + 1, 0, F.Wc - 1), xc = clampi(xpos - F.pad_cx + 2, 0, F.Wc - 1);
         const int a0 = r0[xa], a1 = r0[xb], a2 = r0[xc], b0 = r1[xa], b1 = r1[xb], b2 = r1[xc];
         const int h00 = a0 * (8 - l) + a1 * l, h01 = a1 * (8 - l) + a2 * l, h10 = b0 * (8 - l) + b1 * l, h11 = b1 * (8 - l) + b2 * l;
-        jc.pred[j][ic] = (uint8_t)((h00 * (8 - k) + h10 * k + 32) >> 6);
-        jc.pred[j][ic + 1] = (uint8_t)((h01 * (8 - k) + h11 * k + 32) >> 6);
+        // ic is even: the two samples go out as one 16-bit store
+        *reinterpret_cast<uint16_t *>(&jc.pred[j][ic]) = (uint16_t)(((h00 * (8 - k) + h10 * k + 32) >> 6) | (((h01 * (8 - k) + h11 * k + 32) >> 6) << 8));
       } else {
         const uint8_t *planes = (uv ? F.ref_cr : F.ref_cb)[mb.ref];
         const uint8_t *src = planes + (size_t)((jj & F.mask_y) * F.sub_x + (ii & F.mask_x)) * F.Wcp * F.Hcp + (size_t)ypos * F.Wcp + xpos;
-        jc.pred[j][ic] = src[0]; jc.pred[j][ic + 1] = src[1];
+        *reinterpret_cast<uint16_t *>(&jc.pred[j][ic]) = (uint16_t)(src[0] | (src[1] << 8));
       }
       const uint8_t *cs = (uv ? F.cur_v : F.cur_u) + (size_t)(mby * F.mb_ch + j) * F.Wc + mbx * F.mb_cw + ic;
-      jc.src[j][ic] = cs[0]; jc.src[j][ic + 1] = cs[1];
+      *reinterpret_cast<uint16_t *>(&jc.src[j][ic]) = *reinterpret_cast<const uint16_t *>(cs);      // even column of an even-width plane: aligned
       if (q == 0) { jc.quant = 1; jc.quant_dc = 2; jc.uv = uv; jc.cr_cbp_in = 0; jc.intra16_unused = 0; }
     }
   }
