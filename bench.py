@@ -292,6 +292,9 @@ def main():
     sbuf = torch.zeros(max(chunk, 4), dtype=torch.uint8, device=dev)
     gbuf = torch.zeros(max(chunk * world, 4), dtype=torch.uint8, device=dev)
 
+    # the uploads and zero-fills above ran on torch's current stream; the library's own stream (non-blocking) and RCCL's consume
+    # them without any ordering in between: settle them before the first step
+    torch.cuda.synchronize()
     first = [True]
     # N > 1: the all-gather is enqueued on the context's own stream (stream-ordered with the kernels round it, no host sync)
     ext = torch.cuda.ExternalStream(ctx.stream_ptr(), device=dev) if world > 1 else None

@@ -514,14 +514,7 @@ __global__ __launch_bounds__(1024) void deblock_lds_kernel(DeblockDev D, int S)
   }
 }
 
-int ensure_recon(jmhip_ctx *c)
-{
-  if (c->rec_y) return JMHIP_OK;
-  if (hipMalloc((void **)&c->rec_y, (size_t)c->W * c->H) != hipSuccess) return jm_fail(c, JMHIP_ERR_NOMEM, "recon picture");
-  if (c->Wc && (hipMalloc((void **)&c->rec_u, (size_t)c->Wc * c->Hc) != hipSuccess || hipMalloc((void **)&c->rec_v, (size_t)c->Wc * c->Hc) != hipSuccess))
-    return jm_fail(c, JMHIP_ERR_NOMEM, "recon picture");
-  return JMHIP_OK;
-}
+int ensure_recon(jmhip_ctx *c) { return jm_ensure_recon(c); }
 
 }  // namespace
 
@@ -536,7 +529,7 @@ extern "C" int jmhip_recon_upload(jmhip_ctx *c, const void *Y, const void *U, co
     if ((rc = jm_upload_plane(c, c->rec_u, U, c->Wc, c->Hc, pel_bytes, c->Wc, 0))) return rc;
     if ((rc = jm_upload_plane(c, c->rec_v, V, c->Wc, c->Hc, pel_bytes, c->Wc, 0))) return rc;
   }
-  c->rec_has_pic = true;
+  c->rec_has_pic = true; c->rec_valid = true;
   return JMHIP_OK;
 }
 
@@ -679,7 +672,7 @@ __global__ __launch_bounds__(256) void deblock_inputs_kernel(const jmhip_me_mb *
 extern "C" int jmhip_deblock_frame(jmhip_ctx *c, const jmhip_deblock_mb *mbs, const jmhip_deblock_blk *blks, int mvlimit, int mb_row0, int mb_rows)
 {
   if (!c || !mbs || !blks) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_deblock_frame: NULL argument") : JMHIP_ERR_ARG;
-  if (!c->rec_y || !(c->fr_n > 0 || c->rec_has_pic)) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_deblock_frame: no recon picture yet");
+  if (!c->rec_y || !c->rec_valid) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_deblock_frame: no recon picture yet");
   if (mb_rows <= 0) { mb_row0 = 0; mb_rows = c->mbh; }
   if (mb_row0 < 0 || mb_row0 + mb_rows > c->mbh) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_deblock_frame: row band outside the picture");
   if (mvlimit != 4 && mvlimit != 2) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_deblock_frame: mvlimit is 4 (frame) or 2 (field)");

@@ -230,13 +230,7 @@ __global__ __launch_bounds__(64) void finalize_kernel(FrameDev F, const jmhip_me
 
 int ensure_frame_buffers(jmhip_ctx *c, int n)
 {
-  if (!c->rec_y) {
-    if (hipMalloc((void **)&c->rec_y, (size_t)c->W * c->H) != hipSuccess) return jm_fail(c, JMHIP_ERR_NOMEM, "recon picture");
-    if (c->Wc) {
-      if (hipMalloc((void **)&c->rec_u, (size_t)c->Wc * c->Hc) != hipSuccess || hipMalloc((void **)&c->rec_v, (size_t)c->Wc * c->Hc) != hipSuccess)
-        return jm_fail(c, JMHIP_ERR_NOMEM, "recon picture");
-    }
-  }
+  { int rc = jm_ensure_recon(c); if (rc) return rc; }
   if (c->fr_capacity >= n) return JMHIP_OK;
   void **bufs[] = {&c->fr_jobs_y, &c->fr_jobs_c, &c->fr_res_y, &c->fr_res_c, &c->fr_modes};
   for (auto b : bufs) { if (*b) JM_HIP_CHECK(c, hipFree(*b)); *b = nullptr; }
@@ -247,7 +241,10 @@ int ensure_frame_buffers(jmhip_ctx *c, int n)
             hipMalloc(&c->fr_res_y, sizeof(jmhip_tq_result) * (size_t)n) == hipSuccess &&
             hipMalloc(&c->fr_res_c, sizeof(jmhip_tq_result) * (size_t)n * 2) == hipSuccess &&
             hipMalloc(&c->fr_modes, (sizeof(jmhip_mb_mode) * 2 + sizeof(MbCoded)) * (size_t)n) == hipSuccess;
-  if (!ok) return jm_fail(c, JMHIP_ERR_NOMEM, "frame-stage arrays");
+  if (!ok) {                                            // leave nothing half-allocated behind (fr_capacity stays 0)
+    for (auto b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
+    return jm_fail(c, JMHIP_ERR_NOMEM, "frame-stage arrays");
+  }
   JM_HIP_CHECK(c, hipMemsetAsync(c->fr_jobs_c, 0, sizeof(jmhip_tq_job) * (size_t)n * 2, c->stream));
   JM_HIP_CHECK(c, hipMemsetAsync(c->fr_res_y, 0, sizeof(jmhip_tq_result) * (size_t)n, c->stream));
   JM_HIP_CHECK(c, hipMemsetAsync(c->fr_res_c, 0, sizeof(jmhip_tq_result) * (size_t)n * 2, c->stream));
@@ -341,7 +338,7 @@ extern "C" int jmhip_residual_frame_q(jmhip_ctx *c, const jmhip_mb_mode *modes, 
   }
   jm_stage_end(c, JMHIP_STAGE_TQ);
   if (rc) return rc;
-  c->fr_n = n;
+  c->fr_n = n; c->rec_valid = true;
   return JMHIP_OK;
 }
 
@@ -375,7 +372,7 @@ extern "C" int jmhip_recon_to_ref(jmhip_ctx *c, int ref)
 {
   if (!c) return JMHIP_ERR_ARG;
   if (ref < 0 || ref >= (int)c->refs.size()) return jm_fail(c, JMHIP_ERR_ARG, "ref slot out of range");
-  if (!c->rec_y || !(c->fr_n > 0 || c->rec_has_pic)) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_recon_to_ref: no recon picture yet");
+  if (!c->rec_y || !c->rec_valid) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_recon_to_ref: no recon picture yet");
   RefSlot &r = c->refs[ref];
   JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
   std::swap(r.y, c->rec_y);
@@ -385,6 +382,9 @@ extern "C" int jmhip_recon_to_ref(jmhip_ctx *c, int ref)
     c->table_fix.idx = ref; c->table_fix.ptr = r.y;
   }
   r.has_pic = true; r.has_luma_sub = false; r.has_cr_sub = false;
+  // the recon planes now hold the slot's OLD picture: nothing may read them as "the reconstruction" until the next
+  // jmhip_residual_frame / jmhip_recon_upload has written a new one
+  c->rec_valid = false;
   return JMHIP_OK;
 }
 
@@ -400,7 +400,7 @@ int jm_flush_table_fix(jmhip_ctx *c)
 extern "C" int jmhip_recon_copy_band(jmhip_ctx *c, void *Y, void *U, void *V, int mb_row0, int mb_rows)
 {
   if (!c || !Y) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_recon_copy_band: NULL destination") : JMHIP_ERR_ARG;
-  if (!c->rec_y || !(c->fr_n > 0 || c->rec_has_pic)) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_recon_copy_band: no recon picture yet");
+  if (!c->rec_y || !c->rec_valid) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_recon_copy_band: no recon picture yet");
   if (mb_row0 < 0 || mb_rows <= 0 || mb_row0 + mb_rows > c->mbh) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_recon_copy_band: band outside the picture");
   const size_t y0 = (size_t)mb_row0 * 16 * c->W, yn = (size_t)mb_rows * 16 * c->W;
   JM_HIP_CHECK(c, hipMemcpyAsync(Y, c->rec_y + y0, yn, hipMemcpyDeviceToDevice, c->stream));
@@ -459,7 +459,7 @@ extern "C" size_t jmhip_band_chunk_bytes(jmhip_ctx *c, int band_rows)
 extern "C" int jmhip_recon_pack_band(jmhip_ctx *c, void *chunk, int rank, int band_rows)
 {
   if (!c || !chunk || rank < 0 || band_rows <= 0) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_recon_pack_band: arguments") : JMHIP_ERR_ARG;
-  if (!c->rec_y || !(c->fr_n > 0 || c->rec_has_pic)) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_recon_pack_band: no recon picture yet");
+  if (!c->rec_y || !c->rec_valid) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_recon_pack_band: no recon picture yet");
   if ((c->W & 3) || (c->Wc & 3)) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_recon_pack_band: plane widths must be multiples of 4");
   JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
   const BandGeom g = band_geom(c->W, c->Wc, c->H, c->Hc, c->Wc ? c->cg.mb_h : 0, band_rows);
@@ -486,7 +486,7 @@ extern "C" int jmhip_ref_unpack_bands(jmhip_ctx *c, int ref, const void *chunks,
 extern "C" int jmhip_recon_download(jmhip_ctx *c, void *Y, void *U, void *V, int pel_bytes)
 {
   if (!c || !Y) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_recon_download: NULL output") : JMHIP_ERR_ARG;
-  if (!c->rec_y || !(c->fr_n > 0 || c->rec_has_pic)) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_recon_download: no recon picture yet");
+  if (!c->rec_y || !c->rec_valid) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_recon_download: no recon picture yet");
   int rc = jm_download_planes(c, c->rec_y, (size_t)c->W * c->H, Y, pel_bytes);
   if (rc) return rc;
   if (c->Wc && U && V) {

@@ -219,6 +219,23 @@ static int ensure_stage(jmhip_ctx *c, size_t bytes)
 }
 
 // copy one plane (w x h samples) into a tightly packed 8-bit device plane
+// the recon picture: all three planes or none (a failed chroma allocation must not leave a luma plane that later calls take
+// as "allocated" and launch on null chroma pointers)
+int jm_ensure_recon(jmhip_ctx *c)
+{
+  if (c->rec_y && (!c->Wc || (c->rec_u && c->rec_v))) return JMHIP_OK;
+  bool ok = hipMalloc((void **)&c->rec_y, (size_t)c->W * c->H) == hipSuccess;
+  if (ok && c->Wc) ok = hipMalloc((void **)&c->rec_u, (size_t)c->Wc * c->Hc) == hipSuccess && hipMalloc((void **)&c->rec_v, (size_t)c->Wc * c->Hc) == hipSuccess;
+  if (!ok) {
+    if (c->rec_y) (void)hipFree(c->rec_y);
+    if (c->rec_u) (void)hipFree(c->rec_u);
+    if (c->rec_v) (void)hipFree(c->rec_v);
+    c->rec_y = c->rec_u = c->rec_v = nullptr;
+    return jm_fail(c, JMHIP_ERR_NOMEM, "recon picture");
+  }
+  return JMHIP_OK;
+}
+
 int jm_upload_plane(jmhip_ctx *c, uint8_t *dst, const void *src, int w, int h, int pel_bytes, int stride, int device_ptrs)
 {
   if (!src) return jm_fail(c, JMHIP_ERR_ARG, "NULL plane");

@@ -53,6 +53,7 @@ struct jmhip_ctx {
   int fr_capacity = 0, fr_n = 0;
   jmhip_quant fr_quant_host[4];
   uint8_t *rec_y = nullptr, *rec_u = nullptr, *rec_v = nullptr;
+  bool rec_valid = false;                             // the recon planes hold a reconstruction (cleared by jmhip_recon_to_ref's plane swap)
   bool rec_has_pic = false;                           // recon planes loaded by jmhip_recon_upload
   void *dbk_dev = nullptr; size_t dbk_cap = 0;        // deblocking: macroblock / block / edge arrays
   // TQ arrays
@@ -96,6 +97,7 @@ int jm_launch_interp_chroma(jmhip_ctx *ctx, int ref, int prow0 = 0, int prow1 = 
 constexpr int JMHIP_TQ_SELECT = 0x100;   // frame stage: each luma kernel takes only the macroblocks of its transform size
 int jm_launch_tq(jmhip_ctx *ctx, int kind, int yuv_format, const void *jobs, const void *quants, void *results, int n);
 int jm_ensure_ref_table(jmhip_ctx *ctx);
+int jm_ensure_recon(jmhip_ctx *ctx);                                                       // jmhip_ctx.hip: all three recon planes or none
 int jm_flush_table_fix(jmhip_ctx *ctx);                                                    // frame.hip
 struct MeDev;
 int jm_me_sub_tables(jmhip_ctx *ctx);                                                   // me_sub.hip

@@ -1063,7 +1063,7 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
   if ((2 * R + 1) * (2 * R + 1) + 1 >= (1 << TIE_BITS))
     return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_me_frame: search_range > 44 does not fit the packed argmin key");
   for (int k = 0; k < 3; k++)
-    if (prm->lambda[k] < 0 || prm->lambda[k] > 30000000) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_me_frame: lambda factor out of the 32-bit cost range");
+    if (prm->lambda[k] < 0 || prm->lambda[k] >= (1 << 24)) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_me_frame: lambda factor must be below 2^24 (the kernels multiply it with __umul24; JM's largest, QP 51, is 5.5e6)");
   if (!c->has_cur) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_frame: current picture not uploaded");
   if (!(prm->partition_mask & ((1ull << JMHIP_NPART) - 1))) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_frame: empty partition mask");
   if (prm->wp_enable && (prm->wp_denom < 0 || prm->wp_denom > 7 || prm->wp_round < 0 || prm->wp_round > 64)) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_frame: weighted-prediction denominator / rounding out of range");
@@ -1081,7 +1081,12 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
     for (size_t k = 0; k < c->refs.size(); k++)
       if (((ref_mask >> k) & 1) && (!c->refs[k].has_pic || (prm->subpel && !c->refs[k].has_luma_sub)))
         return jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_frame: reference slot of the resident jobs is not ready");
-  } else { max_uw = max_uh = 0; ref_mask = 0; c->me_fast_idx.clear(); c->me_gen_idx.clear(); }
+  } else {
+    // a new upload invalidates the resident job set until it has been validated AND copied: an early return below must not
+    // leave me_n describing the previous upload next to half-built index lists (a later resident call would launch on them)
+    c->me_n = 0;
+    max_uw = max_uh = 0; ref_mask = 0; c->me_fast_idx.clear(); c->me_gen_idx.clear();
+  }
   const bool full_mask = (prm->partition_mask & ((1ull << JMHIP_NPART) - 1)) == ((1ull << JMHIP_NPART) - 1);
   for (int i = 0; i < n && !resident; i++) {
     const jmhip_me_mb &m = mbs[i];

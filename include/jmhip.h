@@ -350,7 +350,11 @@ int jmhip_residual_frame_q(jmhip_ctx *ctx, const jmhip_mb_mode *modes, const jmh
  * thresholding of src/macroblock.c:1236-1258, :1386-1392 and the chroma cr_cbp. Any output pointer may be NULL. */
 int jmhip_residual_download(jmhip_ctx *ctx, jmhip_tq_result *luma, jmhip_tq_result *chroma, jmhip_mb_mode *modes_out,
                             int32_t *cbp, int64_t *cbp_blk, int n);
-/* Make the recon picture the integer-pel picture of reference slot `ref` (device-to-device), e.g. for the next frame. */
+/* Make the recon picture the integer-pel picture of reference slot `ref`, e.g. for the next frame. Nothing is copied: the
+ * slot's planes and the recon planes TRADE PLACES. Consequences: (1) device pointers handed out earlier by
+ * jmhip_ref_device_planes / jmhip_ref_planes_peek for this slot are stale -- ask again; (2) the recon picture is INVALID
+ * afterwards (it holds the slot's old picture): jmhip_recon_download / _copy_band / _pack_band / jmhip_deblock_* and a second
+ * jmhip_recon_to_ref return JMHIP_ERR_ARG until jmhip_residual_frame or jmhip_recon_upload has produced a new one. */
 int jmhip_recon_to_ref(jmhip_ctx *ctx, int ref);
 /* Copy the band of macroblock rows [mb_row0, mb_row0+mb_rows) of the recon picture into caller-provided DEVICE buffers
  * (tightly packed rows): the send buffer of the per-frame all-gather of reconstructed slice bands. */
