@@ -185,6 +185,70 @@ int  jmo_fastfull_search(const jmo_me_params *p, const jmo_fastfull *ff, int opi
                          int pic_pix_x, int pic_pix_y, int blocktype, int pred_mv_x, int pred_mv_y,
                          short *mv_x, short *mv_y, int min_mcost, int lambda_factor);
 
+
+/* computeUniPred[level + 3*apply_weights] (mv-search.c:400-424) and the jmo_dist a search function fills from its parameters */
+int  jmo_uni_pred(const jmo_me_params *p, int level, const jmo_dist *d, const jmo_pel *src, int bsy, int bsx, int min_mcost, int cx, int cy);
+void jmo_dist_from_params(const jmo_me_params *p, const jmo_ref *ref, jmo_dist *d);
+/* computeBiPred1/2[level] by metric (mv-search.c:403-423; SSE is not restated) */
+int  jmo_bipred_dist(const jmo_bipred *b, int metric, const jmo_pel *src, int bsy, int bsx, int min_mcost, int x1, int y1, int x2, int y2);
+
+/* ------------------------------------------------------------------ EPZS (jmo_epzs.c; me_epzs.c of the reference) */
+
+#define JMO_MAX_LIST 33          /* MAX_LIST_SIZE, mbuffer.h:18 */
+#define JMO_MAX_REFS 32          /* MAX_REFERENCE_PICTURES, defines.h:152 */
+
+typedef struct jmo_epzs jmo_epzs;                 /* the file-static state of me_epzs.c */
+typedef struct {
+  int search_range;              /* input->search_range */
+  int bipred_me, bipred_search_range;  /* input->BiPredMotionEstimation, input->BiPredMESearchRange (size of the visited map, :341) */
+  int pattern, dual, fixed, temporal, spatial_mem;   /* EPZSPattern, EPZSDual, EPZSFixed, EPZSTemporal, EPZSSpatialMem */
+  int min_scale, med_scale, max_scale, subpel_scale; /* EPZS{Min,Med,Max,SubPel}ThresScale */
+  int width, height, width_cr, height_cr;            /* img->width ... */
+  int bitdepth_luma, bitdepth_chroma;
+  int chroma_me, chroma_me_weight;                   /* input->ChromaMEEnable (thresholds, :338), input->ChromaMEWeight */
+  int max_refs;                  /* img->max_num_references */
+} jmo_epzs_config;
+jmo_epzs *jmo_epzs_create(const jmo_epzs_config *cfg);            /* EPZSInit :333 */
+void jmo_epzs_destroy(jmo_epzs *e);
+int *jmo_epzs_distortion_row(jmo_epzs *e, int list, int blocktype_m1);   /* EPZSDistortion[list][blocktype-1] (mv-search.c:595 reads it) */
+int jmo_epzs_threshold(const jmo_epzs *e, int which /*0 min 1 med 2 max 3 sub*/, int blocktype);
+int jmo_epzs_mv_scale(const jmo_epzs *e, int list, int i, int k);
+const short *jmo_epzs_colocated(const jmo_epzs *e);               /* [2][H/4][W/4][2] */
+
+/* EPZSSliceInit :501 for a frame picture of a frame_mbs_only sequence */
+typedef struct {
+  int is_b_slice;
+  int poc;                                 /* enc_picture->poc */
+  int list_size[2];                        /* listXsize[0..1] */
+  int list_poc[2][JMO_MAX_LIST];           /* listX[j][i]->poc */
+  int num_ref_idx_l0_active;
+  long long ref_pic_num_l0[JMO_MAX_LIST];  /* enc_picture->ref_pic_num[LIST_0][i] */
+  const short *col_mv[2];                  /* mv[LIST_0] of listX[LIST_1 if B else LIST_0][0] and [1] ([0] again if the list has one entry), [H/4][W/4][2] */
+  const long long *col_ref_id[2];          /* ref_id[LIST_0] of the same two pictures, [H/4][W/4] */
+} jmo_epzs_slice;
+void jmo_epzs_slice_init(jmo_epzs *e, const jmo_epzs_slice *s);
+
+/* the A, B, C, D neighbours of getLuma4x4Neighbour (before EPZS' own block_c fix-up), with refPic / tmp_mv read at their positions */
+typedef struct { int available[4]; int ref[4]; short mv[4][2]; } jmo_epzs_nbr;
+
+/* EPZSPelBlockMotionSearch :1500. allmv = img->all_mv[block_y][block_x][list] as [ref][blocktype][2]; p->apply_weights as :1546. */
+int jmo_epzs_pel_search(jmo_epzs *e, const jmo_me_params *p, const jmo_ref *ref_pic, const jmo_pel *cur_pic, int ref, int list,
+                        const jmo_epzs_nbr *nb, const short (*allmv)[8][2], int is_p_slice, int current_mb_nr, int opix_x, int opix_y,
+                        int pic_pix_x, int pic_pix_y, int blocktype, const short pred_mv[2], short mv[2], int search_range,
+                        int min_mcost, int lambda_factor);
+/* EPZSBiPredBlockMotionSearch :1971 */
+int jmo_epzs_bipred_search(jmo_epzs *e, jmo_bipred *b, const jmo_pel *cur_pic, int ref, int list, const jmo_epzs_nbr *nb,
+                           int opix_x, int opix_y, int pic_pix_x, int pic_pix_y, int blocktype, const short pred_mv1[2], const short pred_mv2[2],
+                           short mv[2], const short s_mv[2], int search_range, int min_mcost, int lambda_factor);
+/* EPZSSubPelBlockMotionSearch :2390 */
+int jmo_epzs_subpel_search(const jmo_epzs *e, const jmo_me_params *p, const jmo_ref *ref_pic, const jmo_pel *orig_pic,
+                           int pic_pix_x, int pic_pix_y, int blocktype, const short pred_mv[2], short mv[2],
+                           int search_pos2, int search_pos4, int min_mcost, const int *lambda);
+/* EPZSSubPelBlockSearchBiPred :2728 */
+int jmo_epzs_subpel_bipred(jmo_bipred *b, const jmo_pel *orig_pic, int pic_pix_x, int pic_pix_y, int blocktype,
+                           const short pred_mv1[2], const short pred_mv2[2], short mv[2], const short s_mv[2],
+                           int search_pos2, int search_pos4, int min_mcost, const int *lambda);
+
 /* ------------------------------------------------------------------ transform / quant */
 
 void jmo_forward4x4 (int (*block)[16], int (*tblock)[16], int pos_y, int pos_x);   /* transform.c:31  */

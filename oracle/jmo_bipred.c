@@ -66,7 +66,7 @@ int jmo_bipred_satd(const jmo_bipred *b, const jmo_pel *src_pic, int bsy, int bs
   return mcost;
 }
 
-static int bipred_dist(const jmo_bipred *b, int metric, const jmo_pel *src, int bsy, int bsx, int min_mcost,
+int jmo_bipred_dist(const jmo_bipred *b, int metric, const jmo_pel *src, int bsy, int bsx, int min_mcost,
                        int x1, int y1, int x2, int y2)
 {
   /* computeBiPred1/2[] selection, mv-search.c:403-423: SAD, (SSE not restated), SATD */
@@ -100,7 +100,7 @@ int jmo_fullpel_bipred(jmo_bipred *b, const jmo_pel *orig_pic, int pic_pix_x, in
     mcost = jmo_mv_cost(lambda_factor, r1cx << 2, r1cy << 2, pred_x1, pred_y1);
     mcost += jmo_mv_cost(lambda_factor, cand_x, cand_y, pred_x2, pred_y2);
     if (mcost >= min_mcost) continue;
-    mcost += bipred_dist(b, b->metric[JMO_F_PEL], orig_pic, bsy, bsx, min_mcost - mcost,
+    mcost += jmo_bipred_dist(b, b->metric[JMO_F_PEL], orig_pic, bsy, bsx, min_mcost - mcost,
                          (r1cx << 2) + JMO_PAD4, (r1cy << 2) + JMO_PAD4, cand_x + JMO_PAD4, cand_y + JMO_PAD4);
     if (mcost < min_mcost) { best_pos = pos; min_mcost = mcost; }
   }
@@ -129,7 +129,7 @@ int jmo_subpel_bipred(jmo_bipred *b, const jmo_pel *orig_pic, int pic_pix_x, int
     cx = *mv_x + (s9x[pos] << 1); cy = *mv_y + (s9y[pos] << 1);
     mcost = jmo_mv_cost(lambda_factor, cx, cy, pred_mv_x, pred_mv_y);
     if (mcost >= min_mcost) continue;
-    mcost += bipred_dist(b, b->metric[JMO_H_PEL], orig_pic, bsy, bsx, min_mcost - mcost, smv_x, smv_y, cx + pic4_pix_x, cy + pic4_pix_y);
+    mcost += jmo_bipred_dist(b, b->metric[JMO_H_PEL], orig_pic, bsy, bsx, min_mcost - mcost, smv_x, smv_y, cx + pic4_pix_x, cy + pic4_pix_y);
     if (mcost < min_mcost) { min_mcost = mcost; best_pos = pos; }
   }
   if (best_pos) { *mv_x += s9x[best_pos] << 1; *mv_y += s9y[best_pos] << 1; }
@@ -142,7 +142,7 @@ int jmo_subpel_bipred(jmo_bipred *b, const jmo_pel *orig_pic, int pic_pix_x, int
     cx = *mv_x + s9x[pos]; cy = *mv_y + s9y[pos];
     mcost = jmo_mv_cost(lambda_factor, cx, cy, pred_mv_x, pred_mv_y);
     if (mcost >= min_mcost) continue;
-    mcost += bipred_dist(b, b->metric[JMO_Q_PEL], orig_pic, bsy, bsx, min_mcost - mcost, smv_x, smv_y, cx + pic4_pix_x, cy + pic4_pix_y);
+    mcost += jmo_bipred_dist(b, b->metric[JMO_Q_PEL], orig_pic, bsy, bsx, min_mcost - mcost, smv_x, smv_y, cx + pic4_pix_x, cy + pic4_pix_y);
     if (mcost < min_mcost) { min_mcost = mcost; best_pos = pos; }
   }
   if (best_pos) { *mv_x += s9x[best_pos]; *mv_y += s9y[best_pos]; }

@@ -83,7 +83,7 @@ void jmo_block_size(int blocktype, int *bsx, int *bsy)
   *bsx = bx[blocktype]; *bsy = by[blocktype];
 }
 
-static void dist_from_params(const jmo_me_params *p, const jmo_ref *ref, jmo_dist *d)
+void jmo_dist_from_params(const jmo_me_params *p, const jmo_ref *ref, jmo_dist *d)
 {
   memset(d, 0, sizeof(*d));
   d->ref = ref;
@@ -97,7 +97,7 @@ static void dist_from_params(const jmo_me_params *p, const jmo_ref *ref, jmo_dis
 }
 
 /* computeUniPred[level + 3*apply_weights], mv-search.c:400-424 */
-static int uni_pred(const jmo_me_params *p, int level, const jmo_dist *d, const jmo_pel *src, int bsy, int bsx,
+int jmo_uni_pred(const jmo_me_params *p, int level, const jmo_dist *d, const jmo_pel *src, int bsy, int bsx,
                     int min_mcost, int cx, int cy)
 {
   switch (p->metric[level]) {
@@ -137,7 +137,7 @@ int jmo_fullpel_search(const jmo_me_params *p, const jmo_ref *ref, const jmo_pel
   jmo_dist d;
   jmo_block_size(blocktype, &bsx, &bsy);
   spiral_cached(search_range, &sx, &sy);
-  dist_from_params(p, ref, &d);
+  jmo_dist_from_params(p, ref, &d);
   d.chroma_me = p->chroma_me ? 1 : 0;                  /* mv-search.c:612 */
   d.test8x8 = p->transform8x8_mode && blocktype <= 4;  /* mv-search.c:640 */
   /* :110-118 */
@@ -151,7 +151,7 @@ int jmo_fullpel_search(const jmo_me_params *p, const jmo_ref *ref, const jmo_pel
     if (check_for_00 && cand_x == pic_pix_x && cand_y == pic_pix_y)     /* :129 (quarter-pel vs pel, as in JM) */
       mcost -= (lambda_factor * 16) >> 16;
     if (mcost >= min_mcost) continue;
-    mcost += uni_pred(p, JMO_F_PEL, &d, orig_pic, bsy, bsx, min_mcost - mcost, cand_x + JMO_PAD4, cand_y + JMO_PAD4);
+    mcost += jmo_uni_pred(p, JMO_F_PEL, &d, orig_pic, bsy, bsx, min_mcost - mcost, cand_x + JMO_PAD4, cand_y + JMO_PAD4);
     if (mcost < min_mcost) { best_pos = pos; min_mcost = mcost; }
   }
   if (best_pos) { *mv_x += sx[best_pos]; *mv_y += sy[best_pos]; }
@@ -178,7 +178,7 @@ int jmo_subpel_search(const jmo_me_params *p, const jmo_ref *ref, const jmo_pel 
   jmo_block_size(blocktype, &bsx, &bsy);
   max_pos_x4 = (ref->W - bsx + 2 * JMO_PAD) << 2;
   max_pos_y4 = (ref->H - bsy + 2 * JMO_PAD) << 2;
-  dist_from_params(p, ref, &d);
+  jmo_dist_from_params(p, ref, &d);
   d.chroma_me = (p->chroma_me == 2) ? 1 : 0;           /* mv-search.c:779 (ME_YUV_FP_SP == 2, global.h:91-92) */
   d.test8x8 = p->transform8x8_mode && blocktype <= 4;
 
@@ -191,7 +191,7 @@ int jmo_subpel_search(const jmo_me_params *p, const jmo_ref *ref, const jmo_pel 
     mcost = jmo_mv_cost(lambda_factor, cand_mv_x, cand_mv_y, pred_mv_x, pred_mv_y);
     if (mcost >= min_mcost) continue;
     cmv_x = cand_mv_x + pic4_pix_x; cmv_y = cand_mv_y + pic4_pix_y;
-    mcost += uni_pred(p, JMO_H_PEL, &d, orig_pic, bsy, bsx, min_mcost - mcost, cmv_x, cmv_y);
+    mcost += jmo_uni_pred(p, JMO_H_PEL, &d, orig_pic, bsy, bsx, min_mcost - mcost, cmv_x, cmv_y);
     if (pos == 0 && check_position0) mcost -= (lambda_factor * 16) >> 16;   /* :439-442 */
     if (mcost < min_mcost) { min_mcost = mcost; best_pos = pos; }
   }
@@ -208,7 +208,7 @@ int jmo_subpel_search(const jmo_me_params *p, const jmo_ref *ref, const jmo_pel 
     mcost = jmo_mv_cost(lambda_factor, cand_mv_x, cand_mv_y, pred_mv_x, pred_mv_y);
     if (mcost >= min_mcost) continue;
     cmv_x = cand_mv_x + pic4_pix_x; cmv_y = cand_mv_y + pic4_pix_y;
-    mcost += uni_pred(p, JMO_Q_PEL, &d, orig_pic, bsy, bsx, min_mcost - mcost, cmv_x, cmv_y);
+    mcost += jmo_uni_pred(p, JMO_Q_PEL, &d, orig_pic, bsy, bsx, min_mcost - mcost, cmv_x, cmv_y);
     if (mcost < min_mcost) { min_mcost = mcost; best_pos = pos; }
   }
   if (best_pos) { *mv_x += s9x[best_pos]; *mv_y += s9y[best_pos]; }

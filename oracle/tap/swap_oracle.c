@@ -15,6 +15,7 @@
  *   0x100 bi-predictive full-pel + sub-pel search (FullPelBlockMotionBiPred, SubPelBlockSearchBiPred)
  *   0x200 low-complexity mode-decision costs (TransformDecision, GetSkipCostMB)
  *   0x400 in-loop deblocking filter (DeblockFrame)
+ *   0x800 EPZS walkers (EPZSInit/SliceInit state, EPZSPel/BiPred/SubPel/SubPelBiPred searches; frame pictures, EPZSSubPelGrid 0)
  * JMO_SWAP_STATS=1 prints per-symbol call counts at exit.
  */
 #define _GNU_SOURCE
@@ -31,6 +32,8 @@
 #include "me_distortion.h"
 #include "q_matrix.h"
 #include "q_offsets.h"
+#include "mb_access.h"
+#include "me_epzs.h"
 
 #include "jmo.h"
 
@@ -40,12 +43,13 @@ extern void SetMotionVectorPredictor(short pmv[2], char **refPic, short ***tmp_m
                                      int block_x, int block_y, int blockshape_x, int blockshape_y);
 extern const int LEVELMVLIMIT[17][6];
 
-static unsigned swap_mask = 0x7ff;
-static long n_calls[17];
-enum { C_LUMA, C_CHROMA, C_SAD, C_SATD, C_FULL, C_SUB, C_FAST, C_D4, C_D8, C_D16, C_DCR, C_PRIM, C_BIFULL, C_BISUB, C_TDEC, C_SKIPC, C_DEBLOCK };
+static unsigned swap_mask = 0xfff;
+static long n_calls[21];
+enum { C_LUMA, C_CHROMA, C_SAD, C_SATD, C_FULL, C_SUB, C_FAST, C_D4, C_D8, C_D16, C_DCR, C_PRIM, C_BIFULL, C_BISUB, C_TDEC, C_SKIPC, C_DEBLOCK, C_EPZS_PEL, C_EPZS_SUB, C_EPZS_BI, C_EPZS_BISUB };
 static const char *c_names[] = { "getSubImagesLuma", "getSubImagesChroma", "computeSAD*", "computeSATD*",
   "FullPelBlockMotionSearch", "SubPelBlockMotionSearch", "FastFullPelBlockMotionSearch", "dct_4x4",
-  "dct_8x8", "dct_16x16", "dct_chroma", "transform primitives", "FullPelBlockMotionBiPred", "SubPelBlockSearchBiPred", "TransformDecision", "GetSkipCostMB", "DeblockFrame" };
+  "dct_8x8", "dct_16x16", "dct_chroma", "transform primitives", "FullPelBlockMotionBiPred", "SubPelBlockSearchBiPred", "TransformDecision", "GetSkipCostMB", "DeblockFrame",
+  "EPZSPelBlockMotionSearch", "EPZSSubPelBlockMotionSearch", "EPZSBiPredBlockMotionSearch", "EPZSSubPelBlockSearchBiPred" };
 
 static void *next_sym(const char *name)
 {
@@ -59,7 +63,7 @@ static void print_stats(void)
   int i;
   if (!getenv("JMO_SWAP_STATS")) return;
   fprintf(stderr, "swap_oracle: mask=0x%x\n", swap_mask);
-  for (i = 0; i <= C_DEBLOCK; i++) fprintf(stderr, "  %-30s %ld\n", c_names[i], n_calls[i]);
+  for (i = 0; i <= C_EPZS_BISUB; i++) fprintf(stderr, "  %-30s %ld\n", c_names[i], n_calls[i]);
 }
 
 int main(int argc, char **argv)
@@ -374,6 +378,249 @@ int SubPelBlockSearchBiPred(imgpel *orig_pic, short ref, int list, int pic_pix_x
     }
     return jmo_subpel_bipred(&b, orig_pic, pic_pix_x, pic_pix_y, blocktype, pred_mv_x, pred_mv_y, mv_x, mv_y, s_mv_x, s_mv_y,
                              search_pos2, search_pos4, min_mcost, lambda);
+  }
+}
+
+
+/* ------------------------------------------------------------------ 0x800 EPZS */
+
+static jmo_epzs *epzs_state;
+
+static int epzs_swapped(void)
+{
+  return (swap_mask & 0x800) && epzs_state;
+}
+
+int EPZSInit(void)
+{
+  static int (*orig)(void);
+  int r;
+  if (!orig) orig = next_sym("EPZSInit");
+  r = orig();                                   /* JM keeps its own state too: the unswapped configurations and mv-search.c:595 use it */
+  if ((swap_mask & 0x800) && !input->EPZSSubPelGrid && !input->PicInterlace && !input->MbInterlace) {
+    jmo_epzs_config c;
+    memset(&c, 0, sizeof(c));
+    c.search_range = input->search_range; c.bipred_me = input->BiPredMotionEstimation; c.bipred_search_range = input->BiPredMESearchRange;
+    c.pattern = input->EPZSPattern; c.dual = input->EPZSDual; c.fixed = input->EPZSFixed; c.temporal = input->EPZSTemporal;
+    c.spatial_mem = input->EPZSSpatialMem;
+    c.min_scale = input->EPZSMinThresScale; c.med_scale = input->EPZSMedThresScale; c.max_scale = input->EPZSMaxThresScale;
+    c.subpel_scale = input->EPZSSubPelThresScale;
+    c.width = img->width; c.height = img->height; c.width_cr = img->width_cr; c.height_cr = img->height_cr;
+    c.bitdepth_luma = img->bitdepth_luma; c.bitdepth_chroma = img->bitdepth_chroma;
+    c.chroma_me = input->ChromaMEEnable; c.chroma_me_weight = input->ChromaMEWeight;
+    c.max_refs = img->max_num_references;
+    epzs_state = jmo_epzs_create(&c);
+  }
+  return r;
+}
+
+void EPZSSliceInit(EPZSColocParams *p, StorablePicture **lx[6])
+{
+  static void (*orig)(EPZSColocParams *, StorablePicture **[6]);
+  if (!orig) orig = next_sym("EPZSSliceInit");
+  orig(p, lx);
+  if (epzs_swapped()) {
+    jmo_epzs_slice s;
+    const int list = img->type == B_SLICE ? LIST_1 : LIST_0, w4 = img->width / 4, h4 = img->height / 4;
+    StorablePicture *fs[2];
+    short *cmv[2] = {NULL, NULL}; long long *cid[2] = {NULL, NULL};
+    int i, j, k;
+    memset(&s, 0, sizeof(s));
+    s.is_b_slice = img->type == B_SLICE; s.poc = enc_picture->poc;
+    for (j = 0; j < 2; j++) { s.list_size[j] = listXsize[j]; for (i = 0; i < listXsize[j]; i++) s.list_poc[j][i] = lx[j][i]->poc; }
+    s.num_ref_idx_l0_active = img->num_ref_idx_l0_active;
+    for (i = 0; i < MAX_LIST_SIZE; i++) s.ref_pic_num_l0[i] = enc_picture->ref_pic_num[LIST_0][i];
+    if (input->EPZSTemporal) {
+      fs[0] = lx[list][0]; fs[1] = listXsize[list] > 1 ? lx[list][1] : lx[list][0];
+      for (k = 0; k < 2; k++) {
+        cmv[k] = malloc(sizeof(short) * 2 * w4 * h4); cid[k] = malloc(sizeof(long long) * w4 * h4);
+        for (j = 0; j < h4; j++) for (i = 0; i < w4; i++) {
+          cmv[k][(j * w4 + i) * 2] = fs[k]->mv[LIST_0][j][i][0]; cmv[k][(j * w4 + i) * 2 + 1] = fs[k]->mv[LIST_0][j][i][1];
+          cid[k][j * w4 + i] = fs[k]->ref_id[LIST_0][j][i];
+        }
+        s.col_mv[k] = cmv[k]; s.col_ref_id[k] = cid[k];
+      }
+    }
+    jmo_epzs_slice_init(epzs_state, &s);
+    if (getenv("JMO_SWAP_VERIFY") && input->EPZSTemporal) {
+      const short *c = jmo_epzs_colocated(epzs_state);
+      long bad = 0;
+      for (k = 0; k < 2; k++) for (j = 0; j < h4; j++) for (i = 0; i < w4; i++)
+        bad += c[((k * h4 + j) * w4 + i) * 2] != p->mv[k][j][i][0] || c[((k * h4 + j) * w4 + i) * 2 + 1] != p->mv[k][j][i][1];
+      if (bad) fprintf(stderr, "EPZS COLOCATED MISMATCH: %ld vectors\n", bad);
+    }
+    for (k = 0; k < 2; k++) { free(cmv[k]); free(cid[k]); }
+  }
+}
+
+static void epzs_neighbours(jmo_epzs_nbr *nb, int mb_x, int mb_y, int bsx, char **refPic, short ***tmp_mv)
+{
+  PixelPos blk[4];
+  int k;
+  getLuma4x4Neighbour(img->current_mb_nr, mb_x - 1, mb_y, &blk[0]);
+  getLuma4x4Neighbour(img->current_mb_nr, mb_x, mb_y - 1, &blk[1]);
+  getLuma4x4Neighbour(img->current_mb_nr, mb_x + bsx, mb_y - 1, &blk[2]);
+  getLuma4x4Neighbour(img->current_mb_nr, mb_x - 1, mb_y - 1, &blk[3]);
+  memset(nb, 0, sizeof(*nb));
+  for (k = 0; k < 4; k++) {
+    nb->available[k] = blk[k].available;
+    if (blk[k].available) {
+      nb->ref[k] = refPic[blk[k].pos_y][blk[k].pos_x];
+      nb->mv[k][0] = tmp_mv[blk[k].pos_y][blk[k].pos_x][0]; nb->mv[k][1] = tmp_mv[blk[k].pos_y][blk[k].pos_x][1];
+    }
+  }
+}
+
+int EPZSPelBlockMotionSearch(imgpel *cur_pic, short ref, int list, int list_offset, char ***refPic, short ****tmp_mv, int pic_pix_x, int pic_pix_y,
+                             int blocktype, short pred_mv[2], short mv[2], int search_range, int min_mcost, int lambda_factor)
+{
+  static int (*orig)(imgpel *, short, int, int, char ***, short ****, int, int, int, short[2], short[2], int, int, int);
+  n_calls[C_EPZS_PEL]++;
+  if (!epzs_swapped() || img->MbaffFrameFlag || img->structure != FRAME || list_offset) {
+    if (!orig) orig = next_sym("EPZSPelBlockMotionSearch");
+    return orig(cur_pic, ref, list, list_offset, refPic, tmp_mv, pic_pix_x, pic_pix_y, blocktype, pred_mv, mv, search_range, min_mcost, lambda_factor);
+  }
+  {
+    jmo_me_params p; jmo_ref r; jmo_epzs_nbr nb;
+    short allmv[JMO_MAX_REFS][8][2];
+    const int mb_x = pic_pix_x - img->opix_x, mb_y = pic_pix_y - img->opix_y, px2 = pic_pix_x >> 2;
+    int rr, bt, cost;
+    fill_me_params(&p, list, ref, list_offset);
+    p.apply_weights = (active_pps->weighted_pred_flag > 0 || (active_pps->weighted_bipred_idc && (img->type == B_SLICE))) && input->UseWeightedReferenceME;   /* :1546 */
+    if (p.apply_weights) {
+      p.weight_luma = wp_weight[list + list_offset][ref][0]; p.offset_luma = wp_offset[list + list_offset][ref][0];
+      p.weight_cr[0] = wp_weight[list + list_offset][ref][1]; p.weight_cr[1] = wp_weight[list + list_offset][ref][2];
+      p.offset_cr[0] = wp_offset[list + list_offset][ref][1]; p.offset_cr[1] = wp_offset[list + list_offset][ref][2];
+    }
+    fill_ref(&r, listX[list + list_offset][ref]);
+    jm_side_effects(listX[list + list_offset][ref]);
+    epzs_neighbours(&nb, mb_x, mb_y, input->blc_size[blocktype][0], refPic[list], tmp_mv[list]);
+    memset(allmv, 0, sizeof(allmv));
+    for (rr = 0; rr < img->max_num_references && rr < JMO_MAX_REFS; rr++) for (bt = 0; bt < 8; bt++) {
+      allmv[rr][bt][0] = img->all_mv[mb_y >> 2][mb_x >> 2][list][rr][bt][0]; allmv[rr][bt][1] = img->all_mv[mb_y >> 2][mb_x >> 2][list][rr][bt][1];
+    }
+    if (getenv("JMO_SWAP_VERIFY")) {
+      short jm[2] = {mv[0], mv[1]}, om[2] = {mv[0], mv[1]};
+      int c1, before = EPZSDistortion[list][blocktype - 1][px2];
+      if (!orig) orig = next_sym("EPZSPelBlockMotionSearch");
+      c1 = orig(cur_pic, ref, list, list_offset, refPic, tmp_mv, pic_pix_x, pic_pix_y, blocktype, pred_mv, jm, search_range, min_mcost, lambda_factor);
+      jmo_epzs_distortion_row(epzs_state, list, blocktype - 1)[px2] = before;
+      cost = jmo_epzs_pel_search(epzs_state, &p, &r, cur_pic, ref, list, &nb, allmv, img->type == P_SLICE, img->current_mb_nr, img->opix_x, img->opix_y,
+                                 pic_pix_x, pic_pix_y, blocktype, pred_mv, om, search_range, min_mcost, lambda_factor);
+      if (c1 != cost || jm[0] != om[0] || jm[1] != om[1] || EPZSDistortion[list][blocktype - 1][px2] != jmo_epzs_distortion_row(epzs_state, list, blocktype - 1)[px2])
+        fprintf(stderr, "EPZS PEL MISMATCH mb=%d ref=%d list=%d pix=(%d,%d) bt=%d pred=(%d,%d) in=(%d,%d): jm=(%d,%d,%d,sad %d) or=(%d,%d,%d,sad %d)\n", img->current_mb_nr, ref, list,
+                pic_pix_x, pic_pix_y, blocktype, pred_mv[0], pred_mv[1], mv[0], mv[1], jm[0], jm[1], c1, EPZSDistortion[list][blocktype - 1][px2], om[0], om[1], cost,
+                jmo_epzs_distortion_row(epzs_state, list, blocktype - 1)[px2]);
+      jmo_epzs_distortion_row(epzs_state, list, blocktype - 1)[px2] = EPZSDistortion[list][blocktype - 1][px2];
+      mv[0] = jm[0]; mv[1] = jm[1];
+      return c1;
+    }
+    cost = jmo_epzs_pel_search(epzs_state, &p, &r, cur_pic, ref, list, &nb, allmv, img->type == P_SLICE, img->current_mb_nr, img->opix_x, img->opix_y,
+                               pic_pix_x, pic_pix_y, blocktype, pred_mv, mv, search_range, min_mcost, lambda_factor);
+    EPZSDistortion[list][blocktype - 1][px2] = jmo_epzs_distortion_row(epzs_state, list, blocktype - 1)[px2];      /* mv-search.c:595,783 read JM's array */
+    img_width = r.W; img_height = r.H;
+    return cost;
+  }
+}
+
+int EPZSSubPelBlockMotionSearch(imgpel *orig_pic, short ref, int list, int pic_pix_x, int pic_pix_y, int blocktype, short pred_mv[2], short mv[2],
+                                int search_pos2, int search_pos4, int min_mcost, int *lambda)
+{
+  static int (*orig)(imgpel *, short, int, int, int, int, short[2], short[2], int, int, int, int *);
+  const int list_offset = img->mb_data[img->current_mb_nr].list_offset;
+  n_calls[C_EPZS_SUB]++;
+  if (!epzs_swapped() || img->MbaffFrameFlag || img->structure != FRAME || list_offset) {
+    if (!orig) orig = next_sym("EPZSSubPelBlockMotionSearch");
+    return orig(orig_pic, ref, list, pic_pix_x, pic_pix_y, blocktype, pred_mv, mv, search_pos2, search_pos4, min_mcost, lambda);
+  }
+  {
+    jmo_me_params p; jmo_ref r;
+    fill_me_params(&p, list, ref, list_offset);
+    fill_ref(&r, listX[list + list_offset][ref]);
+    jm_side_effects(listX[list + list_offset][ref]);
+    if (getenv("JMO_SWAP_VERIFY")) {
+      short jm[2] = {mv[0], mv[1]}, om[2] = {mv[0], mv[1]};
+      int c1, c2;
+      if (!orig) orig = next_sym("EPZSSubPelBlockMotionSearch");
+      c1 = orig(orig_pic, ref, list, pic_pix_x, pic_pix_y, blocktype, pred_mv, jm, search_pos2, search_pos4, min_mcost, lambda);
+      c2 = jmo_epzs_subpel_search(epzs_state, &p, &r, orig_pic, pic_pix_x, pic_pix_y, blocktype, pred_mv, om, search_pos2, search_pos4, min_mcost, lambda);
+      if (c1 != c2 || jm[0] != om[0] || jm[1] != om[1])
+        fprintf(stderr, "EPZS SUBPEL MISMATCH mb=%d ref=%d pix=(%d,%d) bt=%d pred=(%d,%d) in=(%d,%d) min=%d: jm=(%d,%d,%d) or=(%d,%d,%d)\n", img->current_mb_nr, ref, pic_pix_x, pic_pix_y,
+                blocktype, pred_mv[0], pred_mv[1], mv[0], mv[1], min_mcost, jm[0], jm[1], c1, om[0], om[1], c2);
+      mv[0] = jm[0]; mv[1] = jm[1];
+      return c1;
+    }
+    return jmo_epzs_subpel_search(epzs_state, &p, &r, orig_pic, pic_pix_x, pic_pix_y, blocktype, pred_mv, mv, search_pos2, search_pos4, min_mcost, lambda);
+  }
+}
+
+int EPZSBiPredBlockMotionSearch(imgpel *cur_pic, short ref, int list, int list_offset, char ***refPic, short ****tmp_mv, int pic_pix_x, int pic_pix_y,
+                                int blocktype, short *pred_mv1, short *pred_mv2, short mv[2], short s_mv[2], int search_range, int min_mcost, int lambda_factor)
+{
+  static int (*orig)(imgpel *, short, int, int, char ***, short ****, int, int, int, short *, short *, short[2], short[2], int, int, int);
+  n_calls[C_EPZS_BI]++;
+  if (!epzs_swapped() || !bipred_swappable() || img->MbaffFrameFlag || img->structure != FRAME || list_offset) {
+    if (!orig) orig = next_sym("EPZSBiPredBlockMotionSearch");
+    return orig(cur_pic, ref, list, list_offset, refPic, tmp_mv, pic_pix_x, pic_pix_y, blocktype, pred_mv1, pred_mv2, mv, s_mv, search_range, min_mcost, lambda_factor);
+  }
+  {
+    jmo_bipred b; jmo_ref r1, r2; jmo_epzs_nbr nb;
+    fill_bipred(&b, &r1, &r2, ref, list, blocktype);
+    /* EPZS reads wp_offset[..][0][0] for list 1 (:2013, :2017) where the full search reads [0][ref] (me_fullsearch.c:190-191) */
+    if (b.apply_weights) {
+      short o1 = list == 0 ? wp_offset[list_offset][ref][0] : wp_offset[list_offset + LIST_1][0][0];
+      short o2 = list == 0 ? wp_offset[list_offset + LIST_1][ref][0] : wp_offset[list_offset][0][0];
+      b.offset_bi = (o1 + o2 + 1) >> 1;
+    }
+    epzs_neighbours(&nb, pic_pix_x - img->opix_x, pic_pix_y - img->opix_y, input->blc_size[blocktype][0], refPic[list], tmp_mv[list]);
+    if (getenv("JMO_SWAP_VERIFY")) {
+      short jm[2] = {mv[0], mv[1]}, om[2] = {mv[0], mv[1]};
+      int c1, c2;
+      if (!orig) orig = next_sym("EPZSBiPredBlockMotionSearch");
+      c1 = orig(cur_pic, ref, list, list_offset, refPic, tmp_mv, pic_pix_x, pic_pix_y, blocktype, pred_mv1, pred_mv2, jm, s_mv, search_range, min_mcost, lambda_factor);
+      c2 = jmo_epzs_bipred_search(epzs_state, &b, cur_pic, ref, list, &nb, img->opix_x, img->opix_y, pic_pix_x, pic_pix_y, blocktype, pred_mv1, pred_mv2, om, s_mv, search_range, min_mcost, lambda_factor);
+      if (c1 != c2 || jm[0] != om[0] || jm[1] != om[1])
+        fprintf(stderr, "EPZS BIPRED MISMATCH mb=%d list=%d pix=(%d,%d) in=(%d,%d) s=(%d,%d) R=%d: jm=(%d,%d,%d) or=(%d,%d,%d)\n", img->current_mb_nr, list, pic_pix_x, pic_pix_y,
+                mv[0], mv[1], s_mv[0], s_mv[1], search_range, jm[0], jm[1], c1, om[0], om[1], c2);
+      mv[0] = jm[0]; mv[1] = jm[1];
+      return c1;
+    }
+    return jmo_epzs_bipred_search(epzs_state, &b, cur_pic, ref, list, &nb, img->opix_x, img->opix_y, pic_pix_x, pic_pix_y, blocktype, pred_mv1, pred_mv2,
+                                  mv, s_mv, search_range, min_mcost, lambda_factor);
+  }
+}
+
+int EPZSSubPelBlockSearchBiPred(imgpel *orig_pic, short ref, int list, int pic_pix_x, int pic_pix_y, int blocktype, short *pred_mv1, short *pred_mv2,
+                                short mv[2], short s_mv[2], int search_pos2, int search_pos4, int min_mcost, int *lambda)
+{
+  static int (*orig)(imgpel *, short, int, int, int, int, short *, short *, short[2], short[2], int, int, int, int *);
+  const int list_offset = img->mb_data[img->current_mb_nr].list_offset;
+  n_calls[C_EPZS_BISUB]++;
+  if (!epzs_swapped() || !bipred_swappable() || img->MbaffFrameFlag || img->structure != FRAME || list_offset) {
+    if (!orig) orig = next_sym("EPZSSubPelBlockSearchBiPred");
+    return orig(orig_pic, ref, list, pic_pix_x, pic_pix_y, blocktype, pred_mv1, pred_mv2, mv, s_mv, search_pos2, search_pos4, min_mcost, lambda);
+  }
+  {
+    jmo_bipred b; jmo_ref r1, r2;
+    fill_bipred(&b, &r1, &r2, ref, list, blocktype);
+    if (b.apply_weights) {                                  /* :2747-2748 */
+      short o1 = list == 0 ? wp_offset[list_offset][ref][0] : wp_offset[list_offset + 1][0][0];
+      short o2 = list == 0 ? wp_offset[list_offset + 1][ref][0] : wp_offset[list_offset][0][0];
+      b.offset_bi = (o1 + o2 + 1) >> 1;
+    }
+    if (getenv("JMO_SWAP_VERIFY")) {
+      short jm[2] = {mv[0], mv[1]}, om[2] = {mv[0], mv[1]};
+      int c1, c2;
+      if (!orig) orig = next_sym("EPZSSubPelBlockSearchBiPred");
+      c1 = orig(orig_pic, ref, list, pic_pix_x, pic_pix_y, blocktype, pred_mv1, pred_mv2, jm, s_mv, search_pos2, search_pos4, min_mcost, lambda);
+      c2 = jmo_epzs_subpel_bipred(&b, orig_pic, pic_pix_x, pic_pix_y, blocktype, pred_mv1, pred_mv2, om, s_mv, search_pos2, search_pos4, min_mcost, lambda);
+      if (c1 != c2 || jm[0] != om[0] || jm[1] != om[1])
+        fprintf(stderr, "EPZS BIPRED SUBPEL MISMATCH mb=%d list=%d pix=(%d,%d) in=(%d,%d) s=(%d,%d): jm=(%d,%d,%d) or=(%d,%d,%d)\n", img->current_mb_nr, list, pic_pix_x, pic_pix_y,
+                mv[0], mv[1], s_mv[0], s_mv[1], jm[0], jm[1], c1, om[0], om[1], c2);
+      mv[0] = jm[0]; mv[1] = jm[1];
+      return c1;
+    }
+    return jmo_epzs_subpel_bipred(&b, orig_pic, pic_pix_x, pic_pix_y, blocktype, pred_mv1, pred_mv2, mv, s_mv, search_pos2, search_pos4, min_mcost, lambda);
   }
 }
 
