@@ -249,6 +249,35 @@ int jmo_epzs_subpel_bipred(jmo_bipred *b, const jmo_pel *orig_pic, int pic_pix_x
                            const short pred_mv1[2], const short pred_mv2[2], short mv[2], const short s_mv[2],
                            int search_pos2, int search_pos4, int min_mcost, const int *lambda);
 
+/* ------------------------------------------------------------------ UMHexagonS (jmo_umhex.c; me_umhex.c of the reference) */
+
+typedef struct jmo_umhex jmo_umhex;               /* the global state of me_umhex.h */
+typedef struct {
+  int search_range, bipred_search_range;   /* input->search_range, input->BiPredMESearchRange */
+  int dsr, scale, qp_n;                    /* input->UMHexDSR, input->UMHexScale, input->qpN */
+  int bipred_me, full_search;              /* input->BiPredMotionEstimation, input->full_search (RestrictSearchRange) */
+  int successive_bframe;                   /* input->successive_Bframe */
+  int width, height, max_refs;
+} jmo_umhex_config;
+jmo_umhex *jmo_umhex_create(const jmo_umhex_config *cfg);          /* UMHEX_get_mem :154 + UMHEX_DefineThreshold :78 */
+void jmo_umhex_destroy(jmo_umhex *u);
+void jmo_umhex_thresholds(const jmo_umhex *u, int *median, int *bighex, int *multiref, int *dsr, float *bsize, float *alpha1, float *alpha2); /* [8] each */
+void jmo_umhex_decide_intrabk_sad(jmo_umhex *u, int is_i_slice, int pix_x, int pix_y);                              /* :745 */
+void jmo_umhex_skip_intrabk_sad(jmo_umhex *u, int best_mode, int ref_max, int img_number, int is_i_slice, int pix_x); /* :769 */
+typedef struct { int available[4]; int ref[4]; short mv[4][2]; int pos_x[4], pos_y[4]; } jmo_umhex_nbr;   /* A, B, C, D; positions in 4x4 units */
+void jmo_umhex_set_mv_predictor(jmo_umhex *u, short pmv[2], const jmo_umhex_nbr *nb, int ref_frame, int list, int block_x, int block_y,
+                                int blockshape_x, int blockshape_y, int umhex_blocktype, int bipred_flag, const int (*blocktype_lut)[4],
+                                int *search_range);                                                               /* :1298 */
+/* allmv = img->all_mv[block_y][block_x] as [list][ref][blocktype 0..8][2]; frame_ctr_b = frame_ctr[B_SLICE] */
+int jmo_umhex_pel_search(jmo_umhex *u, const jmo_me_params *p, const jmo_ref *ref_pic, const jmo_pel *orig_pic, int ref, int list,
+                         const short (*allmv)[JMO_MAX_REFS][9][2], int frame_ctr_b, int opix_x, int opix_y, int pic_pix_x, int pic_pix_y,
+                         int blocktype, int pred_mv_x, int pred_mv_y, short *mv_x, short *mv_y, int search_range, int min_mcost, int lambda_factor); /* :229 */
+int jmo_umhex_bipred_search(jmo_umhex *u, jmo_bipred *b, const jmo_pel *cur_pic, int list, const short bipred_mv_l1[2], int frame_ctr_b,
+                            int opix_x, int opix_y, int pic_pix_x, int pic_pix_y, int blocktype, int pred_mv_x1, int pred_mv_y1, int pred_mv_x2, int pred_mv_y2,
+                            short *mv_x, short *mv_y, const short *s_mv_x, const short *s_mv_y, int search_range, int min_mcost, int lambda_factor); /* :916 */
+int jmo_umhex_subpel_search(jmo_umhex *u, const jmo_me_params *p, const jmo_ref *ref_pic, const jmo_pel *orig_pic, int pic_pix_x, int pic_pix_y,
+                            int blocktype, int pred_mv_x, int pred_mv_y, short *mv_x, short *mv_y, int min_mcost, int lambda_factor);               /* :562 */
+
 /* ------------------------------------------------------------------ transform / quant */
 
 void jmo_forward4x4 (int (*block)[16], int (*tblock)[16], int pos_y, int pos_x);   /* transform.c:31  */

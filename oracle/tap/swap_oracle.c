@@ -15,6 +15,7 @@
  *   0x100 bi-predictive full-pel + sub-pel search (FullPelBlockMotionBiPred, SubPelBlockSearchBiPred)
  *   0x200 low-complexity mode-decision costs (TransformDecision, GetSkipCostMB)
  *   0x400 in-loop deblocking filter (DeblockFrame)
+ *   0x1000 UMHexagonS (predictor + dynamic search range, integer / bi-predictive / sub-pel walks, intra-block SAD flags; frame pictures)
  *   0x800 EPZS walkers (EPZSInit/SliceInit state, EPZSPel/BiPred/SubPel/SubPelBiPred searches; frame pictures, EPZSSubPelGrid 0)
  * JMO_SWAP_STATS=1 prints per-symbol call counts at exit.
  */
@@ -34,6 +35,7 @@
 #include "q_offsets.h"
 #include "mb_access.h"
 #include "me_epzs.h"
+#include "me_umhex.h"
 
 #include "jmo.h"
 
@@ -43,13 +45,14 @@ extern void SetMotionVectorPredictor(short pmv[2], char **refPic, short ***tmp_m
                                      int block_x, int block_y, int blockshape_x, int blockshape_y);
 extern const int LEVELMVLIMIT[17][6];
 
-static unsigned swap_mask = 0xfff;
-static long n_calls[21];
-enum { C_LUMA, C_CHROMA, C_SAD, C_SATD, C_FULL, C_SUB, C_FAST, C_D4, C_D8, C_D16, C_DCR, C_PRIM, C_BIFULL, C_BISUB, C_TDEC, C_SKIPC, C_DEBLOCK, C_EPZS_PEL, C_EPZS_SUB, C_EPZS_BI, C_EPZS_BISUB };
+static unsigned swap_mask = 0x1fff;
+static long n_calls[25], n_served[25];       /* calls seen / calls answered by the oracle (walker groups) */
+enum { C_LUMA, C_CHROMA, C_SAD, C_SATD, C_FULL, C_SUB, C_FAST, C_D4, C_D8, C_D16, C_DCR, C_PRIM, C_BIFULL, C_BISUB, C_TDEC, C_SKIPC, C_DEBLOCK, C_EPZS_PEL, C_EPZS_SUB, C_EPZS_BI, C_EPZS_BISUB, C_UM_PRED, C_UM_PEL, C_UM_SUB, C_UM_BI };
 static const char *c_names[] = { "getSubImagesLuma", "getSubImagesChroma", "computeSAD*", "computeSATD*",
   "FullPelBlockMotionSearch", "SubPelBlockMotionSearch", "FastFullPelBlockMotionSearch", "dct_4x4",
   "dct_8x8", "dct_16x16", "dct_chroma", "transform primitives", "FullPelBlockMotionBiPred", "SubPelBlockSearchBiPred", "TransformDecision", "GetSkipCostMB", "DeblockFrame",
-  "EPZSPelBlockMotionSearch", "EPZSSubPelBlockMotionSearch", "EPZSBiPredBlockMotionSearch", "EPZSSubPelBlockSearchBiPred" };
+  "EPZSPelBlockMotionSearch", "EPZSSubPelBlockMotionSearch", "EPZSBiPredBlockMotionSearch", "EPZSSubPelBlockSearchBiPred",
+  "UMHEXSetMotionVectorPredictor", "UMHEXIntegerPelBlockMotionSearch", "UMHEXSubPelBlockMotionSearch", "UMHEXBipredIntegerPelBlockMotionSearch" };
 
 static void *next_sym(const char *name)
 {
@@ -63,7 +66,7 @@ static void print_stats(void)
   int i;
   if (!getenv("JMO_SWAP_STATS")) return;
   fprintf(stderr, "swap_oracle: mask=0x%x\n", swap_mask);
-  for (i = 0; i <= C_EPZS_BISUB; i++) fprintf(stderr, "  %-30s %ld\n", c_names[i], n_calls[i]);
+  for (i = 0; i <= C_UM_BI; i++) fprintf(stderr, "  %-30s %ld served %ld\n", c_names[i], n_calls[i], n_served[i]);
 }
 
 int main(int argc, char **argv)
@@ -480,6 +483,7 @@ int EPZSPelBlockMotionSearch(imgpel *cur_pic, short ref, int list, int list_offs
     if (!orig) orig = next_sym("EPZSPelBlockMotionSearch");
     return orig(cur_pic, ref, list, list_offset, refPic, tmp_mv, pic_pix_x, pic_pix_y, blocktype, pred_mv, mv, search_range, min_mcost, lambda_factor);
   }
+  n_served[C_EPZS_PEL]++;
   {
     jmo_me_params p; jmo_ref r; jmo_epzs_nbr nb;
     short allmv[JMO_MAX_REFS][8][2];
@@ -533,6 +537,7 @@ int EPZSSubPelBlockMotionSearch(imgpel *orig_pic, short ref, int list, int pic_p
     if (!orig) orig = next_sym("EPZSSubPelBlockMotionSearch");
     return orig(orig_pic, ref, list, pic_pix_x, pic_pix_y, blocktype, pred_mv, mv, search_pos2, search_pos4, min_mcost, lambda);
   }
+  n_served[C_EPZS_SUB]++;
   {
     jmo_me_params p; jmo_ref r;
     fill_me_params(&p, list, ref, list_offset);
@@ -563,6 +568,7 @@ int EPZSBiPredBlockMotionSearch(imgpel *cur_pic, short ref, int list, int list_o
     if (!orig) orig = next_sym("EPZSBiPredBlockMotionSearch");
     return orig(cur_pic, ref, list, list_offset, refPic, tmp_mv, pic_pix_x, pic_pix_y, blocktype, pred_mv1, pred_mv2, mv, s_mv, search_range, min_mcost, lambda_factor);
   }
+  n_served[C_EPZS_BI]++;
   {
     jmo_bipred b; jmo_ref r1, r2; jmo_epzs_nbr nb;
     fill_bipred(&b, &r1, &r2, ref, list, blocktype);
@@ -600,6 +606,7 @@ int EPZSSubPelBlockSearchBiPred(imgpel *orig_pic, short ref, int list, int pic_p
     if (!orig) orig = next_sym("EPZSSubPelBlockSearchBiPred");
     return orig(orig_pic, ref, list, pic_pix_x, pic_pix_y, blocktype, pred_mv1, pred_mv2, mv, s_mv, search_pos2, search_pos4, min_mcost, lambda);
   }
+  n_served[C_EPZS_BISUB]++;
   {
     jmo_bipred b; jmo_ref r1, r2;
     fill_bipred(&b, &r1, &r2, ref, list, blocktype);
@@ -621,6 +628,153 @@ int EPZSSubPelBlockSearchBiPred(imgpel *orig_pic, short ref, int list, int pic_p
       return c1;
     }
     return jmo_epzs_subpel_bipred(&b, orig_pic, pic_pix_x, pic_pix_y, blocktype, pred_mv1, pred_mv2, mv, s_mv, search_pos2, search_pos4, min_mcost, lambda);
+  }
+}
+
+
+/* ------------------------------------------------------------------ 0x1000 UMHexagonS */
+
+static jmo_umhex *umhex_state;
+static int umhex_decided, umhex_on;
+
+/* decided once: the state is either all the oracle's or all JM's */
+static int umhex_swapped(void)
+{
+  if (!umhex_decided) {
+    umhex_decided = 1;
+    umhex_on = (swap_mask & 0x1000) && !input->PicInterlace && !input->MbInterlace &&
+               !(input->BiPredMotionEstimation && (input->ChromaMEEnable || !bipred_swappable()));
+    if (umhex_on) {
+      jmo_umhex_config c;
+      memset(&c, 0, sizeof(c));
+      c.search_range = input->search_range; c.bipred_search_range = input->BiPredMotionEstimation ? input->BiPredMESearchRange : 0;
+      c.dsr = input->UMHexDSR; c.scale = input->UMHexScale; c.qp_n = input->qpN;
+      c.bipred_me = input->BiPredMotionEstimation; c.full_search = input->full_search; c.successive_bframe = input->successive_Bframe;
+      c.width = img->width; c.height = img->height; c.max_refs = img->max_num_references;
+      umhex_state = jmo_umhex_create(&c);
+    }
+  }
+  return umhex_on;
+}
+
+void UMHEX_decide_intrabk_SAD(void)
+{
+  static void (*orig)(void);
+  if (!umhex_swapped()) { if (!orig) orig = next_sym("UMHEX_decide_intrabk_SAD"); orig(); return; }
+  jmo_umhex_decide_intrabk_sad(umhex_state, img->type == I_SLICE, img->pix_x, img->pix_y);
+}
+
+void UMHEX_skip_intrabk_SAD(int best_mode, int ref_max)
+{
+  static void (*orig)(int, int);
+  if (!umhex_swapped()) { if (!orig) orig = next_sym("UMHEX_skip_intrabk_SAD"); orig(best_mode, ref_max); return; }
+  jmo_umhex_skip_intrabk_sad(umhex_state, best_mode, ref_max, img->number, img->type == I_SLICE, img->pix_x);
+}
+
+void UMHEXSetMotionVectorPredictor(short pmv[2], char **refPic, short ***tmp_mv, short ref_frame, int list, int block_x, int block_y,
+                                   int blockshape_x, int blockshape_y, int *search_range)
+{
+  static void (*orig)(short[2], char **, short ***, short, int, int, int, int, int, int *);
+  n_calls[C_UM_PRED]++;
+  if (!umhex_swapped()) {
+    if (!orig) orig = next_sym("UMHEXSetMotionVectorPredictor");
+    orig(pmv, refPic, tmp_mv, ref_frame, list, block_x, block_y, blockshape_x, blockshape_y, search_range);
+    return;
+  }
+  n_served[C_UM_PRED]++;
+  {
+    PixelPos blk[4];
+    jmo_umhex_nbr nb;
+    const int mb_x = 4 * block_x, mb_y = 4 * block_y;
+    int k;
+    getLuma4x4Neighbour(img->current_mb_nr, mb_x - 1, mb_y, &blk[0]);
+    getLuma4x4Neighbour(img->current_mb_nr, mb_x, mb_y - 1, &blk[1]);
+    getLuma4x4Neighbour(img->current_mb_nr, mb_x + blockshape_x, mb_y - 1, &blk[2]);
+    getLuma4x4Neighbour(img->current_mb_nr, mb_x - 1, mb_y - 1, &blk[3]);
+    memset(&nb, 0, sizeof(nb));
+    for (k = 0; k < 4; k++) {
+      nb.available[k] = blk[k].available;
+      if (blk[k].available) {
+        nb.ref[k] = refPic[blk[k].pos_y][blk[k].pos_x];
+        nb.mv[k][0] = tmp_mv[blk[k].pos_y][blk[k].pos_x][0]; nb.mv[k][1] = tmp_mv[blk[k].pos_y][blk[k].pos_x][1];
+        nb.pos_x[k] = blk[k].pos_x; nb.pos_y[k] = blk[k].pos_y;
+      }
+    }
+    jmo_umhex_set_mv_predictor(umhex_state, pmv, &nb, ref_frame, list, block_x, block_y, blockshape_x, blockshape_y, UMHEX_blocktype, bipred_flag,
+                               (const int (*)[4])input->blocktype_lut, search_range);
+  }
+}
+
+static void umhex_allmv(short (*allmv)[JMO_MAX_REFS][9][2], int block_y, int block_x)
+{
+  int l, r, bt;
+  memset(allmv, 0, sizeof(short) * 2 * JMO_MAX_REFS * 9 * 2);
+  for (l = 0; l < 2; l++) for (r = 0; r < img->max_num_references && r < JMO_MAX_REFS; r++) for (bt = 0; bt < 9; bt++) {
+    allmv[l][r][bt][0] = img->all_mv[block_y][block_x][l][r][bt][0]; allmv[l][r][bt][1] = img->all_mv[block_y][block_x][l][r][bt][1];
+  }
+}
+
+int UMHEXIntegerPelBlockMotionSearch(imgpel *orig_pic, short ref, int list, int pic_pix_x, int pic_pix_y, int blocktype, short pred_mv_x, short pred_mv_y,
+                                     short *mv_x, short *mv_y, int search_range, int min_mcost, int lambda_factor)
+{
+  static int (*orig)(imgpel *, short, int, int, int, int, short, short, short *, short *, int, int, int);
+  n_calls[C_UM_PEL]++;
+  if (!umhex_swapped()) {
+    if (!orig) orig = next_sym("UMHEXIntegerPelBlockMotionSearch");
+    return orig(orig_pic, ref, list, pic_pix_x, pic_pix_y, blocktype, pred_mv_x, pred_mv_y, mv_x, mv_y, search_range, min_mcost, lambda_factor);
+  }
+  n_served[C_UM_PEL]++;
+  {
+    jmo_me_params p; jmo_ref r;
+    short allmv[2][JMO_MAX_REFS][9][2];
+    fill_me_params(&p, list, ref, 0);
+    fill_ref(&r, listX[list][ref]);
+    jm_side_effects(listX[list][ref]);
+    umhex_allmv(allmv, (pic_pix_y - img->opix_y) >> 2, (pic_pix_x - img->opix_x) >> 2);
+    img_width = r.W; img_height = r.H;
+    return jmo_umhex_pel_search(umhex_state, &p, &r, orig_pic, ref, list, (const short (*)[JMO_MAX_REFS][9][2])allmv, frame_ctr[B_SLICE], img->opix_x, img->opix_y,
+                                pic_pix_x, pic_pix_y, blocktype, pred_mv_x, pred_mv_y, mv_x, mv_y, search_range, min_mcost, lambda_factor);
+  }
+}
+
+int UMHEXSubPelBlockMotionSearch(imgpel *orig_pic, short ref, int list, int pic_pix_x, int pic_pix_y, int blocktype, short pred_mv_x, short pred_mv_y,
+                                 short *mv_x, short *mv_y, int search_pos2, int search_pos4, int min_mcost, int lambda_factor)
+{
+  static int (*orig)(imgpel *, short, int, int, int, int, short, short, short *, short *, int, int, int, int);
+  n_calls[C_UM_SUB]++;
+  if (!umhex_swapped()) {
+    if (!orig) orig = next_sym("UMHEXSubPelBlockMotionSearch");
+    return orig(orig_pic, ref, list, pic_pix_x, pic_pix_y, blocktype, pred_mv_x, pred_mv_y, mv_x, mv_y, search_pos2, search_pos4, min_mcost, lambda_factor);
+  }
+  n_served[C_UM_SUB]++;
+  {
+    jmo_me_params p; jmo_ref r;
+    fill_me_params(&p, list, ref, 0);
+    fill_ref(&r, listX[list][ref]);
+    jm_side_effects(listX[list][ref]);
+    return jmo_umhex_subpel_search(umhex_state, &p, &r, orig_pic, pic_pix_x, pic_pix_y, blocktype, pred_mv_x, pred_mv_y, mv_x, mv_y, min_mcost, lambda_factor);
+  }
+}
+
+int UMHEXBipredIntegerPelBlockMotionSearch(imgpel *cur_pic, short ref, int list, int pic_pix_x, int pic_pix_y, int blocktype, short pred_mv_x1, short pred_mv_y1,
+                                           short pred_mv_x2, short pred_mv_y2, short *mv_x, short *mv_y, short *s_mv_x, short *s_mv_y, int search_range,
+                                           int min_mcost, int lambda_factor)
+{
+  static int (*orig)(imgpel *, short, int, int, int, int, short, short, short, short, short *, short *, short *, short *, int, int, int);
+  n_calls[C_UM_BI]++;
+  if (!umhex_swapped()) {
+    if (!orig) orig = next_sym("UMHEXBipredIntegerPelBlockMotionSearch");
+    return orig(cur_pic, ref, list, pic_pix_x, pic_pix_y, blocktype, pred_mv_x1, pred_mv_y1, pred_mv_x2, pred_mv_y2, mv_x, mv_y, s_mv_x, s_mv_y, search_range, min_mcost, lambda_factor);
+  }
+  n_served[C_UM_BI]++;
+  {
+    jmo_bipred b; jmo_ref r1, r2;
+    const int block_y = (pic_pix_y - img->opix_y) >> 2, block_x = (pic_pix_x - img->opix_x) >> 2;
+    short ******bmv = list ? img->bipred_mv1 : img->bipred_mv2;
+    short l1[2] = { bmv[block_y][block_x][1][0][blocktype][0], bmv[block_y][block_x][1][0][blocktype][1] };
+    fill_bipred(&b, &r1, &r2, ref, list, blocktype);           /* offsets as :963-964 == me_fullsearch.c:190-191 */
+    return jmo_umhex_bipred_search(umhex_state, &b, cur_pic, list, l1, frame_ctr[B_SLICE], img->opix_x, img->opix_y, pic_pix_x, pic_pix_y, blocktype,
+                                   pred_mv_x1, pred_mv_y1, pred_mv_x2, pred_mv_y2, mv_x, mv_y, s_mv_x, s_mv_y, search_range, min_mcost, lambda_factor);
   }
 }
 

@@ -93,6 +93,22 @@ VARIANTS = {
     "baseline slices deblock across": "-d encoder_baseline.cfg -p SearchMode=0 -p SliceMode=1 -p SliceArgument=40 -p LoopFilterParametersFlag=1 -p LoopFilterAlphaC0Offset=-3 -p LoopFilterBetaOffset=4",
     "high 8x8 deblock qp40": "-d encoder.cfg -p SearchMode=0 -p Transform8x8Mode=1 -p QPISlice=40 -p QPPSlice=40 -p QPBSlice=41",
     "422 deblock qp38 8x8": "-d encoder_yuv422.cfg -p SearchMode=0 -p Transform8x8Mode=1 -p QPISlice=38 -p QPPSlice=38 -p QPBSlice=39",
+    # EPZS (oracle/jmo_epzs.c) and UMHexagonS (oracle/jmo_umhex.c) walkers swapped in: more than the cfg x SearchMode rows above
+    "epzs 422": "-d encoder_yuv422.cfg -p SearchMode=3 -p WeightedPrediction=1 -p UseWeightedReferenceME=1",
+    "epzs SATD-fpel 8x8 (config 3)": "-d encoder.cfg -p SearchMode=3 -p MEDistortionFPel=2 -p Transform8x8Mode=1",
+    "epzs rdopt0": "-d encoder_main.cfg -p SearchMode=3 -p RDOptimization=0",
+    "epzs patterns sb/pmvfast fixed1": "-d encoder_main.cfg -p SearchMode=3 -p EPZSPattern=4 -p EPZSDualRefinement=6 -p EPZSFixedPredictors=1",
+    "epzs no temporal no spatial-mem square": "-d encoder_main.cfg -p SearchMode=3 -p EPZSTemporal=0 -p EPZSSpatialMem=0 -p EPZSPattern=1 -p EPZSDualRefinement=0",
+    "epzs ChromaME1": "-d encoder_main.cfg -p SearchMode=3 -p ChromaMEEnable=1",
+    "epzs WBP implicit": "-d encoder_main.cfg -p SearchMode=3 -p WeightedBiprediction=2",
+    "epzs R32 3 refs": "-d encoder_baseline.cfg -p SearchMode=3 -p SearchRange=32 -p NumberReferenceFrames=3",
+    "umhex 422 WP (config 5)": "-d encoder_yuv422.cfg -p SearchMode=1 -p WeightedPrediction=1 -p UseWeightedReferenceME=1",
+    "umhex rdopt0": "-d encoder_main.cfg -p SearchMode=1 -p RDOptimization=0",
+    "umhex no DSR R32": "-d encoder_main.cfg -p SearchMode=1 -p UMHexDSR=0 -p SearchRange=32",
+    "umhex 3 refs restricted range": "-d encoder_baseline.cfg -p SearchMode=1 -p NumberReferenceFrames=3 -p RestrictSearchRange=0",
+    "umhex SATD-fpel 8x8": "-d encoder.cfg -p SearchMode=1 -p MEDistortionFPel=2 -p Transform8x8Mode=1",
+    "umhex WBP implicit qp40": "-d encoder_main.cfg -p SearchMode=1 -p WeightedBiprediction=2 -p QPPSlice=40 -p QPISlice=40",
+    "umhex scale0 qp20": "-d encoder_main.cfg -p SearchMode=1 -p UMHexScale=0 -p QPPSlice=20 -p QPISlice=20 -p QPBSlice=22",
     "444": "-d encoder_yuv422.cfg -p YUVFormat=3 -p ProfileIDC=244 -p InputFile=foreman_part_qcif_444.yuv",
 }
 
@@ -103,3 +119,19 @@ def test_bitstream_identical_with_oracle_swapped_in(rundir, name, args):
     plain = _run("jm_plain", rundir, args)
     swapped = _run("jm_swap", rundir, args)
     assert plain == swapped, name
+
+
+@pytest.mark.parametrize("args,names", [
+    ("-d encoder_main.cfg -p SearchMode=3", ["EPZSPelBlockMotionSearch", "EPZSSubPelBlockMotionSearch", "EPZSBiPredBlockMotionSearch", "EPZSSubPelBlockSearchBiPred"]),
+    ("-d encoder_main.cfg -p SearchMode=1", ["UMHEXSetMotionVectorPredictor", "UMHEXIntegerPelBlockMotionSearch", "UMHEXSubPelBlockMotionSearch",
+                                             "UMHEXBipredIntegerPelBlockMotionSearch"]),
+])
+def test_walkers_are_answered_by_the_oracle(rundir, args, names):
+    """The byte-identical rows above would also pass if the harness silently forwarded to JM: every walker call must be SERVED."""
+    import re
+    e = dict(os.environ, JMO_SWAP_STATS="1")
+    r = subprocess.run([os.path.join(RDIR, "jm_swap")] + args.split(), cwd=rundir, env=e, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=600)
+    err = r.stderr.decode()
+    for n in names:
+        m = re.search(r"%s\s+(\d+) served (\d+)" % n, err)
+        assert m and int(m.group(1)) > 0 and m.group(1) == m.group(2), (n, m and m.groups())
