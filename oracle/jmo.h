@@ -278,6 +278,43 @@ int jmo_umhex_bipred_search(jmo_umhex *u, jmo_bipred *b, const jmo_pel *cur_pic,
 int jmo_umhex_subpel_search(jmo_umhex *u, const jmo_me_params *p, const jmo_ref *ref_pic, const jmo_pel *orig_pic, int pic_pix_x, int pic_pix_y,
                             int blocktype, int pred_mv_x, int pred_mv_y, short *mv_x, short *mv_y, int min_mcost, int lambda_factor);               /* :562 */
 
+/* ------------------------------------------------------------------ low-complexity P-slice inter decision (jmo_lowcplx.c) */
+
+#define JMO_LC_REFS 4            /* references kept in the per-macroblock record (the driver itself takes up to JMO_MAX_REFS) */
+typedef struct {
+  int search_mode;               /* -1 FullSearch, 0 FastFullSearch, 1 UMHexagonS, 3 EPZS */
+  int search_range, num_refs, full_search;     /* input->search_range, listXsize[LIST_0], input->full_search (RestrictSearchRange) */
+  int valid[8];                  /* enc_mb.valid[1..7] = input->InterSearch[0][1..7] */
+  int lambda_mf[3];              /* enc_mb.lambda_mf[F/H/Q_PEL] */
+  int ref_cost1;                 /* (int)(2 * enc_mb.lambda_me[Q_PEL]): reference cost of ref > 0 when rdopt = 0 (mode_decision.c:276) */
+  int md_metric;                 /* input->ModeDecisionMetric (skip cost) */
+  int wp_pred;                   /* active_pps->weighted_pred_flag: LumaPrediction uses explicit weights */
+  int wp_weight[JMO_MAX_REFS], wp_offset[JMO_MAX_REFS];   /* wp_weight[0][ref][0], wp_offset[0][ref][0] */
+  jmo_me_params me;              /* rdopt 0; apply_weights = weighted reference ME */
+  int epzs_subpel_me;            /* input->EPZSSubPelME */
+  int W, H;
+  const int *slice_id;           /* per macroblock, NULL = one slice */
+  jmo_epzs *epzs; jmo_umhex *umhex;      /* state objects of the search mode in use (slice-initialised by the caller) */
+  int frame_ctr_b, img_number;   /* frame_ctr[B_SLICE], img->number (UMHEX) */
+  int blocktype_lut[4][4];       /* input->blocktype_lut */
+  short *all_mv_state;           /* img->all_mv[4][4][LIST_0][JMO_MAX_REFS][9][2] as the previous macroblock in coding order left it (in/out; JM
+                                    never resets it, and EPZS reads it: me_epzs.c:1433). NULL: zeros. */
+} jmo_lowcplx_params;
+
+/* what JM knows of one macroblock after encode_one_macroblock_low, plus every BlockMotionSearch call's outcome (41 partitions per reference) */
+typedef struct {
+  int best_mode;                 /* 1, 2, 3 or 8 (P8x8) */
+  int min_cost;
+  int b8mode[4], b8ref[4];
+  short final_mv[16][2];         /* enc_picture->mv[LIST_0] of the macroblock, raster 4x4 */
+  short skip_mv[2];              /* all_mv[..][0][0][0] */
+  short pred[JMO_LC_REFS][41][2], mv_int[JMO_LC_REFS][41][2], mv[JMO_LC_REFS][41][2];
+  int cost_int[JMO_LC_REFS][41], cost[JMO_LC_REFS][41];
+} jmo_mb_inter;
+
+void jmo_lowcplx_p_slice(const jmo_lowcplx_params *q, const jmo_ref *refs, const jmo_pel *cur, int cur_stride,
+                         signed char *ref_idx, short *mv, int mb_first, int mb_count, jmo_mb_inter *out);
+
 /* ------------------------------------------------------------------ transform / quant */
 
 void jmo_forward4x4 (int (*block)[16], int (*tblock)[16], int pos_y, int pos_x);   /* transform.c:31  */

@@ -467,3 +467,147 @@ def deblock_frame(Y, U, V, yuv_format, mbs, blks, mvlimit=4):
     ptr = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
     L.jmo_deblock_frame(ptr(planes[0]), ptr(planes[1]), ptr(planes[2]), W, H, yuv_format, 8, ptr(mbs), ptr(blks), mvlimit)
     return [p.astype(np.uint8) if p is not None else None for p in planes]
+
+
+# ------------------------------------------------------------------ EPZS / UMHexagonS state + the low-complexity P-slice driver
+
+MAX_LIST, MAX_REFS, LC_REFS = 33, 32, 4
+
+
+class EpzsConfig(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("search_range", "bipred_me", "bipred_search_range", "pattern", "dual", "fixed", "temporal", "spatial_mem",
+                                       "min_scale", "med_scale", "max_scale", "subpel_scale", "width", "height", "width_cr", "height_cr",
+                                       "bitdepth_luma", "bitdepth_chroma", "chroma_me", "chroma_me_weight", "max_refs")]
+
+
+class EpzsSlice(C.Structure):
+    _fields_ = [("is_b_slice", C.c_int), ("poc", C.c_int), ("list_size", C.c_int * 2), ("list_poc", (C.c_int * MAX_LIST) * 2),
+                ("num_ref_idx_l0_active", C.c_int), ("ref_pic_num_l0", C.c_longlong * MAX_LIST), ("col_mv", C.c_void_p * 2), ("col_ref_id", C.c_void_p * 2)]
+
+
+class UmhexConfig(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("search_range", "bipred_search_range", "dsr", "scale", "qp_n", "bipred_me", "full_search", "successive_bframe",
+                                       "width", "height", "max_refs")]
+
+
+class LowcplxParams(C.Structure):
+    _fields_ = [("search_mode", C.c_int), ("search_range", C.c_int), ("num_refs", C.c_int), ("full_search", C.c_int), ("valid", C.c_int * 8),
+                ("lambda_mf", C.c_int * 3), ("ref_cost1", C.c_int), ("md_metric", C.c_int), ("wp_pred", C.c_int),
+                ("wp_weight", C.c_int * MAX_REFS), ("wp_offset", C.c_int * MAX_REFS), ("me", MeParams), ("epzs_subpel_me", C.c_int),
+                ("W", C.c_int), ("H", C.c_int), ("slice_id", C.c_void_p), ("epzs", C.c_void_p), ("umhex", C.c_void_p),
+                ("frame_ctr_b", C.c_int), ("img_number", C.c_int), ("blocktype_lut", (C.c_int * 4) * 4), ("all_mv_state", C.c_void_p)]
+
+
+MB_INTER_DTYPE = np.dtype([("best_mode", "<i4"), ("min_cost", "<i4"), ("b8mode", "<i4", (4,)), ("b8ref", "<i4", (4,)),
+                           ("final_mv", "<i2", (16, 2)), ("skip_mv", "<i2", (2,)),
+                           ("pred", "<i2", (LC_REFS, 41, 2)), ("mv_int", "<i2", (LC_REFS, 41, 2)), ("mv", "<i2", (LC_REFS, 41, 2)),
+                           ("cost_int", "<i4", (LC_REFS, 41)), ("cost", "<i4", (LC_REFS, 41))], align=True)
+
+# JM's shipped defaults (bin/encoder_*.cfg: EPZSPattern 2, Dual 3, Fixed 2, Temporal 1, SpatialMem 1, thresholds 0/1/2, sub-pel 2; UMHexDSR 1, UMHexScale 3)
+EPZS_DEFAULTS = dict(pattern=2, dual=3, fixed=2, temporal=1, spatial_mem=1, min_scale=0, med_scale=1, max_scale=2, subpel_scale=2)
+
+
+def _walker_protos():
+    L = lib()
+    if getattr(L, "_walker_ready", False):
+        return L
+    vp, ip = C.c_void_p, C.c_int
+    L.jmo_epzs_create.restype = vp
+    L.jmo_epzs_create.argtypes = [C.POINTER(EpzsConfig)]
+    L.jmo_epzs_destroy.argtypes = [vp]
+    L.jmo_epzs_slice_init.argtypes = [vp, C.POINTER(EpzsSlice)]
+    L.jmo_umhex_create.restype = vp
+    L.jmo_umhex_create.argtypes = [C.POINTER(UmhexConfig)]
+    L.jmo_umhex_destroy.argtypes = [vp]
+    L.jmo_lowcplx_p_slice.argtypes = [C.POINTER(LowcplxParams), vp, vp, ip, vp, vp, ip, ip, vp]
+    L.jmo_lowcplx_p_slice.restype = None
+    L._walker_ready = True
+    return L
+
+
+class Epzs:
+    def __init__(self, W, H, search_range, max_refs, yuv_format=1, **kw):
+        c = EpzsConfig()
+        o = dict(EPZS_DEFAULTS)
+        o.update(kw)
+        for k, v in o.items():
+            setattr(c, k, v)
+        c.search_range, c.width, c.height, c.max_refs = search_range, W, H, max_refs
+        c.width_cr, c.height_cr = (W // 2, H // 2) if yuv_format == 1 else (W // 2, H) if yuv_format == 2 else (W, H)
+        c.bitdepth_luma = c.bitdepth_chroma = 8
+        self.cfg = c
+        self.h = _walker_protos().jmo_epzs_create(C.byref(c))
+
+    def slice_init(self, poc, list_pocs, ref_pic_nums, col_mv, col_ref_id, num_ref_idx_l0_active=None, is_b=False):
+        """col_mv: two (H/4, W/4, 2) int16 arrays, col_ref_id: two (H/4, W/4) int64 arrays (the co-located pictures listX[list][0], [1])."""
+        s = EpzsSlice()
+        s.is_b_slice, s.poc = int(is_b), poc
+        s.list_size[0] = len(list_pocs)
+        for i, p in enumerate(list_pocs):
+            s.list_poc[0][i] = p
+            s.ref_pic_num_l0[i] = int(ref_pic_nums[i])
+        s.num_ref_idx_l0_active = num_ref_idx_l0_active or len(list_pocs)
+        self._keep = [np.ascontiguousarray(a, dtype=np.int16) for a in col_mv] + [np.ascontiguousarray(a, dtype=np.int64) for a in col_ref_id]
+        s.col_mv[0], s.col_mv[1] = self._keep[0].ctypes.data, self._keep[1].ctypes.data
+        s.col_ref_id[0], s.col_ref_id[1] = self._keep[2].ctypes.data, self._keep[3].ctypes.data
+        lib().jmo_epzs_slice_init(self.h, C.byref(s))
+
+    def close(self):
+        if self.h:
+            lib().jmo_epzs_destroy(self.h)
+            self.h = None
+
+
+class Umhex:
+    def __init__(self, W, H, search_range, max_refs, qp_n, dsr=1, scale=3, full_search=2, successive_bframe=0):
+        c = UmhexConfig()
+        c.search_range, c.width, c.height, c.max_refs, c.qp_n = search_range, W, H, max_refs, qp_n
+        c.dsr, c.scale, c.full_search, c.successive_bframe = dsr, scale, full_search, successive_bframe
+        self.cfg = c
+        self.h = _walker_protos().jmo_umhex_create(C.byref(c))
+
+    def close(self):
+        if self.h:
+            lib().jmo_umhex_destroy(self.h)
+            self.h = None
+
+
+BLOCKTYPE_LUT = {(0, 0): 7, (0, 1): 6, (1, 0): 5, (1, 1): 4, (1, 3): 3, (3, 1): 2, (3, 3): 1}     # configfile.c:830-836
+
+
+def lowcplx_params(search_mode, search_range, num_refs, lambda_mf, ref_cost1, W, H, epzs=None, umhex=None, full_search=2, metric=(0, 2, 2),
+                   md_metric=2, valid=(1, 1, 1, 1, 1, 1, 1), frame_ctr_b=0, img_number=1, level_mv=(-511, 511), all_mv_state=None):
+    q = LowcplxParams()
+    q.search_mode, q.search_range, q.num_refs, q.full_search = search_mode, search_range, num_refs, full_search
+    for m in range(1, 8):
+        q.valid[m] = valid[m - 1]
+    q.lambda_mf[0], q.lambda_mf[1], q.lambda_mf[2] = lambda_mf
+    q.ref_cost1, q.md_metric = ref_cost1, md_metric
+    q.me = me_params(rdopt=0, metric=metric, level_mv=level_mv)
+    q.epzs_subpel_me = 1
+    q.W, q.H = W, H
+    q.epzs = epzs.h if epzs else None
+    q.umhex = umhex.h if umhex else None
+    q.frame_ctr_b, q.img_number = frame_ctr_b, img_number
+    for (a, b), v in BLOCKTYPE_LUT.items():
+        q.blocktype_lut[a][b] = v
+    if all_mv_state is not None:             # np.int16 (4, 4, MAX_REFS, 9, 2), carried from call to call by the caller
+        q._keep_all_mv = all_mv_state
+        q.all_mv_state = all_mv_state.ctypes.data
+    return q
+
+
+def lowcplx_p_slice(q, refpics, curY, ref_idx=None, mv=None, mb_first=0, mb_count=None):
+    """Runs macroblocks [mb_first, mb_first+mb_count) of a P picture. Returns (records, ref_idx, mv): per-macroblock MB_INTER_DTYPE records and the
+    picture-level LIST_0 arrays ((H/4, W/4) int8, (H/4, W/4, 2) int16), updated in place when passed in."""
+    L = _walker_protos()
+    W, H = q.W, q.H
+    if ref_idx is None:
+        ref_idx = np.full((H // 4, W // 4), -1, np.int8)
+        mv = np.zeros((H // 4, W // 4, 2), np.int16)
+    n = (W // 16) * (H // 16) if mb_count is None else mb_count
+    out = np.zeros(n, MB_INTER_DTYPE)
+    refs = (Ref * len(refpics))(*[r.ref for r in refpics])
+    cur = np.ascontiguousarray(curY, dtype=np.uint16)
+    L.jmo_lowcplx_p_slice(C.byref(q), refs, cur.ctypes.data, cur.shape[1], ref_idx.ctypes.data, mv.ctypes.data, mb_first, n, out.ctypes.data)
+    return out, ref_idx, mv

@@ -1,0 +1,79 @@
+"""Pins the oracle's low-complexity P-slice driver (oracle/jmo_lowcplx.c: predictor, block / partition motion search orchestration, the
+rdopt = 0 inter decision, and -- through it -- the EPZS / UMHexagonS walkers with their cross-macroblock state) on frame-level
+fixtures captured from the REAL JM (tests/golden/field_*.npz, generator tests/golden/make_golden_field.py + oracle/tap/tap_field.c):
+every BlockMotionSearch call of every P picture (predictor, vector, cost) and the final vector / reference / mode field."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import oracle
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = {"field_full_r16_1ref": -1, "field_fastfull_r16_2ref": 0, "field_epzs_r16_2ref": 3, "field_umhex_r16_2ref": 1}
+QP_N = 28          # QPPSlice of bin/encoder_baseline.cfg (UMHEX thresholds, me_umhex.c:110)
+
+
+def part_index(bt, bx, by):
+    b8 = (by >> 1) * 2 + (bx >> 1)
+    return {1: 0, 2: 1 + (by >> 1), 3: 3 + (bx >> 1), 4: 5 + b8, 5: 9 + b8 * 2 + (by & 1), 6: 17 + b8 * 2 + (bx & 1),
+            7: 25 + b8 * 4 + (by & 1) * 2 + (bx & 1)}[bt]
+
+
+def replay(name, mode, on_frame=None):
+    """Runs every P picture of a fixture through the oracle driver (state carried across pictures like JM's) and yields per picture
+    (fixture arrays, driver records, final ref_idx, final mv)."""
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    n = int(z["n_frames"])
+    head0 = z["f0_head"]
+    W, H = int(head0[0]), int(head0[1])
+    R, max_refs = 16, 2
+    epzs = oracle.Epzs(W, H, R, max_refs) if mode == 3 else None
+    umhex = oracle.Umhex(W, H, R, max_refs, QP_N) if mode == 1 else None
+    out = []
+    all_mv_state = np.zeros((4, 4, oracle.MAX_REFS, 9, 2), np.int16)
+    for k in range(n):
+        head = z["f%d_head" % k]
+        nref = int(head[3])
+        refinfo = z["f%d_refinfo" % k]
+        refs = [oracle.RefPic(z["f%d_refs" % k][r], yuv_format=0) for r in range(nref)]
+        if epzs:
+            ids = (refinfo[:, 1].astype(np.int64) & 0xffffffff) | (refinfo[:, 2].astype(np.int64) << 32)
+            epzs.slice_init(int(head[10]), [int(v) for v in refinfo[:, 0]], ids, z["f%d_col_mv" % k], z["f%d_col_ref_id" % k],
+                            num_ref_idx_l0_active=int(head[11]))
+        q = oracle.lowcplx_params(mode, R, nref, [int(v) for v in head[6:9]], int(head[9]), W, H, epzs=epzs, umhex=umhex,
+                                  frame_ctr_b=int(head[5]), img_number=int(head[4]), all_mv_state=all_mv_state)
+        rec, ref_idx, mv = oracle.lowcplx_p_slice(q, refs, z["f%d_cur" % k])
+        out.append((dict(calls=z["f%d_calls" % k], mb=z["f%d_mb" % k], field=z["f%d_field" % k], nref=nref), rec, ref_idx, mv))
+    if epzs:
+        epzs.close()
+    if umhex:
+        umhex.close()
+    return out
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_every_block_motion_search_call_and_the_final_field_match_jm(name):
+    for k, (fx, rec, ref_idx, mv) in enumerate(replay(name, CASES[name])):
+        bad = 0
+        for (mb, ref, bt, bx, by, px, py, mx, my, cost, rng, lam) in fx["calls"]:
+            p = part_index(int(bt), int(bx), int(by))
+            r = rec[int(mb)]
+            got = (r["pred"][ref, p, 0], r["pred"][ref, p, 1], r["mv"][ref, p, 0], r["mv"][ref, p, 1], r["cost"][ref, p])
+            if got != (px, py, mx, my, cost):
+                if not bad:
+                    first = "picture %d mb %d ref %d blocktype %d block (%d,%d): JM pred (%d,%d) mv (%d,%d) cost %d, oracle %s" % (
+                        k, mb, ref, bt, bx, by, px, py, mx, my, cost, got)
+                bad += 1
+        assert bad == 0, "%d of %d calls differ; first: %s" % (bad, len(fx["calls"]), first)
+        assert np.array_equal(ref_idx, fx["field"][..., 0]), "picture %d: final ref_idx field" % k
+        assert np.array_equal(mv, fx["field"][..., 1:]), "picture %d: final vector field" % k
+        # modes: JM turns a 16x16 macroblock whose vector equals the skip vector and whose residual quantises to nothing into mb_type 0
+        # afterwards (md_low.c:617-627; needs the transform): 0 in the fixture must be 1 with the skip vector here
+        jm_type = fx["mb"][:, 0]
+        for i in range(len(rec)):
+            if jm_type[i] == 0:
+                assert rec["best_mode"][i] == 1 and tuple(rec["final_mv"][i][0]) == tuple(rec["skip_mv"][i]) and rec["b8ref"][i][0] == 0
+            else:
+                assert rec["best_mode"][i] == jm_type[i], (k, i)
+                assert np.array_equal(rec["b8mode"][i], fx["mb"][i, 2:6]), (k, i)
