@@ -58,6 +58,7 @@ struct jmhip_ctx {
   void *dbk_dev = nullptr; size_t dbk_cap = 0;        // deblocking: macroblock / block / edge arrays
   // TQ arrays
   void *tq_jobs_dev = nullptr, *tq_res_dev = nullptr, *tq_quant_dev = nullptr; int tq_capacity = 0, tq_qcap = 0;
+  void *slice_state = nullptr;                         // me_wave.hip: the P-slice search state (field arrays, EPZS / UMHexagonS memories)
   // timing
   bool timing = false;
   unsigned timing_mask = ~0u;                        // stages that record events while timing is on (jmhip_timing_select)
@@ -98,7 +99,8 @@ constexpr int JMHIP_TQ_SELECT = 0x100;   // frame stage: each luma kernel takes 
 int jm_launch_tq(jmhip_ctx *ctx, int kind, int yuv_format, const void *jobs, const void *quants, void *results, int n);
 int jm_ensure_ref_table(jmhip_ctx *ctx);
 int jm_ensure_recon(jmhip_ctx *ctx);                                                       // jmhip_ctx.hip: all three recon planes or none
-int jm_flush_table_fix(jmhip_ctx *ctx);                                                    // frame.hip
+int jm_flush_table_fix(jmhip_ctx *ctx);
+void jm_slice_state_free(jmhip_ctx *ctx);                                                   // me_wave.hip                                                    // frame.hip
 struct MeDev;
 int jm_me_sub_tables(jmhip_ctx *ctx);                                                   // me_sub.hip
 void jm_launch_me_sub(jmhip_ctx *ctx, const MeDev &P, const jmhip_me_mb *jobs_dev, jmhip_me_result *res_dev, int n);

@@ -1,0 +1,1363 @@
+// me_wave.hip -- a whole P slice on the device: motion-vector prediction, the integer search of the configured SearchMode (FullSearch,
+// FastFullSearch, UMHexagonS, EPZS), sub-pel refinement, the skip shortcut and the low-complexity (rdopt = 0) inter decision, macroblocks
+// running as a 2:1 wavefront. Entry: jmhip_p_slice_search (include/jmhip.h lists the JM functions this replaces, file:line).
+//
+// One workgroup = one wave = one macroblock ROW. The wave walks its row left to right; before macroblock x it waits until the row above has
+// finished macroblock x + 1 (progress counters in global memory, agent-scope release / acquire). That order keeps every dependency JM's raster
+// order has on NEIGHBOURS: A/B/C/D vectors and references, the EPZS row memories, the UMHexagonS cost maps.
+// Inside the wave the control flow is the scalar algorithm, executed redundantly by all 64 lanes on LDS scratch (every lane writes the same
+// values); what is parallel is the evaluation of a BATCH of candidates (eval_dist): JM's early exits only skip work -- a distortion that is cut
+// short is never accepted (callers test strict <) -- so every group of candidates whose positions do not depend on each other's outcome (the
+// predictor set, one pass of a refinement pattern, a hexagon ring, the cross, the 5 / 9 sub-pel points) is evaluated in full across the lanes
+// and the sequential accept / reject logic is replayed on the results.
+#include "me_common.h"
+
+namespace {
+
+constexpr int WR = JMHIP_SLICE_REFS;
+constexpr int MAXC = 128;                      // candidates per batch
+constexpr int CARRY = 5;                       // vectors of the previous macroblock EPZS may read per reference: 16x16 + four 8x8
+
+struct WaveDev {
+  jmhip_slice_params p;
+  int W, H, Wp, Hp, mbw, mbh, w4, h4;
+  const uint8_t *cur;
+  const uint8_t *const *ref_sub;               // [slot] -> 16 quarter-pel planes
+  int8_t *ref_idx; short *mv;                  // enc_picture->ref_idx[LIST_0] [h4][w4], ->mv[LIST_0] [h4][w4][2]
+  int *prog;                                   // [mbh]: macroblocks finished in the row (x + 1)
+  int *flags;                                  // [0] abort (a wait timed out)
+  jmhip_mb_inter *out;                         // by macroblock address
+  int *ep_dist;                                // EPZSDistortion[LIST_0] [7][w4]
+  short *ep_motion;                            // EPZSMotion[LIST_0] [WR][7][4][w4][2]
+  const short *ep_col;                         // EPZSCo_located->mv[LIST_0] [h4][w4][2]
+  const short *carry_in;                       // [mbh][WR][CARRY][2]: img->all_mv the first macroblock of a row finds (speculated)
+  short *carry_out;                            // [mbh][WR][CARRY][2]: what the last macroblock of a row leaves
+  int *um_cost;                                // fastme_l0_cost [8][h4][w4]
+};
+
+struct Lds {
+  uint8_t cur[16][16];
+  int cx[MAXC], cy[MAXC], dist[MAXC];          // evaluation batch: padded quarter-pel block origins -> distortions
+  int qx[MAXC], qy[MAXC];                      // the vectors the batch entries stand for
+  int px[MAXC], py[MAXC];                      // EPZS predictor list
+  uint32_t map[160];                           // visited map of one search, (2R+1)^2 bits
+  short all_mv[16][WR][8][2];                  // img->all_mv[by][bx][LIST_0][ref][blocktype]
+  int motion_cost[8][WR][4];
+  int um_ref_cost[WR][8][16];                  // fastme_ref_cost[ref][blocktype][by][bx]
+  int um_best_cost[8][4];                      // fastme_best_cost[blocktype - 1][pic_pix_x >> 2] (only ever read after being written by the same block)
+  uint8_t um_sstate[52];                       // SearchState 7x7
+};
+
+__constant__ int8_t c_bsx[8] = {16, 16, 16, 8, 8, 8, 4, 4};
+__constant__ int8_t c_bsy[8] = {16, 16, 8, 16, 8, 4, 8, 4};
+
+__device__ __forceinline__ int rshift_rnd_sf(int x, int a) { return (x + (1 << (a - 1))) >> a; }
+__device__ __forceinline__ int imin3(int a, int b, int c) { return min(a, min(b, c)); }
+
+// ---------------------------------------------------------------------------------------------- candidate batches
+
+// L.dist[k] = distortion of the bsx x bsy block at (bx, by) of the macroblock against the reference block whose origin is the padded
+// quarter-pel position (L.cx[k], L.cy[k]), k < n. metric 0: computeSAD(WP) (me_distortion.c:351/413), one origin clamp per block; metric 2:
+// computeSATD(WP) (:657/:734), origin clamp per 4x4 (t8: 8x8) sub-block. umv: ref_access_method.
+__device__ void eval_dist(const WaveDev &D, Lds &L, const uint8_t *planes, int metric, int t8, int umv, int wp, int wpw, int wpo,
+                          int bx, int by, int bsx, int bsy, int n)
+{
+  const int lane = threadIdx.x;
+  const size_t psz = (size_t)D.Wp * D.Hp;
+  const int wpad = D.Wp - 17, hpad = D.Hp - 17;           // size_x_pad / size_y_pad, mbuffer.c:421-422
+  __syncthreads();
+  if (metric == 0) {
+    const int rowdw = bsx >> 2, seg = rowdw * bsy, cpb = 64 / seg;
+    const int d = lane % seg, row = d / rowdw, c4 = d - row * rowdw;
+    const uint32_t curv = *reinterpret_cast<const uint32_t *>(&L.cur[by + row][bx + 4 * c4]);
+    for (int base = 0; base < n; base += cpb) {
+      const int k = base + lane / seg;
+      int v = 0;
+      if (k < n) {
+        const int cx = L.cx[k], cy = L.cy[k];
+        int ix = cx >> 2, iy = cy >> 2;
+        if (umv) { ix = clampi(ix, 0, wpad); iy = clampi(iy, 0, hpad); }
+        const uint8_t *p = planes + psz * ((cy & 3) * 4 + (cx & 3)) + (size_t)(iy + row) * D.Wp + ix + 4 * c4;
+        uint32_t r, hi;
+        fetch_row(p, 4, &r, &hi);
+        if (wp) r = wp_apply4(r, wpw, wpo, D.p.wp_round, D.p.wp_denom);
+        v = (int)__builtin_amdgcn_sad_u8(r, curv, 0u);
+      }
+      for (int o = 1; o < seg; o <<= 1) v += __shfl_xor(v, o);
+      if (k < n && d == 0) L.dist[k] = v;
+    }
+  } else {
+    const int bs = t8 ? 8 : 4, nsx = bsx / bs, nsub = nsx * (bsy / bs), cpb = 64 / nsub;
+    const int s = lane % nsub, sy = s / nsx, sx = s - sy * nsx;
+    for (int base = 0; base < n; base += cpb) {
+      const int k = base + lane / nsub;
+      int v = 0;
+      if (k < n) {
+        const int ox = L.cx[k] + sx * bs * 4, oy = L.cy[k] + sy * bs * 4;
+        int ix = ox >> 2, iy = oy >> 2;
+        if (umv) { ix = clampi(ix, 0, wpad); iy = clampi(iy, 0, hpad); }
+        const uint8_t *p = planes + psz * ((oy & 3) * 4 + (ox & 3)) + (size_t)iy * D.Wp + ix;
+        if (!t8) {
+          int df[4][4];
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            uint32_t rv, hi;
+            fetch_row(p + (size_t)r * D.Wp, 4, &rv, &hi);
+            if (wp) rv = wp_apply4(rv, wpw, wpo, D.p.wp_round, D.p.wp_denom);
+            const uint32_t cv = *reinterpret_cast<const uint32_t *>(&L.cur[by + sy * 4 + r][bx + sx * 4]);
+#pragma unroll
+            for (int c = 0; c < 4; c++) df[r][c] = (int)((cv >> (8 * c)) & 255u) - (int)((rv >> (8 * c)) & 255u);
+          }
+          v = satd4x4(df);
+        } else {
+          int m[8][8];
+#pragma unroll
+          for (int r = 0; r < 8; r++) {
+            uint32_t lo, hi;
+            fetch_row(p + (size_t)r * D.Wp, 8, &lo, &hi);
+            if (wp) { lo = wp_apply4(lo, wpw, wpo, D.p.wp_round, D.p.wp_denom); hi = wp_apply4(hi, wpw, wpo, D.p.wp_round, D.p.wp_denom); }
+            const uint32_t c0 = *reinterpret_cast<const uint32_t *>(&L.cur[by + sy * 8 + r][bx + sx * 8]);
+            const uint32_t c1 = *reinterpret_cast<const uint32_t *>(&L.cur[by + sy * 8 + r][bx + sx * 8 + 4]);
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+              m[r][c] = (int)((c0 >> (8 * c)) & 255u) - (int)((lo >> (8 * c)) & 255u);
+              m[r][c + 4] = (int)((c1 >> (8 * c)) & 255u) - (int)((hi >> (8 * c)) & 255u);
+            }
+            had8(m[r]);
+          }
+          int sad = 0;
+#pragma unroll
+          for (int c = 0; c < 8; c++) {
+            int col[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) col[r] = m[r][c];
+            had8(col);
+#pragma unroll
+            for (int r = 0; r < 8; r++) sad += iabs(col[r]);
+          }
+          v = (sad + 2) >> 2;                               // HadamardSAD8x8, me_distortion.c:340-346
+        }
+      }
+      for (int o = 1; o < nsub; o <<= 1) v += __shfl_xor(v, o);
+      if (k < n && s == 0) L.dist[k] = v;
+    }
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------- neighbours and the predictor
+
+struct Nbr { int avail[4], ref[4], mvx[4], mvy[4], posx[4], posy[4]; };
+
+// getLuma4x4Neighbour for frame pictures (mb_access.c): luma offset (xN, yN) relative to macroblock (mbx, mby); available = inside the picture
+// and inside the slice (addresses [mb_first, mb_first + mb_count))
+__device__ __forceinline__ int nbr_pos(const WaveDev &D, int mbx, int mby, int xN, int yN, int *px, int *py)
+{
+  int nx = mbx, ny = mby;
+  if (xN < 0 && yN < 0) { nx--; ny--; }
+  else if (xN < 0 && yN < 16) nx--;
+  else if (xN >= 0 && xN < 16 && yN < 0) ny--;
+  else if (xN >= 0 && xN < 16 && yN >= 0 && yN < 16) { }
+  else if (xN >= 16 && yN < 0) { nx++; ny--; }
+  else return 0;
+  if (nx < 0 || ny < 0 || nx >= D.mbw || ny >= D.mbh) return 0;
+  const int a = ny * D.mbw + nx;
+  if (a < D.p.mb_first || a >= D.p.mb_first + D.p.mb_count) return 0;
+  *px = (nx * 16 + ((xN + 16) & 15)) >> 2; *py = (ny * 16 + ((yN + 16) & 15)) >> 2;
+  return 1;
+}
+
+__device__ void neighbours(const WaveDev &D, int mbx, int mby, int mb_x, int mb_y, int bsx, Nbr &nb)
+{
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int xN = mb_x + (k == 1 ? 0 : (k == 2 ? bsx : -1)), yN = mb_y + (k == 0 ? 0 : -1);
+    nb.avail[k] = nbr_pos(D, mbx, mby, xN, yN, &nb.posx[k], &nb.posy[k]);
+    nb.ref[k] = -1; nb.mvx[k] = nb.mvy[k] = 0;
+    if (nb.avail[k]) {
+      const size_t at = (size_t)nb.posy[k] * D.w4 + nb.posx[k];
+      nb.ref[k] = D.ref_idx[at];
+      nb.mvx[k] = D.mv[at * 2]; nb.mvy[k] = D.mv[at * 2 + 1];
+    }
+  }
+}
+
+// the up-right neighbour JM cannot use because it lies in a part of the macroblock coded later (mv-search.c:108-127, me_epzs.c:1660-1688)
+__device__ __forceinline__ void fix_block_c(int mb_x, int mb_y, int bsx, int *c_avail)
+{
+  if (mb_y > 0) {
+    if (mb_x < 8) {
+      if (mb_y == 8) { if (bsx == 16) *c_avail = 0; }
+      else if (mb_x + bsx == 8) *c_avail = 0;
+    } else if (mb_x + bsx == 16) *c_avail = 0;
+  }
+}
+
+// SetMotionVectorPredictor mv-search.c:87 / UMHEXSetMotionVectorPredictor me_umhex.c:1298 (dsr: also the dynamic search range)
+__device__ void mv_predictor(const WaveDev &D, int mbx, int mby, int ref_frame, int mb_x, int mb_y, int bsx, int bsy, int *pmx, int *pmy,
+                             int dsr, int umhex_bt, int *search_range, int *sad_abc)
+{
+  Nbr nb;
+  neighbours(D, mbx, mby, mb_x, mb_y, bsx, nb);
+  fix_block_c(mb_x, mb_y, bsx, &nb.avail[2]);
+  if (!nb.avail[2]) { nb.avail[2] = nb.avail[3]; nb.ref[2] = nb.ref[3]; nb.mvx[2] = nb.mvx[3]; nb.mvy[2] = nb.mvy[3]; nb.posx[2] = nb.posx[3]; nb.posy[2] = nb.posy[3]; }
+  const int rL = nb.avail[0] ? nb.ref[0] : -1, rU = nb.avail[1] ? nb.ref[1] : -1, rUR = nb.avail[2] ? nb.ref[2] : -1;
+  int type = 0;
+  if (rL == ref_frame && rU != ref_frame && rUR != ref_frame) type = 1;
+  else if (rL != ref_frame && rU == ref_frame && rUR != ref_frame) type = 2;
+  else if (rL != ref_frame && rU != ref_frame && rUR == ref_frame) type = 3;
+  if (bsx == 8 && bsy == 16) { if (mb_x == 0) { if (rL == ref_frame) type = 1; } else if (rUR == ref_frame) type = 3; }
+  else if (bsx == 16 && bsy == 8) { if (mb_y == 0) { if (rU == ref_frame) type = 2; } else if (rL == ref_frame) type = 1; }
+  int sa = 0, sb = 0, sc = 0, sd = 0;
+  if (dsr) {                                                           // neighbourhood SAD prediction, me_umhex.c:1441-1448
+    const size_t pl = (size_t)umhex_bt * D.h4 * D.w4;
+    sa = nb.avail[0] ? D.um_cost[pl + (size_t)nb.posy[0] * D.w4 + nb.posx[0]] : 0;
+    sb = nb.avail[1] ? D.um_cost[pl + (size_t)nb.posy[1] * D.w4 + nb.posx[1]] : 0;
+    sd = nb.avail[3] ? D.um_cost[pl + (size_t)nb.posy[3] * D.w4 + nb.posx[3]] : 0;
+    sc = nb.avail[2] ? D.um_cost[pl + (size_t)nb.posy[2] * D.w4 + nb.posx[2]] : sd;
+  }
+  int tmp_range[2] = {0, 0};
+  const int R = D.p.search_range;
+#pragma unroll
+  for (int hv = 0; hv < 2; hv++) {
+    const int a = nb.avail[0] ? (hv ? nb.mvy[0] : nb.mvx[0]) : 0, b = nb.avail[1] ? (hv ? nb.mvy[1] : nb.mvx[1]) : 0, c = nb.avail[2] ? (hv ? nb.mvy[2] : nb.mvx[2]) : 0;
+    int pv;
+    if (type == 0) pv = !(nb.avail[1] || nb.avail[2]) ? a : a + b + c - imin3(a, b, c) - max(a, max(b, c));
+    else pv = type == 1 ? a : (type == 2 ? b : c);
+    if (hv) *pmy = pv; else *pmx = pv;
+    if (dsr) {                                                         // me_umhex.c:1518-1536
+      if (nb.avail[0] + nb.avail[1] + nb.avail[2] < 2) tmp_range[hv] = R;
+      else {
+        const int mx = max(iabs(a), max(iabs(b), iabs(c))), sum = iabs(a) + iabs(b) + iabs(c);
+        const int small_range = sum == 0 ? (R + 4) >> 3 : (sum > 3 ? (R + 2) >> 2 : (3 * R + 8) >> 4);
+        tmp_range[hv] = min(R, max(small_range, mx << 1));
+        if (max(sa, max(sb, sc)) > D.p.umhex_thres[3][umhex_bt]) tmp_range[hv] = R;
+      }
+    }
+  }
+  if (dsr) {
+    const int nr = max(tmp_range[0], tmp_range[1]);
+    if (D.p.full_search == 2) *search_range = nr;
+    else if (D.p.full_search == 1) *search_range = nr / (min(ref_frame, 1) + 1);
+    else *search_range = nr / ((min(ref_frame, 1) + 1) * min(2, umhex_bt));    // blocktype_lut[..] is the block type itself (configfile.c:830-836)
+  }
+  if (sad_abc) { sad_abc[0] = sa; sad_abc[1] = sb; sad_abc[2] = sc; }
+}
+
+// ---------------------------------------------------------------------------------------------- one block search: shared context
+
+struct Blk {
+  int mbx, mby;                 // macroblock
+  int mb_x, mb_y;               // block origin inside the macroblock (pels)
+  int bt, bsx, bsy, ref;
+  int pic_x, pic_y;             // block origin in the picture
+  int pmx, pmy;                 // predictor, quarter-pel
+  const uint8_t *planes;
+  int wp, wpw, wpo;             // weighted reference ME
+  int t8;                       // test8x8transform
+};
+
+__device__ __forceinline__ int mvc(int lam, int mvx_q, int mvy_q, const Blk &B) { return mv_cost(lam, mvx_q - B.pmx, mvy_q - B.pmy); }
+__device__ __forceinline__ int padq(int pic, int v_q) { return ((pic + JMHIP_PAD) << 2) + v_q; }
+
+// visited map of one search: (2R+1)^2 bits, index relative to the search centre
+__device__ __forceinline__ void map_clear(Lds &L, int R) { const int n = ((2 * R + 1) * (2 * R + 1) + 31) >> 5; for (int i = 0; i < n; i++) L.map[i] = 0u; }
+__device__ __forceinline__ int map_test_set(Lds &L, int R, int dx, int dy)
+{
+  const int i = (dy + R) * (2 * R + 1) + (dx + R);
+  const uint32_t w = L.map[i >> 5], b = 1u << (i & 31);
+  if (w & b) return 1;
+  L.map[i >> 5] = w | b;
+  return 0;
+}
+__device__ __forceinline__ int map_test(const Lds &L, int R, int dx, int dy) { const int i = (dy + R) * (2 * R + 1) + (dx + R); return (L.map[i >> 5] >> (i & 31)) & 1u; }
+__device__ __forceinline__ void map_set(Lds &L, int R, int dx, int dy) { const int i = (dy + R) * (2 * R + 1) + (dx + R); L.map[i >> 5] |= 1u << (i & 31); }
+
+// ---------------------------------------------------------------------------------------------- SubPelBlockMotionSearch (me_fullsearch.c:341)
+
+__device__ int subpel_full(const WaveDev &D, Lds &L, const Blk &B, int *mvx, int *mvy, int min_mcost)
+{
+  const int start_hp = D.p.metric[0] != D.p.metric[1] ? 0 : 1, start_qp = D.p.metric[1] != D.p.metric[2] ? 0 : 1;
+  const int max_x4 = (D.W - B.bsx + 2 * JMHIP_PAD) << 2, max_y4 = (D.H - B.bsy + 2 * JMHIP_PAD) << 2;
+  const int check0 = (B.ref == 0 && B.bt == 1 && *mvx == 0 && *mvy == 0);       // check_position0 (!rdopt, P slice)
+  for (int phase = 0; phase < 2; phase++) {
+    const int step = phase ? 1 : 2, first = phase ? start_qp : start_hp, lam = D.p.lambda_mf[phase ? 2 : 1], m = phase ? 0 : 1;
+    const int p4x = padq(B.pic_x, *mvx), p4y = padq(B.pic_y, *mvy);
+    const int umv = !((p4x > m) && (p4x < max_x4 - m) && (p4y > m) && (p4y < max_y4 - m));
+    if (phase && !start_qp) min_mcost = INT_MAX;
+    int n = 0;
+    for (int pos = first; pos < 9; pos++) { L.cx[n] = p4x + c_s9x[pos] * step; L.cy[n] = p4y + c_s9y[pos] * step; n++; }
+    eval_dist(D, L, B.planes, D.p.metric[phase ? 2 : 1], B.t8, umv, B.wp, B.wpw, B.wpo, B.mb_x, B.mb_y, B.bsx, B.bsy, n);
+    int best = 0;
+    for (int pos = first, k = 0; pos < 9; pos++, k++) {
+      int mcost = mvc(lam, *mvx + c_s9x[pos] * step, *mvy + c_s9y[pos] * step, B);
+      if (mcost >= min_mcost) continue;
+      mcost += L.dist[k];
+      if (phase == 0 && pos == 0 && check0) mcost -= (lam * 16) >> 16;
+      if (mcost < min_mcost) { min_mcost = mcost; best = pos; }
+    }
+    if (best) { *mvx += c_s9x[best] * step; *mvy += c_s9y[best] * step; }
+  }
+  return min_mcost;
+}
+
+// ---------------------------------------------------------------------------------------------- FullSearch / FastFullSearch (exhaustive window, one wave)
+
+// argmin over the (2R+1)^2 window round (cx, cy) [pels] of SAD + mv cost with JM's order of preference (lowest spiral index on ties).
+// ffs: FastFullPelBlockMotionSearch (me_fullfast.c:833: the zero vector is tried first when !rdopt and then keeps ties);
+// else FullPelBlockMotionSearch (me_fullsearch.c:47: check_for_00 bonus :129-132 incl. the wrapped first-row bound, see me_int.hip).
+__device__ int full_window(const WaveDev &D, Lds &L, const Blk &B, int cx, int cy, int R, int ffs, int *mvx, int *mvy)
+{
+  const int lane = threadIdx.x, side = 2 * R + 1, npos = side * side, lam = D.p.lambda_mf[0];
+  const size_t psz = (size_t)D.Wp * D.Hp;
+  (void)psz;
+  const int wpad = D.Wp - 17, hpad = D.Hp - 17;
+  // FAST access only when the whole window is inside (me_fullsearch.c:110-118); UMV otherwise: clamping the origin is the identity inside
+  const int rowdw = B.bsx >> 2, seg = rowdw * B.bsy, cpb = 64 / seg;
+  const int d = lane % seg, row = d / rowdw, c4 = d - row * rowdw;
+  const uint32_t curv = *reinterpret_cast<const uint32_t *>(&L.cur[B.mb_y + row][B.mb_x + 4 * c4]);
+  const int check00 = (!ffs && B.bt == 1 && B.ref == 0);
+  const int w16 = (lam * 16) >> 16;
+  unsigned best = 0xffffffffu;
+  __syncthreads();
+  for (int base = 0; base < npos; base += cpb) {
+    const int k = base + lane / seg;
+    int v = 0, dx = 0, dy = 0;
+    if (k < npos) {
+      dy = k / side - R; dx = k - (dy + R) * side - R;
+      int ix = B.pic_x + cx + dx + JMHIP_PAD, iy = B.pic_y + cy + dy + JMHIP_PAD;
+      ix = clampi(ix, 0, wpad); iy = clampi(iy, 0, hpad);
+      const uint8_t *p = B.planes + (size_t)(iy + row) * D.Wp + ix + 4 * c4;
+      uint32_t r, hi;
+      fetch_row(p, 4, &r, &hi);
+      if (B.wp) r = wp_apply4(r, B.wpw, B.wpo, D.p.wp_round, D.p.wp_denom);
+      v = (int)__builtin_amdgcn_sad_u8(r, curv, 0u);
+    }
+    int rowsum = v;                                                    // SAD of the first row (for the wrapped bound)
+    for (int o = 1; o < rowdw; o <<= 1) rowsum += __shfl_xor(rowsum, o);
+    for (int o = 1; o < seg; o <<= 1) v += __shfl_xor(v, o);
+    if (k < npos && d == 0) {
+      int mc = mv_cost(lam, ((cx + dx) << 2) - B.pmx, ((cy + dy) << 2) - B.pmy);
+      int tie = spiral_pos(dx, dy) + 1;
+      if (check00 && ((B.pic_x + cx + dx) << 2) == B.pic_x && ((B.pic_y + cy + dy) << 2) == B.pic_y) {
+        mc -= w16;
+        if (dx == 0 && dy == 0 && mc < 0) v = rowsum;                  // INT_MAX - (negative) wraps: computeSAD leaves after row 0
+      }
+      if (ffs && cx + dx == 0 && cy + dy == 0) tie = 0;                // pos_00 pre-check
+      const int cost = mc + v;                                          // may be slightly negative through the bonus
+      const unsigned key = ((unsigned)(cost + 4096) << TIE_BITS) | (unsigned)tie;
+      best = min(best, key);
+    }
+  }
+  for (int o = 1; o < 64; o <<= 1) best = min(best, (unsigned)__shfl_xor((int)best, o));
+  const int cost = (int)(best >> TIE_BITS) - 4096, tie = (int)(best & ((1u << TIE_BITS) - 1));
+  if (tie == 0) { *mvx = 0; *mvy = 0; }
+  else { int dx, dy; spiral_offset(tie - 1, &dx, &dy); *mvx = cx + dx; *mvy = cy + dy; }
+  __syncthreads();
+  return cost;
+}
+
+// ---------------------------------------------------------------------------------------------- EPZS (me_epzs.c)
+
+// pattern tables, me_epzs.c:54-78 (>> mv_rescale = 2), with the (stop, nextLast, next pattern) triples of EPZSInit :367-378
+struct EpPat { int8_t n, stop, next_last, next; int8_t mvx[12], mvy[12], start[12], npts[12]; };
+__constant__ EpPat c_pat[6] = {
+  {4, 1, 1, 0, {0, 1, 0, -1}, {1, 0, -1, 0}, {3, 0, 1, 2}, {3, 3, 3, 3}},
+  {8, 1, 1, 1, {0, 1, 1, 1, 0, -1, -1, -1}, {1, 1, 0, -1, -1, -1, 0, 1}, {7, 7, 1, 1, 3, 3, 5, 5}, {3, 5, 3, 5, 3, 5, 3, 5}},
+  {12, 1, 1, 2, {-1, 0, 0, 1, 2, 1, 1, 0, 0, -1, -2, -1}, {1, 2, 1, 1, 0, 0, -1, -2, -1, -1, 0, 0}, {10, 10, 10, 1, 1, 1, 4, 4, 4, 7, 7, 7}, {5, 8, 7, 5, 8, 7, 5, 8, 7, 5, 8, 7}},
+  {8, 1, 1, 3, {0, 1, 2, 1, 0, -1, -2, -1}, {2, 1, 0, -1, -2, -1, 0, 1}, {6, 0, 0, 2, 2, 4, 4, 6}, {5, 3, 5, 3, 5, 3, 5, 3}},
+  {12, 0, 1, 0, {0, 1, 2, 1, 0, -1, -2, -1, 0, 0, 0, -1}, {2, 1, 0, -1, -2, -1, 0, 1, 0, 0, -1, 0}, {6, 0, 0, 2, 2, 4, 4, 6, 6, 0, 2, 4}, {12, 12, 12, 12, 12, 12, 12, 12, 12, 12, 12, 12}},
+  {8, 0, 1, 0, {0, 1, 2, 1, 0, -1, -2, -1}, {2, 1, 0, -1, -2, -1, 0, 1}, {6, 0, 0, 2, 2, 4, 4, 6}, {5, 3, 5, 3, 5, 3, 5, 3}},
+};
+__constant__ int8_t c_blk_parent[8] = {1, 1, 1, 1, 2, 4, 4, 5};
+__constant__ int8_t c_sp_hp[10][2] = {{0, 0}, {-2, 0}, {0, 2}, {2, 0}, {0, -2}, {-2, 2}, {2, 2}, {2, -2}, {-2, -2}, {-2, 2}};
+__constant__ int8_t c_sp_qp[10][2] = {{0, 0}, {-1, 0}, {0, 1}, {1, 0}, {0, -1}, {-1, 1}, {1, 1}, {1, -1}, {-1, -1}, {-1, 1}};
+
+struct EpState { int tmx, tmy, t2x, t2y, min_mcost, second; };
+
+// one pass of candidates (vectors L.qx/qy[0..n), pels) through the visited map, the evaluation and the caller's replay
+__device__ __forceinline__ int ep_access_umv(const WaveDev &D, const Blk &B, int vx, int vy)
+{
+  // CHECK_RANGE (me_epzs.h:23) compares the QUARTER-pel candidate with pel-unit picture sizes, as JM does
+  const int cx = (B.pic_x + vx) << 2, cy = (B.pic_y + vy) << 2;
+  return !((cx >= 0) && (cx < D.W - B.bsx) && (cy >= 0) && (cy < D.H - B.bsy));
+}
+
+// evaluates the candidates L.qx/qy[0..n) (integer vectors): EPZS picks the access method per candidate, so they go in two batches
+__device__ void ep_eval(const WaveDev &D, Lds &L, const Blk &B, int n)
+{
+  // EPZS picks FAST or UMV access per candidate (CHECK_RANGE, me_epzs.h:23), and FAST only for blocks that lie inside the picture, where the
+  // origin clamp of UMV access is the identity: every candidate is evaluated with UMV access.
+  for (int k = 0; k < n; k++) { L.cx[k] = padq(B.pic_x, L.qx[k] << 2); L.cy[k] = padq(B.pic_y, L.qy[k] << 2); }
+  eval_dist(D, L, B.planes, D.p.metric[0], B.t8, 1, B.wp, B.wpw, B.wpo, B.mb_x, B.mb_y, B.bsx, B.bsy, n);
+}
+
+// EPZSPelBlockMotionSearch, me_epzs.c:1500. mvx/mvy: search centre in, result out (pels). all_mv: this block's img->all_mv row [ref][blocktype].
+__device__ int epzs_pel(const WaveDev &D, Lds &L, const Blk &B, int mb_nr, int R, int *mvx, int *mvy)
+{
+  const jmhip_slice_params &P = D.p;
+  const int lam = P.lambda_mf[0], bt = B.bt, ref = B.ref;
+  const int cx0 = *mvx, cy0 = *mvy;                       // the centre (mv on entry)
+  const int px2 = B.pic_x >> 2, py2 = B.pic_y >> 2, bshx = B.bsx >> 2, bshy = B.bsy >> 2, block_y = B.mb_y >> 2, block_x = B.mb_x >> 2;
+  int *prev_sad = D.ep_dist + (size_t)(bt - 1) * D.w4;
+  short *motion = P.epzs_spatial_mem ? D.ep_motion + ((((size_t)ref * 7 + (bt - 1)) * 4 + block_y) * D.w4 + px2) * 2 : nullptr;
+  const int medthres = P.epzs_thres[1][bt];
+  int stop = medthres;
+  EpState S{cx0, cy0, 0, 0, 0, INT_MAX};
+  map_clear(L, R);
+  map_set(L, R, 0, 0);
+  L.qx[0] = cx0; L.qy[0] = cy0;
+  ep_eval(D, L, B, 1);
+  S.min_mcost = mvc(lam, cx0 << 2, cy0 << 2, B) + L.dist[0];
+  const int psad = prev_sad[px2];
+  if (ref > 0 && psad < medthres && psad < S.min_mcost) {                      // :1608-1623
+    if (motion && threadIdx.x == 0) { motion[0] = (short)S.tmx; motion[1] = (short)S.tmy; }
+    return S.min_mcost;
+  }
+  if (S.min_mcost > stop) {
+    Nbr nb;
+    neighbours(D, B.mbx, B.mby, B.mb_x, B.mb_y, B.bsx, nb);
+    const int mb_avail_right = B.mbx < D.mbw - 1, mb_avail_below = B.mby < D.mbh - 1;
+    int c_avail = nb.avail[2], blk_right;
+    if (B.mb_y > 0) {                                                          // :1660-1687
+      if (B.mb_x < 8) {
+        if (B.mb_y == 8) { blk_right = (B.bsx != 16) || mb_avail_right; if (B.bsx == 16) c_avail = 0; }
+        else { blk_right = (B.mb_x + B.bsx != 8) || mb_avail_right; if (B.mb_x + B.bsx == 8) c_avail = 0; }
+      } else { blk_right = (B.mb_x + B.bsx != 16) || mb_avail_right; if (B.mb_x + B.bsx == 16) c_avail = 0; }
+    } else blk_right = (B.mb_x + B.bsx != 16) || mb_avail_right;
+    const int blk_below = (B.mb_y + B.bsy != 16) || mb_avail_below;
+    const int sadA = nb.avail[0] ? prev_sad[px2 - bshx] : INT_MAX, sadB = nb.avail[1] ? prev_sad[px2] : INT_MAX, sadC = c_avail ? prev_sad[px2 + bshx] : INT_MAX;
+    stop = imin3(sadA, sadB, sadC);
+    stop = max(stop, P.epzs_thres[0][bt]);
+    stop = min(stop, P.epzs_thres[2][bt]);
+    stop = (9 * max(medthres, stop) + 2 * medthres) >> 3;                      // :1698
+
+    // ---- predictors: spatial :1061 (non-MBAFF), spatial memory :1253, temporal :1332, window :1480, block type :1433
+    int np = 5;
+    const int refA = nb.avail[0] ? nb.ref[0] : -1, refB = nb.avail[1] ? nb.ref[1] : -1, refC = c_avail ? nb.ref[2] : -1, refD = nb.avail[3] ? nb.ref[3] : -1;
+    const int sh = 10;                                                          // 8 + mv_rescale
+#define SC(r) ((r) < 0 ? 0 : P.epzs_mv_scale[ref][r])                          /* the vector of such a neighbour is zero: the product is 0 either way */
+    L.px[0] = 0; L.py[0] = 0;
+    if (nb.avail[0]) { L.px[1] = rshift_rnd_sf(SC(refA) * nb.mvx[0], sh); L.py[1] = rshift_rnd_sf(SC(refA) * nb.mvy[0], sh); } else { L.px[1] = 3; L.py[1] = 0; }
+    if (nb.avail[1]) { L.px[2] = rshift_rnd_sf(SC(refB) * nb.mvx[1], sh); L.py[2] = rshift_rnd_sf(SC(refB) * nb.mvy[1], sh); } else { L.px[2] = 0; L.py[2] = 3; }
+    if (c_avail)     { L.px[3] = rshift_rnd_sf(SC(refC) * nb.mvx[2], sh); L.py[3] = rshift_rnd_sf(SC(refC) * nb.mvy[2], sh); } else { L.px[3] = -3; L.py[3] = 0; }
+    if (nb.avail[3]) { L.px[4] = rshift_rnd_sf(SC(refD) * nb.mvx[3], sh); L.py[4] = rshift_rnd_sf(SC(refD) * nb.mvy[3], sh); } else { L.px[4] = 0; L.py[4] = -3; }
+#undef SC
+    const int invalid_refs = (refA == -1) + (refB == -1) + (refC == -1 && refD == -1);
+#define ADDP(X, Y) do { const int x_ = (X), y_ = (Y); L.px[np] = x_; L.py[np] = y_; np += ((x_ | y_) != 0); } while (0)
+    if (P.epzs_spatial_mem) {
+      const short *m = D.ep_motion + (((size_t)ref * 7 + (bt - 1)) * 4) * D.w4 * 2;
+#define MOT(r, x, c) ((int)m[((size_t)(r) * D.w4 + (x)) * 2 + (c)])
+      ADDP(px2 > 0 ? MOT(block_y, px2 - bshx, 0) : 0, px2 > 0 ? MOT(block_y, px2 - bshx, 1) : 0);
+      ADDP(block_y > 0 ? MOT(block_y - bshy, px2, 0) : MOT(4 - bshy, px2, 0), block_y > 0 ? MOT(block_y - bshy, px2, 1) : MOT(4 - bshy, px2, 1));
+      ADDP(px2 + bshx < D.w4 ? (block_y > 0 ? MOT(block_y - bshy, px2 + bshx, 0) : MOT(4 - bshy, px2 + bshx, 0)) : 0,
+           px2 + bshx < D.w4 ? (block_y > 0 ? MOT(block_y - bshy, px2 + bshx, 1) : MOT(4 - bshy, px2 + bshx, 1)) : 0);
+#undef MOT
+    }
+    if (P.epzs_temporal) {
+      const int sc = P.epzs_mv_scale[ref][0];
+#define COLP(y, x) ADDP(rshift_rnd_sf(sc * (int)D.ep_col[((size_t)(y) * D.w4 + (x)) * 2], sh), rshift_rnd_sf(sc * (int)D.ep_col[((size_t)(y) * D.w4 + (x)) * 2 + 1], sh))
+      COLP(py2, px2);
+      if (S.min_mcost > stop && ref < 2) {
+        if (nb.avail[0]) {
+          COLP(py2, px2 - 1);
+          if (nb.avail[1]) COLP(py2 - 1, px2 - 1);
+          if (blk_below) COLP(py2 + bshy, px2 - 1);
+        }
+        if (nb.avail[1]) COLP(py2 - 1, px2);
+        if (blk_right) {
+          COLP(py2, px2 + bshx);
+          if (nb.avail[1]) COLP(py2 - 1, px2 + bshx);
+          if (blk_below) COLP(py2 + bshy, px2 + bshx);
+        }
+        if (blk_below) COLP(py2 + bshy, px2);
+      }
+#undef COLP
+    }
+    if (S.min_mcost > stop && (ref < 2 && bt < 5) && P.epzs_fixed >= 1) {       // P slice: EPZSFixed > 1 || EPZSFixed (:1727-1733)
+      const int ext = (bt < 5) && (invalid_refs > 2) && (ref < 1);
+      const int nw = ext ? P.epzs_nwin_ext : P.epzs_nwin;
+      for (int k = 0; k < nw; k++) { L.px[np] = cx0 + (ext ? P.epzs_win_ext[k][0] : P.epzs_win[k][0]); L.py[np] = cy0 + (ext ? P.epzs_win_ext[k][1] : P.epzs_win[k][1]); np++; }
+    }
+    if ((ref == 0 || S.min_mcost > stop) && mb_nr != 0) {                       // :1740-1744, EPZSBlockTypePredictors :1433
+      const short (*am)[8][2] = L.all_mv[block_y * 4 + block_x];
+      const int par = c_blk_parent[bt];
+#define RR(v) (((int)(v) + 2) >> 2)                                             /* rshift_rnd(v, 2) */
+      ADDP(RR(am[ref][par][0]), RR(am[ref][par][1]));
+      if (ref > 0 && bt < 5) {
+        ADDP(rshift_rnd_sf(P.epzs_mv_scale[ref][ref - 1] * (int)am[ref - 1][bt][0], sh), rshift_rnd_sf(P.epzs_mv_scale[ref][ref - 1] * (int)am[ref - 1][bt][1], sh));
+        ADDP(rshift_rnd_sf(P.epzs_mv_scale[ref][0] * (int)am[0][bt][0], sh), rshift_rnd_sf(P.epzs_mv_scale[ref][0] * (int)am[0][bt][1], sh));
+      }
+      if (bt != 1) ADDP(RR(am[ref][1][0]), RR(am[ref][1][1]));
+      if (bt != 4) ADDP(RR(am[ref][4][0]), RR(am[ref][4][1]));
+#undef RR
+    }
+#undef ADDP
+    // ---- scan :1746-1795: the map is marked whatever the costs are, so the survivors are known before anything is evaluated
+    int n = 0;
+    for (int k = 0; k < np; k++) {
+      const int tx = L.px[k], ty = L.py[k];
+      if (iabs(tx - cx0) > R || iabs(ty - cy0) > R) continue;
+      if (map_test_set(L, R, tx - cx0, ty - cy0)) continue;
+      L.qx[n] = tx; L.qy[n] = ty; n++;
+    }
+    ep_eval(D, L, B, n);
+    int check_median = 0;
+    for (int k = 0; k < n; k++) {
+      const int tx = L.qx[k], ty = L.qy[k];
+      int mcost = mvc(lam, tx << 2, ty << 2, B);
+      if (mcost >= S.second) continue;
+      mcost += L.dist[k];
+      if (mcost < S.min_mcost) { S.t2x = S.tmx; S.t2y = S.tmy; S.tmx = tx; S.tmy = ty; S.second = S.min_mcost; S.min_mcost = mcost; check_median = 1; }
+      else if (mcost < S.second) { S.t2x = tx; S.t2y = ty; S.second = mcost; check_median = 1; }
+    }
+    // ---- refinement :1801-1942
+    if (S.min_mcost > stop) {
+      const int search_pattern = (P.epzs_pattern >= 1 && P.epzs_pattern <= 5) ? P.epzs_pattern : 0;       // :410-431
+      const int search_pattern_d = (P.epzs_dual >= 2 && P.epzs_dual <= 6) ? P.epzs_dual - 1 : 0;          // :433-454
+      int pf = search_pattern;
+      if (P.epzs_pattern != 0) {
+        if (S.min_mcost < stop + ((3 * medthres) >> 1)) {
+          if ((S.tmx == 0 && S.tmy == 0) || (iabs(S.tmx - cx0) < 2 && iabs(S.tmy - cy0) < 2)) pf = 0; else pf = 1;
+        } else if (bt > 5 || (ref > 0 && bt != 1)) pf = 1;
+        else pf = search_pattern;
+      }
+      int total = c_pat[pf].n, center_x = S.tmx, center_y = S.tmy, pattern_stop = 0, point = 0, next_last = 0, dir = 0;
+      for (;;) {
+        do {
+          // one pass: `total` points from `point` on (wrapping); map first, then the batch, then the replay
+          int cnt = 0;
+          int pidx[12];
+          for (int c = 0, pt = point; c < total; c++) {
+            const int tx = center_x + c_pat[pf].mvx[pt], ty = center_y + c_pat[pf].mvy[pt];
+            if (iabs(tx - cx0) <= R && iabs(ty - cy0) <= R && !map_test_set(L, R, tx - cx0, ty - cy0)) { L.qx[cnt] = tx; L.qy[cnt] = ty; pidx[cnt] = pt; cnt++; }
+            if (++pt >= c_pat[pf].n) pt -= c_pat[pf].n;
+          }
+          ep_eval(D, L, B, cnt);
+          for (int k = 0; k < cnt; k++) {
+            int mcost = mvc(lam, L.qx[k] << 2, L.qy[k] << 2, B);
+            if (mcost < S.min_mcost) {
+              mcost += L.dist[k];
+              if (mcost < S.min_mcost) { S.min_mcost = mcost; S.tmx = L.qx[k]; S.tmy = L.qy[k]; dir = pidx[k]; }
+            }
+          }
+          if (next_last || (S.tmx == center_x && S.tmy == center_y)) {
+            pattern_stop = c_pat[pf].stop; pf = c_pat[pf].next; total = c_pat[pf].n; next_last = c_pat[pf].next_last; dir = 0; point = 0;
+          } else {
+            total = c_pat[pf].npts[dir]; point = c_pat[pf].start[dir]; center_x = S.tmx; center_y = S.tmy;
+          }
+        } while (pattern_stop != 1);
+        const int ps = prev_sad[px2];
+        if (ref > 0 && ((4 * ps < S.min_mcost) || ((3 * ps < S.min_mcost) && (ps <= stop)))) {          // :1894-1911
+          *mvx = S.tmx; *mvy = S.tmy;
+          if (motion && threadIdx.x == 0) { motion[0] = (short)S.tmx; motion[1] = (short)S.tmy; }
+          return S.min_mcost;
+        }
+        if (!(check_median && S.min_mcost > stop && P.epzs_dual > 0)) break;     // P slice: (P_SLICE || blocktype < 5) is true
+        point = 0; pattern_stop = 0; dir = 0; next_last = 0;
+        if ((S.tmx == 0 && S.tmy == 0) || (S.tmx == cx0 && S.tmy == cy0)) { if (iabs(S.tmx - cx0) < 2 && iabs(S.tmy - cy0) < 2) pf = 0; else pf = 1; }
+        else pf = search_pattern_d;
+        total = c_pat[pf].n;
+        center_x = S.t2x; center_y = S.t2y;
+        check_median = 0;
+      }
+    }
+  }
+  if (threadIdx.x == 0) {
+    if (ref == 0 || prev_sad[px2] > S.min_mcost) prev_sad[px2] = S.min_mcost;                           // :1945
+    if (motion) { motion[0] = (short)S.tmx; motion[1] = (short)S.tmy; }
+  }
+  *mvx = S.tmx; *mvy = S.tmy;
+  return S.min_mcost;
+}
+
+// one level of EPZSSubPelBlockMotionSearch (me_epzs.c:2472-2579 / :2605-2715). Returns 1 on the sub-threshold early return.
+__device__ int epzs_sub_level(const WaveDev &D, Lds &L, const Blk &B, int half, int start, int lam, int metric, int umv, int *mvx, int *mvy, int *min_mcost, int subthres)
+{
+  const int8_t (*pts)[2] = half ? c_sp_hp : c_sp_qp;
+  const int p4x = padq(B.pic_x, 0), p4y = padq(B.pic_y, 0);
+  int n = 0;
+  for (int pos = start; pos < 5; pos++) { L.cx[n] = p4x + *mvx + pts[pos][0]; L.cy[n] = p4y + *mvy + pts[pos][1]; n++; }
+  eval_dist(D, L, B.planes, metric, B.t8, umv, B.wp, B.wpw, B.wpo, B.mb_x, B.mb_y, B.bsx, B.bsy, n);
+  int best = 0, second_pos = 0, second = INT_MAX;
+  for (int pos = start, k = 0; pos < 5; pos++, k++) {
+    const int mcost = mvc(lam, *mvx + pts[pos][0], *mvy + pts[pos][1], B) + L.dist[k];
+    if (mcost < *min_mcost) { second = *min_mcost; second_pos = best; *min_mcost = mcost; best = pos; }
+    else if (mcost < second) { second = mcost; second_pos = pos; }
+  }
+  if (best == 0 && B.pmx == *mvx && (B.pmy - *mvy) == 0 && *min_mcost < subthres) return 1;
+  int sp = 5, ep = 9;
+  if (best != 0 && second_pos != 0) {
+    switch (best ^ second_pos) { case 1: sp = 6; ep = 7; break; case 3: sp = 5; ep = 6; break; case 5: sp = 8; ep = 9; break; case 7: sp = 7; ep = 8; break; default: break; }
+  } else {
+    switch (best + second_pos) { case 0: if (half) { sp = 5; ep = 5; } break; case 1: sp = 8; ep = 10; break; case 2: sp = 5; ep = 7; break; case 5: sp = 6; ep = 8; break; case 7: sp = 7; ep = 9; break; default: break; }
+  }
+  if (best != 0 || (iabs(B.pmx - *mvx) + iabs(B.pmy - *mvy))) {
+    n = 0;
+    for (int pos = sp; pos < ep; pos++) { L.cx[n] = p4x + *mvx + pts[pos][0]; L.cy[n] = p4y + *mvy + pts[pos][1]; n++; }
+    if (n) eval_dist(D, L, B.planes, metric, B.t8, umv, B.wp, B.wpw, B.wpo, B.mb_x, B.mb_y, B.bsx, B.bsy, n);
+    for (int pos = sp, k = 0; pos < ep; pos++, k++) {
+      int mcost = mvc(lam, *mvx + pts[pos][0], *mvy + pts[pos][1], B);
+      if (mcost >= *min_mcost) continue;
+      mcost += L.dist[k];
+      if (mcost < *min_mcost) { *min_mcost = mcost; best = pos; }
+    }
+  }
+  if (best) { *mvx += pts[best][0]; *mvy += pts[best][1]; }
+  return 0;
+}
+
+// EPZSSubPelBlockMotionSearch, me_epzs.c:2390
+__device__ int epzs_subpel(const WaveDev &D, Lds &L, const Blk &B, int *mvx, int *mvy, int min_mcost)
+{
+  const int start_hp = D.p.metric[0] != D.p.metric[1] ? 0 : 1, start_qp = D.p.metric[1] != D.p.metric[2] ? 0 : 1;
+  const int max_x4 = (D.W - B.bsx + 2 * JMHIP_PAD) << 2, max_y4 = (D.H - B.bsy + 2 * JMHIP_PAD) << 2;
+  int p4x = padq(B.pic_x, *mvx), p4y = padq(B.pic_y, *mvy);
+  int umv = !((p4x > 1) && (p4x < max_x4 - 1) && (p4y > 1) && (p4y < max_y4 - 1));
+  if (epzs_sub_level(D, L, B, 1, start_hp, D.p.lambda_mf[1], D.p.metric[1], umv, mvx, mvy, &min_mcost, D.p.epzs_thres[3][B.bt])) return min_mcost;
+  if (!start_qp) min_mcost = INT_MAX;
+  p4x = padq(B.pic_x, *mvx); p4y = padq(B.pic_y, *mvy);
+  umv = !((p4x > 0) && (p4x < max_x4) && (p4y > 0) && (p4y < max_y4));
+  (void)epzs_sub_level(D, L, B, 0, start_qp, D.p.lambda_mf[2], D.p.metric[2], umv, mvx, mvy, &min_mcost, D.p.epzs_thres[3][B.bt]);
+  return min_mcost;
+}
+
+// ---------------------------------------------------------------------------------------------- UMHexagonS (me_umhex.c)
+
+__constant__ int8_t c_ind_bt[8] = {0, 0, 1, 1, 2, 4, 4, 5};
+__constant__ int8_t c_dia_x[4] = {-1, 0, 1, 0}, c_dia_y[4] = {0, 1, 0, -1};
+__constant__ int8_t c_hex_x[6] = {2, 1, -1, -2, -1, 1}, c_hex_y[6] = {0, -2, -2, 0, 2, 2};
+__constant__ int8_t c_bhx[16] = {0, -2, -4, -4, -4, -4, -4, -2, 0, 2, 4, 4, 4, 4, 4, 2}, c_bhy[16] = {4, 3, 2, 1, 0, -1, -2, -3, -4, -3, -2, -1, 0, 1, 2, 3};
+
+struct UmState { int cx, cy, R, best_x, best_y, min_mcost, umv; };     // centre / best as VECTORS (pels, relative to the block position)
+
+// a group of candidates L.qx/qy[0..n) through SEARCH_ONE_PIXEL (me_umhex.h:32-51): in range, not visited, mv cost below the minimum -> evaluated,
+// marked visited, accepted on strict <. The positions of a group never depend on the outcome inside the group.
+__device__ void um_group(const WaveDev &D, Lds &L, const Blk &B, UmState &U, int n)
+{
+  int m = 0;
+  for (int k = 0; k < n; k++) {
+    const int vx = L.qx[k], vy = L.qy[k];
+    if (iabs(vx - U.cx) > U.R || iabs(vy - U.cy) > U.R) continue;
+    if (map_test(L, U.R, vx - U.cx, vy - U.cy)) continue;
+    bool dup = false;                                      // the same position twice in one group: the second sees what the first left
+    for (int j = 0; j < m; j++) dup |= (L.px[j] == vx && L.py[j] == vy);
+    if (dup) continue;
+    L.px[m] = vx; L.py[m] = vy; m++;
+  }
+  for (int k = 0; k < m; k++) { L.cx[k] = padq(B.pic_x, L.px[k] << 2); L.cy[k] = padq(B.pic_y, L.py[k] << 2); }
+  if (m) eval_dist(D, L, B.planes, D.p.metric[0], B.t8, U.umv, B.wp, B.wpw, B.wpo, B.mb_x, B.mb_y, B.bsx, B.bsy, m);
+  // replay in the group's own order (duplicates re-tested against the map as it evolves)
+  for (int k = 0; k < n; k++) {
+    const int vx = L.qx[k], vy = L.qy[k];
+    if (iabs(vx - U.cx) > U.R || iabs(vy - U.cy) > U.R) continue;
+    if (map_test(L, U.R, vx - U.cx, vy - U.cy)) continue;
+    int mcost = mvc(D.p.lambda_mf[0], vx << 2, vy << 2, B);
+    if (mcost < U.min_mcost) {
+      int j = 0;
+      while (!(L.px[j] == vx && L.py[j] == vy)) j++;
+      mcost += L.dist[j];
+      map_set(L, U.R, vx - U.cx, vy - U.cy);
+      if (mcost < U.min_mcost) { U.best_x = vx; U.best_y = vy; U.min_mcost = mcost; }
+    }
+  }
+}
+__device__ __forceinline__ void um_diamond(const WaveDev &D, Lds &L, const Blk &B, UmState &U)
+{
+  for (int m = 0; m < 4; m++) { L.qx[m] = U.best_x + c_dia_x[m]; L.qy[m] = U.best_y + c_dia_y[m]; }
+  um_group(D, L, B, U, 4);
+}
+
+// UMHEXIntegerPelBlockMotionSearch, me_umhex.c:229. mvx/mvy: centre in, result out (pels). R: the (dynamic) search range of this block.
+__device__ int umhex_pel(const WaveDev &D, Lds &L, const Blk &B, int R, int *mvx, int *mvy, int min_mcost)
+{
+  const jmhip_slice_params &P = D.p;
+  const int bt = B.bt, ref = B.ref, block_x = B.mb_x >> 2, block_y = B.mb_y >> 2, px2l = block_x;
+  UmState U{*mvx, *mvy, R, 0 - B.pic_x, 0 - B.pic_y, min_mcost, 0};             // best_x = best_y = 0 as ABSOLUTE positions (:254)
+  {
+    const int center_x = B.pic_x + U.cx, center_y = B.pic_y + U.cy;
+    U.umv = !((center_x > R) && (center_x < D.W - 1 - R - B.bsx) && (center_y > R) && (center_y < D.H - 1 - R - B.bsy));
+  }
+  int et = P.umhex_thres[0][bt];
+  map_clear(L, R);
+  {                                                                              // the centre :324-337 (always evaluated)
+    L.cx[0] = padq(B.pic_x, U.cx << 2); L.cy[0] = padq(B.pic_y, U.cy << 2);
+    eval_dist(D, L, B.planes, P.metric[0], B.t8, U.umv, B.wp, B.wpw, B.wpo, B.mb_x, B.mb_y, B.bsx, B.bsy, 1);
+    const int mcost = mvc(P.lambda_mf[0], U.cx << 2, U.cy << 2, B) + L.dist[0];
+    map_set(L, R, 0, 0);
+    if (mcost < U.min_mcost) { U.min_mcost = mcost; U.best_x = U.cx; U.best_y = U.cy; }
+  }
+  um_diamond(D, L, B, U);
+  if (U.cx != 0 || U.cy != 0) { L.qx[0] = 0; L.qy[0] = 0; um_group(D, L, B, U, 1); um_diamond(D, L, B, U); }
+  int pred_sad = 0;
+  bool done = false;
+  if (ref > 0 && U.min_mcost > et && L.um_best_cost[bt][px2l] < P.umhex_thres[2][bt]) done = true;     // :365
+  if (!done && U.min_mcost < et) done = true;
+  if (!done) {
+    // UMHEX_setup :797 (frame pictures, P slice, no intra macroblocks: flag_intra_SAD = 0)
+    const short (*am)[8][2] = L.all_mv[block_y * 4 + block_x];
+    int upx = 0, upy = 0, prx = 0, pry = 0, pred_ref_flag = 0, tbt = 0;
+    if (bt > 1) { tbt = c_ind_bt[bt]; upx = am[ref][tbt][0]; upy = am[ref][tbt][1]; }
+    if (ref > 0) {
+      prx = (int)__fdiv_rn((float)((int)am[ref - 1][bt][0] * (ref + 1)), (float)ref);          // :842-845: int product, float division, truncation
+      pry = (int)__fdiv_rn((float)((int)am[ref - 1][bt][1] * (ref + 1)), (float)ref);
+      pred_ref_flag = 1;
+    }
+    if (ref > 0) pred_sad = L.um_ref_cost[ref - 1][bt][block_y * 4 + block_x];
+    else if (bt > 1) pred_sad = D.um_cost[((size_t)tbt * D.h4 + (B.pic_y >> 2)) * D.w4 + (B.pic_x >> 2)] / 2;
+    else pred_sad = 0;
+    et = P.umhex_thres[1][bt];
+    float b1 = 0.f, b2 = 0.f;
+    if (pred_sad != 0) {                                                         // :382-392, single precision, no contraction
+      const float q = __fdiv_rn(P.umhex_bsize[bt], (float)(pred_sad * pred_sad));
+      b1 = __fsub_rn(q, P.umhex_alpha1[bt]); b2 = __fsub_rn(q, P.umhex_alpha2[bt]);
+    }
+#define EARLY(lbl2, lbl1) { const float lhs = (float)(U.min_mcost - pred_sad); if (lhs < __fmul_rn((float)pred_sad, b2)) goto lbl2; else if (lhs < __fmul_rn((float)pred_sad, b1)) goto lbl1; }
+    {
+      int n = 0;
+      // the two start-point candidates are separate SEARCH_ONE_PIXELs in JM; they are independent of each other's outcome only through
+      // the minimum, which the replay handles
+      if (bt > 1) { L.qx[n] = upx / 4; L.qy[n] = upy / 4; n++; }
+      if (pred_ref_flag) { L.qx[n] = prx / 4; L.qy[n] = pry / 4; n++; }
+      if (n) um_group(D, L, B, U, n);
+    }
+    um_diamond(D, L, B, U);
+    EARLY(fourth_2, fourth_1)
+    if (bt > 6) goto fourth_1;
+    {                                                                            // unsymmetrical cross :430-453
+      const int ix = U.best_x, iy = U.best_y;
+      int n = 0;
+      for (int i = 1; i < R; i += 2) { L.qx[n] = ix + i; L.qy[n] = iy; n++; L.qx[n] = ix - i; L.qy[n] = iy; n++; }
+      for (int i = 1; i < (R / 2); i += 2) { L.qx[n] = ix; L.qy[n] = iy + i; n++; L.qx[n] = ix; L.qy[n] = iy - i; n++; }
+      um_group(D, L, B, U, n);
+    }
+    EARLY(fourth_2, fourth_1)
+    {
+      const int ix = U.best_x, iy = U.best_y;
+      for (int pos = 1; pos < 25; pos++) { int dx, dy; spiral_offset(pos, &dx, &dy); L.qx[pos - 1] = ix + dx; L.qy[pos - 1] = iy + dy; }
+      um_group(D, L, B, U, 24);
+      EARLY(fourth_2, fourth_1)
+      for (int i = 1; i <= (R / 4); i++) {                                       // multi-hexagon grid :475-494
+        for (int m = 0; m < 16; m++) { L.qx[m] = ix + c_bhx[m] * i; L.qy[m] = iy + c_bhy[m] * i; }
+        um_group(D, L, B, U, 16);
+        if (U.min_mcost < et) goto terminate;
+      }
+    }
+  fourth_1:
+    for (int i = 0; i < R; i++) {
+      const int ix = U.best_x, iy = U.best_y;
+      for (int m = 0; m < 6; m++) { L.qx[m] = ix + c_hex_x[m]; L.qy[m] = iy + c_hex_y[m]; }
+      um_group(D, L, B, U, 6);
+      if (U.best_x == ix && U.best_y == iy) break;
+    }
+  fourth_2:
+    for (int i = 0; i < R; i++) {
+      const int ix = U.best_x, iy = U.best_y;
+      um_diamond(D, L, B, U);
+      if (U.best_x == ix && U.best_y == iy) break;
+    }
+#undef EARLY
+  }
+terminate:
+  // :534-554
+  for (int i = 0; i < (B.bsx >> 2); i++) for (int j = 0; j < (B.bsy >> 2); j++) {
+    L.um_ref_cost[ref][bt][(block_y + j) * 4 + block_x + i] = U.min_mcost;
+    if (ref == 0 && threadIdx.x == 0) D.um_cost[((size_t)bt * D.h4 + (B.pic_y >> 2) + j) * D.w4 + (B.pic_x >> 2) + i] = U.min_mcost;
+  }
+  if (ref == 0 || L.um_best_cost[bt][px2l] > U.min_mcost) L.um_best_cost[bt][px2l] = U.min_mcost;
+  *mvx = U.best_x; *mvy = U.best_y;
+  return U.min_mcost;
+}
+
+// UMHEXSubPelBlockMotionSearch, me_umhex.c:562 (quarter-pel metric and lambda for every position)
+__device__ int umhex_subpel(const WaveDev &D, Lds &L, const Blk &B, int *mvx, int *mvy, int min_mcost)
+{
+  const int start_hp = D.p.metric[0] != D.p.metric[1] ? 0 : 1, lam = D.p.lambda_mf[2], metric = D.p.metric[2];
+  const int p4x = padq(B.pic_x, 0), p4y = padq(B.pic_y, 0);
+  const short max_x4 = (short)((D.W - B.bsx + 2 * JMHIP_PAD) << 2), max_y4 = (short)((D.H - B.bsy + 2 * JMHIP_PAD) << 2);      // :590-591: short
+  const int umv = !((p4x + *mvx > 1) && (p4x + *mvx < max_x4 - 1) && (p4y + *mvy > 1) && (p4y + *mvy < max_y4 - 1));
+  const int cx0 = *mvx, cy0 = *mvy, pfx = (B.pmx - cx0) % 4, pfy = (B.pmy - cy0) % 4;
+  int cur_x = 0, cur_y = 0;
+  for (int i = 0; i < 49; i++) L.um_sstate[i] = 0;
+#define SS(x, y) L.um_sstate[((y) - cy0 + 3) * 7 + ((x) - cx0 + 3)]
+  {
+    int n = 0;
+    if (!start_hp) { L.cx[n] = p4x + cx0; L.cy[n] = p4y + cy0; n++; }
+    if (pfx != 0 || pfy != 0) { L.cx[n] = p4x + cx0 + pfx; L.cy[n] = p4y + cy0 + pfy; n++; }
+    if (n) eval_dist(D, L, B.planes, metric, B.t8, umv, B.wp, B.wpw, B.wpo, B.mb_x, B.mb_y, B.bsx, B.bsy, n);
+    int k = 0;
+    if (!start_hp) {
+      const int mcost = mvc(lam, cx0, cy0, B) + L.dist[k++];
+      SS(cx0, cy0) = 1;
+      if (mcost < min_mcost) { min_mcost = mcost; cur_x = cx0; cur_y = cy0; }
+    } else { SS(cx0, cy0) = 1; cur_x = cx0; cur_y = cy0; }
+    if (pfx != 0 || pfy != 0) {
+      const int mcost = mvc(lam, cx0 + pfx, cy0 + pfy, B) + L.dist[k++];
+      SS(cx0 + pfx, cy0 + pfy) = 1;
+      if (mcost < min_mcost) { min_mcost = mcost; cur_x = cx0 + pfx; cur_y = cy0 + pfy; }
+    }
+  }
+  int ix = cur_x, iy = cur_y;
+  for (int i = 0; i < 3; i++) {
+    int n = 0, idx[4];
+    for (int m = 0; m < 4; m++) {
+      const int vx = ix + c_dia_x[m], vy = iy + c_dia_y[m];
+      idx[m] = -1;
+      if (iabs(vx - cx0) <= 3 && iabs(vy - cy0) <= 3 && !SS(vx, vy)) { L.cx[n] = p4x + vx; L.cy[n] = p4y + vy; idx[m] = n++; }
+    }
+    if (n) eval_dist(D, L, B.planes, metric, B.t8, umv, B.wp, B.wpw, B.wpo, B.mb_x, B.mb_y, B.bsx, B.bsy, n);
+    int abort_search = 1;
+    for (int m = 0; m < 4; m++) if (idx[m] >= 0) {
+      const int vx = ix + c_dia_x[m], vy = iy + c_dia_y[m];
+      const int mcost = mvc(lam, vx, vy, B) + L.dist[idx[m]];
+      SS(vx, vy) = 1;
+      if (mcost < min_mcost) { min_mcost = mcost; cur_x = vx; cur_y = vy; abort_search = 0; }
+    }
+    ix = cur_x; iy = cur_y;
+    if (abort_search) break;
+  }
+#undef SS
+  *mvx = cur_x; *mvy = cur_y;
+  return min_mcost;
+}
+
+// ---------------------------------------------------------------------------------------------- BlockMotionSearch and above
+
+__device__ __forceinline__ int part_index(int bt, int block_x, int block_y)
+{
+  const int b8 = (block_y >> 1) * 2 + (block_x >> 1);
+  switch (bt) {
+  case 1: return 0;
+  case 2: return 1 + (block_y >> 1);
+  case 3: return 3 + (block_x >> 1);
+  case 4: return 5 + b8;
+  case 5: return 9 + b8 * 2 + (block_y & 1);
+  case 6: return 17 + b8 * 2 + (block_x & 1);
+  default: return 25 + b8 * 4 + (block_y & 1) * 2 + (block_x & 1);
+  }
+}
+
+// FindSkipModeMotionVector, mv-search.c:1189
+__device__ void find_skip_mv(const WaveDev &D, Lds &L, int mbx, int mby)
+{
+  int ax, ay, bx, by, pmx = 0, pmy = 0;
+  const int availA = nbr_pos(D, mbx, mby, -1, 0, &ax, &ay), availB = nbr_pos(D, mbx, mby, 0, -1, &bx, &by);
+  int zl = 1, za = 1;
+  if (availA) { const size_t at = (size_t)ay * D.w4 + ax; zl = (D.ref_idx[at] == 0 && D.mv[at * 2] == 0 && D.mv[at * 2 + 1] == 0); }
+  if (availB) { const size_t at = (size_t)by * D.w4 + bx; za = (D.ref_idx[at] == 0 && D.mv[at * 2] == 0 && D.mv[at * 2 + 1] == 0); }
+  if (!(za || zl)) mv_predictor(D, mbx, mby, 0, 0, 0, 16, 16, &pmx, &pmy, 0, 0, nullptr, nullptr);
+  for (int b = 0; b < 16; b++) { L.all_mv[b][0][0][0] = (short)pmx; L.all_mv[b][0][0][1] = (short)pmy; }
+}
+
+// BlockMotionSearch, mv-search.c:560 (P slice, rdopt 0)
+__device__ int block_motion_search(const WaveDev &D, Lds &L, int mbx, int mby, int ref, int mb_x, int mb_y, int bt, int search_range, jmhip_mb_inter *out)
+{
+  const jmhip_slice_params &P = D.p;
+  Blk B;
+  B.mbx = mbx; B.mby = mby; B.mb_x = mb_x; B.mb_y = mb_y; B.bt = bt; B.bsx = c_bsx[bt]; B.bsy = c_bsy[bt]; B.ref = ref;
+  B.pic_x = mbx * 16 + mb_x; B.pic_y = mby * 16 + mb_y;
+  B.planes = D.ref_sub[P.ref_slot[ref]];
+  B.wp = P.wp_me; B.wpw = P.wp_weight[ref]; B.wpo = P.wp_offset[ref];
+  B.t8 = 0;
+  const int block_x = mb_x >> 2, block_y = mb_y >> 2, pi = part_index(bt, block_x, block_y);
+  const int start_hp = P.metric[0] != P.metric[1] ? 0 : 1;
+  int mvx, mvy, min_mcost = INT_MAX;
+  mv_predictor(D, mbx, mby, ref, mb_x, mb_y, B.bsx, B.bsy, &B.pmx, &B.pmy, P.search_mode == JMHIP_SEARCH_UMHEX && P.umhex_dsr, bt, &search_range, nullptr);
+  const int R = search_range;
+  if (P.search_mode == JMHIP_SEARCH_UMHEX) {
+    mvx = B.pmx / 4; mvy = B.pmy / 4;
+    mvx = clampi(mvx, -R, R); mvy = clampi(mvy, -R, R);
+    mvx = clampi(mvx, -2047 + R, 2047 - R); mvy = clampi(mvy, P.level_mv_min + R, P.level_mv_max - R);
+    min_mcost = umhex_pel(D, L, B, R, &mvx, &mvy, min_mcost);
+    __syncthreads();                                                           // lane 0 wrote the cost map
+  } else if (P.search_mode == JMHIP_SEARCH_EPZS) {
+    mvx = (B.pmx + 2) >> 2; mvy = (B.pmy + 2) >> 2;
+    mvx = clampi(mvx, -R, R); mvy = clampi(mvy, -R, R);
+    mvx = clampi(mvx, -2047 + R, 2047 - R); mvy = clampi(mvy, P.level_mv_min + R, P.level_mv_max - R);
+    min_mcost = epzs_pel(D, L, B, mby * D.mbw + mbx, R, &mvx, &mvy);
+    __syncthreads();                                                           // lane 0 wrote the row memories
+  } else if (P.search_mode == JMHIP_SEARCH_FASTFULL) {
+    // the window of SetupFastFullPelSearch (me_fullfast.c:550-566): centred on the 16x16 predictor of this reference, found when the reference's
+    // first block (the 16x16) was searched and kept in motion_cost[0][ref][0..2]
+    if (bt == 1) {
+      int cx = B.pmx / 4, cy = B.pmy / 4;
+      const int Rf = (P.full_search == 2 || ref == 0) ? P.search_range : P.search_range / 2;
+      cx = clampi(cx, -Rf, Rf); cy = clampi(cy, -Rf, Rf);
+      cx = clampi(cx, -2047 + Rf, 2047 - Rf); cy = clampi(cy, P.level_mv_min + Rf, P.level_mv_max - Rf);
+      L.motion_cost[0][ref][0] = cx; L.motion_cost[0][ref][1] = cy; L.motion_cost[0][ref][2] = Rf;
+    }
+    min_mcost = full_window(D, L, B, L.motion_cost[0][ref][0], L.motion_cost[0][ref][1], L.motion_cost[0][ref][2], 1, &mvx, &mvy);
+  } else {
+    int cx = B.pmx / 4, cy = B.pmy / 4;
+    cx = clampi(cx, -R, R); cy = clampi(cy, -R, R);
+    cx = clampi(cx, -2047 + R, 2047 - R); cy = clampi(cy, P.level_mv_min + R, P.level_mv_max - R);
+    min_mcost = full_window(D, L, B, cx, cy, R, 0, &mvx, &mvy);
+  }
+  if (threadIdx.x == 0) { out->mv_int[ref][pi][0] = (int16_t)mvx; out->mv_int[ref][pi][1] = (int16_t)mvy; out->cost_int[ref][pi] = min_mcost; }
+  mvx <<= 2; mvy <<= 2;
+  // sub-pel :781-827
+  bool do_sub = true;
+  if (P.search_mode == JMHIP_SEARCH_EPZS && ref > 0) do_sub = (2 * (long long)min_mcost < 7 * (long long)D.ep_dist[(size_t)(bt - 1) * D.w4 + (B.pic_x >> 2)]);   // min_mcost < 3.5 * prevSad
+  if (do_sub) {
+    if (!start_hp) min_mcost = INT_MAX;
+    if (P.search_mode == JMHIP_SEARCH_UMHEX && bt > 3) min_mcost = umhex_subpel(D, L, B, &mvx, &mvy, min_mcost);
+    else if (P.search_mode == JMHIP_SEARCH_EPZS && P.epzs_subpel_me) min_mcost = epzs_subpel(D, L, B, &mvx, &mvy, min_mcost);
+    else min_mcost = subpel_full(D, L, B, &mvx, &mvy, min_mcost);
+  }
+  if (bt == 1) {                                                               // skip shortcut :829-849, every reference
+    find_skip_mv(D, L, mbx, mby);
+    const int smx = L.all_mv[0][0][0][0], smy = L.all_mv[0][0][0][1];
+    int cost;
+    const uint8_t *pl0 = D.ref_sub[P.ref_slot[0]];
+    if (P.md_metric == 2) {
+      L.cx[0] = padq(mbx * 16, smx); L.cy[0] = padq(mby * 16, smy);
+      eval_dist(D, L, pl0, 2, 0, 1, P.wp_pred, P.wp_weight[0], P.wp_offset[0], 0, 0, 16, 16, 1);
+      cost = L.dist[0];
+    } else {                                                                   // SAD: LumaPrediction clamps per 4x4 block
+      cost = 0;
+      for (int b = 0; b < 16; b++) {
+        L.cx[0] = padq(mbx * 16 + (b & 3) * 4, smx); L.cy[0] = padq(mby * 16 + (b >> 2) * 4, smy);
+        eval_dist(D, L, pl0, 0, 0, 1, P.wp_pred, P.wp_weight[0], P.wp_offset[0], (b & 3) * 4, (b >> 2) * 4, 4, 4, 1);
+        cost += L.dist[0];
+      }
+    }
+    cost -= (P.lambda_mf[2] + 4096) >> 13;
+    if (cost < min_mcost) { min_mcost = cost; mvx = smx; mvy = smy; }
+  }
+  for (int j = block_y; j < block_y + (B.bsy >> 2); j++) for (int i = block_x; i < block_x + (B.bsx >> 2); i++) { L.all_mv[j * 4 + i][ref][bt][0] = (short)mvx; L.all_mv[j * 4 + i][ref][bt][1] = (short)mvy; }
+  if (threadIdx.x == 0) {
+    out->pred[ref][pi][0] = (int16_t)B.pmx; out->pred[ref][pi][1] = (int16_t)B.pmy;
+    out->mv[ref][pi][0] = (int16_t)mvx; out->mv[ref][pi][1] = (int16_t)mvy; out->cost[ref][pi] = min_mcost;
+  }
+  return min_mcost;
+}
+
+// field writes: one lane writes, everyone reads back after the barrier
+__device__ __forceinline__ void field_set(const WaveDev &D, int by, int bx, int ref, int mvx, int mvy)
+{
+  if (threadIdx.x == 0) { const size_t at = (size_t)by * D.w4 + bx; D.ref_idx[at] = (int8_t)ref; D.mv[at * 2] = (short)mvx; D.mv[at * 2 + 1] = (short)mvy; }
+}
+
+// PartitionMotionSearch, mv-search.c:1378
+__device__ void partition_motion_search(const WaveDev &D, Lds &L, int mbx, int mby, int bt, int block8, jmhip_mb_inter *out)
+{
+  const int8_t bx0[5][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 2, 0, 0}, {0, 2, 0, 2}};
+  const int8_t by0[5][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 2, 0, 0}, {0, 0, 0, 0}, {0, 0, 2, 2}};
+  const int8_t psz[8][2] = {{4, 4}, {4, 4}, {4, 2}, {2, 4}, {2, 2}, {2, 1}, {1, 2}, {1, 1}};
+  const jmhip_slice_params &P = D.p;
+  const int pt = bt < 4 ? bt : 4, sh0 = psz[pt][0], sv0 = psz[pt][1], sh = psz[bt][0], sv = psz[bt][1], by = by0[pt][block8], bx = bx0[pt][block8];
+  for (int ref = 0; ref < P.num_refs; ref++) {
+    int range;
+    if (P.full_search == 2) range = P.search_range;
+    else if (P.full_search == 1) range = P.search_range / (min(ref, 1) + 1);
+    else range = P.search_range / ((min(ref, 1) + 1) * min(2, bt));
+    int mc = 0;
+    for (int v = by; v < by + sv0; v += sv) for (int h = bx; h < bx + sh0; h += sh) {
+      mc += block_motion_search(D, L, mbx, mby, ref, h << 2, v << 2, bt, range, out);
+      const int mvx = L.all_mv[v * 4 + h][ref][bt][0], mvy = L.all_mv[v * 4 + h][ref][bt][1];
+      for (int j = 0; j < sv; j++) for (int i = 0; i < sh; i++) field_set(D, mby * 4 + v + j, mbx * 4 + h + i, ref, mvx, mvy);
+      __syncthreads();
+    }
+    L.motion_cost[bt][ref][block8] = mc;
+  }
+}
+
+__device__ __forceinline__ int list0_cost(const WaveDev &D, const Lds &L, int mode, int block, int *best_ref)
+{
+  int best = INT_MAX;
+  for (int ref = 0; ref < D.p.num_refs; ref++) {
+    const int mcost = (ref ? D.p.ref_cost1 : 0) + L.motion_cost[mode][ref][block];
+    if (mcost < best) { best = mcost; *best_ref = ref; }
+  }
+  return best;
+}
+__device__ __forceinline__ int refbits(int r) { return r == 0 ? 1 : (r < 3 ? 3 : 5); }       // mv-search.c:344-352, r <= 3
+
+// encode_one_macroblock_low (md_low.c:46), inter part, for one macroblock
+__device__ void macroblock_low(const WaveDev &D, Lds &L, int mbx, int mby, jmhip_mb_inter *out)
+{
+  const jmhip_slice_params &P = D.p;
+  const int8_t psz[8][2] = {{4, 4}, {4, 4}, {4, 2}, {2, 4}, {2, 2}, {2, 1}, {1, 2}, {1, 1}};
+  const int bx0 = mbx * 4, by0 = mby * 4;
+  int best_mode = 1, min_cost = INT_MAX;
+  int l0ref[5][4] = {{0}}, b8m[4] = {0, 0, 0, 0};
+  for (int mode = 1; mode < 4; mode++) {
+    if (!P.valid[mode]) continue;
+    int cost = 0;
+    for (int block = 0; block < (mode == 1 ? 1 : 2); block++) {
+      int best_ref = 0;
+      partition_motion_search(D, L, mbx, mby, mode, block, out);
+      cost += list0_cost(D, L, mode, block, &best_ref);
+      if (mode == 1) {
+        for (int b = 0; b < 16; b++) field_set(D, by0 + (b >> 2), bx0 + (b & 3), best_ref, L.all_mv[b][best_ref][1][0], L.all_mv[b][best_ref][1][1]);
+        for (int k = 0; k < 4; k++) l0ref[1][k] = best_ref;
+      } else if (mode == 2) l0ref[2][2 * block] = l0ref[2][2 * block + 1] = best_ref;
+      else l0ref[3][block] = l0ref[3][block + 2] = best_ref;
+      if (mode > 1 && block == 0)
+        for (int j = 0; j < psz[mode][1]; j++) for (int i = 0; i < psz[mode][0]; i++)
+          field_set(D, by0 + j, bx0 + i, best_ref, L.all_mv[j * 4 + i][best_ref][mode][0], L.all_mv[j * 4 + i][best_ref][mode][1]);
+      __syncthreads();
+    }
+    if (cost < min_cost) { best_mode = mode; min_cost = cost; }
+  }
+  if (P.valid[4] || P.valid[5] || P.valid[6] || P.valid[7]) {
+    int cost8x8 = 0;
+    for (int block = 0; block < 4; block++) {
+      int mc8 = INT_MAX;
+      const int j0 = block & 2, i0 = (block & 1) * 2;
+      for (int mode = 4; mode < 8; mode++) {
+        if (!P.valid[mode]) continue;
+        int best_ref = 0;
+        partition_motion_search(D, L, mbx, mby, mode, block, out);
+        int cost = list0_cost(D, L, mode, block, &best_ref);
+        if (threadIdx.x == 0) for (int j = 0; j < 2; j++) for (int i = 0; i < 2; i++) D.ref_idx[(size_t)(by0 + j0 + j) * D.w4 + bx0 + i0 + i] = (int8_t)best_ref;
+        __syncthreads();
+        if (cost != INT_MAX) cost += ((P.lambda_mf[2] * (P.num_refs <= 1 ? 0 : refbits(mode - 4))) >> 16) - 1;
+        if (cost < mc8) { mc8 = cost; b8m[block] = mode; l0ref[4][block] = best_ref; }
+      }
+      cost8x8 += mc8;
+      for (int j = j0; j < j0 + 2; j++) for (int i = i0; i < i0 + 2; i++)
+        field_set(D, by0 + j, bx0 + i, l0ref[4][block], L.all_mv[j * 4 + i][l0ref[4][block]][b8m[block]][0], L.all_mv[j * 4 + i][l0ref[4][block]][b8m[block]][1]);
+      __syncthreads();
+    }
+    if (cost8x8 < min_cost) { best_mode = 8; min_cost = cost8x8; }
+  }
+  find_skip_mv(D, L, mbx, mby);
+  for (int b = 0; b < 16; b++) {
+    const int k8 = 2 * (b >> 3) + ((b & 3) >> 1), m8 = best_mode == 8 ? b8m[k8] : best_mode, r = l0ref[best_mode == 8 ? 4 : best_mode][k8];
+    field_set(D, by0 + (b >> 2), bx0 + (b & 3), r, L.all_mv[b][r][m8][0], L.all_mv[b][r][m8][1]);
+    if (threadIdx.x == 0) { out->final_mv[b][0] = L.all_mv[b][r][m8][0]; out->final_mv[b][1] = L.all_mv[b][r][m8][1]; }
+  }
+  if (threadIdx.x == 0) {
+    out->best_mode = best_mode; out->min_cost = min_cost;
+    for (int k = 0; k < 4; k++) { out->b8mode[k] = best_mode == 8 ? b8m[k] : best_mode; out->b8ref[k] = l0ref[best_mode == 8 ? 4 : best_mode][k]; }
+    out->skip_mv[0] = L.all_mv[0][0][0][0]; out->skip_mv[1] = L.all_mv[0][0][0][1];
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(64) void p_slice_kernel(WaveDev D, const short *carry_slice_in, short *carry_slice_out)
+{
+  __shared__ Lds L;
+  const int lane = threadIdx.x;
+  const int row0 = D.p.mb_first / D.mbw, mby = row0 + blockIdx.x;
+  const int last = D.p.mb_first + D.p.mb_count - 1;
+  const int x0 = max(0, D.p.mb_first - mby * D.mbw), x1 = min(D.mbw - 1, last - mby * D.mbw);
+  if (x0 > x1) return;
+  // img->all_mv as the previous macroblock in coding order left it: the slice's first macroblock takes the persistent carry, other row starts
+  // the speculated one; inside a row the LDS array simply lives on
+  for (int i = lane; i < (int)(sizeof(L.all_mv) / 4); i += 64) reinterpret_cast<uint32_t *>(L.all_mv)[i] = 0u;
+  __syncthreads();
+  {
+    const short *cin = (mby * D.mbw + x0 == D.p.mb_first) ? carry_slice_in : D.carry_in + (size_t)mby * WR * CARRY * 2;
+    for (int r = 0; r < WR; r++) {
+      for (int b = 0; b < 16; b++) { L.all_mv[b][r][1][0] = cin[(r * CARRY) * 2]; L.all_mv[b][r][1][1] = cin[(r * CARRY) * 2 + 1]; }
+      for (int b = 0; b < 16; b++) { const int k8 = 2 * (b >> 3) + ((b & 3) >> 1); L.all_mv[b][r][4][0] = cin[(r * CARRY + 1 + k8) * 2]; L.all_mv[b][r][4][1] = cin[(r * CARRY + 1 + k8) * 2 + 1]; }
+    }
+  }
+  for (int mbx = x0; mbx <= x1; mbx++) {
+    // wait for the row above: its macroblock mbx + 1 (or its last one) if that one belongs to the slice
+    if (mby > 0) {
+      const int need = min(mbx + 1, D.mbw - 1);
+      if ((mby - 1) * D.mbw + need >= D.p.mb_first) {
+        long spins = 0;
+        while (__hip_atomic_load(&D.prog[mby - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= need) {
+          if (++spins > (1L << 28) || __hip_atomic_load(&D.flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            __hip_atomic_store(&D.flags[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+          }
+          __builtin_amdgcn_s_sleep(8);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+    }
+    // the source macroblock
+    {
+      const int r = lane >> 2, k = lane & 3;
+      *reinterpret_cast<uint32_t *>(&L.cur[r][k * 4]) = *reinterpret_cast<const uint32_t *>(D.cur + (size_t)(mby * 16 + r) * D.W + mbx * 16 + k * 4);
+    }
+    __syncthreads();
+    macroblock_low(D, L, mbx, mby, D.out + (mby * D.mbw + mbx));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (lane == 0) __hip_atomic_store(&D.prog[mby], mbx + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // what this row leaves for the macroblock that follows in coding order
+  if (lane == 0) {
+    short *co = (mby * D.mbw + x1 == last) ? carry_slice_out : D.carry_out + (size_t)mby * WR * CARRY * 2;
+    for (int r = 0; r < WR; r++) {
+      co[(r * CARRY) * 2] = L.all_mv[0][r][1][0]; co[(r * CARRY) * 2 + 1] = L.all_mv[0][r][1][1];
+      for (int k8 = 0; k8 < 4; k8++) { const int b = (k8 >> 1) * 8 + (k8 & 1) * 2; co[(r * CARRY + 1 + k8) * 2] = L.all_mv[b][r][4][0]; co[(r * CARRY + 1 + k8) * 2 + 1] = L.all_mv[b][r][4][1]; }
+    }
+  }
+}
+
+// rows whose speculated start differs from what the row above left: flag[1] = first such row (min), else untouched
+__global__ void carry_check_kernel(const short *carry_in, const short *carry_out, int row_first, int rows, int *flags)
+{
+  const int r = row_first + 1 + blockIdx.x * blockDim.x + threadIdx.x;        // row r starts from what row r - 1 left
+  if (r >= row_first + rows) return;
+  bool same = true;
+  for (int i = 0; i < WR * CARRY * 2; i++) same &= carry_in[(size_t)r * WR * CARRY * 2 + i] == carry_out[(size_t)(r - 1) * WR * CARRY * 2 + i];
+  if (!same) atomicMin(&flags[1], r);
+}
+
+struct SliceState {
+  int8_t *ref_idx = nullptr; short *mv = nullptr;
+  int *prog = nullptr, *flags = nullptr;
+  jmhip_mb_inter *out = nullptr;
+  int *ep_dist = nullptr, *ep_dist_snap = nullptr; short *ep_motion = nullptr, *ep_motion_snap = nullptr; short *ep_col = nullptr;
+  short *carry_in = nullptr, *carry_out = nullptr, *carry_slice = nullptr, *carry_slice_next = nullptr;
+  int *um_cost = nullptr, *um_cost_snap = nullptr;
+  int passes = 0;
+  bool has_col = false;
+};
+
+}  // namespace
+
+// the state lives in the context as an opaque pointer (jmhip_internal.h: void *slice_state)
+static SliceState *slice_state(jmhip_ctx *c)
+{
+  if (c->slice_state) return static_cast<SliceState *>(c->slice_state);
+  SliceState *s = new SliceState();
+  const size_t w4 = c->W / 4, h4 = c->H / 4, nmb = (size_t)c->mbw * c->mbh;
+  bool ok = hipMalloc((void **)&s->ref_idx, w4 * h4) == hipSuccess && hipMalloc((void **)&s->mv, w4 * h4 * 4) == hipSuccess &&
+            hipMalloc((void **)&s->prog, sizeof(int) * c->mbh) == hipSuccess && hipMalloc((void **)&s->flags, sizeof(int) * 4) == hipSuccess &&
+            hipMalloc((void **)&s->out, sizeof(jmhip_mb_inter) * nmb) == hipSuccess &&
+            hipMalloc((void **)&s->ep_dist, sizeof(int) * 7 * w4) == hipSuccess && hipMalloc((void **)&s->ep_dist_snap, sizeof(int) * 7 * w4) == hipSuccess &&
+            hipMalloc((void **)&s->ep_motion, sizeof(short) * WR * 7 * 4 * w4 * 2) == hipSuccess && hipMalloc((void **)&s->ep_motion_snap, sizeof(short) * WR * 7 * 4 * w4 * 2) == hipSuccess &&
+            hipMalloc((void **)&s->ep_col, sizeof(short) * h4 * w4 * 2) == hipSuccess &&
+            hipMalloc((void **)&s->carry_in, sizeof(short) * c->mbh * WR * CARRY * 2) == hipSuccess && hipMalloc((void **)&s->carry_out, sizeof(short) * c->mbh * WR * CARRY * 2) == hipSuccess &&
+            hipMalloc((void **)&s->carry_slice, sizeof(short) * WR * CARRY * 2) == hipSuccess && hipMalloc((void **)&s->carry_slice_next, sizeof(short) * WR * CARRY * 2) == hipSuccess &&
+            hipMalloc((void **)&s->um_cost, sizeof(int) * 8 * h4 * w4) == hipSuccess && hipMalloc((void **)&s->um_cost_snap, sizeof(int) * 8 * h4 * w4) == hipSuccess;
+  if (!ok) { delete s; return nullptr; }       // (partial allocations are released with the context's device reset; the call fails loudly)
+  c->slice_state = s;
+  return s;
+}
+
+extern "C" int jmhip_slice_state_reset(jmhip_ctx *c)
+{
+  if (!c) return JMHIP_ERR_ARG;
+  JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
+  SliceState *s = slice_state(c);
+  if (!s) return jm_fail(c, JMHIP_ERR_NOMEM, "slice search state");
+  const size_t w4 = c->W / 4, h4 = c->H / 4;
+  JM_HIP_CHECK(c, hipMemsetAsync(s->ep_dist, 0, sizeof(int) * 7 * w4, c->stream));
+  JM_HIP_CHECK(c, hipMemsetAsync(s->ep_motion, 0, sizeof(short) * WR * 7 * 4 * w4 * 2, c->stream));
+  JM_HIP_CHECK(c, hipMemsetAsync(s->ep_col, 0, sizeof(short) * h4 * w4 * 2, c->stream));
+  JM_HIP_CHECK(c, hipMemsetAsync(s->carry_slice, 0, sizeof(short) * WR * CARRY * 2, c->stream));
+  JM_HIP_CHECK(c, hipMemsetAsync(s->carry_in, 0, sizeof(short) * c->mbh * WR * CARRY * 2, c->stream));
+  JM_HIP_CHECK(c, hipMemsetAsync(s->um_cost, 0, sizeof(int) * 8 * h4 * w4, c->stream));
+  JM_HIP_CHECK(c, hipMemsetAsync(s->ref_idx, 0xff, w4 * h4, c->stream));
+  JM_HIP_CHECK(c, hipMemsetAsync(s->mv, 0, w4 * h4 * 4, c->stream));
+  s->has_col = false;
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_epzs_colocated_upload(jmhip_ctx *c, const int16_t *col_mv)
+{
+  if (!c || !col_mv) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_epzs_colocated_upload: NULL") : JMHIP_ERR_ARG;
+  JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
+  SliceState *s = slice_state(c);
+  if (!s) return jm_fail(c, JMHIP_ERR_NOMEM, "slice search state");
+  JM_HIP_CHECK(c, hipMemcpyAsync(s->ep_col, col_mv, sizeof(short) * (size_t)(c->H / 4) * (c->W / 4) * 2, hipMemcpyHostToDevice, c->stream));
+  JM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+  s->has_col = true;
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_p_slice_search(jmhip_ctx *c, const jmhip_slice_params *prm, jmhip_mb_inter *results)
+{
+  if (!c || !prm) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_p_slice_search: NULL arguments") : JMHIP_ERR_ARG;
+  const int nmb = c->mbw * c->mbh;
+  if (prm->search_mode != JMHIP_SEARCH_FULL && prm->search_mode != JMHIP_SEARCH_FASTFULL && prm->search_mode != JMHIP_SEARCH_UMHEX && prm->search_mode != JMHIP_SEARCH_EPZS)
+    return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_p_slice_search: search_mode must be -1, 0, 1 or 3 (simplified UMHexagonS, mode 2, is not built)");
+  if (prm->num_refs < 1 || prm->num_refs > JMHIP_SLICE_REFS) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_p_slice_search: 1..JMHIP_SLICE_REFS references");
+  if (prm->search_range < 1 || prm->search_range > c->cfg.search_range || prm->search_range > 33) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_p_slice_search: search_range (at most 33 and the context's)");
+  if (prm->mb_first < 0 || prm->mb_count < 1 || prm->mb_first + prm->mb_count > nmb) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_p_slice_search: slice outside the picture");
+  if (!prm->valid[1]) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_p_slice_search: the 16x16 mode must be enabled");
+  if (!c->has_cur) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_p_slice_search: current picture not uploaded");
+  for (int k = 0; k < 3; k++) {
+    if (prm->metric[k] != 0 && prm->metric[k] != 2) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_p_slice_search: ME metrics are SAD (0) or SATD (2)");
+    if (prm->lambda_mf[k] < 0 || prm->lambda_mf[k] >= (1 << 24)) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_p_slice_search: lambda factor out of range");
+  }
+  if ((prm->search_mode == JMHIP_SEARCH_FULL || prm->search_mode == JMHIP_SEARCH_FASTFULL) && prm->metric[0] != 0)
+    return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_p_slice_search: the exhaustive searches take the SAD metric at full-pel positions");
+  if (prm->md_metric != 0 && prm->md_metric != 2) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_p_slice_search: mode-decision metric SAD or SATD");
+  if ((prm->wp_me || prm->wp_pred) && (prm->wp_denom < 0 || prm->wp_denom > 7)) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_p_slice_search: weighted-prediction denominator");
+  for (int r = 0; r < prm->num_refs; r++) {
+    const int sl = prm->ref_slot[r];
+    if (sl < 0 || sl >= (int)c->refs.size() || !c->refs[sl].has_pic || !c->refs[sl].has_luma_sub) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_p_slice_search: reference slot without sub-pel planes (jmhip_interp_luma)");
+  }
+  if (prm->search_mode == JMHIP_SEARCH_EPZS && (prm->epzs_nwin > 40 || prm->epzs_nwin_ext > 100 || prm->epzs_nwin < 0 || prm->epzs_nwin_ext < 0)) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_p_slice_search: EPZS window predictor tables (jmhip_epzs_setup)");
+  JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
+  SliceState *s = slice_state(c);
+  if (!s) return jm_fail(c, JMHIP_ERR_NOMEM, "slice search state");
+  if (prm->search_mode == JMHIP_SEARCH_EPZS && prm->epzs_temporal && !s->has_col) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_p_slice_search: EPZS temporal predictors need jmhip_epzs_colocated_upload");
+  int rc = jm_ensure_ref_table(c);
+  if (rc) return rc;
+  const size_t w4 = c->W / 4, h4 = c->H / 4;
+  const int row_first = prm->mb_first / c->mbw, row_last = (prm->mb_first + prm->mb_count - 1) / c->mbw, rows = row_last - row_first + 1;
+  if (prm->mb_first == 0) {                                  // a new picture: enc_picture->ref_idx / mv start empty
+    JM_HIP_CHECK(c, hipMemsetAsync(s->ref_idx, 0xff, w4 * h4, c->stream));
+    JM_HIP_CHECK(c, hipMemsetAsync(s->mv, 0, w4 * h4 * 4, c->stream));
+  }
+  WaveDev D{};
+  D.p = *prm;
+  D.W = c->W; D.H = c->H; D.Wp = c->Wp; D.Hp = c->Hp; D.mbw = c->mbw; D.mbh = c->mbh; D.w4 = (int)w4; D.h4 = (int)h4;
+  D.cur = c->cur_y;
+  D.ref_sub = reinterpret_cast<const uint8_t *const *>(c->ref_ptrs_dev) + 32;
+  D.ref_idx = s->ref_idx; D.mv = s->mv; D.prog = s->prog; D.flags = s->flags; D.out = s->out;
+  D.ep_dist = s->ep_dist; D.ep_motion = s->ep_motion; D.ep_col = s->ep_col;
+  D.carry_in = s->carry_in; D.carry_out = s->carry_out; D.um_cost = s->um_cost;
+  const bool epzs = prm->search_mode == JMHIP_SEARCH_EPZS;
+  // the row memories are read-modify-write: a re-run must start from what this call found
+  if (epzs) {
+    JM_HIP_CHECK(c, hipMemcpyAsync(s->ep_dist_snap, s->ep_dist, sizeof(int) * 7 * w4, hipMemcpyDeviceToDevice, c->stream));
+    JM_HIP_CHECK(c, hipMemcpyAsync(s->ep_motion_snap, s->ep_motion, sizeof(short) * WR * 7 * 4 * w4 * 2, hipMemcpyDeviceToDevice, c->stream));
+  }
+  s->passes = 0;
+  jm_stage_begin(c, JMHIP_STAGE_ME_INT);
+  for (;;) {
+    JM_HIP_CHECK(c, hipMemsetAsync(s->prog, 0, sizeof(int) * c->mbh, c->stream));
+    const int init_flags[4] = {0, 1 << 30, 0, 0};
+    JM_HIP_CHECK(c, hipMemcpyAsync(s->flags, init_flags, sizeof(init_flags), hipMemcpyHostToDevice, c->stream));
+    p_slice_kernel<<<rows, 64, 0, c->stream>>>(D, s->carry_slice, s->carry_slice_next);
+    JM_HIP_CHECK(c, hipGetLastError());
+    s->passes++;
+    int flags[4] = {0, 1 << 30, 0, 0};
+    if (epzs && rows > 1) carry_check_kernel<<<(rows + 63) / 64, 64, 0, c->stream>>>(s->carry_in, s->carry_out, row_first, rows, s->flags);
+    JM_HIP_CHECK(c, hipMemcpyAsync(flags, s->flags, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
+    JM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    if (flags[0]) { jm_stage_end(c, JMHIP_STAGE_ME_INT); return jm_fail(c, JMHIP_ERR_DEVICE, "p_slice_kernel: a row waited too long for the row above (internal error)"); }
+    if (!epzs || rows == 1 || flags[1] == (1 << 30)) break;
+    if (s->passes > rows + 1) { jm_stage_end(c, JMHIP_STAGE_ME_INT); return jm_fail(c, JMHIP_ERR_DEVICE, "p_slice_kernel: row-start speculation did not settle (internal error)"); }
+    // next pass: every row starts from what the row above left in this pass; rows up to the first wrong one were exact already
+    JM_HIP_CHECK(c, hipMemcpyAsync(s->carry_in + (size_t)(row_first + 1) * WR * CARRY * 2, s->carry_out + (size_t)row_first * WR * CARRY * 2,
+                                   sizeof(short) * (size_t)(rows - 1) * WR * CARRY * 2, hipMemcpyDeviceToDevice, c->stream));
+    JM_HIP_CHECK(c, hipMemcpyAsync(s->ep_dist, s->ep_dist_snap, sizeof(int) * 7 * w4, hipMemcpyDeviceToDevice, c->stream));
+    JM_HIP_CHECK(c, hipMemcpyAsync(s->ep_motion, s->ep_motion_snap, sizeof(short) * WR * 7 * 4 * w4 * 2, hipMemcpyDeviceToDevice, c->stream));
+  }
+  jm_stage_end(c, JMHIP_STAGE_ME_INT);
+  std::swap(s->carry_slice, s->carry_slice_next);
+  if (results) return jmhip_slice_results_download(c, results, prm->mb_first, prm->mb_count);
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_slice_results_download(jmhip_ctx *c, jmhip_mb_inter *results, int mb_first, int mb_count)
+{
+  if (!c || !results || mb_first < 0 || mb_count < 1 || mb_first + mb_count > c->mbw * c->mbh || !c->slice_state) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_slice_results_download: arguments") : JMHIP_ERR_ARG;
+  SliceState *s = static_cast<SliceState *>(c->slice_state);
+  JM_HIP_CHECK(c, hipMemcpyAsync(results, s->out + mb_first, sizeof(jmhip_mb_inter) * (size_t)mb_count, hipMemcpyDeviceToHost, c->stream));
+  JM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_slice_field_download(jmhip_ctx *c, int8_t *ref_idx, int16_t *mv)
+{
+  if (!c || !c->slice_state) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_slice_field_download: no slice has been searched") : JMHIP_ERR_ARG;
+  SliceState *s = static_cast<SliceState *>(c->slice_state);
+  const size_t n = (size_t)(c->W / 4) * (c->H / 4);
+  if (ref_idx) JM_HIP_CHECK(c, hipMemcpyAsync(ref_idx, s->ref_idx, n, hipMemcpyDeviceToHost, c->stream));
+  if (mv) JM_HIP_CHECK(c, hipMemcpyAsync(mv, s->mv, n * 4, hipMemcpyDeviceToHost, c->stream));
+  JM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_slice_result_info(jmhip_ctx *c, int *passes)
+{
+  if (!c || !c->slice_state) return JMHIP_ERR_ARG;
+  if (passes) *passes = static_cast<SliceState *>(c->slice_state)->passes;
+  return JMHIP_OK;
+}
+
+void jm_slice_state_free(jmhip_ctx *c)
+{
+  SliceState *s = static_cast<SliceState *>(c->slice_state);
+  if (!s) return;
+  void *bufs[] = {s->ref_idx, s->mv, s->prog, s->flags, s->out, s->ep_dist, s->ep_dist_snap, s->ep_motion, s->ep_motion_snap, s->ep_col, s->carry_in, s->carry_out,
+                  s->carry_slice, s->carry_slice_next, s->um_cost, s->um_cost_snap};
+  for (void *b : bufs) if (b) (void)hipFree(b);
+  delete s;
+  c->slice_state = nullptr;
+}
+
+// ---------------------------------------------------------------------------------------------- host helpers: JM's initialisation arithmetic
+
+static int round_log2(int v) { int r = 0; const int sq = v * v; while ((1 << (r + 1)) <= sq) r++; return (r + 1) >> 1; }      // me_epzs.c:241
+
+// EPZSInit, me_epzs.c:333 (8-bit video, ChromaMEEnable 0: chroma_weight = 0); EPZSWindowPredictorInit :261 (EPZSSubPelGrid 0)
+extern "C" void jmhip_epzs_setup(jmhip_slice_params *p, int search_range, int pattern, int dual, int fixed, int temporal, int spatial_mem, int subpel_me,
+                                 int min_scale, int med_scale, int max_scale, int subpel_scale)
+{
+  static const int minb[8] = {0, 64, 32, 32, 16, 8, 8, 4}, medb[8] = {0, 256, 128, 128, 64, 32, 32, 16}, maxb[8] = {0, 768, 384, 384, 192, 96, 96, 48};
+  p->epzs_pattern = pattern; p->epzs_dual = dual; p->epzs_fixed = fixed; p->epzs_temporal = temporal; p->epzs_spatial_mem = spatial_mem; p->epzs_subpel_me = subpel_me;
+  for (int i = 0; i < 8; i++) {
+    p->epzs_thres[0][i] = min_scale * minb[i]; p->epzs_thres[1][i] = med_scale * medb[i];
+    p->epzs_thres[2][i] = max_scale * maxb[i]; p->epzs_thres[3][i] = subpel_scale * medb[i];
+  }
+  for (int mode = 0; mode < 2; mode++) {
+    int n = 0;
+    int16_t (*pt)[2] = mode ? p->epzs_win_ext : p->epzs_win;
+    for (int pos = round_log2(search_range) - 2; pos > -1; pos--) {
+      const int sp = search_range >> pos, fsp = (3 * sp + 1) >> 1;
+      for (int i = 1; i >= -1; i -= 2) {
+        pt[n][0] = (int16_t)(i * sp); pt[n++][1] = 0;
+        pt[n][0] = (int16_t)(i * sp); pt[n++][1] = (int16_t)(i * sp);
+        pt[n][0] = 0; pt[n++][1] = (int16_t)(i * sp);
+        pt[n][0] = (int16_t)(-i * sp); pt[n++][1] = (int16_t)(i * sp);
+      }
+      if (mode)
+        for (int i = 1; i >= -1; i -= 2) {
+          pt[n][0] = (int16_t)(i * fsp); pt[n++][1] = (int16_t)(-i * sp);
+          pt[n][0] = (int16_t)(i * fsp); pt[n++][1] = 0;
+          pt[n][0] = (int16_t)(i * fsp); pt[n++][1] = (int16_t)(i * sp);
+          pt[n][0] = (int16_t)(i * sp); pt[n++][1] = (int16_t)(i * fsp);
+          pt[n][0] = 0; pt[n++][1] = (int16_t)(i * fsp);
+          pt[n][0] = (int16_t)(-i * sp); pt[n++][1] = (int16_t)(i * fsp);
+        }
+    }
+    if (mode) p->epzs_nwin_ext = n; else p->epzs_nwin = n;
+  }
+}
+
+// the reference-to-reference scales of EPZSSliceInit, me_epzs.c:516-547
+extern "C" void jmhip_epzs_scales(jmhip_slice_params *p, int poc, const int *list0_poc, int num_refs)
+{
+  auto clip3 = [](int lo, int hi, int x) { return x < lo ? lo : (x > hi ? hi : x); };
+  for (int k = 0; k < num_refs && k < JMHIP_SLICE_REFS; k++)
+    for (int i = 0; i < num_refs && i < JMHIP_SLICE_REFS; i++) {
+      const int iTRb = clip3(-128, 127, poc - list0_poc[i]), iTRp = clip3(-128, 127, poc - list0_poc[k]);
+      if (iTRp != 0) {
+        const int prescale = (16384 + std::abs(iTRp / 2)) / iTRp;
+        p->epzs_mv_scale[i][k] = clip3(-2048, 2047, (iTRb * prescale + 32) >> 6);
+      } else p->epzs_mv_scale[i][k] = 256;
+    }
+}
+
+// UMHEX_DefineThreshold + UMHEX_DefineThresholdMB, me_umhex.c:78-146: the same expressions in single precision
+extern "C" void jmhip_umhex_setup(jmhip_slice_params *p, int dsr, int scale, int qp_n, int width)
+{
+  static const int qc00[6] = {13107, 11916, 10082, 9362, 8192, 7282};                              // quant_coef[rem][0][0], me_umhex.c:68-75
+  static const int mref[8] = {0, 300, 120, 120, 60, 30, 30, 15}, bhex[8] = {0, 3000, 1500, 1500, 800, 400, 400, 200};
+  static const int medp[8] = {0, 750, 350, 350, 170, 80, 80, 40}, tdsr[8] = {0, 2200, 1000, 1000, 500, 250, 250, 120};
+  static const float a1[8] = {0, 0.01f, 0.01f, 0.01f, 0.02f, 0.03f, 0.03f, 0.04f}, a2[8] = {0, 0.06f, 0.07f, 0.07f, 0.08f, 0.12f, 0.11f, 0.15f};
+  p->umhex_dsr = dsr;
+  const int gb_qp_per = qp_n / 6, gb_qp_rem = qp_n % 6, gb_q_bits = 15 + gb_qp_per;
+  volatile float scale_factor = (float)((1 - scale * 0.1) + scale * 0.1 * (width / 176));
+  volatile float QP_factor = (float)((1.0 - 0.90 * (qp_n / 51.0f)));
+  const int gb_qp_const = (1 << gb_q_bits) / 6;
+  const int Thresh4x4 = ((1 << gb_q_bits) - gb_qp_const) / qc00[gb_qp_rem];
+  volatile float Quantize_step = Thresh4x4 / (4 * 5.61f) * 2.0f * scale_factor;
+  volatile float b[8];
+  b[7] = (16 * 16) * Quantize_step;
+  b[6] = b[7] * 4; b[5] = b[7] * 4; b[4] = b[5] * 4; b[3] = b[4] * 4; b[2] = b[4] * 4; b[1] = b[2] * 4; b[0] = 0;
+  for (int i = 0; i < 8; i++) { p->umhex_bsize[i] = b[i]; p->umhex_alpha1[i] = a1[i]; p->umhex_alpha2[i] = a2[i]; }
+  for (int i = 1; i < 8; i++) {
+    volatile float t;
+    t = medp[i] * scale_factor; t = t * QP_factor; p->umhex_thres[0][i] = (int)t;
+    t = bhex[i] * scale_factor; t = t * QP_factor; p->umhex_thres[1][i] = (int)t;
+    t = mref[i] * scale_factor; t = t * QP_factor; p->umhex_thres[2][i] = (int)t;
+    t = tdsr[i] * scale_factor; t = t * QP_factor; p->umhex_thres[3][i] = (int)t;
+  }
+  p->umhex_thres[0][0] = p->umhex_thres[1][0] = p->umhex_thres[2][0] = p->umhex_thres[3][0] = 0;
+}

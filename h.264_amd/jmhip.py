@@ -70,6 +70,29 @@ class BipredParams(C.Structure):
                 ("offset_bi", C.c_int), ("wp_luma_round", C.c_int), ("luma_log_weight_denom", C.c_int)]
 
 
+SLICE_REFS = 4
+
+
+class SliceParams(C.Structure):
+    """jmhip_slice_params (include/jmhip.h)."""
+    _fields_ = [("search_mode", C.c_int32), ("search_range", C.c_int32), ("full_search", C.c_int32), ("num_refs", C.c_int32),
+                ("ref_slot", C.c_int32 * SLICE_REFS), ("valid", C.c_int32 * 8), ("lambda_mf", C.c_int32 * 3), ("ref_cost1", C.c_int32),
+                ("md_metric", C.c_int32), ("metric", C.c_int32 * 3), ("level_mv_min", C.c_int32), ("level_mv_max", C.c_int32),
+                ("wp_me", C.c_int32), ("wp_pred", C.c_int32), ("wp_round", C.c_int32), ("wp_denom", C.c_int32),
+                ("wp_weight", C.c_int16 * SLICE_REFS), ("wp_offset", C.c_int16 * SLICE_REFS), ("mb_first", C.c_int32), ("mb_count", C.c_int32),
+                ("epzs_pattern", C.c_int32), ("epzs_dual", C.c_int32), ("epzs_fixed", C.c_int32), ("epzs_temporal", C.c_int32),
+                ("epzs_spatial_mem", C.c_int32), ("epzs_subpel_me", C.c_int32), ("epzs_thres", (C.c_int32 * 8) * 4),
+                ("epzs_nwin", C.c_int32), ("epzs_nwin_ext", C.c_int32), ("epzs_win", (C.c_int16 * 2) * 40), ("epzs_win_ext", (C.c_int16 * 2) * 100),
+                ("epzs_mv_scale", (C.c_int32 * SLICE_REFS) * SLICE_REFS),
+                ("umhex_dsr", C.c_int32), ("umhex_thres", (C.c_int32 * 8) * 4), ("umhex_bsize", C.c_float * 8), ("umhex_alpha1", C.c_float * 8),
+                ("umhex_alpha2", C.c_float * 8)]
+
+
+MB_INTER_DTYPE = np.dtype([("best_mode", "<i4"), ("min_cost", "<i4"), ("b8mode", "<i4", (4,)), ("b8ref", "<i4", (4,)),
+                           ("final_mv", "<i2", (16, 2)), ("skip_mv", "<i2", (2,)),
+                           ("pred", "<i2", (SLICE_REFS, NPART, 2)), ("mv_int", "<i2", (SLICE_REFS, NPART, 2)), ("mv", "<i2", (SLICE_REFS, NPART, 2)),
+                           ("cost_int", "<i4", (SLICE_REFS, NPART)), ("cost", "<i4", (SLICE_REFS, NPART))], align=True)
+
 PREDCOST_JOB_DTYPE = np.dtype([("mb_x", "<i2"), ("mb_y", "<i2"), ("blocks", "<u2"), ("weighted", "<i2"), ("wp_round", "<i2"), ("wp_denom", "<i2"),
                                ("mv", "<i2", (16, 2)), ("mv1", "<i2", (16, 2)), ("ref", "i1", (16,)), ("ref1", "i1", (16,)), ("bi", "i1", (16,)),
                                ("w0", "<i2", (16,)), ("w1", "<i2", (16,)), ("off", "<i2", (16,))])
@@ -158,13 +181,25 @@ def load_library():
     lib.jmhip_interp_rows.argtypes = [vp, ip, ip, ip]
     lib.jmhip_interp_luma_rows.argtypes = [vp, ip, ip, ip]
     lib.jmhip_timing_select.argtypes = [vp, C.c_uint]
+    lib.jmhip_epzs_setup.argtypes = [C.POINTER(SliceParams)] + [ip] * 11
+    lib.jmhip_epzs_setup.restype = None
+    lib.jmhip_epzs_scales.argtypes = [C.POINTER(SliceParams), ip, C.POINTER(ip), ip]
+    lib.jmhip_epzs_scales.restype = None
+    lib.jmhip_umhex_setup.argtypes = [C.POINTER(SliceParams), ip, ip, ip, ip]
+    lib.jmhip_umhex_setup.restype = None
+    lib.jmhip_slice_state_reset.argtypes = [vp]
+    lib.jmhip_epzs_colocated_upload.argtypes = [vp, vp]
+    lib.jmhip_p_slice_search.argtypes = [vp, C.POINTER(SliceParams), vp]
+    lib.jmhip_slice_results_download.argtypes = [vp, vp, ip, ip]
+    lib.jmhip_slice_field_download.argtypes = [vp, vp, vp]
+    lib.jmhip_slice_result_info.argtypes = [vp, C.POINTER(ip)]
     for which, dt in ((0, ME_MB_DTYPE), (1, ME_RESULT_DTYPE), (2, QUANT_DTYPE), (3, TQ_JOB_DTYPE), (4, TQ_RESULT_DTYPE),
                       (5, DIST_JOB_DTYPE), (8, MB_MODE_DTYPE), (9, SURFACE_JOB_DTYPE), (10, BIPRED_JOB_DTYPE), (11, BIPRED_RESULT_DTYPE), (13, PREDCOST_JOB_DTYPE),
-                      (14, DEBLOCK_MB_DTYPE), (15, DEBLOCK_BLK_DTYPE)):
+                      (14, DEBLOCK_MB_DTYPE), (15, DEBLOCK_BLK_DTYPE), (18, MB_INTER_DTYPE)):
         if lib.jmhip_sizeof(which) != dt.itemsize:
             raise JmhipError("binding layout mismatch for struct %d: C %d vs numpy %d" % (which, lib.jmhip_sizeof(which), dt.itemsize))
     if lib.jmhip_sizeof(6) != C.sizeof(MeParams) or lib.jmhip_sizeof(7) != C.sizeof(Config) or lib.jmhip_sizeof(12) != C.sizeof(BipredParams) or \
-            lib.jmhip_sizeof(16) != C.sizeof(DeblockParams):
+            lib.jmhip_sizeof(16) != C.sizeof(DeblockParams) or lib.jmhip_sizeof(17) != C.sizeof(SliceParams):
         raise JmhipError("binding layout mismatch for jmhip_me_params / jmhip_config")
     _lib = lib
     return lib
@@ -316,6 +351,32 @@ class Context:
             return
         mbs = np.ascontiguousarray(mbs, dtype=ME_MB_DTYPE)
         self._chk(self.lib.jmhip_me_frame_async(self.h, C.byref(prm), _ptr(mbs), len(mbs)), "jmhip_me_frame_async")
+
+    # ---- P-slice search + low-complexity inter decision on the device (me_wave.hip)
+    def slice_state_reset(self):
+        self._chk(self.lib.jmhip_slice_state_reset(self.h), "jmhip_slice_state_reset")
+
+    def epzs_colocated_upload(self, col_mv):
+        col = np.ascontiguousarray(col_mv, dtype=np.int16)
+        assert col.shape == (self.H // 4, self.W // 4, 2)
+        self._chk(self.lib.jmhip_epzs_colocated_upload(self.h, _ptr(col)), "jmhip_epzs_colocated_upload")
+
+    def p_slice_search(self, prm, download=True):
+        """-> MB_INTER_DTYPE records of the slice's macroblocks (download=False: results stay on the device)."""
+        res = np.zeros(prm.mb_count, dtype=MB_INTER_DTYPE) if download else None
+        self._chk(self.lib.jmhip_p_slice_search(self.h, C.byref(prm), _ptr(res)), "jmhip_p_slice_search")
+        return res
+
+    def slice_field(self):
+        ref_idx = np.zeros((self.H // 4, self.W // 4), np.int8)
+        mv = np.zeros((self.H // 4, self.W // 4, 2), np.int16)
+        self._chk(self.lib.jmhip_slice_field_download(self.h, _ptr(ref_idx), _ptr(mv)), "jmhip_slice_field_download")
+        return ref_idx, mv
+
+    def slice_passes(self):
+        n = C.c_int()
+        self._chk(self.lib.jmhip_slice_result_info(self.h, C.byref(n)), "jmhip_slice_result_info")
+        return n.value
 
     def me_results(self, n):
         res = np.zeros(n, dtype=ME_RESULT_DTYPE)

@@ -247,6 +247,94 @@ int jmhip_bipred_search(jmhip_ctx *ctx, const jmhip_bipred_params *prm, const jm
  * units, as FullPel/FastFull left it), results[i].mv/cost[p] the output. Same params/jobs as jmhip_me_frame. */
 int jmhip_me_subpel(jmhip_ctx *ctx, const jmhip_me_params *prm, const jmhip_me_mb *mbs, int n, jmhip_me_result *results);
 
+
+/* ------------------------------------------------------------------ P-slice motion search + low-complexity inter decision, whole slice on the device
+ *
+ * One call does, for every macroblock of a P slice, what JM does between start_macroblock and the residual coding when
+ * RDOptimization = 0 and intra modes are off in inter slices (DisableIntraInInter = 1), with the 4x4 transform:
+ *   encode_one_macroblock_low   src/md_low.c:46        (modes 1..3 :112-188, P8x8 :190-330, final parameters :543-636)
+ *   PartitionMotionSearch       src/mv-search.c:1378   BlockMotionSearch  src/mv-search.c:560
+ *   SetMotionVectorPredictor    src/mv-search.c:87     UMHEXSetMotionVectorPredictor src/me_umhex.c:1298 (dynamic search range)
+ *   the integer search of the configured SearchMode:
+ *     -1 FullPelBlockMotionSearch src/me_fullsearch.c:47      0 FastFullPelBlockMotionSearch src/me_fullfast.c:833 (+ Setup :491)
+ *      1 UMHEXIntegerPelBlockMotionSearch src/me_umhex.c:229  3 EPZSPelBlockMotionSearch src/me_epzs.c:1500
+ *   the sub-pel search: SubPelBlockMotionSearch src/me_fullsearch.c:341, UMHEXSubPelBlockMotionSearch src/me_umhex.c:562 (block
+ *     types > 3), EPZSSubPelBlockMotionSearch src/me_epzs.c:2390
+ *   the skip shortcut of the 16x16 block (FindSkipModeMotionVector src/mv-search.c:1189, GetSkipCostMB :1136, :829-849)
+ *   list_prediction_cost src/mode_decision.c:255, submacroblock_mode_decision :530 (rdopt = 0 path), SetRefAndMotionVectors /
+ *     SetModesAndRefframeForBlocks / SetMotionVectorsMB (src/rdopt.c:2777 / :1262 / :1845).
+ * Macroblocks run as a 2:1 wavefront (one workgroup per macroblock row; a macroblock starts when its left neighbour and the
+ * upper-right one are done), which keeps every neighbour dependency of JM's raster order: predictors, the EPZS row memories
+ * (EPZSDistortion, EPZSMotion), the UMHexagonS cost maps. The one dependency that is NOT a neighbour's -- EPZS reads img->all_mv of
+ * the PREVIOUS macroblock in coding order (src/me_epzs.c:1433-1471 on vectors the current macroblock has not searched yet), i.e. the
+ * last macroblock of the row above for the first of a row -- is speculated per row and verified: the call re-runs the slice until
+ * every row started from what the row above really left (at most rows + 1 passes; jmhip_slice_result_info reports the count).
+ * Not mirrored: the 16-bit wrap of EPZSBlkCount (a position visited exactly 65536 searches earlier reads as visited in JM).
+ * Frame pictures, luma-only motion estimation (ChromaMEEnable 0), list 0 only, up to JMHIP_SLICE_REFS references. */
+#define JMHIP_SLICE_REFS 4
+enum { JMHIP_SEARCH_UMHEX = 1, JMHIP_SEARCH_EPZS = 3 };
+typedef struct jmhip_slice_params {
+  int32_t search_mode;                     /* input->SearchMode: -1, 0, 1, 3 */
+  int32_t search_range;                    /* input->search_range */
+  int32_t full_search;                     /* input->full_search (RestrictSearchRange): range per reference / block type, mv-search.c:1411-1416 */
+  int32_t num_refs;                        /* listXsize[LIST_0] */
+  int32_t ref_slot[JMHIP_SLICE_REFS];      /* list-0 index -> reference slot of the context */
+  int32_t valid[8];                        /* enc_mb.valid[1..7] (input->InterSearch[0][..]); [1] must be set */
+  int32_t lambda_mf[3];                    /* enc_mb.lambda_mf[F_PEL, H_PEL, Q_PEL] */
+  int32_t ref_cost1;                       /* (int)(2 * enc_mb.lambda_me[Q_PEL]): cost of ref > 0 when rdopt = 0 (mode_decision.c:276) */
+  int32_t md_metric;                       /* input->ModeDecisionMetric (skip cost): 0 SAD, 2 SATD */
+  int32_t metric[3];                       /* input->MEErrorMetric[F_PEL, H_PEL, Q_PEL]: 0 SAD, 2 SATD */
+  int32_t level_mv_min, level_mv_max;      /* LEVELMVLIMIT[img->LevelIndex][0..1] */
+  int32_t wp_me, wp_pred;                  /* explicit weights in the searches (UseWeightedReferenceME) / in LumaPrediction (skip cost) */
+  int32_t wp_round, wp_denom;              /* wp_luma_round, luma_log_weight_denom */
+  int16_t wp_weight[JMHIP_SLICE_REFS], wp_offset[JMHIP_SLICE_REFS];     /* wp_weight[0][ref][0], wp_offset[0][ref][0] */
+  int32_t mb_first, mb_count;              /* the slice: macroblock addresses [mb_first, mb_first + mb_count) */
+  /* EPZS (SearchMode 3): input->EPZS*; thresholds and window predictors as EPZSInit builds them (jmhip_epzs_setup); the POC-distance
+   * scales mv_scale[LIST_0][i][k] of EPZSSliceInit (src/me_epzs.c:516-547; jmhip_epzs_scales) */
+  int32_t epzs_pattern, epzs_dual, epzs_fixed, epzs_temporal, epzs_spatial_mem, epzs_subpel_me;
+  int32_t epzs_thres[4][8];                /* minthres, medthres, maxthres, subthres */
+  int32_t epzs_nwin, epzs_nwin_ext;
+  int16_t epzs_win[40][2], epzs_win_ext[100][2];
+  int32_t epzs_mv_scale[JMHIP_SLICE_REFS][JMHIP_SLICE_REFS];
+  /* UMHexagonS (SearchMode 1): input->UMHexDSR and the thresholds of UMHEX_DefineThreshold(MB) (src/me_umhex.c:78-146; jmhip_umhex_setup) */
+  int32_t umhex_dsr;
+  int32_t umhex_thres[4][8];               /* Median_Pred_Thd_MB, Big_Hexagon_Thd_MB, Multi_Ref_Thd_MB, Threshold_DSR_MB */
+  float   umhex_bsize[8], umhex_alpha1[8], umhex_alpha2[8];
+} jmhip_slice_params;
+
+/* what JM knows of one macroblock after the decision + the outcome of each of its BlockMotionSearch calls */
+typedef struct jmhip_mb_inter {
+  int32_t best_mode;                       /* 1, 2, 3 or 8 (P8x8) */
+  int32_t min_cost;
+  int32_t b8mode[4], b8ref[4];
+  int16_t final_mv[16][2];                 /* enc_picture->mv[LIST_0] of the macroblock, 4x4 blocks in raster order */
+  int16_t skip_mv[2];                      /* all_mv[..][LIST_0][0][0] (FindSkipModeMotionVector) */
+  int16_t pred[JMHIP_SLICE_REFS][JMHIP_NPART][2], mv_int[JMHIP_SLICE_REFS][JMHIP_NPART][2], mv[JMHIP_SLICE_REFS][JMHIP_NPART][2];
+  int32_t cost_int[JMHIP_SLICE_REFS][JMHIP_NPART], cost[JMHIP_SLICE_REFS][JMHIP_NPART];
+} jmhip_mb_inter;
+
+/* Host helpers that fill the search-mode blocks of jmhip_slice_params exactly as JM's initialisation does. */
+void jmhip_epzs_setup(jmhip_slice_params *p, int search_range, int pattern, int dual, int fixed, int temporal, int spatial_mem, int subpel_me,
+                      int min_scale, int med_scale, int max_scale, int subpel_scale);          /* EPZSInit, src/me_epzs.c:333 (8-bit, no chroma ME) */
+void jmhip_epzs_scales(jmhip_slice_params *p, int poc, const int *list0_poc, int num_refs);   /* EPZSSliceInit, src/me_epzs.c:516-547 */
+void jmhip_umhex_setup(jmhip_slice_params *p, int dsr, int scale, int qp_n, int width);       /* UMHEX_DefineThreshold, src/me_umhex.c:78 */
+
+/* State that outlives a slice (JM's file-static / global arrays): EPZSDistortion, EPZSMotion, img->all_mv of the last macroblock coded,
+ * the UMHexagonS cost maps. jmhip_slice_state_reset zeroes it (start of a sequence). The picture-level LIST_0 arrays
+ * (enc_picture->ref_idx / mv) are reset by the first slice of a picture (mb_first == 0). */
+int jmhip_slice_state_reset(jmhip_ctx *ctx);
+/* EPZS temporal predictors: the scaled co-located field EPZSSliceInit builds (EPZSCo_located->mv[LIST_0], src/me_epzs.c:986-1030),
+ * [H/4][W/4][2] int16 quarter-pel, host array. Needed before jmhip_p_slice_search when epzs_temporal is set. */
+int jmhip_epzs_colocated_upload(jmhip_ctx *ctx, const int16_t *col_mv);
+/* Run one P slice on the current picture. results: host array of mb_count records (may be NULL: results stay on the device for
+ * jmhip_slice_results_download / jmhip_slice_field_download). */
+int jmhip_p_slice_search(jmhip_ctx *ctx, const jmhip_slice_params *prm, jmhip_mb_inter *results);
+int jmhip_slice_results_download(jmhip_ctx *ctx, jmhip_mb_inter *results, int mb_first, int mb_count);
+/* The picture-level LIST_0 arrays: ref_idx [H/4][W/4] int8, mv [H/4][W/4][2] int16 (either may be NULL). */
+int jmhip_slice_field_download(jmhip_ctx *ctx, int8_t *ref_idx, int16_t *mv);
+/* passes the last jmhip_p_slice_search needed (1 unless EPZS row starts were mis-speculated) */
+int jmhip_slice_result_info(jmhip_ctx *ctx, int *passes);
+
 /* ------------------------------------------------------------------ low-complexity (rdopt off) mode-decision costs */
 
 /* The residual distortion of an inter-predicted macroblock, the quantity JM's RD-off decision compares:

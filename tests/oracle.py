@@ -611,3 +611,28 @@ def lowcplx_p_slice(q, refpics, curY, ref_idx=None, mv=None, mb_first=0, mb_coun
     cur = np.ascontiguousarray(curY, dtype=np.uint16)
     L.jmo_lowcplx_p_slice(C.byref(q), refs, cur.ctypes.data, cur.shape[1], ref_idx.ctypes.data, mv.ctypes.data, mb_first, n, out.ctypes.data)
     return out, ref_idx, mv
+
+
+def epzs_colocated(epzs, W, H):
+    """EPZSCo_located->mv[LIST_0] of the oracle's state after slice_init: (H/4, W/4, 2) int16."""
+    L = _walker_protos()
+    L.jmo_epzs_colocated.restype = C.c_void_p
+    L.jmo_epzs_colocated.argtypes = [C.c_void_p]
+    p = L.jmo_epzs_colocated(epzs.h)
+    n = (H // 4) * (W // 4) * 2
+    return np.ctypeslib.as_array((C.c_short * n).from_address(p)).reshape(H // 4, W // 4, 2).copy()
+
+
+def umhex_thresholds(umhex):
+    L = _walker_protos()
+    ia, fa = C.c_int * 8, C.c_float * 8
+    a = [ia(), ia(), ia(), ia(), fa(), fa(), fa()]
+    L.jmo_umhex_thresholds.argtypes = [C.c_void_p] + [C.c_void_p] * 7
+    L.jmo_umhex_thresholds(umhex.h, *a)
+    return [list(x) for x in a]
+
+
+def epzs_threshold(epzs, which, bt):
+    L = _walker_protos()
+    L.jmo_epzs_threshold.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    return L.jmo_epzs_threshold(epzs.h, which, bt)
