@@ -16,7 +16,10 @@ namespace {
 
 constexpr int WR = JMHIP_SLICE_REFS;
 constexpr int MAXC = 128;                      // candidates per batch
-constexpr int CARRY = 5;                       // vectors of the previous macroblock EPZS may read per reference: 16x16 + four 8x8
+constexpr int CARRY = 5;
+constexpr int SURF_PLANES = 20;                // the sixteen 4x4 blocks + the four 8x8 blocks of a macroblock
+constexpr int SURF_MARGIN = 4;                 // FullSearch: the surface is built round the 16x16 centre, this much wider than the range
+constexpr int WIN_MAX = 96;                    // LDS reference window side: 2 * (33 + SURF_MARGIN) + 1 + 15 = 90                       // vectors of the previous macroblock EPZS may read per reference: 16x16 + four 8x8
 
 struct WaveDev {
   jmhip_slice_params p;
@@ -33,6 +36,9 @@ struct WaveDev {
   const short *carry_in;                       // [mbh][WR][CARRY][2]: img->all_mv the first macroblock of a row finds (speculated)
   short *carry_out;                            // [mbh][WR][CARRY][2]: what the last macroblock of a row leaves
   int *um_cost;                                // fastme_l0_cost [8][h4][w4]
+  uint16_t *surf;                              // exhaustive searches: per row, per reference, SAD surfaces [SURF_PLANES][surf_n]
+  int surf_n;                                  // candidates per plane (capacity)
+  int debug;                                   // JMHIP_WAVE_DEBUG (timing experiments only; results are wrong): 1 no sub-pel, 2 no integer search, 4 no skip cost
 };
 
 struct Lds {
@@ -46,6 +52,8 @@ struct Lds {
   int um_ref_cost[WR][8][16];                  // fastme_ref_cost[ref][blocktype][by][bx]
   int um_best_cost[8][4];                      // fastme_best_cost[blocktype - 1][pic_pix_x >> 2] (only ever read after being written by the same block)
   uint8_t um_sstate[52];                       // SearchState 7x7
+  int surf_c[WR][4];                           // per reference: surface centre (pels), half side, valid
+  __attribute__((aligned(16))) uint8_t win[WIN_MAX * WIN_MAX];     // reference window of the surface pass
 };
 
 __constant__ int8_t c_bsx[8] = {16, 16, 16, 8, 8, 8, 4, 4};
@@ -354,6 +362,118 @@ __device__ int full_window(const WaveDev &D, Lds &L, const Blk &B, int cx, int c
   if (tie == 0) { *mvx = 0; *mvy = 0; }
   else { int dx, dy; spiral_offset(tie - 1, &dx, &dy); *mvx = cx + dx; *mvy = cy + dy; }
   __syncthreads();
+  return cost;
+}
+
+
+// ---------------------------------------------------------------------------------------------- exhaustive searches through SAD surfaces
+
+// SAD is independent of the predictor: once per (macroblock, reference) the SADs of the sixteen 4x4 blocks (and their 8x8 sums) are computed
+// for every displacement in a window round (scx, scy) and kept; every partition then finds its own argmin of (SAD + its own mv cost) over its
+// own window -- SetupFastFullPelSearch / SetupLargerBlocks (me_fullfast.c:491, :210) made macroblock-wide. lane <-> displacement.
+__device__ void surface_build(const WaveDev &D, Lds &L, const Blk &B, int scx, int scy, int Rs)
+{
+  const int lane = threadIdx.x, side = 2 * Rs + 1, wside = side + 15, n = side * side;
+  const int ox = B.mbx * 16 + scx - Rs + JMHIP_PAD, oy = B.mby * 16 + scy - Rs + JMHIP_PAD;     // window origin in the padded integer plane
+  __syncthreads();
+  for (int i = lane; i < wside * wside; i += 64) {
+    const int wy = i / wside, wx = i - wy * wside;
+    const int py = clampi(oy + wy, 0, D.Hp - 1), px = clampi(ox + wx, 0, D.Wp - 1);                // the ring replicates the edge: per-sample clamp == origin clamp
+    int v = B.planes[(size_t)py * D.Wp + px];
+    if (B.wp) v = min(max(((B.wpw * v + D.p.wp_round) >> D.p.wp_denom) + B.wpo, 0), 255);
+    L.win[i] = (uint8_t)v;
+  }
+  __syncthreads();
+  uint16_t *sf = D.surf + ((size_t)blockIdx.x * WR + B.ref) * SURF_PLANES * D.surf_n;
+  for (int k = lane; k < n; k += 64) {
+    const int dy = k / side, dx = k - dy * side;
+    unsigned s4[16];
+#pragma unroll
+    for (int by = 0; by < 4; by++) {
+      unsigned a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const uint8_t *w = &L.win[(dy + by * 4 + r) * wside + dx];
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(reinterpret_cast<uintptr_t>(w) & ~uintptr_t(3));
+        const unsigned sh = (unsigned)(reinterpret_cast<uintptr_t>(w) & 3);
+        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+        const uint32_t *c = reinterpret_cast<const uint32_t *>(&L.cur[by * 4 + r][0]);
+        a0 = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(d1, d0, sh), c[0], a0);
+        a1 = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(d2, d1, sh), c[1], a1);
+        a2 = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(d3, d2, sh), c[2], a2);
+        a3 = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(d4, d3, sh), c[3], a3);
+      }
+      s4[by * 4] = a0; s4[by * 4 + 1] = a1; s4[by * 4 + 2] = a2; s4[by * 4 + 3] = a3;
+    }
+#pragma unroll
+    for (int b = 0; b < 16; b++) sf[(size_t)b * D.surf_n + k] = (uint16_t)s4[b];
+#pragma unroll
+    for (int b8 = 0; b8 < 4; b8++) {
+      const int b = (b8 >> 1) * 8 + (b8 & 1) * 2;
+      sf[(size_t)(16 + b8) * D.surf_n + k] = (uint16_t)(s4[b] + s4[b + 1] + s4[b + 4] + s4[b + 5]);
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  L.surf_c[B.ref][0] = scx; L.surf_c[B.ref][1] = scy; L.surf_c[B.ref][2] = Rs; L.surf_c[B.ref][3] = 1;
+}
+
+// argmin of SAD + mv cost over the (2R+1)^2 window round (cx, cy) from the surface of B.ref. Returns INT_MIN when the window is not covered.
+__device__ int surface_search(const WaveDev &D, Lds &L, const Blk &B, int cx, int cy, int R, int ffs, int *mvx, int *mvy)
+{
+  const int scx = L.surf_c[B.ref][0], scy = L.surf_c[B.ref][1], Rs = L.surf_c[B.ref][2];
+  if (!L.surf_c[B.ref][3] || cx - R < scx - Rs || cx + R > scx + Rs || cy - R < scy - Rs || cy + R > scy + Rs) return INT_MIN;
+  const int lane = threadIdx.x, side = 2 * R + 1, npos = side * side, sside = 2 * Rs + 1, lam = D.p.lambda_mf[0];
+  const uint16_t *sf = D.surf + ((size_t)blockIdx.x * WR + B.ref) * SURF_PLANES * D.surf_n;
+  const int x4 = B.mb_x >> 2, y4 = B.mb_y >> 2, w4 = B.bsx >> 2, h4 = B.bsy >> 2;
+  // the planes this partition sums: whole 8x8 blocks where it covers them, 4x4 blocks otherwise
+  int pl[4], npl = 0;
+  if (w4 >= 2 && h4 >= 2) { for (int j = y4 >> 1; j < (y4 + h4) >> 1; j++) for (int i = x4 >> 1; i < (x4 + w4) >> 1; i++) pl[npl++] = 16 + j * 2 + i; }
+  else { for (int j = y4; j < y4 + h4; j++) for (int i = x4; i < x4 + w4; i++) pl[npl++] = j * 4 + i; }
+  const int check00 = (!ffs && B.bt == 1 && B.ref == 0), w16 = (lam * 16) >> 16;
+  unsigned best = 0xffffffffu;
+  // the surface reads are L2 hits with a long latency: eight candidates per lane are in flight at a time
+  constexpr int UN = 8;
+  const uint16_t *p0 = sf + (size_t)pl[0] * D.surf_n, *p1 = sf + (size_t)pl[npl > 1 ? 1 : 0] * D.surf_n;
+  const uint16_t *p2 = sf + (size_t)pl[npl > 2 ? 2 : 0] * D.surf_n, *p3 = sf + (size_t)pl[npl > 3 ? 3 : 0] * D.surf_n;
+  const int m1 = npl > 1 ? 0xffff : 0, m2 = npl > 2 ? 0xffff : 0, m3 = npl > 3 ? 0xffff : 0;
+  for (int k0 = lane; k0 < npos; k0 += 64 * UN) {
+    int v[UN], ddx[UN], ddy[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const int k = min(k0 + 64 * u, npos - 1);                       // past the end: the last candidate again (harmless for a minimum)
+      const int dy = k / side - R, dx = k - (dy + R) * side - R;
+      const int si = (cy + dy - scy + Rs) * sside + (cx + dx - scx + Rs);
+      ddx[u] = dx; ddy[u] = dy;
+      v[u] = (int)p0[si] + ((int)p1[si] & m1) + ((int)p2[si] & m2) + ((int)p3[si] & m3);
+    }
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const int dx = ddx[u], dy = ddy[u];
+      int mc = mv_cost(lam, ((cx + dx) << 2) - B.pmx, ((cy + dy) << 2) - B.pmy);
+      int tie = spiral_pos(dx, dy) + 1;
+      bool skip = false;
+      if (check00 && ((B.pic_x + cx + dx) << 2) == B.pic_x && ((B.pic_y + cy + dy) << 2) == B.pic_y) {
+        mc -= w16;
+        skip = (dx == 0 && dy == 0 && mc < 0);                         // the wrapped first-row bound: settled below
+      }
+      if (ffs && cx + dx == 0 && cy + dy == 0) tie = 0;
+      const unsigned key = ((unsigned)(mc + v[u] + 4096) << TIE_BITS) | (unsigned)tie;
+      best = min(best, skip ? 0xffffffffu : key);
+    }
+  }
+  for (int o = 1; o < 64; o <<= 1) best = min(best, (unsigned)__shfl_xor((int)best, o));
+  if (check00 && ((B.pic_x + cx) << 2) == B.pic_x && ((B.pic_y + cy) << 2) == B.pic_y) {
+    const int mc = mv_cost(lam, (cx << 2) - B.pmx, (cy << 2) - B.pmy) - w16;
+    if (mc < 0) {                                                      // me_fullsearch.c:138 with min_mcost = INT_MAX: computeSAD leaves after row 0
+      L.cx[0] = padq(B.pic_x, cx << 2); L.cy[0] = padq(B.pic_y, cy << 2);
+      eval_dist(D, L, B.planes, 0, 0, 1, B.wp, B.wpw, B.wpo, 0, 0, 16, 1, 1);
+      best = min(best, ((unsigned)(mc + L.dist[0] + 4096) << TIE_BITS) | 1u);
+    }
+  }
+  const int cost = (int)(best >> TIE_BITS) - 4096, tie = (int)(best & ((1u << TIE_BITS) - 1));
+  if (tie == 0) { *mvx = 0; *mvy = 0; }
+  else { int dx, dy; spiral_offset(tie - 1, &dx, &dy); *mvx = cx + dx; *mvy = cy + dy; }
   return cost;
 }
 
@@ -864,7 +984,8 @@ __device__ int block_motion_search(const WaveDev &D, Lds &L, int mbx, int mby, i
   int mvx, mvy, min_mcost = INT_MAX;
   mv_predictor(D, mbx, mby, ref, mb_x, mb_y, B.bsx, B.bsy, &B.pmx, &B.pmy, P.search_mode == JMHIP_SEARCH_UMHEX && P.umhex_dsr, bt, &search_range, nullptr);
   const int R = search_range;
-  if (P.search_mode == JMHIP_SEARCH_UMHEX) {
+  if (D.debug & 2) { mvx = clampi((B.pmx + 2) >> 2, -R, R); mvy = clampi((B.pmy + 2) >> 2, -R, R); min_mcost = 1000; }
+  else if (P.search_mode == JMHIP_SEARCH_UMHEX) {
     mvx = B.pmx / 4; mvy = B.pmy / 4;
     mvx = clampi(mvx, -R, R); mvy = clampi(mvy, -R, R);
     mvx = clampi(mvx, -2047 + R, 2047 - R); mvy = clampi(mvy, P.level_mv_min + R, P.level_mv_max - R);
@@ -885,26 +1006,30 @@ __device__ int block_motion_search(const WaveDev &D, Lds &L, int mbx, int mby, i
       cx = clampi(cx, -Rf, Rf); cy = clampi(cy, -Rf, Rf);
       cx = clampi(cx, -2047 + Rf, 2047 - Rf); cy = clampi(cy, P.level_mv_min + Rf, P.level_mv_max - Rf);
       L.motion_cost[0][ref][0] = cx; L.motion_cost[0][ref][1] = cy; L.motion_cost[0][ref][2] = Rf;
+      surface_build(D, L, B, cx, cy, Rf);
     }
-    min_mcost = full_window(D, L, B, L.motion_cost[0][ref][0], L.motion_cost[0][ref][1], L.motion_cost[0][ref][2], 1, &mvx, &mvy);
+    min_mcost = surface_search(D, L, B, L.motion_cost[0][ref][0], L.motion_cost[0][ref][1], L.motion_cost[0][ref][2], 1, &mvx, &mvy);
+    if (min_mcost == INT_MIN) min_mcost = full_window(D, L, B, L.motion_cost[0][ref][0], L.motion_cost[0][ref][1], L.motion_cost[0][ref][2], 1, &mvx, &mvy);
   } else {
     int cx = B.pmx / 4, cy = B.pmy / 4;
     cx = clampi(cx, -R, R); cy = clampi(cy, -R, R);
     cx = clampi(cx, -2047 + R, 2047 - R); cy = clampi(cy, P.level_mv_min + R, P.level_mv_max - R);
-    min_mcost = full_window(D, L, B, cx, cy, R, 0, &mvx, &mvy);
+    if (bt == 1) surface_build(D, L, B, cx, cy, min(R + SURF_MARGIN, 33 + SURF_MARGIN));     // the other partitions' centres are usually within the margin
+    min_mcost = surface_search(D, L, B, cx, cy, R, 0, &mvx, &mvy);
+    if (min_mcost == INT_MIN) min_mcost = full_window(D, L, B, cx, cy, R, 0, &mvx, &mvy);      // a centre the surface does not cover: direct evaluation
   }
   if (threadIdx.x == 0) { out->mv_int[ref][pi][0] = (int16_t)mvx; out->mv_int[ref][pi][1] = (int16_t)mvy; out->cost_int[ref][pi] = min_mcost; }
   mvx <<= 2; mvy <<= 2;
   // sub-pel :781-827
   bool do_sub = true;
   if (P.search_mode == JMHIP_SEARCH_EPZS && ref > 0) do_sub = (2 * (long long)min_mcost < 7 * (long long)D.ep_dist[(size_t)(bt - 1) * D.w4 + (B.pic_x >> 2)]);   // min_mcost < 3.5 * prevSad
-  if (do_sub) {
+  if (do_sub && !(D.debug & 1)) {
     if (!start_hp) min_mcost = INT_MAX;
     if (P.search_mode == JMHIP_SEARCH_UMHEX && bt > 3) min_mcost = umhex_subpel(D, L, B, &mvx, &mvy, min_mcost);
     else if (P.search_mode == JMHIP_SEARCH_EPZS && P.epzs_subpel_me) min_mcost = epzs_subpel(D, L, B, &mvx, &mvy, min_mcost);
     else min_mcost = subpel_full(D, L, B, &mvx, &mvy, min_mcost);
   }
-  if (bt == 1) {                                                               // skip shortcut :829-849, every reference
+  if (bt == 1 && !(D.debug & 4)) {                                             // skip shortcut :829-849, every reference
     find_skip_mv(D, L, mbx, mby);
     const int smx = L.all_mv[0][0][0][0], smy = L.all_mv[0][0][0][1];
     int cost;
@@ -981,6 +1106,7 @@ __device__ void macroblock_low(const WaveDev &D, Lds &L, int mbx, int mby, jmhip
   const int bx0 = mbx * 4, by0 = mby * 4;
   int best_mode = 1, min_cost = INT_MAX;
   int l0ref[5][4] = {{0}}, b8m[4] = {0, 0, 0, 0};
+  for (int r = 0; r < WR; r++) L.surf_c[r][3] = 0;
   for (int mode = 1; mode < 4; mode++) {
     if (!P.valid[mode]) continue;
     int cost = 0;
@@ -1108,6 +1234,7 @@ struct SliceState {
   int *ep_dist = nullptr, *ep_dist_snap = nullptr; short *ep_motion = nullptr, *ep_motion_snap = nullptr; short *ep_col = nullptr;
   short *carry_in = nullptr, *carry_out = nullptr, *carry_slice = nullptr, *carry_slice_next = nullptr;
   int *um_cost = nullptr, *um_cost_snap = nullptr;
+  uint16_t *surf = nullptr; size_t surf_rows = 0; int surf_n = 0;
   int passes = 0;
   bool has_col = false;
 };
@@ -1201,8 +1328,20 @@ extern "C" int jmhip_p_slice_search(jmhip_ctx *c, const jmhip_slice_params *prm,
     JM_HIP_CHECK(c, hipMemsetAsync(s->ref_idx, 0xff, w4 * h4, c->stream));
     JM_HIP_CHECK(c, hipMemsetAsync(s->mv, 0, w4 * h4 * 4, c->stream));
   }
+  const bool exhaustive = prm->search_mode == JMHIP_SEARCH_FULL || prm->search_mode == JMHIP_SEARCH_FASTFULL;
+  if (exhaustive) {
+    const int rs = prm->search_range + SURF_MARGIN, n = ((2 * rs + 1) * (2 * rs + 1) + 63) & ~63;
+    if (s->surf_rows < (size_t)rows || s->surf_n < n) {
+      if (s->surf) JM_HIP_CHECK(c, hipFree(s->surf));
+      s->surf = nullptr; s->surf_rows = 0;
+      if (hipMalloc((void **)&s->surf, sizeof(uint16_t) * (size_t)rows * WR * SURF_PLANES * n) != hipSuccess) return jm_fail(c, JMHIP_ERR_NOMEM, "SAD surfaces of the slice search");
+      s->surf_rows = rows; s->surf_n = n;
+    }
+  }
   WaveDev D{};
   D.p = *prm;
+  D.surf = s->surf; D.surf_n = s->surf_n;
+  D.debug = getenv("JMHIP_WAVE_DEBUG") ? atoi(getenv("JMHIP_WAVE_DEBUG")) : 0;
   D.W = c->W; D.H = c->H; D.Wp = c->Wp; D.Hp = c->Hp; D.mbw = c->mbw; D.mbh = c->mbh; D.w4 = (int)w4; D.h4 = (int)h4;
   D.cur = c->cur_y;
   D.ref_sub = reinterpret_cast<const uint8_t *const *>(c->ref_ptrs_dev) + 32;
@@ -1275,7 +1414,7 @@ void jm_slice_state_free(jmhip_ctx *c)
   SliceState *s = static_cast<SliceState *>(c->slice_state);
   if (!s) return;
   void *bufs[] = {s->ref_idx, s->mv, s->prog, s->flags, s->out, s->ep_dist, s->ep_dist_snap, s->ep_motion, s->ep_motion_snap, s->ep_col, s->carry_in, s->carry_out,
-                  s->carry_slice, s->carry_slice_next, s->um_cost, s->um_cost_snap};
+                  s->carry_slice, s->carry_slice_next, s->um_cost, s->um_cost_snap, s->surf};
   for (void *b : bufs) if (b) (void)hipFree(b);
   delete s;
   c->slice_state = nullptr;

@@ -11,7 +11,12 @@
  * 0x10 dct_4x4/dct_16x16, 0x20 dct_8x8, 0x40 dct_chroma, 0x100 distortion surfaces for EPZS / UMHexagonS integer walks,
  * 0x200 bi-predictive full-pel + sub-pel search,
  * 0x400 RD-off mode-decision costs (TransformDecision, GetSkipCostMB),
- * 0x800 in-loop deblocking filter (DeblockFrame).
+ * 0x800 in-loop deblocking filter (DeblockFrame),
+ * 0x1000 SLICE-LEVEL binding: in low-complexity mode with intra off in P slices (RDOptimization 0, DisableIntraInInter 1, no B pictures,
+ *        4x4 transform) the whole motion search + inter decision of a P slice is ONE device call (jmhip_p_slice_search) issued when JM
+ *        asks for the slice's first block; every BlockMotionSearch call of the slice is then answered from its result record -- after
+ *        checking that JM's own motion-vector predictor equals the one the device used (anything else is a fatal error, never a
+ *        silent difference).
  *
  * The proof of the drop-in claim is tests/test_jm_shim_gpu.py: the bitstream and the reconstruction this encoder
  * writes are byte-identical to the unmodified encoder's.
@@ -30,6 +35,7 @@
 #include "me_distortion.h"
 #include "q_matrix.h"
 #include "q_offsets.h"
+#include "me_epzs.h"
 
 #include "jmhip.h"
 
@@ -40,13 +46,14 @@ extern void SetMotionVectorPredictor(short pmv[2], char **refPic, short ***tmp_m
 extern const int LEVELMVLIMIT[17][6];
 extern int *mvbits;                       /* src/mv-search.c:59 */
 
-enum { S_LUMA, S_CHROMA, S_FULL, S_SUB, S_FAST, S_D4, S_D8, S_D16, S_DCR, S_WALK, S_SAD, S_SATD, S_BIFULL, S_BISUB, S_TDEC, S_SKIPC, S_BIDC, S_DEBLOCK, S_COUNT };
+enum { S_LUMA, S_CHROMA, S_FULL, S_SUB, S_FAST, S_D4, S_D8, S_D16, S_DCR, S_WALK, S_SAD, S_SATD, S_BIFULL, S_BISUB, S_TDEC, S_SKIPC, S_BIDC, S_DEBLOCK, S_SLICE, S_BMS, S_COUNT };
 static const char *s_names[S_COUNT] = { "getSubImagesLuma", "getSubImagesChroma", "FullPelBlockMotionSearch",
   "SubPelBlockMotionSearch", "FastFullPelBlockMotionSearch", "dct_4x4", "dct_8x8", "dct_16x16", "dct_chroma",
   "EPZS_UMHex_integer_walks", "computeSAD", "computeSATD", "FullPelBlockMotionBiPred", "SubPelBlockSearchBiPred",
-  "TransformDecision", "GetSkipCostMB", "BIDPartitionCost", "DeblockFrame" };
+  "TransformDecision", "GetSkipCostMB", "BIDPartitionCost", "DeblockFrame",
+  "P slices (one device call each)", "BlockMotionSearch" };
 static long n_dev[S_COUNT], n_fwd[S_COUNT];
-static unsigned shim_mask = 0xfff;
+static unsigned shim_mask = 0x1fff;
 static int verify;            /* JMHIP_SHIM_VERIFY=1: run JM's own search beside the device's and report differences */
 static jmhip_ctx *g;
 static int g_w, g_h;
@@ -65,12 +72,14 @@ static void die(const char *what, int rc)
 }
 #define OK(call) do { int rc_ = (call); if (rc_) die(#call, rc_); } while (0)
 
+static long sl_slices(void), sl_passes(void);
 static void print_stats(void)
 {
   int i;
   if (!getenv("JMHIP_SHIM_STATS")) return;
   fprintf(stderr, "jm_shim: mask=0x%x\n", shim_mask);
   for (i = 0; i < S_COUNT; i++) fprintf(stderr, "  %-30s device %8ld  forwarded %8ld\n", s_names[i], n_dev[i], n_fwd[i]);
+  if (sl_slices()) fprintf(stderr, "  slice binding: %ld slices, %ld kernel passes\n", sl_slices(), sl_passes());
 }
 
 int main(int argc, char **argv)
@@ -915,6 +924,138 @@ int dct_chroma(Macroblock *currMB, int uv, int cr_cbp)
 }
 
 /* ------------------------------------------------------------------ 0x800 in-loop deblocking filter */
+
+
+/* ------------------------------------------------------------------ 0x1000 slice-level binding */
+
+extern void FindSkipModeMotionVector(Macroblock *currMB);
+extern int frame_ctr[5];
+
+static struct {
+  int active;                 /* results below belong to the slice being coded */
+  unsigned long serial;       /* pic_serial of the picture they belong to */
+  int slice_nr, mb_first, mb_count;
+  jmhip_mb_inter *rec; int cap;
+  int decided, on;            /* once per run: is the configuration covered? */
+  int started;                /* device state reset done */
+  long passes, slices;
+} sl;
+
+static int slice_mode_covered(void)
+{
+  int m;
+  if (!sl.decided) {
+    sl.decided = 1;
+    sl.on = (shim_mask & 0x1000) && input->rdopt == 0 && input->DisableIntraInInter && input->successive_Bframe == 0 && !input->PicInterlace &&
+            !input->MbInterlace && !input->ChromaMEEnable && input->Transform8x8Mode == 0 && !input->DisableSubpelME &&
+            (input->SearchMode == -1 || input->SearchMode == 0 || input->SearchMode == 1 || input->SearchMode == 3) &&
+            !(input->SearchMode <= 0 && input->MEErrorMetric[F_PEL] != ERROR_SAD) && !input->EPZSSubPelGrid &&
+            input->search_range <= 33 && input->num_ref_frames <= JMHIP_SLICE_REFS && (input->slice_mode == 0 || input->slice_mode == 1) &&
+            input->num_slice_groups_minus1 == 0 && !input->sp_periodicity && !input->BiPredMotionEstimation && input->InterSearch[0][1] &&
+            !input->RestrictRef && !input->CtxAdptLagrangeMult && !input->RCEnable;
+    for (m = 0; m < 3; m++) if (input->MEErrorMetric[m] != ERROR_SAD && input->MEErrorMetric[m] != ERROR_SATD) sl.on = 0;
+    if (input->ModeDecisionMetric != ERROR_SAD && input->ModeDecisionMetric != ERROR_SATD) sl.on = 0;
+  }
+  return sl.on;
+}
+
+/* one device call for the slice that begins at the current macroblock */
+static void slice_run(int *lambda_factor)
+{
+  jmhip_slice_params p;
+  const int nmb = (int)img->PicSizeInMbs, first = img->current_mb_nr;
+  int r, m, count = nmb - first, pocs[JMHIP_SLICE_REFS];
+  memset(&p, 0, sizeof(p));
+  if (input->slice_mode == 1 && input->slice_argument < count) count = input->slice_argument;
+  p.search_mode = input->SearchMode; p.search_range = input->search_range; p.full_search = input->full_search; p.num_refs = listXsize[LIST_0];
+  for (r = 0; r < listXsize[LIST_0]; r++) {
+    p.ref_slot[r] = slot_find(listX[LIST_0][r]);
+    if (p.ref_slot[r] < 0) { fprintf(stderr, "jm_shim: slice binding: reference %d has no device slot\n", r); exit(95); }
+    pocs[r] = listX[LIST_0][r]->poc;
+    if (active_pps->weighted_pred_flag) { p.wp_weight[r] = (int16_t)wp_weight[0][r][0]; p.wp_offset[r] = (int16_t)wp_offset[0][r][0]; }   /* allocated only with WP (lencod.c:2063) */
+  }
+  for (m = 1; m < 8; m++) p.valid[m] = input->InterSearch[0][m] != 0;
+  if (input->Transform8x8Mode == 2) p.valid[5] = p.valid[6] = p.valid[7] = 0;
+  for (m = 0; m < 3; m++) { p.lambda_mf[m] = lambda_factor[m]; p.metric[m] = input->MEErrorMetric[m]; }
+  p.ref_cost1 = (int)(2 * img->lambda_me[img->type][img->qp][Q_PEL]);
+  p.md_metric = input->ModeDecisionMetric;
+  p.level_mv_min = LEVELMVLIMIT[img->LevelIndex][0]; p.level_mv_max = LEVELMVLIMIT[img->LevelIndex][1];
+  p.wp_pred = active_pps->weighted_pred_flag != 0; p.wp_me = p.wp_pred && input->UseWeightedReferenceME;
+  p.wp_round = wp_luma_round; p.wp_denom = luma_log_weight_denom;
+  p.mb_first = first; p.mb_count = count;
+  if (!sl.started) { OK(jmhip_slice_state_reset(g)); sl.started = 1; }
+  if (input->SearchMode == 3) {
+    jmhip_epzs_setup(&p, input->search_range, input->EPZSPattern, input->EPZSDual, input->EPZSFixed, input->EPZSTemporal, input->EPZSSpatialMem,
+                     input->EPZSSubPelME, input->EPZSMinThresScale, input->EPZSMedThresScale, input->EPZSMaxThresScale, input->EPZSSubPelThresScale);
+    jmhip_epzs_scales(&p, enc_picture->poc, pocs, listXsize[LIST_0]);
+    if (input->EPZSTemporal) {                          /* the scaled co-located field JM's EPZSSliceInit just built (src/me_epzs.c:986-1030) */
+      const int w4 = img->width / 4, h4 = img->height / 4;
+      int16_t *col = malloc(sizeof(int16_t) * 2 * w4 * h4);
+      int i, j;
+      for (j = 0; j < h4; j++) for (i = 0; i < w4; i++) { col[(j * w4 + i) * 2] = EPZSCo_located->mv[LIST_0][j][i][0]; col[(j * w4 + i) * 2 + 1] = EPZSCo_located->mv[LIST_0][j][i][1]; }
+      OK(jmhip_epzs_colocated_upload(g, col));
+      free(col);
+    }
+  }
+  if (input->SearchMode == 1) jmhip_umhex_setup(&p, input->UMHexDSR, input->UMHexScale, input->qpN, img->width);
+  if (sl.cap < count) { free(sl.rec); sl.rec = malloc(sizeof(jmhip_mb_inter) * (size_t)count); sl.cap = count; }
+  OK(jmhip_p_slice_search(g, &p, sl.rec));
+  { int n = 0; jmhip_slice_result_info(g, &n); sl.passes += n; }
+  sl.slices++;
+  sl.active = 1; sl.serial = pic_serial; sl.slice_nr = img->current_slice_nr; sl.mb_first = first; sl.mb_count = count;
+  n_dev[S_SLICE]++;
+}
+
+static long sl_slices(void) { return sl.slices; }
+static long sl_passes(void) { return sl.passes; }
+
+int BlockMotionSearch(short ref, int list, int mb_x, int mb_y, int blocktype, int search_range, int *lambda_factor)
+{
+  static int (*orig)(short, int, int, int, int, int, int *);
+  int covered = slice_mode_covered() && img->type == P_SLICE && list == 0 && img->structure == FRAME && !img->MbaffFrameFlag && ctx_ready() && cur_ready() &&
+                listXsize[LIST_0] <= JMHIP_SLICE_REFS;
+  if (!covered) {
+    if (!orig) orig = next_sym("BlockMotionSearch");
+    n_fwd[S_BMS]++;
+    return orig(ref, list, mb_x, mb_y, blocktype, search_range, lambda_factor);
+  }
+  if (!(sl.active && sl.serial == pic_serial && sl.slice_nr == img->current_slice_nr && img->current_mb_nr >= sl.mb_first && img->current_mb_nr < sl.mb_first + sl.mb_count))
+    slice_run(lambda_factor);
+  {
+    const jmhip_mb_inter *r = &sl.rec[img->current_mb_nr - sl.mb_first];
+    const int p = partition_of(blocktype, mb_x, mb_y), bx = mb_x >> 2, by = mb_y >> 2, bsx = input->blc_size[blocktype][0], bsy = input->blc_size[blocktype][1];
+    short pmv[2], *pred_mv = img->pred_mv[by][bx][list][ref][blocktype];
+    int i, j;
+    /* the device predicted from ITS picture arrays; JM predicts from enc_picture: they must agree, or the slice has diverged */
+    SetMotionVectorPredictor(pmv, enc_picture->ref_idx[list], enc_picture->mv[list], ref, list, bx, by, bsx, bsy);
+    if (p < 0 || pmv[0] != r->pred[ref][p][0] || pmv[1] != r->pred[ref][p][1]) {
+      fprintf(stderr, "jm_shim: slice binding diverged at mb %d ref %d blocktype %d block (%d,%d): JM predictor (%d,%d), device (%d,%d)\n",
+              img->current_mb_nr, ref, blocktype, bx, by, pmv[0], pmv[1], p < 0 ? 0 : r->pred[ref][p][0], p < 0 ? 0 : r->pred[ref][p][1]);
+      exit(95);
+    }
+    pred_mv[0] = pmv[0]; pred_mv[1] = pmv[1];
+    for (j = by; j < by + (bsy >> 2); j++) for (i = bx; i < bx + (bsx >> 2); i++) {
+      img->all_mv[j][i][list][ref][blocktype][0] = r->mv[ref][p][0]; img->all_mv[j][i][list][ref][blocktype][1] = r->mv[ref][p][1];
+    }
+    /* what BlockMotionSearch leaves behind besides its results (src/mv-search.c:612, :640, :779, :837) */
+    ChromaMEEnable = 0;
+    test8x8transform = input->Transform8x8Mode && blocktype <= 4;
+    jm_side_effects(listX[LIST_0][ref]);
+    if (blocktype == 1) FindSkipModeMotionVector(&img->mb_data[img->current_mb_nr]);
+    if (verify) {
+      short ax = img->all_mv[by][bx][list][ref][blocktype][0], ay = img->all_mv[by][bx][list][ref][blocktype][1];
+      int c;
+      if (!orig) orig = next_sym("BlockMotionSearch");
+      c = orig(ref, list, mb_x, mb_y, blocktype, search_range, lambda_factor);
+      if (c != r->cost[ref][p] || img->all_mv[by][bx][list][ref][blocktype][0] != ax || img->all_mv[by][bx][list][ref][blocktype][1] != ay)
+        fprintf(stderr, "jm_shim VERIFY BlockMotionSearch mb %d ref %d bt %d (%d,%d): jm=(%d,%d,%d) dev=(%d,%d,%d)\n", img->current_mb_nr, ref, blocktype, bx, by,
+                img->all_mv[by][bx][list][ref][blocktype][0], img->all_mv[by][bx][list][ref][blocktype][1], c, ax, ay, r->cost[ref][p]);
+      return c;
+    }
+    n_dev[S_BMS]++;
+    return r->cost[ref][p];
+  }
+}
 
 /* DeblockFrame (src/loopFilter.c:87): the picture goes up, jmhip_deblock_frame filters it in JM's macroblock order, it comes back.
  * MBAFF, field pictures and SP/SI slices stay in JM. */

@@ -64,6 +64,7 @@ LoopFilterAlphaC0Offset = {lfa}
 LoopFilterBetaOffset = {lfb}
 SliceMode = {slicemode}
 SliceArgument = {slicearg}
+DisableIntraInInter = {noi}
 """
 
 CASES = {
@@ -131,6 +132,7 @@ def prepare(tmp_path, name, w=176, h=144, frames=3, R=16, qp=28):
     v.setdefault("bipred", 0)
     v.setdefault("wbp", 0)
     v.setdefault("wp", 0)
+    v.setdefault("noi", 0)
     with open(tmp_path / "case.cfg", "w") as f:
         f.write(CFG.format(**v))
     make_clip(tmp_path / "clip.yuv", w, h, frames + v["bframes"] * (frames - 1), v["yuv"], v.get("fade", 0))
@@ -150,7 +152,7 @@ def test_shim_forwards_everything_when_masked_off(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not HAVE, reason="oracle/_ref/jm_hip did not travel")
-@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("name", [n for n in CASES if not n.startswith("slice_")])
 def test_jm_with_hip_hot_path_is_byte_identical(tmp_path, name):
     prepare(tmp_path, name)
     want = run("jm_plain", tmp_path)
@@ -186,3 +188,42 @@ def test_jm_with_hip_hot_path_is_byte_identical(tmp_path, name):
     if CASES[name].get("bipred"):
         assert served["FullPelBlockMotionBiPred"][0] > 100 and served["FullPelBlockMotionBiPred"][1] == 0
         assert served["SubPelBlockSearchBiPred"][0] > 50 and served["SubPelBlockSearchBiPred"][1] == 0
+
+
+# ------------------------------------------------------------------ slice-level binding (jm_shim.c, mask 0x1000)
+# Low-complexity mode with intra off in P slices: the whole motion search + inter decision of a P slice is ONE jmhip_p_slice_search call and
+# every BlockMotionSearch call is answered from its records (after a predictor check). The EPZS / UMHexagonS walkers, their sub-pel searches
+# and the predictor run on the device: JM's own are never called.
+SLICE_CASES = {
+    "slice_full": dict(search=-1, profile=66, cabac=0, t8x8=0, bframes=0, refs=1, rdopt=0, adrnd=1, yuv=1, noi=1),
+    "slice_fastfull_2ref": dict(search=0, profile=66, cabac=0, t8x8=0, bframes=0, refs=2, rdopt=0, adrnd=0, yuv=1, noi=1),
+    "slice_epzs_2ref": dict(search=3, profile=77, cabac=1, t8x8=0, bframes=0, refs=2, rdopt=0, adrnd=0, yuv=1, noi=1),            # BASELINE config 3's search in small
+    "slice_epzs_satd_fpel": dict(search=3, profile=77, cabac=1, t8x8=0, bframes=0, refs=1, rdopt=0, adrnd=0, yuv=1, noi=1, fpel=2),
+    "slice_umhex_2ref": dict(search=1, profile=66, cabac=0, t8x8=0, bframes=0, refs=2, rdopt=0, adrnd=1, yuv=1, noi=1),
+    "slice_umhex_wp_422": dict(search=1, profile=122, cabac=1, t8x8=0, bframes=0, refs=2, rdopt=0, adrnd=0, yuv=2, wp=1, fade=1, noi=1),   # config 5 in small
+    "slice_epzs_four_slices_midrow": dict(search=3, profile=77, cabac=1, t8x8=0, bframes=0, refs=2, rdopt=0, adrnd=0, yuv=1, noi=1, slicemode=1, slicearg=27, lfflag=1, lfidc=2),
+}
+CASES.update(SLICE_CASES)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not HAVE, reason="oracle/_ref/jm_hip did not travel")
+@pytest.mark.parametrize("name", list(SLICE_CASES))
+def test_jm_slice_level_binding_is_byte_identical(tmp_path, name):
+    prepare(tmp_path, name, frames=4)
+    want = run("jm_plain", tmp_path)
+    got = run("jm_hip", tmp_path, {"JMHIP_SHIM_STATS": "1"})
+    stats = got[2]
+    assert got[0] == want[0], "bitstream differs\n" + stats
+    assert got[1] == want[1], "reconstruction differs\n" + stats
+    m = re.search(r"^\s*BlockMotionSearch\s+device\s+(\d+)\s+forwarded\s+(\d+)", stats, re.M)
+    sl = re.search(r"P slices \(one device call each\)\s+device\s+(\d+)", stats)
+    info = re.search(r"slice binding: (\d+) slices, (\d+) kernel passes", stats)
+    print(name, m.groups(), sl.groups(), info.groups())
+    nslices = 4 if "slices_midrow" in name else 1          # 99 macroblocks in slices of 27
+    assert int(sl.group(1)) == 3 * nslices, "one device call per P slice (3 P pictures)"
+    assert int(m.group(1)) >= 3 * 99 * 41 and int(m.group(2)) == 0, "every BlockMotionSearch call of the P pictures must be served from the slice records"
+    # JM's own search functions must not have run at all in the P pictures
+    for sym in ("FullPelBlockMotionSearch", "FastFullPelBlockMotionSearch", "SubPelBlockMotionSearch", "EPZS_UMHex_integer_walks", "computeSAD", "computeSATD"):
+        mm = re.search(r"^\s*%s\s+device\s+(\d+)\s+forwarded\s+(\d+)" % sym, stats, re.M)
+        assert mm and int(mm.group(1)) == 0 and int(mm.group(2)) == 0, (sym, mm and mm.groups())

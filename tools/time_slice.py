@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Times jmhip_p_slice_search (the macroblock-wavefront P-slice kernel) on a synthetic 1080p picture for each search mode.
+usage: python tools/time_slice.py [--size 1080p|qcif|720p] [--refs N] [--modes 3,1,0,-1] [--range R]"""
+import argparse
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as ge  # noqa: E402
+from tests.test_slice_gpu import slice_params, synth_clip  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", default="1080p")
+    ap.add_argument("--refs", type=int, default=1)
+    ap.add_argument("--modes", default="3,1,0,-1")
+    ap.add_argument("--range", type=int, default=32)
+    ap.add_argument("--reps", type=int, default=3)
+    a = ap.parse_args()
+    W, H = {"1080p": (1920, 1088), "720p": (1280, 720), "qcif": (176, 144), "2160p": (3840, 2160)}[a.size]
+    pkg = ge._load_pkg()
+    lib = pkg.load_library()
+    rng = np.random.default_rng(3)
+    clip = synth_clip(rng, W, H, a.refs + 1)
+    ctx = pkg.Context(W, H, yuv_format=0, max_refs=a.refs, search_range=a.range)
+    for r in range(a.refs):
+        ctx.ref_upload(r, clip[a.refs - 1 - r])
+        ctx.interp_luma(r)
+    ctx.cur_upload(clip[a.refs])
+    lam = int(65536 * np.sqrt(0.85 * 2 ** ((28 - 12) / 3.0)) + 0.5)
+    for mode in [int(m) for m in a.modes.split(",")]:
+        ctx.slice_state_reset()
+        ctx.epzs_colocated_upload(np.zeros((H // 4, W // 4, 2), np.int16))
+        p = slice_params(pkg, mode, a.range, a.refs, [lam] * 3, 10, W, H=H)
+        pocs = [2 * (a.refs - 1 - r) for r in range(a.refs)]
+        lib.jmhip_epzs_scales(p, 2 * a.refs, (C.c_int * a.refs)(*pocs), a.refs)
+        ts = []
+        for k in range(a.reps):
+            t0 = time.perf_counter()
+            ctx.p_slice_search(p, download=False)
+            ctx.sync()
+            ts.append(time.perf_counter() - t0)
+        print("mode %2d  %s  refs %d  R %d:  %s ms per picture  (passes %d)  -> %.0f macroblocks/s" % (
+            mode, a.size, a.refs, a.range, " ".join("%.1f" % (t * 1e3) for t in ts), ctx.slice_passes(), (W // 16) * (H // 16) / min(ts)), flush=True)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
