@@ -175,6 +175,49 @@ def cpu_baseline_reference(frames):
                       % (MBW * MBH, me_ms, tot_ms, MBW * MBH / (tot_ms * 1e-3), wall, os.cpu_count())}
 
 
+def jm_end_to_end(frames):
+    """The reference encoder itself, same 1080p clip (frames 0-1: I + P), FullSearch +-32, low-complexity decision with intra off in the P
+    picture (RDOptimization 0, DisableIntraInInter 1 -- the configuration whose whole P-slice search + inter decision is ONE device call):
+    the unmodified JM (oracle/_ref/jm_plain) against JM bound to libjmhip.so at slice level (oracle/_ref/jm_hip, integration/jm_shim.c,
+    mask 0x1801 = sub-pel planes + slice binding + loop filter on the device, everything else JM's own code). Wall-clock of whole encodes."""
+    import re
+    import subprocess
+    import tempfile
+    exes = [os.path.join(ROOT, "oracle", "_ref", e) for e in ("jm_plain", "jm_hip")]
+    if not all(os.path.exists(e) for e in exes):
+        return None
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "synth1080.yuv"), "wb") as f:
+            for (Y, U, V) in frames[:2]:
+                f.write(Y[:H_SRC].tobytes()); f.write(U[:H_SRC // 2].tobytes()); f.write(V[:H_SRC // 2].tobytes())
+        with open(os.path.join(d, "min.cfg"), "w") as f:
+            f.write((JM_CFG % (QP, QP, R)).replace("RDOptimization = 1", "RDOptimization = 0") + "DisableIntraInInter = 1\n")
+        digests = []
+        for exe, key in zip(exes, ("jm_plain", "jm_hip")):
+            env = dict(os.environ, JMHIP_SHIM="1801", JMHIP_SHIM_STATS="1")
+            t0 = time.perf_counter()
+            try:
+                r = subprocess.run([exe, "-d", "min.cfg"], cwd=d, env=env, capture_output=True, text=True, timeout=400)
+            except Exception:
+                return None
+            out[key + "_s"] = round(time.perf_counter() - t0, 2)
+            m = re.search(r"^0001\(P\)\s+\d+\s+\d+\s+[\d.]+\s+[\d.]+\s+[\d.]+\s+(\d+)\s+(\d+)", r.stdout, re.M)
+            if not m:
+                return None
+            out[key + "_p_frame_ms"] = int(m.group(1))
+            out[key + "_p_frame_me_ms"] = int(m.group(2))
+            with open(os.path.join(d, "out.264"), "rb") as f:
+                digests.append(f.read())
+            if key == "jm_hip":
+                mm = re.search(r"^\s*BlockMotionSearch\s+device\s+(\d+)\s+forwarded\s+(\d+)", r.stderr, re.M)
+                out["block_motion_search_calls_served"] = int(mm.group(1)) if mm else None
+                out["block_motion_search_calls_forwarded"] = int(mm.group(2)) if mm else None
+        out["bitstreams_identical"] = digests[0] == digests[1]
+        out["config"] = "1920x1080 I+P, FullSearch +-32, 1 reference, RDOptimization 0, DisableIntraInInter 1, CAVLC; jm_hip: JMHIP_SHIM=0x1801"
+    return out
+
+
 def cpu_baseline(pkg, frames, n_mbs):
     """The oracle's restated JM algorithm on ONE host core over a bounded sample of the same workload."""
     from tests import oracle
@@ -206,6 +249,45 @@ def cpu_baseline(pkg, frames, n_mbs):
             "sample": "%d MBs (rows %d..%d of frame 1, FullSearch +-%d, 41 partitions + sub-pel + TQ) in %.1f s; "
                       "+ full-frame sub-pel plane generation %.2f s charged per MB; host has %d cores, 1 used (JM is single-threaded)"
                       % (n, rows[0], rows[-1], R, t_mb, t_interp, os.cpu_count())}
+
+
+def parity_check(pkg, ctx, frames, mbs, prm, last_src, prev_ref):
+    """A sample of the LAST step's motion search (integer + sub-pel vectors and costs, all 41 partitions) against the oracle's restatement of JM on
+    the same inputs: the source frame of that step and the reference picture it searched (downloaded before the step)."""
+    from tests import oracle
+    if prev_ref is None:
+        return None
+    res = ctx.me_results(len(mbs))
+    rng = np.random.default_rng(99)
+    pick = np.sort(rng.choice(len(mbs), size=12, replace=False))
+    rp = oracle.RefPic(prev_ref, yuv_format=0)
+    lam = [int(prm.lambda_[0]), int(prm.lambda_[1]), int(prm.lambda_[2])]
+    want = oracle.me_frame(oracle.me_params(rdopt=1), [rp], frames[last_src][0], mbs[pick], -1, R, lam)
+    ok = all(np.array_equal(res[k][pick], want[k]) for k in ("mv_int", "cost_int", "mv", "cost"))
+    return {"macroblocks": int(len(pick)), "partitions_each": 41, "fields": ["mv_int", "cost_int", "mv", "cost"], "vs": "oracle (CPU restatement of JM)", "ok": bool(ok)}
+
+
+def slice_search_times(pkg, ctx, lam):
+    """For information: the JM-exact form of the search -- jmhip_p_slice_search: predictors, search, sub-pel, skip shortcut and the low-complexity
+    inter decision on the device with JM's raster-order dependencies (macroblock wavefront) -- on the bench picture, one reference, per search mode."""
+    import ctypes
+    from tests.test_slice_gpu import slice_params
+    lib = pkg.load_library()
+    out = {}
+    ctx.interp_luma(0)                                  # the last step left a new integer picture in the slot
+    for name, mode in (("FullSearch", -1), ("FastFullSearch", 0), ("EPZS", 3), ("UMHexagonS", 1)):
+        ctx.slice_state_reset()
+        ctx.epzs_colocated_upload(np.zeros((H // 4, W // 4, 2), np.int16))
+        p = slice_params(pkg, mode, R, 1, [lam] * 3, 10, W, H=H)
+        lib.jmhip_epzs_scales(p, 2, (ctypes.c_int * 1)(0), 1)
+        ts = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            ctx.p_slice_search(p, download=False)
+            ctx.sync()
+            ts.append(time.perf_counter() - t0)
+        out[name] = {"ms_per_picture": round(min(ts) * 1e3, 1), "macroblocks_per_s": round(MBW * MBH / min(ts), 1), "passes": ctx.slice_passes()}
+    return out
 
 
 def main():
@@ -367,7 +449,13 @@ def main():
     elapsed = time.perf_counter() - t0
     stage_me = ctx.timing_read()
     ctx.timing_select(list(pkg.STAGES))
+    prev_ref_host = None
     for k in range(3):
+        if k == 2 and world == 1 and args.cpu_mbs > 0:          # the reference picture the last step searches: kept for the parity check
+            ctx.sync()
+            ry, _, _, _, _ = ctx.ref_device_planes_ro(0)
+            prev_ref_host = np.zeros((H, W), np.uint8)
+            ctx.copy_from_device(ry, prev_ref_host)
         step(args.warmup + args.steps + k)
     fence()
     stage = ctx.timing_read()
@@ -404,24 +492,26 @@ def main():
             ("; + in-loop deblocking (NOT the metric's path)" if args.deblock else "")
         out = {
             "metric": "macroblocks/sec (full-search ME + DCT/quant), 1080p; bit-exact MV+coeff vs JM",
+            "metric_note": "predictors are an INPUT of this pipeline (one per macroblock, SURVEY 8(d)'s independent-MBs recipe); `parity_check` compares a sample of the "
+                           "last step with the oracle; `slice_search` gives the JM-exact form (predictors + decision on the device, raster-order dependencies kept)",
             "value": round(total_mbs / elapsed, 1), "unit": "macroblocks/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": workload,
                        "slices": world, "parallelism": "slice%d" % world},
-            "roofline": {"kernel": "me_int_pair_kernel (integer full search, all 41 partitions)", "bound": "hbm",
-                         "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+            "roofline": {"kernel": "me_int_pair_kernel (integer full search, all 41 partitions)", "bound": "valu",
+                         "achieved": round(sad_ops / 1e12, 3), "peak": round(sad_ops / 1e12 * me_avg_ms / valu_floor_ms, 3) if me_launches else None,
+                         "unit": "T abs-diff/s", "frac": round(valu_floor_ms / me_avg_ms, 4) if me_launches else None,
                          "traffic": pmc_traffic("me_int_pair_kernel", n), "avg_launch_ms": round(me_avg_ms, 4), "units_per_launch": n,
-                         "algorithmic_bytes_per_unit": ME_BYTES_PER_MB,
-                         "traffic_note": "bytes per launch = (FETCH_SIZE + WRITE_SIZE) KB x 1024 from profiles/r01_final_pmc_*.csv, raw: the "
-                                         "guide's x2 FETCH_SIZE correction is calibrated for 16 B/lane streaming reads and this kernel "
-                                         "reads dwords, so it is not applied (with it: fetch doubles)",
-                         "note": "full search is integer-VALU bound by construction (about 1e3 integer ops per compulsory byte, SURVEY 8(d)); "
-                                 "the HBM fraction is small by design. The binding roofline is `valu`: the time the search's "
-                                 "irreducible v_sad/add/min work takes at the measured MI355X issue rates",
-                         "valu": {"model_floor_ms": round(valu_floor_ms, 4), "frac": round(valu_floor_ms / me_avg_ms, 4) if me_launches else None,
-                                  "ns_per_wave_candidate_row": round(VALU_NS_PER_WAVE_CANDIDATE, 1), "simds": N_SIMD,
-                                  "abs_diffs_per_s": round(sad_ops, 1)}},
+                         "peak_is": "a MODEL, not a guide constant: the time the search's irreducible work -- per candidate 64 v_sad_u8, 25 + 40 adds, "
+                                    "20.5 v_min3 -- takes at issue rates measured on this chip (tools/ubench/valu_rate2.hip -> "
+                                    "profiles/r01_valu_issue_rates.txt: v_sad_u8 / v_min3_u32 1.89 ns, v_add_u32 1.04 ns per wave-instruction per SIMD, "
+                                    "1024 SIMDs); full search is about 1e3 integer ops per compulsory byte (SURVEY 8(d)), so HBM is not the roof that binds",
+                         "valu_model": {"model_floor_ms": round(valu_floor_ms, 4), "ns_per_wave_candidate_row": round(VALU_NS_PER_WAVE_CANDIDATE, 1), "simds": N_SIMD},
+                         "hbm": {"achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                                 "algorithmic_bytes_per_unit": ME_BYTES_PER_MB,
+                                 "traffic_note": "traffic = (FETCH_SIZE + WRITE_SIZE) KB x 1024 per launch from profiles/r01_final_pmc_*.csv, raw: the guide's x2 "
+                                                 "FETCH_SIZE correction is calibrated for 16 B/lane streaming reads and this kernel reads dwords, so it is not applied"}},
             "stages_ms_per_launch": {k: round(v[0] / max(1, v[1]), 4) for k, v in stage.items()},
             "ref_checksum": ref_sum,
         }
@@ -441,6 +531,12 @@ def main():
             out["cpu_baseline"] = ref if ref is not None else port
             out["cpu_baseline_port"] = port
             out["speedup_vs_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        if world == 1 and args.cpu_mbs > 0:
+            out["parity_check"] = parity_check(pkg, ctx, frames, mbs, prm, last_src=1 + ((args.warmup + args.steps + 2) % (nframes - 1)), prev_ref=prev_ref_host)
+            out["slice_search"] = slice_search_times(pkg, ctx, lam)
+            e2e = jm_end_to_end(frames)
+            if e2e is not None:
+                out["jm_end_to_end"] = e2e
         if solo:
             out = {"DIAGNOSTIC_solo_rank": solo, "ms_per_step_of_this_rank": out["ms_per_step"], "stages_ms_per_launch": out.get("stages_ms_per_launch")}
         print(json.dumps(out))
