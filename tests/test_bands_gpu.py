@@ -139,3 +139,36 @@ def test_one_buffer_band_exchange(pkg):
         chk.copy_from_device(ptr, got)
         assert np.array_equal(got, wantp)
     chk.close()
+
+
+def test_device_chunk_layout_equals_the_host_mirror(pkg):
+    """jmhip_recon_pack_band / jmhip_ref_unpack_bands against h.264_amd/slices.py's host definition of the chunk (what the gloo CPU test exchanges)."""
+    rng = np.random.default_rng(23)
+    w, h, world = 96, 144, 2                            # 9 macroblock rows in bands of 5: the last band is padded
+    mbh = h // 16
+    Y = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    U = rng.integers(0, 256, (h // 2, w // 2), dtype=np.uint8)
+    V = rng.integers(0, 256, (h // 2, w // 2), dtype=np.uint8)
+    ctx = pkg.Context(w, h, yuv_format=1, max_refs=1, search_range=8)
+    ctx.recon_upload(Y, U, V)
+    dev = torch.device("cuda", 0)
+    band = pkg.slices.band_rows(mbh, world, 0)[2]
+    chunk = ctx.band_chunk_bytes(band)
+    assert chunk == pkg.slices.chunk_bytes(w, w // 2, 8, band)
+    g = torch.zeros(chunk * world, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    for r in range(world):
+        ctx.recon_pack_band(g[r * chunk:(r + 1) * chunk].data_ptr(), r, band)
+    ctx.sync()
+    host = g.cpu().numpy()
+    for r in range(world):
+        want = pkg.slices.pack_band_host(np, Y, U, V, r, band, 8)
+        rows_y = min(band * 16, h - r * band * 16)
+        assert np.array_equal(host[r * chunk:r * chunk + rows_y * w], want[:rows_y * w]), "luma rows of chunk %d" % r
+    ctx.ref_unpack_bands(0, g.data_ptr(), world, band)
+    ctx.interp_luma(0)
+    planes = ctx.download_luma_planes(0)
+    assert np.array_equal(planes[0][0][20:20 + h, 20:20 + w], Y)
+    got = pkg.slices.unpack_bands_host(np, host, world, band, h, w, h // 2, w // 2, 8)
+    assert all(np.array_equal(a, b) for a, b in zip(got, (Y, U, V)))
+    ctx.close()

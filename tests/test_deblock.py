@@ -169,12 +169,23 @@ def test_deblock_global_memory_kernel_on_420(pkg, monkeypatch):
 @pytest.mark.gpu
 @pytest.mark.parametrize("idc,slice_rows", [(0, 0), (2, 2)])
 def test_deblock_recon_from_the_frame_stage(pkg, idc, slice_rows):
+    recon_stage_case(pkg, idc, slice_rows, 96, 64, 8)
+
+
+@pytest.mark.gpu
+def test_deblock_recon_2160p_eight_slices(pkg):
+    """BASELINE config 4's layout at size: 3840x2160 cut into 8 slices of whole macroblock rows (17 rows each, the last 16), filter kept inside
+    the slices (idc 2): search -> residual -> filter on the device, against the oracle's DeblockFrame on the same side information."""
+    recon_stage_case(pkg, 2, 17, 3840, 2160, 16, spread=10)
+
+
+def recon_stage_case(pkg, idc, slice_rows, w, h, R, spread=6):
     """jmhip_deblock_recon builds the filter's side information on the device from the results of me_frame + residual_frame.
     Expected: the oracle's filter on the downloaded (unfiltered) reconstruction with the same information assembled on the host."""
     from tests.test_frame import synth
     from tests.test_me import lambda_factors, make_mbs
     rng = np.random.default_rng(12)
-    w, h, R, qp = 96, 64, 8, 38
+    qp = 38
     cur, ref = synth(rng, w, h, 1)
     ctx = pkg.Context(w, h, yuv_format=1, max_refs=1, search_range=R)
     ctx.ref_upload(0, *ref)
@@ -182,7 +193,7 @@ def test_deblock_recon_from_the_frame_stage(pkg, idc, slice_rows):
     ctx.interp_chroma(0)
     ctx.cur_upload(*cur)
     mbw, mbh = w // 16, h // 16
-    mbs_me = make_mbs(pkg, rng, mbw, mbh, 6)
+    mbs_me = make_mbs(pkg, rng, mbw, mbh, spread, per_partition=(w < 1000))
     prm = pkg.MeParams()
     prm.search_mode, prm.search_range, prm.rdopt = -1, R, 1
     prm.level_mv_min, prm.level_mv_max = -511, 511
@@ -191,7 +202,7 @@ def test_deblock_recon_from_the_frame_stage(pkg, idc, slice_rows):
     me = ctx.me_frame(prm, mbs_me)
     quants = np.array([pkg.flat_quant(qp + d, 342, adaptive_rounding=0, adapt_rnd_weight=4, cavlc=1) for d in (0, 0, 3)], dtype=pkg.QUANT_DTYPE)
     ctx.residual_frame(quants, None)
-    got = ctx.residual_download(len(mbs_me))
+    got = ctx.residual_download(len(mbs_me), want_results=(w < 1000))
     before = ctx.recon_download()
     # the same information, assembled on the host
     mbs = np.zeros(mbw * mbh, pkg.DEBLOCK_MB_DTYPE)

@@ -1,5 +1,5 @@
-"""BASELINE config 2 at full size (1920x1088, FullSearch +-32, 8160 macroblocks x 41 partitions) on the device:
- * a sample of macroblocks (picture corners, edges, interior rows) against the oracle's C driver, bit-exact;
+"""BASELINE configs 2 and 4 at full size (1920x1088 and 3840x2160, FullSearch +-32, 41 partitions per macroblock) on the device:
+ * EVERY macroblock of the frame against the oracle's C driver, bit-exact (the oracle runs on the box's host cores in parallel);
  * the whole frame through size-independent properties: the two independent integer-search kernels (pair-lane "fast" path
    and the union-window generic path, forced by masking one partition off) must agree on every other partition of every
    macroblock; a resident re-run reproduces the first run; costs are consistent with the vectors they come with."""
@@ -65,34 +65,39 @@ def test_full_frame_search(pkg, W, H):
     hit = ((got["mv_int"][:, 0, 0] == 5) & (got["mv_int"][:, 0, 1] == -3)).mean()
     assert hit > 0.9, hit
 
-    # ---- oracle on a sample: corners/edges (UMV windows) and interior rows
-    rows = [0, 1, mbh // 2 - 1, mbh // 2, mbh - 2, mbh - 1]
-    sel = np.concatenate([np.arange(r * mbw, (r + 1) * mbw, 3 * (W // 1920)) for r in rows])
+    # ---- the oracle over the WHOLE frame, macroblock rows dealt to host threads (ctypes releases the GIL)
+    from concurrent.futures import ThreadPoolExecutor
     L = oracle.lib()
     p = oracle.me_params(rdopt=1)
     rp = oracle.RefPic(ref, yuv_format=0)
-    xy = np.ascontiguousarray(np.stack([mbs["mb_x"][sel], mbs["mb_y"][sel]], 1).astype(np.int16))
-    preds = np.ascontiguousarray(mbs["pred_mv"][sel].astype(np.int16))
     lam_a = (C.c_int * 3)(*lam)
     cur16 = np.ascontiguousarray(cur, dtype=np.uint16)
-    mv_out = np.zeros((len(sel), 41, 2), np.int16)
-    cost_out = np.zeros((len(sel), 41), np.int32)
+    mv_out = np.zeros((n, 41, 2), np.int16)
+    cost_out = np.zeros((n, 41), np.int32)
     vp = C.c_void_p
     L.jmo_hotpath_mbs.restype = C.c_longlong
     L.jmo_hotpath_mbs.argtypes = [C.POINTER(oracle.MeParams), C.POINTER(oracle.Ref), vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int,
                                   C.POINTER(C.c_int), vp, vp, vp, vp]
-    L.jmo_hotpath_mbs(C.byref(p), C.byref(rp.ref), cur16.ctypes.data, None, None, W, xy.ctypes.data, preds.ctypes.data, len(sel), R, lam_a,
-                      None, None, mv_out.ctypes.data, cost_out.ctypes.data)
-    assert np.array_equal(got["mv"][sel], mv_out), "vectors differ from the oracle on the sampled macroblocks"
-    assert np.array_equal(got["cost"][sel], cost_out), "costs differ from the oracle on the sampled macroblocks"
+    xy = np.ascontiguousarray(np.stack([mbs["mb_x"], mbs["mb_y"]], 1).astype(np.int16))
+    preds = np.ascontiguousarray(mbs["pred_mv"].astype(np.int16))
+
+    def rows(r):
+        a, b = r * mbw, (r + 1) * mbw
+        L.jmo_hotpath_mbs(C.byref(p), C.byref(rp.ref), cur16.ctypes.data, None, None, W, xy[a:b].ctypes.data, preds[a:b].ctypes.data, b - a, R, lam_a,
+                          None, None, mv_out[a:b].ctypes.data, cost_out[a:b].ctypes.data)
+    with ThreadPoolExecutor(max_workers=14) as ex:
+        list(ex.map(rows, range(mbh)))
+    assert np.array_equal(got["mv"], mv_out), "vectors differ from the oracle: %d macroblocks" % int((got["mv"] != mv_out).any(axis=(1, 2)).sum())
+    assert np.array_equal(got["cost"], cost_out), "costs differ from the oracle"
 
 
-def test_full_frame_residual_stage_1080p(pkg):
-    """The frame stage (MC -> residual -> dct_4x4 / dct_chroma -> thresholds -> recon) over all 8160 macroblocks of a 1080p 4:2:0
-    frame; a sample of macroblocks (corners, edges, interior) against the reference assembled from the oracle, and whole-frame
-    properties: recon == prediction wherever the coded block pattern is empty, recon of a second identical run is identical."""
+@pytest.mark.parametrize("W,H,step", [(1920, 1088, 1), (3840, 2160, 9)])
+def test_full_frame_residual_stage(pkg, W, H, step):
+    """The frame stage (MC -> residual -> dct_4x4 / dct_chroma -> thresholds -> recon) over every macroblock of a 1080p / 2160p 4:2:0
+    frame against the reference assembled from the oracle: ALL 8160 macroblocks at 1080p, every 9th (3600, all rows and columns hit) at 2160p;
+    plus: the reconstruction of a second identical run is identical."""
     from h264_amd.jmhip import ME_MB_DTYPE
-    cur, ref = clip()
+    cur, ref = clip(W, H)
     mk = lambda img, s: np.clip(np.round(128 + s * 0.25 * (img[::2, ::2].astype(float) - 128)), 0, 255).astype(np.uint8)
     curs, refs = (cur, mk(cur, 1), mk(cur, -1)), (ref, mk(ref, 1), mk(ref, -1))
     mbw, mbh = W // 16, H // 16
@@ -124,8 +129,7 @@ def test_full_frame_residual_stage_1080p(pkg):
         assert np.array_equal(a, b)
     assert (got["cbp"] & 15).max() > 0 and ((got["cbp"] & 15) == 0).any()       # coded and uncoded macroblocks both occur
 
-    rows = [0, 34, 67]
-    sel = np.concatenate([np.arange(r * mbw, (r + 1) * mbw, 7) for r in rows])
+    sel = np.arange(0, n, step)
     rp = oracle.RefPic(refs[0], refs[1], refs[2], yuv_format=1)
     want = oracle.residual_frame(rp, curs, mbs[sel], me["mv"][sel], got["modes"][sel], quants, pkg.TQ_JOB_DTYPE, yuv_format=1)
     assert np.array_equal(got["cbp"][sel], want["cbp"])
