@@ -26,6 +26,10 @@ struct FrameDev {
   // (reference slots 0..3; see mc_kernel)
   int fly, mul_x, mul_y, pad_cx, pad_cy;
   const uint8_t *ref_u[4], *ref_v[4];
+  // explicit weighted prediction of P slices (LumaPrediction macroblock.c:880-914, ChromaPrediction4x4 :1895-1903), per reference SLOT
+  int wp_on, wp_lround, wp_ldenom, wp_cround, wp_cdenom;
+  short wp_w[16][3], wp_o[16][3];
+  const int8_t *blk_ref;          // [n][4]: reference slot of each 8x8 block (NULL: the macroblock's one reference, jmhip_me_mb.ref)
 };
 
 __device__ __forceinline__ int clampi(int x, int lo, int hi) { return min(max(x, lo), hi); }
@@ -61,6 +65,7 @@ __global__ __launch_bounds__(64) void mc_kernel(FrameDev F, const jmhip_me_mb *_
 {
   __shared__ jmhip_mb_mode s_mode;
   __shared__ short s_mv[16][2];
+  __shared__ int s_ref[4];
   const int i = jm_xcd_item(n_items), tid = threadIdx.x;
   if (i < 0) return;
   const jmhip_me_mb &mb = mbs[i];
@@ -97,6 +102,7 @@ __global__ __launch_bounds__(64) void mc_kernel(FrameDev F, const jmhip_me_mb *_
     const int p = covering_partition(s_mode, tid & 3, tid >> 2);
     s_mv[tid][0] = r.mv[p][0]; s_mv[tid][1] = r.mv[p][1];
   }
+  if (tid < 4) s_ref[tid] = F.blk_ref ? F.blk_ref[(size_t)i * 4 + tid] : mb.ref;
   __syncthreads();
 
   jmhip_tq_job &jy = jobs_y[i];
@@ -108,10 +114,18 @@ __global__ __launch_bounds__(64) void mc_kernel(FrameDev F, const jmhip_me_mb *_
     const int xq = ((mbx * 16 + 4 * x4 - ox4) << 2) + 4 * JMHIP_PAD + s_mv[tid][0];   // pic_opix_x + mv, macroblock.c:851
     const int yq = ((mby * 16 + 4 * y4 - oy4) << 2) + 4 * JMHIP_PAD + s_mv[tid][1];
     const int xpos = clampi(xq >> 2, 0, F.Wp - 1 - 16) + ox4, ypos = clampi(yq >> 2, 0, F.Hp - 1 - 16) + oy4;   // UMVLine4X, refbuf.c:37
-    const uint8_t *src = F.ref_sub[mb.ref] + (size_t)((yq & 3) * 4 + (xq & 3)) * F.Wp * F.Hp + (size_t)ypos * F.Wp + xpos;
+    const int slot = s_ref[2 * (y4 >> 1) + (x4 >> 1)];
+    const uint8_t *src = F.ref_sub[slot] + (size_t)((yq & 3) * 4 + (xq & 3)) * F.Wp * F.Hp + (size_t)ypos * F.Wp + xpos;
 #pragma unroll
     for (int rr = 0; rr < 4; rr++) {
-      *reinterpret_cast<uint32_t *>(&jy.pred[4 * y4 + rr][4 * x4]) = fetch4(src + (size_t)rr * F.Wp);
+      uint32_t pv = fetch4(src + (size_t)rr * F.Wp);
+      if (F.wp_on) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) w |= (uint32_t)clampi((((int)F.wp_w[slot][0] * (int)((pv >> (8 * k)) & 255u) + F.wp_lround) >> F.wp_ldenom) + F.wp_o[slot][0], 0, 255) << (8 * k);
+        pv = w;
+      }
+      *reinterpret_cast<uint32_t *>(&jy.pred[4 * y4 + rr][4 * x4]) = pv;
       *reinterpret_cast<uint32_t *>(&jy.src[4 * y4 + rr][4 * x4]) =
           *reinterpret_cast<const uint32_t *>(F.cur_y + (size_t)(mby * 16 + 4 * y4 + rr) * F.W + mbx * 16 + 4 * x4);
     }
@@ -132,25 +146,32 @@ __global__ __launch_bounds__(64) void mc_kernel(FrameDev F, const jmhip_me_mb *_
       const int width_pad_cr = F.Wcp - 1 - F.mb_cw, height_pad_cr = F.Hcp - 1 - F.mb_ch;      // mbuffer.c:425-426
       const int xpos = clampi(ii >> F.shift_x, 0, width_pad_cr), ypos = clampi(jj >> F.shift_y, 0, height_pad_cr);
       jmhip_tq_job &jc = jobs_c[2 * i + uv];
+      const int slot = s_ref[2 * (by4 >> 1) + (bx4 >> 1)];
+      int p0, p1;
       if (F.fly) {
         // The value plane (jj & mask_y, ii & mask_x) of getSubImagesChroma holds at padded position (ypos, xpos) and (ypos, xpos + 1)
         // (img_chroma.c:412-420, interp_chroma.hip): weights (8-k)(8-l), (8-k)l, k(8-l), kl on the four neighbours with the source
         // coordinates clamped to the picture. The clamp above keeps xpos + 1 and ypos off the plane's never-written last column / row,
         // so the planes' zero cells cannot be asked for. Same integers as the planes, no 64x copy of the chroma picture in HBM.
-        const uint8_t *pic = uv ? F.ref_v[mb.ref] : F.ref_u[mb.ref];
+        const uint8_t *pic = uv ? F.ref_v[slot] : F.ref_u[slot];
         const int k = (jj & F.mask_y) * F.mul_y, l = (ii & F.mask_x) * F.mul_x;
         const uint8_t *r0 = pic + (size_t)clampi(ypos - F.pad_cy, 0, F.Hc - 1) * F.Wc;
         const uint8_t *r1 = pic + (size_t)clampi(ypos - F.pad_cy + 1, 0, F.Hc - 1) * F.Wc;
         const int xa = clampi(xpos - F.pad_cx, 0, F.Wc - 1), xb = clampi(xpos - F.pad_cx + 1, 0, F.Wc - 1), xc = clampi(xpos - F.pad_cx + 2, 0, F.Wc - 1);
         const int a0 = r0[xa], a1 = r0[xb], a2 = r0[xc], b0 = r1[xa], b1 = r1[xb], b2 = r1[xc];
         const int h00 = a0 * (8 - l) + a1 * l, h01 = a1 * (8 - l) + a2 * l, h10 = b0 * (8 - l) + b1 * l, h11 = b1 * (8 - l) + b2 * l;
-        // ic is even: the two samples go out as one 16-bit store
-        *reinterpret_cast<uint16_t *>(&jc.pred[j][ic]) = (uint16_t)(((h00 * (8 - k) + h10 * k + 32) >> 6) | (((h01 * (8 - k) + h11 * k + 32) >> 6) << 8));
+        p0 = (h00 * (8 - k) + h10 * k + 32) >> 6; p1 = (h01 * (8 - k) + h11 * k + 32) >> 6;
       } else {
-        const uint8_t *planes = (uv ? F.ref_cr : F.ref_cb)[mb.ref];
+        const uint8_t *planes = (uv ? F.ref_cr : F.ref_cb)[slot];
         const uint8_t *src = planes + (size_t)((jj & F.mask_y) * F.sub_x + (ii & F.mask_x)) * F.Wcp * F.Hcp + (size_t)ypos * F.Wcp + xpos;
-        *reinterpret_cast<uint16_t *>(&jc.pred[j][ic]) = (uint16_t)(src[0] | (src[1] << 8));
+        p0 = src[0]; p1 = src[1];
       }
+      if (F.wp_on) {
+        p0 = clampi((((int)F.wp_w[slot][uv + 1] * p0 + F.wp_cround) >> F.wp_cdenom) + F.wp_o[slot][uv + 1], 0, 255);
+        p1 = clampi((((int)F.wp_w[slot][uv + 1] * p1 + F.wp_cround) >> F.wp_cdenom) + F.wp_o[slot][uv + 1], 0, 255);
+      }
+      // ic is even: the two samples go out as one 16-bit store
+      *reinterpret_cast<uint16_t *>(&jc.pred[j][ic]) = (uint16_t)(p0 | (p1 << 8));
       const uint8_t *cs = (uv ? F.cur_v : F.cur_u) + (size_t)(mby * F.mb_ch + j) * F.Wc + mbx * F.mb_cw + ic;
       *reinterpret_cast<uint16_t *>(&jc.src[j][ic]) = *reinterpret_cast<const uint16_t *>(cs);      // even column of an even-width plane: aligned
       if (q == 0) { jc.quant = 1; jc.quant_dc = 2; jc.uv = uv; jc.cr_cbp_in = 0; jc.intra16_unused = 0; }
@@ -228,11 +249,17 @@ __global__ __launch_bounds__(64) void finalize_kernel(FrameDev F, const jmhip_me
   (void)jobs_c;
 }
 
-int ensure_frame_buffers(jmhip_ctx *c, int n)
+}  // namespace
+int jm_frame_buffers_ensure(jmhip_ctx *c, int n);
+namespace {
+int ensure_frame_buffers(jmhip_ctx *c, int n) { return jm_frame_buffers_ensure(c, n); }
+}  // namespace
+
+int jm_frame_buffers_ensure(jmhip_ctx *c, int n)
 {
   { int rc = jm_ensure_recon(c); if (rc) return rc; }
   if (c->fr_capacity >= n) return JMHIP_OK;
-  void **bufs[] = {&c->fr_jobs_y, &c->fr_jobs_c, &c->fr_res_y, &c->fr_res_c, &c->fr_modes};
+  void **bufs[] = {&c->fr_jobs_y, &c->fr_jobs_c, &c->fr_res_y, &c->fr_res_c, &c->fr_modes, &c->fr_blk_ref};
   for (auto b : bufs) { if (*b) JM_HIP_CHECK(c, hipFree(*b)); *b = nullptr; }
   c->fr_capacity = 0;
   // the chroma job tiles are only partly written per frame (mb_cr_size columns/rows): zero the rest once
@@ -240,7 +267,8 @@ int ensure_frame_buffers(jmhip_ctx *c, int n)
             hipMalloc(&c->fr_jobs_c, sizeof(jmhip_tq_job) * (size_t)n * 2) == hipSuccess &&
             hipMalloc(&c->fr_res_y, sizeof(jmhip_tq_result) * (size_t)n) == hipSuccess &&
             hipMalloc(&c->fr_res_c, sizeof(jmhip_tq_result) * (size_t)n * 2) == hipSuccess &&
-            hipMalloc(&c->fr_modes, (sizeof(jmhip_mb_mode) * 2 + sizeof(MbCoded)) * (size_t)n) == hipSuccess;
+            hipMalloc(&c->fr_modes, (sizeof(jmhip_mb_mode) * 2 + sizeof(JmMbCoded)) * (size_t)n) == hipSuccess &&
+            hipMalloc(&c->fr_blk_ref, 4 * (size_t)n) == hipSuccess;
   if (!ok) {                                            // leave nothing half-allocated behind (fr_capacity stays 0)
     for (auto b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
     return jm_fail(c, JMHIP_ERR_NOMEM, "frame-stage arrays");
@@ -253,7 +281,14 @@ int ensure_frame_buffers(jmhip_ctx *c, int n)
   return JMHIP_OK;
 }
 
-}  // namespace
+extern "C" int jmhip_frame_wp_set(jmhip_ctx *c, const jmhip_frame_wp *wp)
+{
+  if (!c) return JMHIP_ERR_ARG;
+  if (!wp || !wp->enable) { memset(&c->fr_wp, 0, sizeof(c->fr_wp)); return JMHIP_OK; }
+  if (wp->luma_denom < 0 || wp->luma_denom > 7 || wp->chroma_denom < 0 || wp->chroma_denom > 7) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_frame_wp_set: log weight denominators are 0..7");
+  c->fr_wp = *wp;
+  return JMHIP_OK;
+}
 
 extern "C" int jmhip_residual_frame(jmhip_ctx *c, const jmhip_mb_mode *modes, const jmhip_quant quants[3])
 {
@@ -301,6 +336,7 @@ extern "C" int jmhip_residual_frame_q(jmhip_ctx *c, const jmhip_mb_mode *modes, 
     }
 
   jmhip_mb_mode *modes_in_dev = nullptr, *modes_out_dev = (jmhip_mb_mode *)c->fr_modes;
+  if (!modes && c->fr_from_slices) modes_in_dev = modes_out_dev + n;        // left there by jmhip_slice_to_frame
   if (modes) {
     modes_in_dev = modes_out_dev + n;
     JM_HIP_CHECK(c, hipMemcpyAsync(modes_in_dev, modes, sizeof(jmhip_mb_mode) * (size_t)n, hipMemcpyHostToDevice, c->stream));
@@ -321,6 +357,9 @@ extern "C" int jmhip_residual_frame_q(jmhip_ctx *c, const jmhip_mb_mode *modes, 
   F.rec_y = c->rec_y; F.rec_u = c->rec_u; F.rec_v = c->rec_v;
   F.fly = chroma_fly ? 1 : 0; F.mul_x = c->cg.mul_x; F.mul_y = c->cg.mul_y; F.pad_cx = c->cg.pad_x; F.pad_cy = c->cg.pad_y;
   for (int k = 0; k < 4; k++) { F.ref_u[k] = k < (int)c->refs.size() ? c->refs[k].u : nullptr; F.ref_v[k] = k < (int)c->refs.size() ? c->refs[k].v : nullptr; }
+  F.blk_ref = c->fr_from_slices ? (const int8_t *)c->fr_blk_ref : nullptr;
+  F.wp_on = c->fr_wp.enable ? 1 : 0; F.wp_lround = c->fr_wp.luma_round; F.wp_ldenom = c->fr_wp.luma_denom; F.wp_cround = c->fr_wp.chroma_round; F.wp_cdenom = c->fr_wp.chroma_denom;
+  for (int k = 0; k < 16; k++) for (int q = 0; q < 3; q++) { F.wp_w[k][q] = c->fr_wp.weight[k][q]; F.wp_o[k][q] = c->fr_wp.offset[k][q]; }
 
   jm_stage_begin(c, JMHIP_STAGE_MC);
   mc_kernel<<<jm_xcd_grid(n), 64, 0, c->stream>>>(F, (const jmhip_me_mb *)c->me_jobs_dev, (const jmhip_me_result *)c->me_res_dev, modes_in_dev, modes_out_dev,

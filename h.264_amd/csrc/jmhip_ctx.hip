@@ -33,6 +33,7 @@ extern "C" int jmhip_sizeof(int which)
   case 16: return (int)sizeof(jmhip_deblock_params);
   case 17: return (int)sizeof(jmhip_slice_params);
   case 18: return (int)sizeof(jmhip_mb_inter);
+  case 19: return (int)sizeof(jmhip_frame_wp);
   default: return -1;
   }
 }

@@ -51,6 +51,9 @@ struct jmhip_ctx {
   // frame pipeline (MC -> residual -> TQ -> recon): per-MB luma job/result, 2 chroma jobs/results, recon picture
   void *fr_jobs_y = nullptr, *fr_jobs_c = nullptr, *fr_res_y = nullptr, *fr_res_c = nullptr, *fr_quant = nullptr, *fr_modes = nullptr;
   int fr_capacity = 0, fr_n = 0;
+  void *fr_blk_ref = nullptr;                         // [n][4] reference slot per 8x8 block (frame stage fed from the slice search)
+  bool fr_from_slices = false;                        // modes + per-block references of the frame stage were left on the device by jmhip_slice_to_frame
+  jmhip_frame_wp fr_wp{};                             // explicit weighted prediction of the frame stage (enable = 0: off)
   jmhip_quant fr_quant_host[4];
   uint8_t *rec_y = nullptr, *rec_u = nullptr, *rec_v = nullptr;
   bool rec_valid = false;                             // the recon planes hold a reconstruction (cleared by jmhip_recon_to_ref's plane swap)
@@ -100,7 +103,9 @@ int jm_launch_tq(jmhip_ctx *ctx, int kind, int yuv_format, const void *jobs, con
 int jm_ensure_ref_table(jmhip_ctx *ctx);
 int jm_ensure_recon(jmhip_ctx *ctx);                                                       // jmhip_ctx.hip: all three recon planes or none
 int jm_flush_table_fix(jmhip_ctx *ctx);
-void jm_slice_state_free(jmhip_ctx *ctx);                                                   // me_wave.hip                                                    // frame.hip
+void jm_slice_state_free(jmhip_ctx *ctx);
+int jm_me_arrays_ensure(jmhip_ctx *ctx, int n);                                            // me_int.hip
+int jm_frame_buffers_ensure(jmhip_ctx *ctx, int n);                                        // frame.hip                                                   // me_wave.hip                                                    // frame.hip
 struct MeDev;
 int jm_me_sub_tables(jmhip_ctx *ctx);                                                   // me_sub.hip
 void jm_launch_me_sub(jmhip_ctx *ctx, const MeDev &P, const jmhip_me_mb *jobs_dev, jmhip_me_result *res_dev, int n);

@@ -1051,6 +1051,21 @@ static void host_center(const jmhip_me_params *prm, int pmx, int pmy, int *cx, i
   *cx = mx; *cy = my;
 }
 
+// job / result / index arrays of the search stage for n macroblocks (also filled by jmhip_slice_to_frame, me_wave.hip)
+int jm_me_arrays_ensure(jmhip_ctx *c, int n)
+{
+  if (c->me_capacity >= n) return JMHIP_OK;
+  if (c->me_jobs_dev) JM_HIP_CHECK(c, hipFree(c->me_jobs_dev));
+  if (c->me_res_dev) JM_HIP_CHECK(c, hipFree(c->me_res_dev));
+  if (c->me_idx_dev) JM_HIP_CHECK(c, hipFree(c->me_idx_dev));
+  c->me_jobs_dev = c->me_res_dev = c->me_idx_dev = nullptr; c->me_capacity = 0; c->me_n = 0;
+  if (hipMalloc(&c->me_jobs_dev, sizeof(jmhip_me_mb) * (size_t)n) != hipSuccess) return jm_fail(c, JMHIP_ERR_NOMEM, "ME job array");
+  if (hipMalloc(&c->me_res_dev, sizeof(jmhip_me_result) * (size_t)n) != hipSuccess) return jm_fail(c, JMHIP_ERR_NOMEM, "ME result array");
+  if (hipMalloc(&c->me_idx_dev, sizeof(int) * (size_t)n * FAST_MAX_CENTRES) != hipSuccess) return jm_fail(c, JMHIP_ERR_NOMEM, "ME index array");
+  c->me_capacity = n;
+  return JMHIP_OK;
+}
+
 extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, const jmhip_me_mb *mbs, int n)
 {
   if (!c || !prm || n <= 0) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_frame: NULL/empty arguments") : JMHIP_ERR_ARG;
@@ -1085,6 +1100,7 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
     // a new upload invalidates the resident job set until it has been validated AND copied: an early return below must not
     // leave me_n describing the previous upload next to half-built index lists (a later resident call would launch on them)
     c->me_n = 0;
+    c->fr_from_slices = false;                       // the frame stage's inputs come from this search again
     max_uw = max_uh = 0; ref_mask = 0; c->me_fast_idx.clear(); c->me_gen_idx.clear();
   }
   const bool full_mask = (prm->partition_mask & ((1ull << JMHIP_NPART) - 1)) == ((1ull << JMHIP_NPART) - 1);
@@ -1134,17 +1150,7 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
   if (!c->me_fast_idx.empty() && flds > 60 * 1024) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_me_frame: search range too large for the fast-path LDS window");
   if (lds > 60 * 1024) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_me_frame: search centres of one macroblock are too far apart for one LDS window");
 
-  if (c->me_capacity < n) {
-    if (c->me_jobs_dev) JM_HIP_CHECK(c, hipFree(c->me_jobs_dev));
-    if (c->me_res_dev) JM_HIP_CHECK(c, hipFree(c->me_res_dev));
-    c->me_jobs_dev = c->me_res_dev = nullptr; c->me_capacity = 0;
-    if (hipMalloc(&c->me_jobs_dev, sizeof(jmhip_me_mb) * (size_t)n) != hipSuccess) return jm_fail(c, JMHIP_ERR_NOMEM, "ME job array");
-    if (hipMalloc(&c->me_res_dev, sizeof(jmhip_me_result) * (size_t)n) != hipSuccess) return jm_fail(c, JMHIP_ERR_NOMEM, "ME result array");
-    if (c->me_idx_dev) JM_HIP_CHECK(c, hipFree(c->me_idx_dev));
-    c->me_idx_dev = nullptr;
-    if (hipMalloc(&c->me_idx_dev, sizeof(int) * (size_t)n * FAST_MAX_CENTRES) != hipSuccess) return jm_fail(c, JMHIP_ERR_NOMEM, "ME index array");
-    c->me_capacity = n;
-  }
+  if ((rc = jm_me_arrays_ensure(c, n))) return rc;
   if ((rc = jm_ensure_ref_table(c))) return rc;
   if (!resident) {
     JM_HIP_CHECK(c, hipMemcpyAsync(c->me_jobs_dev, mbs, sizeof(jmhip_me_mb) * (size_t)n, hipMemcpyHostToDevice, c->stream));

@@ -1237,6 +1237,7 @@ struct SliceState {
   uint16_t *surf = nullptr; size_t surf_rows = 0; int surf_n = 0;
   int passes = 0;
   bool has_col = false;
+  int searched_to = 0;                         // macroblocks [0, searched_to) of the current picture have been searched
 };
 
 }  // namespace
@@ -1378,6 +1379,7 @@ extern "C" int jmhip_p_slice_search(jmhip_ctx *c, const jmhip_slice_params *prm,
   }
   jm_stage_end(c, JMHIP_STAGE_ME_INT);
   std::swap(s->carry_slice, s->carry_slice_next);
+  s->searched_to = (prm->mb_first == 0 || prm->mb_first == s->searched_to) ? prm->mb_first + prm->mb_count : 0;
   if (results) return jmhip_slice_results_download(c, results, prm->mb_first, prm->mb_count);
   return JMHIP_OK;
 }
@@ -1406,6 +1408,68 @@ extern "C" int jmhip_slice_result_info(jmhip_ctx *c, int *passes)
 {
   if (!c || !c->slice_state) return JMHIP_ERR_ARG;
   if (passes) *passes = static_cast<SliceState *>(c->slice_state)->passes;
+  return JMHIP_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------- hand-over to the frame stage
+
+namespace {
+// one thread per macroblock: the slice search's record -> the search-stage result layout the frame stage reads (vector per partition: the
+// one of the reference its 8x8 block settled on), the decided mode, the reference slot per 8x8 block
+__global__ void slice_to_frame_kernel(const jmhip_mb_inter *__restrict__ rec, int n, int mbw, int slot0, int slot1, int slot2, int slot3,
+                                      jmhip_me_mb *__restrict__ jobs, jmhip_me_result *__restrict__ res, jmhip_mb_mode *__restrict__ modes, int8_t *__restrict__ blk_ref)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const jmhip_mb_inter &r = rec[i];
+  const int slots[4] = {slot0, slot1, slot2, slot3};
+  jmhip_me_mb &j = jobs[i];
+  j.mb_x = (int16_t)(i % mbw); j.mb_y = (int16_t)(i / mbw); j.ref = (int16_t)slots[r.b8ref[0]]; j.ref_is_0 = (int16_t)(r.b8ref[0] == 0);
+  jmhip_me_result &o = res[i];
+  for (int p = 0; p < JMHIP_NPART; p++) {
+    const PartInfo q = c_part[p];
+    const int ref = r.b8ref[2 * (q.y4 >> 1) + (q.x4 >> 1)];
+    j.pred_mv[p][0] = r.pred[ref][p][0]; j.pred_mv[p][1] = r.pred[ref][p][1];
+    o.mv[p][0] = r.mv[ref][p][0]; o.mv[p][1] = r.mv[ref][p][1]; o.cost[p] = r.cost[ref][p];
+    o.mv_int[p][0] = r.mv_int[ref][p][0]; o.mv_int[p][1] = r.mv_int[ref][p][1]; o.cost_int[p] = r.cost_int[ref][p];
+  }
+  jmhip_mb_mode m;
+  m.mode = (int8_t)r.best_mode;
+  // (P skip is not a mode of the rdopt = 0 decision: md_low.c:655 turns a 16x16 macroblock into a skip AFTER residual coding, when cbp == 0,
+  // ref_idx == 0 and the vector equals skip_mv -- the caller has all three)
+  for (int k = 0; k < 4; k++) { m.b8mode[k] = (int8_t)(r.best_mode == 8 ? r.b8mode[k] : 4); blk_ref[(size_t)i * 4 + k] = (int8_t)slots[r.b8ref[k]]; }
+  m.pad[0] = m.pad[1] = m.pad[2] = 0;
+  modes[i] = m;
+}
+}  // namespace
+
+extern "C" int jmhip_slice_to_frame(jmhip_ctx *c, const int32_t *ref_slot, int num_refs)
+{
+  if (!c || !ref_slot || num_refs < 1 || num_refs > JMHIP_SLICE_REFS) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_slice_to_frame: arguments") : JMHIP_ERR_ARG;
+  if (!c->slice_state) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_slice_to_frame: no slice has been searched");
+  SliceState *s = static_cast<SliceState *>(c->slice_state);
+  const int n = c->mbw * c->mbh;
+  if (s->searched_to != n) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_slice_to_frame: not every macroblock of the picture has been searched (slices must cover it in order)");
+  unsigned mask = 0;
+  int slots[4] = {0, 0, 0, 0};
+  for (int r = 0; r < num_refs; r++) {
+    if (ref_slot[r] < 0 || ref_slot[r] >= (int)c->refs.size() || ref_slot[r] >= 4) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_slice_to_frame: reference slots 0..3");
+    slots[r] = ref_slot[r]; mask |= 1u << ref_slot[r];
+  }
+  JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
+  int rc = jm_me_arrays_ensure(c, n);
+  if (rc) return rc;
+  if ((rc = jm_frame_buffers_ensure(c, n))) return rc;
+  build_part_table();
+  static bool part_uploaded = false;
+  if (!part_uploaded) { JM_HIP_CHECK(c, hipMemcpyToSymbol(HIP_SYMBOL(c_part), h_part, sizeof(h_part))); part_uploaded = true; }
+  slice_to_frame_kernel<<<(n + 127) / 128, 128, 0, c->stream>>>(s->out, n, c->mbw, slots[0], slots[1], slots[2], slots[3], (jmhip_me_mb *)c->me_jobs_dev,
+                                                                (jmhip_me_result *)c->me_res_dev, (jmhip_mb_mode *)c->fr_modes + n, (int8_t *)c->fr_blk_ref);
+  JM_HIP_CHECK(c, hipGetLastError());
+  // the search-stage arrays now hold this picture; a resident re-run of jmhip_me_frame on them is meaningless and is refused (geometry check)
+  c->me_n = n; c->me_ref_mask = mask; c->me_last_mode = 0x7fffffff; c->me_fast_idx.clear(); c->me_gen_idx.clear();
+  c->fr_from_slices = true;
   return JMHIP_OK;
 }
 

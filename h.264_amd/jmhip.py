@@ -73,6 +73,11 @@ class BipredParams(C.Structure):
 SLICE_REFS = 4
 
 
+class FrameWp(C.Structure):
+    _fields_ = [("enable", C.c_int32), ("luma_round", C.c_int32), ("luma_denom", C.c_int32), ("chroma_round", C.c_int32), ("chroma_denom", C.c_int32),
+                ("weight", (C.c_int16 * 3) * 16), ("offset", (C.c_int16 * 3) * 16)]
+
+
 class SliceParams(C.Structure):
     """jmhip_slice_params (include/jmhip.h)."""
     _fields_ = [("search_mode", C.c_int32), ("search_range", C.c_int32), ("full_search", C.c_int32), ("num_refs", C.c_int32),
@@ -193,13 +198,15 @@ def load_library():
     lib.jmhip_slice_results_download.argtypes = [vp, vp, ip, ip]
     lib.jmhip_slice_field_download.argtypes = [vp, vp, vp]
     lib.jmhip_slice_result_info.argtypes = [vp, C.POINTER(ip)]
+    lib.jmhip_slice_to_frame.argtypes = [vp, vp, ip]
+    lib.jmhip_frame_wp_set.argtypes = [vp, vp]
     for which, dt in ((0, ME_MB_DTYPE), (1, ME_RESULT_DTYPE), (2, QUANT_DTYPE), (3, TQ_JOB_DTYPE), (4, TQ_RESULT_DTYPE),
                       (5, DIST_JOB_DTYPE), (8, MB_MODE_DTYPE), (9, SURFACE_JOB_DTYPE), (10, BIPRED_JOB_DTYPE), (11, BIPRED_RESULT_DTYPE), (13, PREDCOST_JOB_DTYPE),
                       (14, DEBLOCK_MB_DTYPE), (15, DEBLOCK_BLK_DTYPE), (18, MB_INTER_DTYPE)):
         if lib.jmhip_sizeof(which) != dt.itemsize:
             raise JmhipError("binding layout mismatch for struct %d: C %d vs numpy %d" % (which, lib.jmhip_sizeof(which), dt.itemsize))
     if lib.jmhip_sizeof(6) != C.sizeof(MeParams) or lib.jmhip_sizeof(7) != C.sizeof(Config) or lib.jmhip_sizeof(12) != C.sizeof(BipredParams) or \
-            lib.jmhip_sizeof(16) != C.sizeof(DeblockParams) or lib.jmhip_sizeof(17) != C.sizeof(SliceParams):
+            lib.jmhip_sizeof(16) != C.sizeof(DeblockParams) or lib.jmhip_sizeof(17) != C.sizeof(SliceParams) or lib.jmhip_sizeof(19) != C.sizeof(FrameWp):
         raise JmhipError("binding layout mismatch for jmhip_me_params / jmhip_config")
     _lib = lib
     return lib
@@ -372,6 +379,25 @@ class Context:
         mv = np.zeros((self.H // 4, self.W // 4, 2), np.int16)
         self._chk(self.lib.jmhip_slice_field_download(self.h, _ptr(ref_idx), _ptr(mv)), "jmhip_slice_field_download")
         return ref_idx, mv
+
+    def slice_to_frame(self, ref_slot):
+        """Hand the searched picture (slices covering it in order) to residual_frame: per-8x8 reference slots, decided modes, vectors."""
+        a = np.ascontiguousarray(ref_slot, dtype=np.int32)
+        self._chk(self.lib.jmhip_slice_to_frame(self.h, _ptr(a), len(a)), "jmhip_slice_to_frame")
+
+    def frame_wp_set(self, wp=None):
+        """wp: None (off) or dict(luma_round, luma_denom, chroma_round, chroma_denom, weight[(slot, comp)], offset[(slot, comp)] as (16,3) arrays)."""
+        if wp is None:
+            self._chk(self.lib.jmhip_frame_wp_set(self.h, None), "jmhip_frame_wp_set")
+            return
+        s = FrameWp()
+        s.enable = 1
+        s.luma_round, s.luma_denom, s.chroma_round, s.chroma_denom = (int(wp[k]) for k in ("luma_round", "luma_denom", "chroma_round", "chroma_denom"))
+        w, o = np.asarray(wp["weight"]), np.asarray(wp["offset"])
+        for k in range(w.shape[0]):
+            for q in range(3):
+                s.weight[k][q] = int(w[k, q]); s.offset[k][q] = int(o[k, q])
+        self._chk(self.lib.jmhip_frame_wp_set(self.h, C.byref(s)), "jmhip_frame_wp_set")
 
     def slice_passes(self):
         n = C.c_int()

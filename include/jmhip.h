@@ -334,6 +334,11 @@ int jmhip_slice_results_download(jmhip_ctx *ctx, jmhip_mb_inter *results, int mb
 int jmhip_slice_field_download(jmhip_ctx *ctx, int8_t *ref_idx, int16_t *mv);
 /* passes the last jmhip_p_slice_search needed (1 unless EPZS row starts were mis-speculated) */
 int jmhip_slice_result_info(jmhip_ctx *ctx, int *passes);
+/* Hand the searched picture (every macroblock: all its slices searched) to the frame stage: the decided modes, the vector and the
+ * reference slot of every 8x8 block become the inputs of jmhip_residual_frame(modes = NULL), which then runs LumaResidualCoding /
+ * ChromaResidualCoding on them (per-8x8 reference pictures: macroblock.c:1009-1110 with SetModesAndRefframe), and of jmhip_deblock_recon.
+ * ref_slot: list-0 index -> reference slot, as in the slice calls. */
+int jmhip_slice_to_frame(jmhip_ctx *ctx, const int32_t *ref_slot, int num_refs);
 
 /* ------------------------------------------------------------------ low-complexity (rdopt off) mode-decision costs */
 
@@ -411,6 +416,16 @@ int jmhip_tq_batch(jmhip_ctx *ctx, int kind, int yuv_format, const jmhip_quant *
                    const jmhip_tq_job *jobs, int n, jmhip_tq_result *results);
 
 /* ------------------------------------------------------------------ frame stage: MC prediction -> residual -> TQ -> recon */
+
+/* Explicit weighted prediction in the frame stage's motion compensation (P slices with active_pps->weighted_pred_flag): every predicted sample
+ * becomes iClip1(255, ((weight * p + round) >> denom) + offset) -- LumaPrediction src/macroblock.c:891-900 with wp_weight[0][ref][0] / wp_offset[0][ref][0],
+ * wp_luma_round, luma_log_weight_denom; ChromaPrediction4x4 :1895-1903 with components 1, 2, wp_chroma_round, chroma_log_weight_denom.
+ * Indexed by reference SLOT; [k][0] luma, [k][1] Cb, [k][2] Cr. wp == NULL or enable == 0: plain prediction. Stays set until changed. */
+typedef struct jmhip_frame_wp {
+  int32_t enable, luma_round, luma_denom, chroma_round, chroma_denom;
+  int16_t weight[16][3], offset[16][3];
+} jmhip_frame_wp;
+int jmhip_frame_wp_set(jmhip_ctx *ctx, const jmhip_frame_wp *wp);
 
 /* Inter mode of one macroblock as JM's mode decision fixed it (the decision itself stays on the host):
  * mode 1 = 16x16, 2 = 16x8, 3 = 8x16, 8 = P8x8 with b8mode[b] in {4,5,6,7} (8x8, 8x4, 4x8, 4x4). */

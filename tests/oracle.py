@@ -364,10 +364,21 @@ def covering_partition(m, x4, y4):
     return 25 + 4 * b8 + 2 * (y4 & 1) + (x4 & 1)
 
 
-def residual_frame(refpic, cur, mbs, mv, modes, quants3, job_dtype, yuv_format=1):
-    """Reference for jmhip_residual_frame. refpic: RefPic with chroma planes; cur = (Y,U,V); mv: (n,41,2) quarter-pel."""
+def residual_frame(refpic, cur, mbs, mv, modes, quants3, job_dtype, yuv_format=1, blk_ref=None, wp=None):
+    """Reference for jmhip_residual_frame. refpic: RefPic with chroma planes; cur = (Y,U,V); mv: (n,41,2) quarter-pel.
+    blk_ref (n,4): refpic is then a LIST of RefPic and each 8x8 block predicts from refpic[blk_ref[i][b8]] (LumaPrediction's l0_ref_idx,
+    macroblock.c:836). wp: explicit weighted uni-prediction (macroblock.c:899-903 luma, :1895-1898 chroma), the dict Context.frame_wp_set takes."""
     Y, U, V = cur
     n = len(mbs)
+    refs = refpic if blk_ref is not None else [refpic]
+    refpic = refs[0]
+
+    def weigh(v, slot, comp):
+        if wp is None:
+            return v
+        rnd, den = (wp["luma_round"], wp["luma_denom"]) if comp == 0 else (wp["chroma_round"], wp["chroma_denom"])
+        return np.clip(((int(wp["weight"][slot][comp]) * v.astype(np.int64) + rnd) >> den) + int(wp["offset"][slot][comp]), 0, 255)
+
     (sx, sy), (px, py) = chroma_geom(yuv_format)
     shift_x, shift_y = (3, 3) if yuv_format == 1 else (3, 2)
     mcw, mch = (8, 8) if yuv_format == 1 else (8, 16)
@@ -389,9 +400,10 @@ def residual_frame(refpic, cur, mbs, mv, modes, quants3, job_dtype, yuv_format=1
                 yq = ((mby * 16 + 4 * y4 - oy4) << 2) + 80 + int(mv[i, p, 1])
                 xpos = min(max(xq >> 2, 0), Wp - 17) + ox4
                 ypos = min(max(yq >> 2, 0), Hp - 17) + oy4
-                jobs_y[i]["pred"][4 * y4:4 * y4 + 4, 4 * x4:4 * x4 + 4] = refpic.luma[yq & 3, xq & 3, ypos:ypos + 4, xpos:xpos + 4]
+                slot = int(blk_ref[i][2 * (y4 >> 1) + (x4 >> 1)]) if blk_ref is not None else 0
+                jobs_y[i]["pred"][4 * y4:4 * y4 + 4, 4 * x4:4 * x4 + 4] = weigh(refs[slot].luma[yq & 3, xq & 3, ypos:ypos + 4, xpos:xpos + 4], slot, 0)
         jobs_y[i]["src"] = Y[mby * 16:mby * 16 + 16, mbx * 16:mbx * 16 + 16]
-        for uv, (planes, C_) in enumerate(((refpic.cb, U), (refpic.cr, V))):
+        for uv, C_ in enumerate((U, V)):
             jc = jobs_c[2 * i + uv]
             jc["quant"], jc["quant_dc"], jc["uv"] = 1, 2, uv
             for j in range(mch):
@@ -401,7 +413,9 @@ def residual_frame(refpic, cur, mbs, mv, modes, quants3, job_dtype, yuv_format=1
                     jj = ((j + mby * mch) << shift_y) + 80 + int(mv4[by4, bx4, 1])
                     xpos = min(max(ii >> shift_x, 0), Wcp - 1 - mcw)
                     ypos = min(max(jj >> shift_y, 0), Hcp - 1 - mch)
-                    jc["pred"][j, ic:ic + 2] = planes[jj & ((1 << shift_y) - 1), ii & ((1 << shift_x) - 1), ypos, xpos:xpos + 2]
+                    slot = int(blk_ref[i][2 * (by4 >> 1) + (bx4 >> 1)]) if blk_ref is not None else 0
+                    planes = refs[slot].cr if uv else refs[slot].cb
+                    jc["pred"][j, ic:ic + 2] = weigh(planes[jj & ((1 << shift_y) - 1), ii & ((1 << shift_x) - 1), ypos, xpos:xpos + 2], slot, uv + 1)
             jc["src"][:mch, :mcw] = C_[mby * mch:mby * mch + mch, mbx * mcw:mbx * mcw + mcw]
     ry = tq_reference("luma4x4", quants3, jobs_y)
     t8 = np.array([int(m["pad"][0]) for m in modes], bool)

@@ -187,3 +187,84 @@ def test_1080p_walkers_match_the_oracle(pkg, mode):
     """BASELINE configs 3 / 5 at their picture width: one 1920x1088 P picture, +-32, two references, every macroblock against the oracle."""
     passes = run_synthetic(pkg, mode, 1920, 1088, 32, 2, nframes=2, seed=11)
     print("passes per slice call:", passes)
+
+
+def upsampled_chroma(rng, Y):
+    H, W = Y.shape
+    U = np.clip(Y[::2, ::2].astype(int) // 2 + 60 + rng.integers(-3, 4, (H // 2, W // 2)), 0, 255).astype(np.uint8)
+    V = np.clip(200 - Y[1::2, 1::2].astype(int) // 2 + rng.integers(-3, 4, (H // 2, W // 2)), 0, 255).astype(np.uint8)
+    return U, V
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,weighted,planes", [(3, False, True), (3, True, False), (-1, True, True), (1, False, False)])
+def test_slice_search_feeds_the_frame_stage(pkg, mode, weighted, planes):
+    """The searched picture goes to jmhip_residual_frame without leaving the device (jmhip_slice_to_frame): every 8x8 block predicts from the
+    reference ITS decision chose (LumaPrediction's l0_ref_idx), optionally with explicit weighted prediction; reconstruction, cbp and cbp_blk of
+    every macroblock against the oracle's LumaResidualCoding / ChromaResidualCoding restatement fed with the same records."""
+    W, H, R, nref = 176, 144, 16, 2
+    rng = np.random.default_rng(23)
+    clip = synth_clip(rng, W, H, 3)
+    clip[0] = np.clip(clip[0].astype(int) + 9, 0, 255).astype(np.uint8)        # a brightness step, so that reference 1 wins for some blocks
+    cur, refs = clip[2], [clip[1], clip[0]]
+    cur_c = upsampled_chroma(rng, cur)
+    refs_c = [upsampled_chroma(rng, r) for r in refs]
+    slot_of = [1, 0]                                                          # list-0 index -> reference slot, deliberately not the identity
+    nmb = (W // 16) * (H // 16)
+    ctx = pkg.Context(W, H, yuv_format=1, max_refs=2, search_range=R)
+    ctx.slice_state_reset()
+    for r in range(nref):
+        ctx.ref_upload(slot_of[r], refs[r], *refs_c[r])
+        ctx.interp_luma(slot_of[r])
+        if planes:
+            ctx.interp_chroma(slot_of[r])
+    ctx.cur_upload(cur, *cur_c)
+    if mode == 3:
+        ctx.epzs_colocated_upload(np.zeros((H // 4, W // 4, 2), np.int16))
+    lam = int(65536 * np.sqrt(0.85 * 2 ** ((28 - 12) / 3.0)) + 0.5)
+    lib = pkg.load_library()
+    recs = []
+    for first, count in ((0, 40), (40, nmb - 40)):
+        p = slice_params(pkg, mode, R, nref, [lam] * 3, 8, W, mb_first=first, mb_count=count)
+        p.ref_slot[0], p.ref_slot[1] = slot_of
+        if mode == 3:
+            lib.jmhip_epzs_scales(p, 4, (C.c_int * 2)(2, 0), 2)
+        recs.append(ctx.p_slice_search(p))
+    rec = np.concatenate(recs)
+    assert (rec["b8ref"] == 1).any() and (rec["b8ref"] == 0).any() and (rec["best_mode"] == 8).any()
+    wp = None
+    if weighted:
+        wp = {"luma_round": 16, "luma_denom": 5, "chroma_round": 8, "chroma_denom": 4, "weight": np.zeros((16, 3), int), "offset": np.zeros((16, 3), int)}
+        wp["weight"][0], wp["offset"][0] = (30, 17, 15), (2, -1, 0)
+        wp["weight"][1], wp["offset"][1] = (34, 16, 14), (-3, 1, 2)
+    ctx.frame_wp_set(wp)
+    ctx.slice_to_frame(slot_of)
+    quants = np.array([pkg.flat_quant(28 + d, 342, adaptive_rounding=1, adapt_rnd_weight=4, cavlc=1) for d in (0, 0, 3)], dtype=pkg.QUANT_DTYPE)
+    ctx.residual_frame(quants, None)
+    got = ctx.residual_download(nmb)
+    recon = ctx.recon_download()
+    ctx.frame_wp_set(None)
+    ctx.close()
+
+    modes = np.zeros(nmb, dtype=pkg.MB_MODE_DTYPE)
+    mbs = np.zeros(nmb, dtype=pkg.ME_MB_DTYPE)
+    mv = np.zeros((nmb, 41, 2), np.int16)
+    blk_ref = np.zeros((nmb, 4), int)
+    parts = pkg.partition_table()
+    for i in range(nmb):
+        mbs[i]["mb_x"], mbs[i]["mb_y"] = i % (W // 16), i // (W // 16)
+        modes[i]["mode"] = rec[i]["best_mode"]
+        modes[i]["b8mode"] = rec[i]["b8mode"] if rec[i]["best_mode"] == 8 else 4
+        blk_ref[i] = [slot_of[int(r)] for r in rec[i]["b8ref"]]
+        for pi in range(41):
+            x4, y4 = parts[pi][1], parts[pi][2]
+            mv[i, pi] = rec[i]["mv"][int(rec[i]["b8ref"][2 * (y4 >> 1) + (x4 >> 1)]), pi]
+    assert np.array_equal(got["modes"]["mode"], modes["mode"]) and np.array_equal(got["modes"]["b8mode"], modes["b8mode"])
+    by_slot = [None, None]
+    for r in range(nref):
+        by_slot[slot_of[r]] = oracle.RefPic(refs[r], *refs_c[r], yuv_format=1)
+    want = oracle.residual_frame(by_slot, (cur,) + cur_c, mbs, mv, modes, quants, pkg.TQ_JOB_DTYPE, yuv_format=1, blk_ref=blk_ref, wp=wp)
+    assert np.array_equal(got["cbp"], want["cbp"]) and np.array_equal(got["cbp_blk"], want["cbp_blk"])
+    for k in range(3):
+        assert np.array_equal(recon[k], want["recon"][k]), "plane %d" % k
+    assert (got["cbp"] != 0).any()
