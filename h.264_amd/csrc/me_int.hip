@@ -37,15 +37,20 @@ namespace {
 // position (0,0) when it is the search centre -- wraps the bound below zero, and computeSAD leaves after its first row
 // (me_distortion.c:364-375). That candidate then competes with  mv cost - bonus + SAD(row 0)  and, being first in the
 // spiral, keeps ties. Found by running the real encoder on the device path (tests/test_jm_shim.py); mirrored here.
+__device__ __forceinline__ void wrapped_bound_00v(const MeDev &P, int mb_x, int mb_y, int ref, int ref_is_0, int pmx0, int pmy0, int cx, int cy, int *mvx, int *mvy, int *cost)
+{
+  if (P.mode != JMHIP_SEARCH_FULL || P.rdopt || P.is_b || !ref_is_0 || mb_x || mb_y || cx || cy) return;
+  const int c0 = mv_cost(P.lam_f, -pmx0, -pmy0) - ((P.lam_f * 16) >> 16);
+  if (c0 >= 0) return;
+  const uint8_t *ref_y = P.ref_y[ref];
+  int row = 0;
+  for (int x = 0; x < 16; x++) row += iabs((int)P.cur[x] - (int)ref_y[x]);
+  if (c0 + row <= *cost) { *mvx = 0; *mvy = 0; *cost = c0 + row; }
+}
 __device__ __forceinline__ void wrapped_bound_00(const MeDev &P, const jmhip_me_mb &job, int cx, int cy, int *mvx, int *mvy, int *cost)
 {
-  if (P.mode != JMHIP_SEARCH_FULL || P.rdopt || P.is_b || !job.ref_is_0 || job.mb_x || job.mb_y || cx || cy) return;
-  const int c0 = mv_cost(P.lam_f, -job.pred_mv[0][0], -job.pred_mv[0][1]) - ((P.lam_f * 16) >> 16);
-  if (c0 >= 0) return;
-  const uint8_t *ref = P.ref_y[job.ref];
-  int row = 0;
-  for (int x = 0; x < 16; x++) row += iabs((int)P.cur[x] - (int)ref[x]);
-  if (c0 + row <= *cost) { *mvx = 0; *mvy = 0; *cost = c0 + row; }
+  if (P.mode != JMHIP_SEARCH_FULL) return;
+  wrapped_bound_00v(P, job.mb_x, job.mb_y, job.ref, job.ref_is_0, job.pred_mv[0][0], job.pred_mv[0][1], cx, cy, mvx, mvy, cost);
 }
 
 __global__ __launch_bounds__(256) void me_int_kernel(MeDev P, const jmhip_me_mb *__restrict__ jobs, const int *__restrict__ job_index,
@@ -989,6 +994,350 @@ __global__ __launch_bounds__(256, 3) void me_int_pair_kernel(MeDev P, const jmhi
   STAMP(6);
 }
 
+// ------------------------------------------------------------------------------------------------ persistent pair-lane search
+//
+// EXPERIMENT, not the default (JMHIP_ME_KERNEL=pers): measured 0.303 ms against the pair kernel's 0.267 ms at 1080p -- see DESIGN.md section 3.
+// me_int_pair_kernel's walk (the same lane pairs, keys and tables) inside a PERSISTENT workgroup: three per CU, each taking every
+// (grid/8)-th item of its XCD's contiguous run. What changes is everything around the walk -- the part that kept the VALU idle
+// (setup 25 %, reduction 6 %, decode 5 % of a workgroup's life, all latency):
+//  * the NEXT item is staged while the current one is walked: its job record, current macroblock and reference window go from HBM/L2
+//    straight into a second LDS buffer with global_load_lds_dword (no VGPRs, no wait until the barrier that ends the item); its mv-bit
+//    tables are built into a second table set from the job record that arrived one item earlier;
+//  * the window is read from plane 0 of the reference's quarter-pel stack (the integer picture with its replicated ring): a dword that
+//    lies outside the picture is a dword of the ring -- four equal bytes -- so clamping the DWORD address is exact and every load is an
+//    aligned dword; one raw copy in LDS, v_alignbyte in the walk (two more VALU per 105-instruction step);
+//  * the 22 keys of a wave are folded with three DPP row shifts each instead of an LDS transpose, and the last 16-way minimum, the
+//    decode and the store of item k run at the top of item k+1's iteration: ONE barrier per item instead of six.
+// Exit condition: a static count of items per workgroup (no queue, no flag): every wave leaves after its last barrier.
+
+typedef __attribute__((address_space(3))) void jm_lds_void;
+typedef const __attribute__((address_space(1))) void jm_glb_void;
+__device__ __forceinline__ void dma_dword(const void *src, void *lds_wave_base)     // LDS address = wave-uniform base + 4 * lane
+{
+  __builtin_amdgcn_global_load_lds((jm_glb_void *)src, (jm_lds_void *)lds_wave_base, 4, 0, 0);
+}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+struct PersShared {                                   // 2R+1 <= 81 on this path (host check)
+  uint32_t job[4][64];                                // jmhip_me_mb records (43 dwords) of items k-1 .. k+2
+  int idx[4];                                         // their job_index words
+  uint32_t cur[2][64];
+  uint32_t gslot[12];                                 // c_pair_g as bytes, table-slot order (half * 24 + local)
+  uint8_t bytab[2][84][48] __attribute__((aligned(16)));
+  uint8_t bxtab[2][84][48] __attribute__((aligned(16)));
+  unsigned red[2][4][4][2][PAIR_NK];                  // [buffer][wave][row of 16 lanes][half][local key]
+};
+
+template <unsigned CTRL> __device__ __forceinline__ unsigned dpp_min(unsigned v)
+{
+  return min(v, (unsigned)__builtin_amdgcn_update_dpp((int)KEY_INVALID, (int)v, CTRL, 0xf, 0xf, false));
+}
+
+__global__ __launch_bounds__(256, 3) void me_int_pers_kernel(MeDev P, const jmhip_me_mb *__restrict__ jobs, const int *__restrict__ job_index,
+                                                            jmhip_me_result *__restrict__ res, int n_items)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t swin[];      // two raw windows, NWP dwords apart
+  __shared__ PersShared S;
+  const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6), half = lane & 1;
+  const int R = P.R, UW = 2 * R + 1, UH = UW, PITCH = P.win_pitch, WROWS = UH + 15, NW = WROWS * PITCH, NWP = P.win_copy_stride;
+  const unsigned pitch_inv = ((1u << 20) + PITCH - 1) / PITCH;          // e / PITCH == (e * pitch_inv) >> 20 for e < 4096, PITCH <= 25
+
+  // static schedule: XCD x takes the contiguous run [x * per, (x + 1) * per) (as jm_xcd_item); workgroup `slot` of the XCD every nslots-th item of it
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+  const int per = (n_items + 7) >> 3;
+  const int run = min(per, n_items - xcd * per);
+  const int niter = run > slot ? (run - slot + nslots - 1) / nslots : 0;
+  if (niter == 0) return;
+  const int item0 = xcd * per + slot;
+
+  const int lam = P.lam_f;
+  const int w16 = (lam * 16) >> 16;
+  const int ff00 = (P.mode == JMHIP_SEARCH_FASTFULL) && !P.rdopt;
+  const int NG = UW >= 64 ? 2 : 1;
+  const int my_slot = tid < JMHIP_NPART ? c_pair_slot[tid] : 0;
+  const int my_area = tid < JMHIP_NPART ? c_part[tid].w4 * c_part[tid].h4 : 1;
+  if (tid < 12) {
+    uint32_t w = 0;
+    for (int k = 0; k < 4; k++) { const int sl = 4 * tid + k; w |= (uint32_t)(uint8_t)c_pair_g[sl / 24][sl % 24] << (8 * k); }
+    S.gslot[tid] = w;
+  }
+
+  auto dma_job = [&](int k, int idx) {                 // wave 0
+    if (lane < 43) dma_dword(reinterpret_cast<const uint32_t *>(jobs + (idx & 0xffffff)) + lane, &S.job[k & 3][0]);
+    if (lane == 0) S.idx[k & 3] = idx;
+  };
+  // header of an item whose job record is in LDS: position, centre, window origin
+  struct Head { int mbx, mby, ref, ref_is_0, rep, mbi, ucx, ucy; };
+  auto head_of = [&](int k) {
+    const uint32_t *jb = S.job[k & 3];
+    const int w0 = uni((int)jb[0]), w1 = uni((int)jb[1]), idx = uni(S.idx[k & 3]);
+    Head h;
+    h.mbx = (short)(w0 & 0xffff); h.mby = w0 >> 16; h.ref = (short)(w1 & 0xffff); h.ref_is_0 = w1 >> 16;
+    h.mbi = idx & 0xffffff; h.rep = (idx >> 24) & 63;
+    const int pm = uni((int)jb[2 + h.rep]);
+    search_center(P, (short)(pm & 0xffff), pm >> 16, &h.ucx, &h.ucy);
+    return h;
+  };
+
+#ifdef JMHIP_STAMPS
+  unsigned long long t_prev = __builtin_amdgcn_s_memtime(), t_acc[6] = {0, 0, 0, 0, 0, 0};
+#define PSTAMP(q) do { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); t_acc[q] += t_now - t_prev; t_prev = t_now; } while (0)
+#else
+#define PSTAMP(q) do { } while (0)
+#endif
+  int idx_pipe = job_index[item0];                    // job_index word of item k + 2 at the top of iteration k
+  if (wave == 0) dma_job(0, idx_pipe);
+  idx_pipe = niter > 1 ? job_index[item0 + nslots] : 0;
+  __syncthreads();
+
+  for (int k = -1; k <= niter; k++) {
+    // ================================================================ A: stage item k + 1 (job record arrived during iteration k - 1)
+    if (k + 1 < niter) {
+      const int k1 = k + 1;
+      if (wave == 0 && k + 2 < niter) dma_job(k + 2, idx_pipe);
+      if (k + 3 < niter) idx_pipe = job_index[item0 + (k + 3) * nslots];
+      const Head h = head_of(k1);
+      const int umin_x = h.ucx - R, umin_y = h.ucy - R;
+      const int bx = h.mbx * 16 + umin_x, by = h.mby * 16 + umin_y, bxa = bx & ~3;
+      const uint8_t *plane = P.ref_sub[h.ref];          // plane 0 of the quarter-pel stack: integer samples, JMHIP_PAD-pel ring, stride Wp
+      uint32_t *wdst = swin + (k1 & 1) * NWP;
+      for (int e0 = 0; e0 < NW; e0 += 256) {
+        const int e = e0 + tid;
+        if (e < NW) {
+          const int row = (int)(((unsigned)e * pitch_inv) >> 20), xw = e - row * PITCH;
+          const int y = clampi(by + row, 0, P.H - 1) + JMHIP_PAD, x = clampi(bxa + 4 * xw, -4, P.W) + JMHIP_PAD;
+          dma_dword(plane + (size_t)y * P.Wp + x, wdst + e0 + wave * 64);
+        }
+      }
+      if (wave == 1) dma_dword(P.cur + (size_t)(h.mby * 16 + (lane >> 2)) * P.W + h.mbx * 16 + (lane & 3) * 4, &S.cur[k1 & 1][0]);
+      // mv-bit tables, four slots (one dword) per element: 12 x (UH + UW) elements; slot = half * 24 + local, unused slots hold 0
+      const uint32_t *jb = S.job[k1 & 3];
+      for (int e = tid; e < 12 * (UH + UW); e += 256) {
+        const bool isx = e >= 12 * UH;
+        const int e2 = isx ? e - 12 * UH : e, line = e2 / 12, q = e2 - line * 12;
+        const int v4 = 4 * ((isx ? umin_x : umin_y) + line);
+        const uint32_t g4 = S.gslot[q];
+        uint32_t w = 0;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+          const int g = (int)(int8_t)(g4 >> (8 * kk));
+          const int pm = (int)jb[2 + max(g, 0)];
+          const int pv = isx ? (int)(short)(pm & 0xffff) : (pm >> 16);
+          w |= (g < 0 ? 0u : (uint32_t)mvbits(v4 - pv)) << (8 * kk);
+        }
+        reinterpret_cast<uint32_t *>(isx ? S.bxtab[k1 & 1][line] : S.bytab[k1 & 1][line])[q] = w;
+      }
+    }
+
+    PSTAMP(0);
+    // ================================================================ B: finish item k - 1 (16-way minimum of the waves' row results, decode, store)
+    if (k >= 1 && tid < JMHIP_NPART) {
+      const int kp = k - 1, p = tid, local = my_slot >> 1, hf = my_slot & 1;
+      const Head h = head_of(kp);
+      unsigned key = KEY_INVALID;
+#pragma unroll
+      for (int w = 0; w < 4; w++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) key = min(key, S.red[kp & 1][w][r][hf][local]);
+      jmhip_me_result &o = res[h.mbi];
+      int cost, tie;
+      if (p == 0) { cost = (int)(key >> TIE_BITS) - w16; tie = (int)(key & ((1u << TIE_BITS) - 1)); }
+      else { cost = (int)(key >> FAST_TIE_BITS); tie = (int)(key & 0xffffu) / my_area; }
+      int rx, ry;
+      if (tie == 0) { rx = 0; ry = 0; }
+      else { int ddx, ddy; spiral_offset(tie - 1, &ddx, &ddy); rx = h.ucx + ddx; ry = h.ucy + ddy; }
+      if (p == 0) { const int pm0 = (int)S.job[kp & 3][2]; wrapped_bound_00v(P, h.mbx, h.mby, h.ref, h.ref_is_0, (short)(pm0 & 0xffff), pm0 >> 16, h.ucx, h.ucy, &rx, &ry, &cost); }
+      bool mine = true;
+      if (P.mode == JMHIP_SEARCH_FULL) {
+        const int pm = (int)S.job[kp & 3][2 + p];
+        int pcx, pcy; search_center(P, (short)(pm & 0xffff), pm >> 16, &pcx, &pcy); mine = (pcx == h.ucx && pcy == h.ucy);
+      }
+      if (mine) {
+        o.mv_int[p][0] = (int16_t)rx; o.mv_int[p][1] = (int16_t)ry; o.cost_int[p] = cost;
+        if (!P.subpel) { o.mv[p][0] = (int16_t)(rx << 2); o.mv[p][1] = (int16_t)(ry << 2); o.cost[p] = cost; }
+      }
+    }
+
+    PSTAMP(1);
+    // ================================================================ C: walk item k
+    if (k >= 0 && k < niter) {
+      const Head h = head_of(k);
+      const int mbx = h.mbx, mby = h.mby, ucx = h.ucx, ucy = h.ucy;
+      const int umin_x = ucx - R, umin_y = ucy - R;
+      const int xoff = (mbx * 16 + umin_x) & 3;
+      const int quirk00 = (P.mode == JMHIP_SEARCH_FULL) && !P.rdopt && !P.is_b && h.ref_is_0;
+      const uint32_t *W = swin + (k & 1) * NWP;
+      const uint8_t (*bytab)[48] = S.bytab[k & 1];
+      const uint8_t (*bxtab)[48] = S.bxtab[k & 1];
+      uint32_t cur[16][2];
+#pragma unroll
+      for (int r = 0; r < 16; r++) { cur[r][0] = S.cur[k & 1][r * 4 + 2 * half]; cur[r][1] = S.cur[k & 1][r * 4 + 2 * half + 1]; }
+
+      unsigned best[PAIR_NK], hold[PAIR_NK], mvc[PAIR_NK];
+#pragma unroll
+      for (int j = 0; j < PAIR_NK; j++) { best[j] = KEY_INVALID; hold[j] = KEY_INVALID; }
+      auto evaluate = [&](auto modec, const uint32_t (&w)[16][2], int base, unsigned tie, bool zero_bonus) __attribute__((always_inline)) {
+        constexpr int mode = decltype(modec)::value;
+        unsigned sad[8];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int sl = (base + r) & 15, b = (r >> 2) * 2;
+          sad[b + 0] = __builtin_amdgcn_sad_hi_u8(w[sl][0], cur[r][0], (r & 3) ? sad[b + 0] : tie);
+          sad[b + 1] = __builtin_amdgcn_sad_hi_u8(w[sl][1], cur[r][1], (r & 3) ? sad[b + 1] : tie);
+        }
+        unsigned ps[PAIR_NK - 1];
+#pragma unroll
+        for (int l = 0; l < 8; l++) ps[l] = sad[l];
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) ps[8 + rg] = sad[rg * 2] + sad[rg * 2 + 1];
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) { ps[12 + 2 * kk] = sad[4 * kk] + sad[4 * kk + 2]; ps[13 + 2 * kk] = sad[4 * kk + 1] + sad[4 * kk + 3]; }
+        ps[16] = ps[8] + ps[9]; ps[17] = ps[10] + ps[11];
+        ps[18] = ps[16] + ps[17];
+        ps[19] = quad_swap_add(ps[16]); ps[20] = quad_swap_add(ps[17]);
+        unsigned c0 = ((ps[19] >> 16) + (ps[20] >> 16)) + mvc[21];
+        if (zero_bonus) c0 -= (unsigned)w16;
+        unsigned key[PAIR_NK];
+#pragma unroll
+        for (int j = 0; j < PAIR_NK - 1; j++) key[j] = ps[j] + mvc[j];
+        key[21] = (c0 << TIE_BITS) + tie;
+#pragma unroll
+        for (int j = 0; j < PAIR_NK; j++) {
+          if (mode == 0) hold[j] = key[j];
+          else if (mode == 1) best[j] = min(min(best[j], hold[j]), key[j]);
+          else best[j] = min(best[j], key[j]);
+        }
+      };
+      auto load_mvc = [&](int colx, int row) __attribute__((always_inline)) {
+        const uint2 *bt = reinterpret_cast<const uint2 *>(&bytab[row][half * 24]), *bxq = reinterpret_cast<const uint2 *>(&bxtab[colx][half * 24]);
+        const uint2 b0 = bt[0], b1 = bt[1], b2 = bt[2], x0 = bxq[0], x1 = bxq[1], x2 = bxq[2];
+        const uint32_t byp[6] = {b0.x, b0.y, b1.x, b1.y, b2.x, b2.y}, bxp[6] = {x0.x, x0.y, x1.x, x1.y, x2.x, x2.y};
+#pragma unroll
+        for (int g = 0; g < 6; g++) {
+          const uint32_t sum4 = bxp[g] + byp[g];
+#pragma unroll
+          for (int kk = 0; kk < 4; kk++) {
+            const int j = 4 * g + kk;
+            if (j < PAIR_NK) {
+              const unsigned prod = __umul24((unsigned)lam, (sum4 >> (8 * kk)) & 255u);
+              mvc[j] = j < PAIR_NK - 1 ? (prod & 0xffff0000u) : ((prod >> 16) + (unsigned)w16);
+            }
+          }
+        }
+      };
+
+      // ---- main grid: 64 columns (two groups of 32 lane pairs) x all rows (two bands), or 32 columns x four bands
+      {
+        const int col = (wave % NG) * 32 + (lane >> 1);
+        const int mvx = umin_x + col, dx = mvx - ucx, adx = iabs(dx);
+        const int tieB = spiral_base_B(dx) + 1, twodx = 2 * dx;
+        const bool qx = quirk00 && (4 * (mbx * 16 + mvx) == mbx * 16);
+        const int bcol = xoff + col + 8 * half;          // byte column of this half's first sample in the raw window
+        const unsigned sh = (unsigned)(bcol & 3);
+        const uint32_t *lbase = W + (bcol >> 2);
+        const int nparts = 4 / NG, part = wave / NG;
+        const int r0 = uni((UH * part) / nparts), r1 = uni((UH * (part + 1)) / nparts), nrows = r1 - r0;
+        // rows of the band whose vertical mv bits differ from the row before (any slot): those steps refresh the cached mv costs
+        unsigned long long chg;
+        {
+          bool f = false;
+          if (lane > 0 && lane < nrows) {
+            const uint4 *a = reinterpret_cast<const uint4 *>(bytab[r0 + lane]), *b = reinterpret_cast<const uint4 *>(bytab[r0 + lane - 1]);
+#pragma unroll
+            for (int g = 0; g < 3; g++) { const uint4 u = a[g], v = b[g]; f = f || u.x != v.x || u.y != v.y || u.z != v.z || u.w != v.w; }
+          }
+          chg = __ballot(f) | 1ull;
+        }
+        uint32_t win[16][2];
+#pragma unroll
+        for (int j = 0; j < 15; j++) {
+          const uint32_t *wp = lbase + (r0 + j) * PITCH;
+          const uint32_t d0 = wp[0], d1 = wp[1], d2 = wp[2];
+          win[j][0] = __builtin_amdgcn_alignbyte(d1, d0, sh); win[j][1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+        }
+        auto step = [&](auto ttc, int t0) __attribute__((always_inline)) {
+          constexpr int tt = decltype(ttc)::value;
+          const int t = t0 + tt;
+          if (t >= nrows) return;
+          const int row = r0 + t;
+          {
+            const uint32_t *wp = lbase + (row + 15) * PITCH;
+            constexpr int sl = (tt + 15) & 15;
+            const uint32_t d0 = wp[0], d1 = wp[1], d2 = wp[2];
+            win[sl][0] = __builtin_amdgcn_alignbyte(d1, d0, sh); win[sl][1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+          }
+          const int mvy = umin_y + row, dy = mvy - ucy;
+          if ((chg >> t) & 1ull) load_mvc(col, row);
+          const int ady = iabs(dy);
+          unsigned tie = (ady > adx) ? (unsigned)(spiral_base_A(dy) + 1 + twodx) : (unsigned)(tieB + 2 * dy);
+          if (ff00 && mvx == 0 && mvy == 0) tie = 0;
+          evaluate(std::integral_constant<int, tt & 1>{}, win, tt, tie, qx && 4 * (mby * 16 + mvy) == mby * 16);
+        };
+        for (int t0 = 0; t0 < nrows; t0 += 16) {
+          step(std::integral_constant<int, 0>{}, t0);  step(std::integral_constant<int, 1>{}, t0);
+          step(std::integral_constant<int, 2>{}, t0);  step(std::integral_constant<int, 3>{}, t0);
+          step(std::integral_constant<int, 4>{}, t0);  step(std::integral_constant<int, 5>{}, t0);
+          step(std::integral_constant<int, 6>{}, t0);  step(std::integral_constant<int, 7>{}, t0);
+          step(std::integral_constant<int, 8>{}, t0);  step(std::integral_constant<int, 9>{}, t0);
+          step(std::integral_constant<int, 10>{}, t0); step(std::integral_constant<int, 11>{}, t0);
+          step(std::integral_constant<int, 12>{}, t0); step(std::integral_constant<int, 13>{}, t0);
+          step(std::integral_constant<int, 14>{}, t0); step(std::integral_constant<int, 15>{}, t0);
+        }
+        if (nrows & 1) {
+#pragma unroll
+          for (int j = 0; j < PAIR_NK; j++) best[j] = min(best[j], hold[j]);
+        }
+      }
+
+      PSTAMP(2);
+      // ---- columns beyond the main grid: one candidate per lane pair, fresh window rows
+      {
+        const int nrc = UW - 32 * NG, nrest = nrc * UH;
+        for (int c = tid >> 1; c < nrest; c += 128) {
+          const int ay = c / nrc, ax = 32 * NG + (c - ay * nrc);
+          const int cmx = umin_x + ax, cmy = umin_y + ay;
+          unsigned tie = (unsigned)spiral_pos(cmx - ucx, cmy - ucy) + 1;
+          if (ff00 && cmx == 0 && cmy == 0) tie = 0;
+          const int bcol = xoff + ax + 8 * half;
+          const unsigned sh = (unsigned)(bcol & 3);
+          const uint32_t *wrow = W + ay * PITCH + (bcol >> 2);
+          uint32_t w[16][2];
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const uint32_t d0 = wrow[r * PITCH], d1 = wrow[r * PITCH + 1], d2 = wrow[r * PITCH + 2];
+            w[r][0] = __builtin_amdgcn_alignbyte(d1, d0, sh); w[r][1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+          }
+          load_mvc(ax, ay);
+          evaluate(std::integral_constant<int, 2>{}, w, 0, tie, quirk00 && 4 * (mbx * 16 + cmx) == mbx * 16 && 4 * (mby * 16 + cmy) == mby * 16);
+        }
+      }
+
+      PSTAMP(3);
+      // ---- fold the wave's keys over the 32 lanes of each half: three row shifts leave a row's minima in its lanes 14 (left) / 15 (right)
+      {
+        unsigned *rd = &S.red[k & 1][wave][lane >> 4][half][0];
+        const bool writer = (lane & 15) >= 14;
+#pragma unroll
+        for (int j = 0; j < PAIR_NK; j++) {
+          unsigned v = best[j];
+          v = dpp_min<0x112>(v); v = dpp_min<0x114>(v); v = dpp_min<0x118>(v);
+          if (writer) rd[j] = v;
+        }
+      }
+    }
+    PSTAMP(4);
+    __syncthreads();                                  // (the compiler waits for the staged loads, vmcnt(0), before it)
+    PSTAMP(5);
+  }
+#ifdef JMHIP_STAMPS
+  if (P.stamps && blockIdx.x < 512 && lane == 0) {
+    unsigned long long cum = 0;
+    P.stamps[(blockIdx.x * 4 + wave) * 8] = 0;
+    for (int q = 0; q < 6; q++) { cum += t_acc[q]; P.stamps[(blockIdx.x * 4 + wave) * 8 + q + 1] = cum; }
+  }
+#endif
+}
+
 int ensure_tables(jmhip_ctx *c)
 {
   static bool uploaded[64] = {false};
@@ -1038,6 +1387,13 @@ static int me_use_pair_kernel()
 {
   const char *e = getenv("JMHIP_ME_KERNEL");         // read per call: tests switch it
   return e && !strcmp(e, "single") ? 0 : 1;
+}
+// JMHIP_ME_KERNEL=pers selects the persistent, double-buffered form of the pair-lane kernel (me_int_pers_kernel): bit-exact, measured
+// 13 % SLOWER than the default at 1080p (0.303 vs 0.267 ms; DESIGN.md section 3 has the counters that say why) -- kept as the measured experiment
+static int me_use_pers_kernel()
+{
+  const char *e = getenv("JMHIP_ME_KERNEL");
+  return e && !strcmp(e, "pers") ? 1 : 0;
 }
 
 static void host_center(const jmhip_me_params *prm, int pmx, int pmy, int *cx, int *cy)
@@ -1192,7 +1548,29 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
     const int use_pair = me_use_pair_kernel();
     size_t plds = ((size_t)3 * fcs + (size_t)fpitch_dw * frows) * 4;          // the window; its memory is reused by the 44 x 128 key transpose
     if (plds < (size_t)44 * 128 * 4) plds = (size_t)44 * 128 * 4;
-    if (use_pair) me_int_pair_kernel<<<jm_xcd_grid(nfast), 256, plds, c->stream>>>(PF, (const jmhip_me_mb *)c->me_jobs_dev, (const int *)c->me_idx_dev, (jmhip_me_result *)c->me_res_dev, nfast);
+    // persistent form: needs the padded integer plane (plane 0 of the quarter-pel stack) of every used reference and no weighted reference ME
+    bool pers = use_pair && me_use_pers_kernel() && !P.wp_on;
+    for (size_t k = 0; k < c->refs.size() && pers; k++) if (((ref_mask >> k) & 1) && !c->refs[k].has_luma_sub) pers = false;
+    if (pers) {
+      const int ppitch = (2 * R + 1 + 17) / 4 + 1, nw = ppitch * frows, nwp = ((nw + 63) & ~63) + 64;
+      const size_t wlds = (size_t)2 * nwp * 4;
+      static int per_cu[64] = {0}, ncu[64] = {0};
+      const int dev = c->cfg.device & 63;
+      if (!ncu[dev]) {
+        hipDeviceProp_t prop;
+        JM_HIP_CHECK(c, hipGetDeviceProperties(&prop, c->cfg.device));
+        int nb = 0;
+        JM_HIP_CHECK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, me_int_pers_kernel, 256, 20480));
+        per_cu[dev] = nb < 1 ? 1 : nb; ncu[dev] = prop.multiProcessorCount;
+      }
+      int grid = (per_cu[dev] * ncu[dev]) & ~7;
+      if (grid < 8) grid = 8;
+      if (const char *e = getenv("JMHIP_ME_PERS_GRID")) { const int g = atoi(e) & ~7; if (g >= 8 && g < grid) grid = g; }     // tests: few workgroups, many items each
+      if (grid > jm_xcd_grid(nfast)) grid = jm_xcd_grid(nfast);
+      PF.win_pitch = ppitch; PF.win_copy_stride = nwp;
+      me_int_pers_kernel<<<grid, 256, wlds, c->stream>>>(PF, (const jmhip_me_mb *)c->me_jobs_dev, (const int *)c->me_idx_dev, (jmhip_me_result *)c->me_res_dev, nfast);
+    }
+    else if (use_pair) me_int_pair_kernel<<<jm_xcd_grid(nfast), 256, plds, c->stream>>>(PF, (const jmhip_me_mb *)c->me_jobs_dev, (const int *)c->me_idx_dev, (jmhip_me_result *)c->me_res_dev, nfast);
     else me_int_fast_kernel<<<jm_xcd_grid(nfast), 256, flds, c->stream>>>(PF, (const jmhip_me_mb *)c->me_jobs_dev, (const int *)c->me_idx_dev, (jmhip_me_result *)c->me_res_dev, nfast);
   }
   if (ngen)

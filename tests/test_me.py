@@ -159,6 +159,26 @@ def test_me_single_lane_kernel_still_agrees(pkg, mode, rdopt, per_partition, spr
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode,rdopt,per_partition,spread", [(0, 1, True, 8), (-1, 0, False, 8), (-1, 1, True, 5), (0, 0, True, 4)])
+def test_me_persistent_kernel_one_item_per_workgroup(pkg, mode, rdopt, per_partition, spread, monkeypatch):
+    """JMHIP_ME_KERNEL=pers: the persistent, double-buffered form of the pair-lane kernel (an experiment that measured slower; kept exact)."""
+    monkeypatch.setenv("JMHIP_ME_KERNEL", "pers")
+    run_case(pkg, 96, 64, "shift", mode, 32, rdopt, spread, per_partition=per_partition, seed=77 + spread)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,mode,rdopt,per_partition,spread,grid,size", [
+    (32, 0, 0, True, 8, 8, (176, 144)), (32, -1, 0, True, 3, 8, (176, 144)), (32, -1, 1, False, 40, 16, (176, 144)), (16, 0, 1, True, 8, 8, (96, 64)),
+    (40, -1, 0, True, 2, 8, (96, 64)), (24, 0, 0, True, 60, 24, (176, 144))])
+def test_me_persistent_kernel_pipelines_many_items_per_workgroup(pkg, R, mode, rdopt, per_partition, spread, grid, size, monkeypatch):
+    """me_int_pers_kernel with a small grid: every workgroup stages item k+1 while it walks item k and finishes item k-1 (dozens of items
+    each, uneven counts per XCD run, windows hanging over every picture edge); bit-exact against the oracle like the one-item launches."""
+    monkeypatch.setenv("JMHIP_ME_KERNEL", "pers")
+    monkeypatch.setenv("JMHIP_ME_PERS_GRID", str(grid))
+    run_case(pkg, size[0], size[1], "shift", mode, R, rdopt, spread, per_partition=per_partition, seed=R + spread + grid)
+
+
+@pytest.mark.gpu
 def test_me_mixed_fast_and_generic_macroblocks(pkg):
     """FullSearch where some MBs have one predictor (fast kernel) and others per-partition predictors (generic)."""
     rng = np.random.default_rng(5)
