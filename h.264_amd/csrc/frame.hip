@@ -13,51 +13,13 @@
 // device picks the partitioning with the smallest summed motion cost.
 #include "jmhip_internal.h"
 #include <utility>
+#include <vector>
+#include <cstring>
+#include <cstdlib>
+
+#include "frame_common.h"
 
 namespace {
-
-struct FrameDev {
-  int W, H, Wp, Hp, Wc, Hc, Wcp, Hcp, mbw;
-  int yuv, shift_x, shift_y, mask_x, mask_y, sub_x, mb_cw, mb_ch;
-  const uint8_t *cur_y, *cur_u, *cur_v;
-  const uint8_t *const *ref_sub, *const *ref_cb, *const *ref_cr;
-  uint8_t *rec_y, *rec_u, *rec_v;
-  // chroma prediction without the eighth-pel planes: the sample a plane WOULD hold, computed from the integer chroma picture
-  // (reference slots 0..3; see mc_kernel)
-  int fly, mul_x, mul_y, pad_cx, pad_cy;
-  const uint8_t *ref_u[4], *ref_v[4];
-  // explicit weighted prediction of P slices (LumaPrediction macroblock.c:880-914, ChromaPrediction4x4 :1895-1903), per reference SLOT
-  int wp_on, wp_lround, wp_ldenom, wp_cround, wp_cdenom;
-  short wp_w[16][3], wp_o[16][3];
-  const int8_t *blk_ref;          // [n][4]: reference slot of each 8x8 block (NULL: the macroblock's one reference, jmhip_me_mb.ref)
-};
-
-__device__ __forceinline__ int clampi(int x, int lo, int hi) { return min(max(x, lo), hi); }
-
-// partition index (me_common.h table order) that covers luma 4x4 block (x4,y4) for a macroblock mode
-__device__ __forceinline__ int covering_partition(const jmhip_mb_mode &m, int x4, int y4)
-{
-  const int b8 = 2 * (y4 >> 1) + (x4 >> 1);
-  switch (m.mode) {
-  case 1: return 0;
-  case 2: return 1 + (y4 >> 1);
-  case 3: return 3 + (x4 >> 1);
-  default:
-    switch (m.b8mode[b8]) {
-    case 4: return 5 + b8;
-    case 5: return 9 + 2 * b8 + (y4 & 1);
-    case 6: return 17 + 2 * b8 + (x4 & 1);
-    default: return 25 + 4 * b8 + 2 * (y4 & 1) + (x4 & 1);
-    }
-  }
-}
-
-__device__ __forceinline__ uint32_t fetch4(const uint8_t *p)
-{
-  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
-  const uint32_t *q = reinterpret_cast<const uint32_t *>(a & ~uintptr_t(3));
-  return __builtin_amdgcn_alignbyte(q[1], q[0], (unsigned)(a & 3));
-}
 
 __global__ __launch_bounds__(64) void mc_kernel(FrameDev F, const jmhip_me_mb *__restrict__ mbs, const jmhip_me_result *__restrict__ me,
                                                const jmhip_mb_mode *__restrict__ modes_in, jmhip_mb_mode *__restrict__ modes_out,
@@ -259,7 +221,7 @@ int jm_frame_buffers_ensure(jmhip_ctx *c, int n)
 {
   { int rc = jm_ensure_recon(c); if (rc) return rc; }
   if (c->fr_capacity >= n) return JMHIP_OK;
-  void **bufs[] = {&c->fr_jobs_y, &c->fr_jobs_c, &c->fr_res_y, &c->fr_res_c, &c->fr_modes, &c->fr_blk_ref};
+  void **bufs[] = {&c->fr_jobs_y, &c->fr_jobs_c, &c->fr_res_y, &c->fr_res_c, &c->fr_modes, &c->fr_blk_ref, &c->fr_rec};
   for (auto b : bufs) { if (*b) JM_HIP_CHECK(c, hipFree(*b)); *b = nullptr; }
   c->fr_capacity = 0;
   // the chroma job tiles are only partly written per frame (mb_cr_size columns/rows): zero the rest once
@@ -268,7 +230,8 @@ int jm_frame_buffers_ensure(jmhip_ctx *c, int n)
             hipMalloc(&c->fr_res_y, sizeof(jmhip_tq_result) * (size_t)n) == hipSuccess &&
             hipMalloc(&c->fr_res_c, sizeof(jmhip_tq_result) * (size_t)n * 2) == hipSuccess &&
             hipMalloc(&c->fr_modes, (sizeof(jmhip_mb_mode) * 2 + sizeof(JmMbCoded)) * (size_t)n) == hipSuccess &&
-            hipMalloc(&c->fr_blk_ref, 4 * (size_t)n) == hipSuccess;
+            hipMalloc(&c->fr_blk_ref, 4 * (size_t)n) == hipSuccess &&
+            hipMalloc(&c->fr_rec, sizeof(JmMbRes) * (size_t)n) == hipSuccess;
   if (!ok) {                                            // leave nothing half-allocated behind (fr_capacity stays 0)
     for (auto b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
     return jm_fail(c, JMHIP_ERR_NOMEM, "frame-stage arrays");
@@ -361,6 +324,20 @@ extern "C" int jmhip_residual_frame_q(jmhip_ctx *c, const jmhip_mb_mode *modes, 
   F.wp_on = c->fr_wp.enable ? 1 : 0; F.wp_lround = c->fr_wp.luma_round; F.wp_ldenom = c->fr_wp.luma_denom; F.wp_cround = c->fr_wp.chroma_round; F.wp_cdenom = c->fr_wp.chroma_denom;
   for (int k = 0; k < 16; k++) for (int q = 0; q < 3; q++) { F.wp_w[k][q] = c->fr_wp.weight[k][q]; F.wp_o[k][q] = c->fr_wp.offset[k][q]; }
 
+  // the common case -- 4:2:0, 4x4 transform everywhere -- is ONE kernel that keeps the tiles on the CU and leaves a dense record per macroblock
+  // (tq.hip frame_fused_kernel); JMHIP_FRAME_FUSED=0 keeps the separate kernels (also taken by 4:2:2, 4:0:0 and 8x8-transform macroblocks)
+  bool fused = F.yuv == JMHIP_YUV420 && !any_t8 && quants[0].adapt_rnd_weight >= 0 && quants[0].adapt_rnd_weight < 32768 &&
+               quants[1].adapt_rnd_weight >= 0 && quants[1].adapt_rnd_weight < 32768;
+  if (const char *e = getenv("JMHIP_FRAME_FUSED")) if (!strcmp(e, "0")) fused = false;
+  if (fused) {
+    jm_stage_begin(c, JMHIP_STAGE_MC);
+    rc = jm_launch_frame_fused(c, &F, c->me_jobs_dev, c->me_res_dev, modes_in_dev, modes_out_dev, c->fr_quant, c->fr_rec, coded_dev, n);
+    jm_stage_end(c, JMHIP_STAGE_MC);                  // (the TQ stage has no launch of its own here: its time reads 0)
+    if (rc) return rc;
+    c->fr_n = n; c->rec_valid = true; c->fr_fused = true;
+    return JMHIP_OK;
+  }
+  c->fr_fused = false;
   jm_stage_begin(c, JMHIP_STAGE_MC);
   mc_kernel<<<jm_xcd_grid(n), 64, 0, c->stream>>>(F, (const jmhip_me_mb *)c->me_jobs_dev, (const jmhip_me_result *)c->me_res_dev, modes_in_dev, modes_out_dev,
                                                   (jmhip_tq_job *)c->fr_jobs_y, (jmhip_tq_job *)c->fr_jobs_c, n);
@@ -386,8 +363,14 @@ extern "C" int jmhip_residual_download(jmhip_ctx *c, jmhip_tq_result *luma, jmhi
 {
   if (!c) return JMHIP_ERR_ARG;
   if (n <= 0 || n > c->fr_n) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_residual_download: more macroblocks requested than processed");
-  if (luma) JM_HIP_CHECK(c, hipMemcpyAsync(luma, c->fr_res_y, sizeof(jmhip_tq_result) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-  if (chroma && c->Wc) JM_HIP_CHECK(c, hipMemcpyAsync(chroma, c->fr_res_c, sizeof(jmhip_tq_result) * (size_t)n * 2, hipMemcpyDeviceToHost, c->stream));
+  std::vector<JmMbRes> recs;
+  if (c->fr_fused && (luma || (chroma && c->Wc))) {
+    recs.resize(n);
+    JM_HIP_CHECK(c, hipMemcpyAsync(recs.data(), c->fr_rec, sizeof(JmMbRes) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  } else {
+    if (luma) JM_HIP_CHECK(c, hipMemcpyAsync(luma, c->fr_res_y, sizeof(jmhip_tq_result) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    if (chroma && c->Wc) JM_HIP_CHECK(c, hipMemcpyAsync(chroma, c->fr_res_c, sizeof(jmhip_tq_result) * (size_t)n * 2, hipMemcpyDeviceToHost, c->stream));
+  }
   if (modes_out) JM_HIP_CHECK(c, hipMemcpyAsync(modes_out, c->fr_modes, sizeof(jmhip_mb_mode) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
   std::vector<MbCoded> coded;
   if (cbp || cbp_blk) {
@@ -398,6 +381,28 @@ extern "C" int jmhip_residual_download(jmhip_ctx *c, jmhip_tq_result *luma, jmhi
   }
   JM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
   for (int i = 0; i < n && (cbp || cbp_blk); i++) { if (cbp) cbp[i] = coded[i].cbp; if (cbp_blk) cbp_blk[i] = coded[i].cbp_blk; }
+  // fused frame stage: expand the dense records into the ABI's result structs -- the fields the separate kernels write, zero elsewhere
+  for (int i = 0; i < n && !recs.empty(); i++) {
+    const JmMbRes &R = recs[i];
+    if (luma) {
+      jmhip_tq_result &o = luma[i];
+      memset(&o, 0, sizeof(o));
+      for (int b = 0; b < 16; b++) {
+        for (int k = 0; k < R.cnt[b]; k++) { o.levels[b][k] = R.lev[b][k]; o.runs[b][k] = R.run[b][k]; }
+        o.coeff_cost[b] = R.coeff_cost[b]; o.nonzero[b] = (R.nonzero >> b) & 1;
+      }
+      for (int y = 0; y < 16; y++) for (int x = 0; x < 16; x++) { o.recon[y][x] = R.recon_y[y][x]; if (c->fr_quant_host[0].adaptive_rounding) o.fadjust[y][x] = R.fadj_y[y][x]; }
+    }
+    for (int uv = 0; uv < 2 && chroma && c->Wc; uv++) {
+      jmhip_tq_result &o = chroma[2 * i + uv];
+      memset(&o, 0, sizeof(o));
+      for (int b = 0; b < 4; b++)
+        for (int k = 0; k < R.cnt[16 + 4 * uv + b]; k++) { o.levels[b][k] = R.ac_zeroed[uv] ? 0 : R.lev[16 + 4 * uv + b][k]; o.runs[b][k] = R.run[16 + 4 * uv + b][k]; }
+      for (int k = 0; k < R.dc_cnt[uv]; k++) { o.dc_levels[k] = R.dc_lev[uv][k]; o.dc_runs[k] = R.dc_run[uv][k]; }
+      for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) { o.recon[y][x] = R.recon_c[uv][y][x]; if (c->fr_quant_host[1].adaptive_rounding) o.fadjust[y][x] = R.fadj_c[uv][y][x]; }
+      o.ret = R.ret[uv]; o.cbp_blk = R.cbp_blk[uv]; o.cbp_clear = R.cbp_clear[uv];
+    }
+  }
   return JMHIP_OK;
 }
 

@@ -51,6 +51,8 @@ struct jmhip_ctx {
   // frame pipeline (MC -> residual -> TQ -> recon): per-MB luma job/result, 2 chroma jobs/results, recon picture
   void *fr_jobs_y = nullptr, *fr_jobs_c = nullptr, *fr_res_y = nullptr, *fr_res_c = nullptr, *fr_quant = nullptr, *fr_modes = nullptr;
   int fr_capacity = 0, fr_n = 0;
+  void *fr_rec = nullptr;                             // fused frame stage: one JmMbRes record per macroblock (frame_common.h)
+  bool fr_fused = false;                              // the last jmhip_residual_frame took the fused kernel: results live in fr_rec
   void *fr_blk_ref = nullptr;                         // [n][4] reference slot per 8x8 block (frame stage fed from the slice search)
   bool fr_from_slices = false;                        // modes + per-block references of the frame stage were left on the device by jmhip_slice_to_frame
   jmhip_frame_wp fr_wp{};                             // explicit weighted prediction of the frame stage (enable = 0: off)

@@ -17,6 +17,7 @@
 // (4x4: 16 lanes per macroblock), all butterflies are 32-bit integer add/shift in registers -- no MFMA: this is
 // not a dense contraction (the 4x4 "matrix" has entries +-1, +-2 applied as shifts).
 #include "jmhip_internal.h"
+#include "frame_common.h"
 #include <cstddef>
 
 namespace {
@@ -656,7 +657,351 @@ __global__ __launch_bounds__(256) void tq_chroma420_kernel(const jmhip_tq_job *_
   }
 }
 
+
+// ---------------------------------------------------------------------------------------- fused 4:2:0 frame stage
+//
+// mc_kernel + tq_luma4x4_kernel + tq_chroma420_kernel + finalize_kernel of the frame stage in ONE launch for the common case (4:2:0, 4x4
+// transform): the prediction and source tiles never leave the CU (registers for luma, 256 B of LDS for chroma) instead of travelling through
+// 1.6 KB of jmhip_tq_job per macroblock, and what the consumers need of the results is one dense 2.4 KB record (JmMbRes) instead of three
+// sparse 5.8 KB structs. Four macroblocks per wave: in the luma phase every lane owns one 4x4 block (16 lanes per macroblock, JM order
+// b8*4+b4, so a DPP quad is an 8x8 block), in the chroma phase lanes 0..31 own the four Cb / four Cr blocks of each macroblock (a quad per
+// component, as tq_chroma420_kernel); all 64 lanes fetch the chroma prediction.
+// Same arithmetic, line for line, as the kernels it replaces (they stay for 4:2:2, 4:0:0, 8x8-transform macroblocks and jmhip_tq_batch).
+__global__ __launch_bounds__(64) void frame_fused_kernel(FrameDev F, const jmhip_me_mb *__restrict__ mbs, const jmhip_me_result *__restrict__ me,
+                                                        const jmhip_mb_mode *__restrict__ modes_in, jmhip_mb_mode *__restrict__ modes_out,
+                                                        const jmhip_quant *__restrict__ quants, JmMbRes *__restrict__ out, JmMbCoded *__restrict__ coded, int n)
+{
+  constexpr int NMB = 4;                               // macroblocks per wave: 16 luma lanes each, then 8 chroma lanes each
+  __shared__ __attribute__((aligned(16))) JmMbRes s_rec[NMB];
+  __shared__ jmhip_mb_mode s_mode[NMB];
+  __shared__ short s_mv[NMB][16][2];
+  __shared__ int s_ref[NMB][4];
+  __shared__ uint32_t s_mvall[NMB][JMHIP_NPART];
+  __shared__ int s_cost[NMB][JMHIP_NPART];
+  __shared__ short s_pos[NMB][2];
+  __shared__ __attribute__((aligned(4))) uint8_t s_pc[NMB][2][8][8], s_sc[NMB][2][8][8];      // chroma prediction / source tiles
+  const int vb = jm_xcd_item((n + NMB - 1) / NMB);
+  if (vb < 0) return;
+  const int tid = threadIdx.x, i0 = vb * NMB;
+  const int nlive = min(NMB, n - i0);                  // the last wave repeats macroblock n-1 in its spare groups and stores nothing for them
+  auto mb_of = [&](int hh) { return min(i0 + hh, n - 1); };
+
+  // the 41 vectors and costs of each macroblock arrive in one round trip (the mode picks among them afterwards, out of LDS)
+  for (int e = tid; e < NMB * JMHIP_NPART; e += 64) {
+    const int hh = e / JMHIP_NPART, p = e - hh * JMHIP_NPART;
+    const jmhip_me_result &r = me[mb_of(hh)];
+    s_mvall[hh][p] = *reinterpret_cast<const uint32_t *>(r.mv[p]);
+    s_cost[hh][p] = r.cost[p];
+  }
+  jmhip_mb_mode m_in;
+  if (tid < NMB && modes_in) m_in = modes_in[mb_of(tid)];
+  if (tid >= 8 && tid < 8 + NMB) { const jmhip_me_mb &mb = mbs[mb_of(tid - 8)]; s_pos[tid - 8][0] = mb.mb_x; s_pos[tid - 8][1] = mb.mb_y; }
+  if (tid >= 16 && tid < 16 + 4 * NMB) { const int hh = (tid - 16) >> 2, k = tid & 3; s_ref[hh][k] = F.blk_ref ? F.blk_ref[(size_t)mb_of(hh) * 4 + k] : mbs[mb_of(hh)].ref; }
+  __syncthreads();
+  if (tid < NMB) {
+    jmhip_mb_mode m;
+    if (modes_in) m = m_in;
+    else {                                             // smallest summed motion cost; ties go to the lower mode number (as mc_kernel)
+      const int *c = s_cost[tid];
+      int c8 = 0;
+      for (int b = 0; b < 4; b++) {
+        const int s4 = c[5 + b], s5 = c[9 + 2 * b] + c[10 + 2 * b], s6 = c[17 + 2 * b] + c[18 + 2 * b];
+        const int s7 = c[25 + 4 * b] + c[26 + 4 * b] + c[27 + 4 * b] + c[28 + 4 * b];
+        int best = s4, bm = 4;
+        if (s5 < best) { best = s5; bm = 5; }
+        if (s6 < best) { best = s6; bm = 6; }
+        if (s7 < best) { best = s7; bm = 7; }
+        m.b8mode[b] = (int8_t)bm; c8 += best;
+      }
+      int best = c[0]; m.mode = 1;
+      if (c[1] + c[2] < best) { best = c[1] + c[2]; m.mode = 2; }
+      if (c[3] + c[4] < best) { best = c[3] + c[4]; m.mode = 3; }
+      if (c8 < best) { best = c8; m.mode = 8; }
+      m.pad[0] = m.pad[1] = m.pad[2] = 0;
+    }
+    s_mode[tid] = m;
+    if (tid < nlive) modes_out[i0 + tid] = m;
+  }
+  __syncthreads();
+  {
+    const int hh = tid >> 4, l = tid & 15;
+    const uint32_t v = s_mvall[hh][covering_partition(s_mode[hh], l & 3, l >> 2)];
+    s_mv[hh][l][0] = (short)(v & 0xffff); s_mv[hh][l][1] = (short)(v >> 16);
+  }
+  __syncthreads();
+
+  // ---- chroma prediction and source into LDS: four sample pairs per lane (mc_kernel's chroma loop, macroblock.c:1626-1650)
+#pragma unroll
+  for (int t = tid; t < NMB * 64; t += 64) {
+    const int h = t >> 6, tt = t & 63;
+    const int mbx = s_pos[h][0], mby = s_pos[h][1];
+    const int uv = tt >> 5, q = tt & 31, j = q >> 2, ic = 2 * (q & 3);
+    const int by4 = j >> 1, bx4 = ic >> 1;
+    const short *mv = s_mv[h][by4 * 4 + bx4];
+    const int ii = ((ic + mbx * 8) << 3) + 4 * JMHIP_PAD + mv[0];
+    const int jj = ((j + mby * 8) << 3) + 4 * JMHIP_PAD + mv[1];
+    const int xpos = clampi(ii >> 3, 0, F.Wcp - 1 - 8), ypos = clampi(jj >> 3, 0, F.Hcp - 1 - 8);
+    const int slot = s_ref[h][2 * (by4 >> 1) + (bx4 >> 1)];
+    int p0, p1;
+    if (F.fly) {
+      const uint8_t *pic = uv ? F.ref_v[slot] : F.ref_u[slot];
+      const int k = (jj & 7) * F.mul_y, lx = (ii & 7) * F.mul_x;
+      const uint8_t *r0 = pic + (size_t)clampi(ypos - F.pad_cy, 0, F.Hc - 1) * F.Wc;
+      const uint8_t *r1 = pic + (size_t)clampi(ypos - F.pad_cy + 1, 0, F.Hc - 1) * F.Wc;
+      const int xa = clampi(xpos - F.pad_cx, 0, F.Wc - 1), xb = clampi(xpos - F.pad_cx + 1, 0, F.Wc - 1), xc = clampi(xpos - F.pad_cx + 2, 0, F.Wc - 1);
+      const int a0 = r0[xa], a1 = r0[xb], a2 = r0[xc], b0 = r1[xa], b1 = r1[xb], b2 = r1[xc];
+      const int h00 = a0 * (8 - lx) + a1 * lx, h01 = a1 * (8 - lx) + a2 * lx, h10 = b0 * (8 - lx) + b1 * lx, h11 = b1 * (8 - lx) + b2 * lx;
+      p0 = (h00 * (8 - k) + h10 * k + 32) >> 6; p1 = (h01 * (8 - k) + h11 * k + 32) >> 6;
+    } else {
+      const uint8_t *planes = (uv ? F.ref_cr : F.ref_cb)[slot];
+      const uint8_t *src = planes + (size_t)((jj & 7) * F.sub_x + (ii & 7)) * F.Wcp * F.Hcp + (size_t)ypos * F.Wcp + xpos;
+      p0 = src[0]; p1 = src[1];
+    }
+    if (F.wp_on) {
+      p0 = clampi((((int)F.wp_w[slot][uv + 1] * p0 + F.wp_cround) >> F.wp_cdenom) + F.wp_o[slot][uv + 1], 0, 255);
+      p1 = clampi((((int)F.wp_w[slot][uv + 1] * p1 + F.wp_cround) >> F.wp_cdenom) + F.wp_o[slot][uv + 1], 0, 255);
+    }
+    *reinterpret_cast<uint16_t *>(&s_pc[h][uv][j][ic]) = (uint16_t)(p0 | (p1 << 8));
+    const uint8_t *cs = (uv ? F.cur_v : F.cur_u) + (size_t)(mby * 8 + j) * F.Wc + mbx * 8 + ic;
+    *reinterpret_cast<uint16_t *>(&s_sc[h][uv][j][ic]) = *reinterpret_cast<const uint16_t *>(cs);
+  }
+
+  int cbp_luma = 0, cbp_blk_luma = 0;                  // after the coefficient-cost thresholds (every luma lane ends up holding them)
+  {
+    // ---- luma block: prediction (LumaPrediction per 4x4 block, macroblock.c:836), residual, dct_4x4 (block.c:843)
+    const int h = tid >> 4, l = tid & 15;
+    const int mbx = s_pos[h][0], mby = s_pos[h][1];
+    const bool live = h < nlive;
+    JmMbRes &R = s_rec[h];
+    const int blk = l, b8 = blk >> 2, b4 = blk & 3;
+    const int x4 = 2 * (b8 & 1) + (b4 & 1), y4 = 2 * (b8 >> 1) + (b4 >> 1), bx = 4 * x4, by = 4 * y4;
+    const jmhip_quant &q = quants[0];
+    const int qp_per = q.qp / 6, q_bits = Q_BITS + qp_per;
+    int m[4][4], pr[4][4];
+    {
+      const short *mv = s_mv[h][y4 * 4 + x4];
+      const int xq = ((mbx * 16 + bx) << 2) + 4 * JMHIP_PAD + mv[0], yq = ((mby * 16 + by) << 2) + 4 * JMHIP_PAD + mv[1];
+      const int xpos = clampi(xq >> 2, 0, F.Wp - 1 - 16), ypos = clampi(yq >> 2, 0, F.Hp - 1 - 16);      // UMVLine4X, refbuf.c:37
+      const int slot = s_ref[h][b8];
+      const uint8_t *src = F.ref_sub[slot] + (size_t)((yq & 3) * 4 + (xq & 3)) * F.Wp * F.Hp + (size_t)ypos * F.Wp + xpos;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t pv = fetch4(src + (size_t)j * F.Wp);
+        const uint32_t sv = *reinterpret_cast<const uint32_t *>(F.cur_y + (size_t)(mby * 16 + by + j) * F.W + mbx * 16 + bx);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          int p = (int)((pv >> (8 * k)) & 255u);
+          if (F.wp_on) p = clampi((((int)F.wp_w[slot][0] * p + F.wp_lround) >> F.wp_ldenom) + F.wp_o[slot][0], 0, 255);
+          pr[j][k] = p; m[j][k] = (int)((sv >> (8 * k)) & 255u) - p;                                     // img->m7, macroblock.c:1059-1068
+        }
+      }
+    }
+    fwd4(m);
+    int scan_pos = 0, run = -1, nonzero = 0, cost = 0;
+    int fa[4][4];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      constexpr int I0[16] = {0,1,0,0,1,2,3,2,1,0,1,2,3,3,2,3}, J0[16] = {0,0,1,2,1,0,0,1,2,3,3,2,1,2,3,3};
+      constexpr int I1[16] = {0,0,1,0,0,1,1,1,2,2,2,2,3,3,3,3}, J1[16] = {0,1,0,2,3,1,2,3,0,1,2,3,0,1,2,3};
+      const int i0 = I0[k], j0 = J0[k], i1 = I1[k], j1 = J1[k];
+      const int c = q.field_scan ? m[j1][i1] : m[j0][i0];
+      const int idx = q.field_scan ? (j1 * 4 + i1) : (j0 * 4 + i0);
+      run++;
+      const int scaled = iabs(c) * q.levelscale[idx];
+      int level = (scaled + q.leveloffset[idx]) >> q_bits;
+      int deq = 0, fadj = 0;
+      if (level != 0) {
+        if (q.adaptive_rounding) fadj = rsr(q.adapt_rnd_weight * (scaled - (level << q_bits)), q_bits + 1);   // block.c:898
+        nonzero = 1;
+        cost += (level > 1) ? MAXV : c_cost4[q.disthres][run];
+        level = sgnab(level, c);
+        R.lev[blk][scan_pos] = (int16_t)level; R.run[blk][scan_pos] = (uint8_t)run; scan_pos++;
+        deq = rsr((level * q.invlevelscale[idx]) << qp_per, 4);                                             // block.c:907
+        run = -1;
+      }
+      if (q.field_scan) { m[j1][i1] = deq; fa[j1][i1] = fadj; } else { m[j0][i0] = deq; fa[j0][i0] = fadj; }
+    }
+    R.cnt[blk] = (uint8_t)scan_pos;
+    R.coeff_cost[blk] = cost;
+    if (q.adaptive_rounding) {
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) R.fadj_y[by + j][bx + k] = (int16_t)fa[j][k];
+    }
+    if (scan_pos) inv4(m);
+    uint32_t rec[4], prd[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      uint32_t w = 0, pw = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int v = scan_pos ? clip1(q.max_val, rsr(m[j][k], DQ_BITS) + pr[j][k]) : pr[j][k];                // block.c:934 / :942
+        w |= (uint32_t)v << (8 * k); pw |= (uint32_t)pr[j][k] << (8 * k);
+      }
+      rec[j] = w; prd[j] = pw;
+      *reinterpret_cast<uint32_t *>(&R.recon_y[by + j][bx]) = w;
+    }
+    // ---- _LUMA_COEFF_COST_ per 8x8 block (a quad) and _LUMA_MB_COEFF_COST_ per macroblock: macroblock.c:1236-1258, :1386-1392 (finalize_kernel)
+    int cost8 = cost;
+    cost8 += __builtin_amdgcn_update_dpp(cost8, cost8, 0xB1, 0xf, 0xf, false);
+    cost8 += __builtin_amdgcn_update_dpp(cost8, cost8, 0x4E, 0xf, 0xf, false);
+    const bool keep8 = cost8 > 4;
+    int sum = keep8 ? cost8 : 0;
+    sum += __shfl_xor(sum, 4); sum += __shfl_xor(sum, 8);
+    const bool keep = keep8 && sum > 5;
+    int bits = (nonzero && keep) ? ((1 << (x4 + 4 * y4)) | (0x10000 << b8)) : 0;      // cbp_blk bit (block_x>>2) + block_y, macroblock.c:1050; cbp bit b8 above it
+    bits |= __shfl_xor(bits, 1); bits |= __shfl_xor(bits, 2); bits |= __shfl_xor(bits, 4); bits |= __shfl_xor(bits, 8);
+    cbp_blk_luma = bits & 0xffff; cbp_luma = bits >> 16;
+    const unsigned long long nz = __ballot(nonzero != 0);
+    if (l == 0) R.nonzero = (uint16_t)(nz >> (16 * h));
+    if (live) {
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        *reinterpret_cast<uint32_t *>(F.rec_y + (size_t)(mby * 16 + by + j) * F.W + mbx * 16 + bx) = keep ? rec[j] : prd[j];
+    }
+  }
+  __syncthreads();                                     // the chroma tiles are complete
+
+  if (tid < 8 * NMB) {
+    // ---- chroma block: dct_chroma for 4:2:0 on a quad of lanes (tq_chroma420_kernel), block.c:1051-1495
+    const int h = tid >> 3, uv = (tid >> 2) & 1, b4 = tid & 3, cb = 16 + 4 * uv + b4;
+    const int mbx = s_pos[h][0], mby = s_pos[h][1];
+    const bool live = h < nlive;
+    JmMbRes &R = s_rec[h];
+    const int bx = 4 * (b4 & 1), by = 4 * (b4 >> 1);
+    const jmhip_quant &q = quants[1];
+    const int qp_per = q.qp / 6, q_bits = Q_BITS + qp_per;
+    int m[4][4], pr[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t s = *reinterpret_cast<const uint32_t *>(&s_sc[h][uv][by + j][bx]);
+      const uint32_t p = *reinterpret_cast<const uint32_t *>(&s_pc[h][uv][by + j][bx]);
+#pragma unroll
+      for (int k = 0; k < 4; k++) { pr[j][k] = (p >> (8 * k)) & 255; m[j][k] = (int)((s >> (8 * k)) & 255) - pr[j][k]; }
+    }
+    fwd4(m);
+    const int d0 = quad_bcast(m[0][0], 0), d1 = quad_bcast(m[0][0], 1), d2 = quad_bcast(m[0][0], 2), d3 = quad_bcast(m[0][0], 3);
+    int m1[4] = {d0 + d1 + d2 + d3, d0 - d1 + d2 - d3, d0 + d1 - d2 - d3, d0 - d1 - d2 + d3};
+    int run = -1, scan_pos = 0, DCcoded = 0, cr_cbp = 0;
+    long long cbp = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      run++;
+      int level = (iabs(m1[k]) * q.levelscale[0] + (q.leveloffset[0] << 1)) >> (q_bits + 1);
+      if (level != 0) {
+        if (q.cavlc && q.img_qp < 4) level = min(level, CAVLC_LEVEL_LIMIT);
+        cbp |= 0xf0000LL << (uv << 2);
+        cr_cbp = max(1, cr_cbp);
+        DCcoded = 1;
+        level = sgnab(level, m1[k]);
+        if (b4 == 0) { R.dc_lev[uv][scan_pos] = (int16_t)level; R.dc_run[uv][scan_pos] = (uint8_t)run; }
+        scan_pos++;
+        run = -1;
+        m1[k] = level;
+      } else m1[k] = 0;
+    }
+    if (b4 == 0) R.dc_cnt[uv] = (uint8_t)scan_pos;
+    {
+      const int m5[4] = {m1[0] + m1[1] + m1[2] + m1[3], m1[0] - m1[1] + m1[2] - m1[3], m1[0] + m1[1] - m1[2] - m1[3], m1[0] - m1[1] - m1[2] + m1[3]};
+      m[0][0] = ((m5[b4] * q.invlevelscale[0]) << qp_per) >> 5;           // block.c:1170-1173
+    }
+    int coeff_cost = 0, any = 0;
+    scan_pos = 0; run = -1;
+    int fa[4][4];
+    fa[0][0] = 0;
+#pragma unroll
+    for (int k = 1; k < 16; k++) {
+      constexpr int I0[16] = {0,1,0,0,1,2,3,2,1,0,1,2,3,3,2,3}, J0[16] = {0,0,1,2,1,0,0,1,2,3,3,2,1,2,3,3};
+      constexpr int I1[16] = {0,0,1,0,0,1,1,1,2,2,2,2,3,3,3,3}, J1[16] = {0,1,0,2,3,1,2,3,0,1,2,3,0,1,2,3};
+      const int i0 = I0[k], j0 = J0[k], i1 = I1[k], j1 = J1[k];
+      const int c = q.field_scan ? m[j1][i1] : m[j0][i0];
+      const int idx = q.field_scan ? (j1 * 4 + i1) : (j0 * 4 + i0);
+      ++run;
+      const int scaled = iabs(c) * q.levelscale[idx];
+      int level = (scaled + q.leveloffset[idx]) >> q_bits;
+      int deq = 0, fadj = 0;
+      if (level != 0) {
+        if (q.adaptive_rounding) fadj = rsr(q.adapt_rnd_weight * (scaled - (level << q_bits)), q_bits + 1);
+        any = 1;
+        coeff_cost += (level > 1) ? MAXV : c_cost4[q.disthres][run];
+        level = sgnab(level, c);
+        R.lev[cb][scan_pos] = (int16_t)level; R.run[cb][scan_pos] = (uint8_t)run;
+        scan_pos++;
+        run = -1;
+        deq = rsr((level * q.invlevelscale[idx]) << qp_per, 4);
+      }
+      if (q.field_scan) { m[j1][i1] = deq; fa[j1][i1] = fadj; } else { m[j0][i0] = deq; fa[j0][i0] = fadj; }
+    }
+    R.cnt[cb] = (uint8_t)scan_pos;
+    if (q.adaptive_rounding) {
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) R.fadj_c[uv][by + j][bx + k] = (int16_t)fa[j][k];
+    }
+    if (any) cbp |= 1LL << (16 + 4 * uv + b4);
+    int total = coeff_cost;
+    total += __builtin_amdgcn_update_dpp(total, total, 0xB1, 0xf, 0xf, false);
+    total += __builtin_amdgcn_update_dpp(total, total, 0x4E, 0xf, 0xf, false);
+    int anyq = any;
+    anyq |= __builtin_amdgcn_update_dpp(anyq, anyq, 0xB1, 0xf, 0xf, false);
+    anyq |= __builtin_amdgcn_update_dpp(anyq, anyq, 0x4E, 0xf, 0xf, false);
+    long long cbp_clear = 0;
+    int cr_cbp_tmp = anyq ? 2 : 0;
+    if (total < 4) {                                                       // _CHROMA_COEFF_COST_, block.c:1384-1410
+      cr_cbp_tmp = 0;
+      if (DCcoded == 0) cbp_clear = 0xf0000LL << (uv << 2);
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (k | j) m[j][k] = 0;
+    }
+    if (b4 == 0) R.ac_zeroed[uv] = (uint8_t)(total < 4);
+    if (cr_cbp_tmp == 2) cr_cbp = 2;
+    unsigned cl = (unsigned)cbp, ch = (unsigned)(cbp >> 32);
+    cl |= (unsigned)__builtin_amdgcn_update_dpp((int)cl, (int)cl, 0xB1, 0xf, 0xf, false);
+    cl |= (unsigned)__builtin_amdgcn_update_dpp((int)cl, (int)cl, 0x4E, 0xf, 0xf, false);
+    cbp = ((long long)ch << 32) | cl;
+    inv4(m);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      uint32_t w = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) w |= (uint32_t)clip1(q.max_val, rsr(m[j][k], DQ_BITS) + pr[j][k]) << (8 * k);
+      *reinterpret_cast<uint32_t *>(&R.recon_c[uv][by + j][bx]) = w;
+      if (live) *reinterpret_cast<uint32_t *>((uv ? F.rec_v : F.rec_u) + (size_t)(mby * 8 + by + j) * F.Wc + mbx * 8 + bx) = w;
+    }
+    if (b4 == 0) { R.ret[uv] = cr_cbp; R.cbp_blk[uv] = cbp & ~cbp_clear; R.cbp_clear[uv] = cbp_clear; }
+  }
+  __syncthreads();
+
+  if ((tid & 15) == 0 && (tid >> 4) < nlive) {         // macroblock.c:2028-2040
+    const JmMbRes &R = s_rec[tid >> 4];
+    const int i = i0 + (tid >> 4);
+    long long cb = cbp_blk_luma;
+    cb = (cb & ~R.cbp_clear[0]) | R.cbp_blk[0];
+    cb = (cb & ~R.cbp_clear[1]) | R.cbp_blk[1];
+    coded[i].cbp = cbp_luma + (max(R.ret[0], R.ret[1]) << 4); coded[i].pad = 0; coded[i].cbp_blk = cb;
+  }
+  {
+    const uint4 *src = reinterpret_cast<const uint4 *>(s_rec);
+    uint4 *dst = reinterpret_cast<uint4 *>(out + i0);
+    for (int k = tid; k < nlive * (int)(sizeof(JmMbRes) / 16); k += 64) dst[k] = src[k];
+  }
+}
+
 }  // namespace
+
+int jm_launch_frame_fused(jmhip_ctx *c, const void *frame_dev, const void *mbs, const void *me, const void *modes_in, void *modes_out,
+                          const void *quants, void *records, void *coded, int n)
+{
+  const FrameDev &F = *static_cast<const FrameDev *>(frame_dev);
+  frame_fused_kernel<<<jm_xcd_grid((n + 3) / 4), 64, 0, c->stream>>>(F, (const jmhip_me_mb *)mbs, (const jmhip_me_result *)me, (const jmhip_mb_mode *)modes_in, (jmhip_mb_mode *)modes_out,
+                                                                     (const jmhip_quant *)quants, (JmMbRes *)records, (JmMbCoded *)coded, n);
+  if (hipGetLastError() != hipSuccess) return jm_fail(c, JMHIP_ERR_DEVICE, "frame_fused_kernel launch");
+  return JMHIP_OK;
+}
 
 extern "C" void jmhip_flat_quant(jmhip_quant *q, int qp, int offset11, int is8x8)
 {
