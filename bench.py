@@ -42,7 +42,7 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 # 1024 SIMDs. (Until the min3 pairing was built the model charged one v_min_u32 per partition: 266 ns.)
 VALU_NS_PER_WAVE_CANDIDATE = 64 * 1.89 + 25 * 1.04 + 40 * 1.04 + 20.5 * 1.89
 N_SIMD = 1024
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_final_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_final_summary.json")
 
 
 def pmc_traffic(kernel, n_units):
@@ -290,6 +290,36 @@ def slice_search_times(pkg, ctx, lam):
     return out
 
 
+def per_partition_predictors(pkg, ctx, lam, prm, mbs):
+    """For information: the integer search fed with JM's OWN predictors -- one per partition, as SetMotionVectorPredictor yields them in raster order
+    (taken from jmhip_p_slice_search, FullSearch, of the bench picture) -- instead of the metric's one predictor per macroblock. FullSearch centres
+    its window on each partition's predictor (mv-search.c:752-762): a macroblock costs one window walk per DISTINCT centre."""
+    import ctypes
+    from tests.test_slice_gpu import slice_params
+    lib = pkg.load_library()
+    ctx.slice_state_reset()
+    p = slice_params(pkg, -1, R, 1, [lam] * 3, 10, W, H=H)
+    rec = ctx.p_slice_search(p)
+    pp = mbs.copy()
+    pp["pred_mv"] = rec["pred"][:, 0]
+    centres = np.clip(np.trunc(pp["pred_mv"].astype(np.int32) / 4.0).astype(np.int32), -2047 + R, 2047 - R)      # rdopt = 1: no clamp to the range
+    distinct = np.array([len({(int(c[0]), int(c[1])) for c in m}) for m in centres])
+    ctx.timing_enable(True)
+    ctx.timing_select(["me_int", "me_sub"])
+    ctx.timing_read()
+    ctx.me_frame_async(prm, pp)
+    for _ in range(3):
+        ctx.me_frame_async(prm, None, len(pp))
+    ctx.sync()
+    t = ctx.timing_read()
+    ctx.timing_enable(False)
+    ctx.me_frame_async(prm, mbs)                       # leave the metric's job set resident again
+    ctx.sync()
+    return {"predictors": "JM's own, per partition (jmhip_p_slice_search, FullSearch)", "distinct_centres_per_mb": {"mean": round(float(distinct.mean()), 2), "max": int(distinct.max())},
+            "me_int_ms": round(t["me_int"][0] / max(1, t["me_int"][1]), 4), "me_sub_ms": round(t["me_sub"][0] / max(1, t["me_sub"][1]), 4),
+            "note": "the fast kernel takes macroblocks with <= 8 distinct centres (one walk each), the union-window kernel the rest"}
+
+
 def main():
     global W, H_SRC, H, MBW, MBH
     ap = argparse.ArgumentParser()
@@ -510,7 +540,7 @@ def main():
                          "valu_model": {"model_floor_ms": round(valu_floor_ms, 4), "ns_per_wave_candidate_row": round(VALU_NS_PER_WAVE_CANDIDATE, 1), "simds": N_SIMD},
                          "hbm": {"achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                                  "algorithmic_bytes_per_unit": ME_BYTES_PER_MB,
-                                 "traffic_note": "traffic = (FETCH_SIZE + WRITE_SIZE) KB x 1024 per launch from profiles/r01_final_pmc_*.csv, raw: the guide's x2 "
+                                 "traffic_note": "traffic = (FETCH_SIZE + WRITE_SIZE) KB x 1024 per launch from profiles/r02_final_pmc_*.csv, raw: the guide's x2 "
                                                  "FETCH_SIZE correction is calibrated for 16 B/lane streaming reads and this kernel reads dwords, so it is not applied"}},
             "stages_ms_per_launch": {k: round(v[0] / max(1, v[1]), 4) for k, v in stage.items()},
             "ref_checksum": ref_sum,
@@ -534,6 +564,7 @@ def main():
         if world == 1 and args.cpu_mbs > 0:
             out["parity_check"] = parity_check(pkg, ctx, frames, mbs, prm, last_src=1 + ((args.warmup + args.steps + 2) % (nframes - 1)), prev_ref=prev_ref_host)
             out["slice_search"] = slice_search_times(pkg, ctx, lam)
+            out["per_partition_pred"] = per_partition_predictors(pkg, ctx, lam, prm, mbs)
             e2e = jm_end_to_end(frames)
             if e2e is not None:
                 out["jm_end_to_end"] = e2e

@@ -38,8 +38,14 @@ struct WaveDev {
   int *um_cost;                                // fastme_l0_cost [8][h4][w4]
   uint16_t *surf;                              // exhaustive searches: per row, per reference, SAD surfaces [SURF_PLANES][surf_n]
   int surf_n;                                  // candidates per plane (capacity)
-  int debug;                                   // JMHIP_WAVE_DEBUG (timing experiments only; results are wrong): 1 no sub-pel, 2 no integer search, 4 no skip cost
+  int debug;                                   // JMHIP_WAVE_DEBUG (timing experiments only; results are wrong): 1 no sub-pel, 2 no integer search, 4 no skip cost, 8 no LDS reference windows (results stay right)
 };
+
+// The slice's parameter block lives in constant memory and the block being searched in LDS, both named directly by every device function:
+// passed by reference to functions that are not inlined they become generic pointers into scratch and every field read a FLAT instruction
+// (853 of them before), which is where a macroblock's 2.6 M cycles went. One slice search per device at a time (the entry point synchronises).
+__constant__ WaveDev c_wave;
+#define D c_wave
 
 struct Lds {
   uint8_t cur[16][16];
@@ -54,7 +60,36 @@ struct Lds {
   uint8_t um_sstate[52];                       // SearchState 7x7
   int surf_c[WR][4];                           // per reference: surface centre (pels), half side, valid
   __attribute__((aligned(16))) uint8_t win[WIN_MAX * WIN_MAX];     // reference window of the surface pass
+  // integer samples round the macroblock, one window per reference of the slice (plane 0 of its quarter-pel stack, padded coordinates
+  // [rw_x0, rw_x0 + WIN_MAX) x [rw_y0, rw_y0 + WIN_MAX)): candidates at integer positions whose block lies inside are evaluated out of LDS
+  const uint8_t *rw_planes[WR];
+  int rw_x0, rw_y0;
+  __attribute__((aligned(16))) uint8_t rwin[WR][WIN_MAX * WIN_MAX];
 };
+
+// ONE instance at file scope: every device function names it directly, so its accesses are LDS instructions (ds_read / ds_write) also where a
+// function is not inlined -- passed by reference it decays to a generic pointer and every access becomes a FLAT instruction
+__shared__ Lds g_lds;
+#define L g_lds
+
+// 4 (8) samples of one window row at any byte offset
+__device__ __forceinline__ void win_row(const uint8_t *w, int off, int n, uint32_t *lo, uint32_t *hi)
+{
+  const uint32_t *q = reinterpret_cast<const uint32_t *>(w) + (off >> 2);
+  const unsigned sh = (unsigned)(off & 3);
+  const uint32_t d0 = q[0], d1 = q[1];
+  *lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
+  if (n == 8) { const uint32_t d2 = q[2]; *hi = __builtin_amdgcn_alignbyte(d2, d1, sh); }
+}
+
+#ifdef JMHIP_WAVE_PROF
+__device__ unsigned long long g_wave_prof[16];
+#define WPROF_T0 unsigned long long wp_t = __builtin_amdgcn_s_memtime()
+#define WPROF(k) do { const unsigned long long wp_n = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) atomicAdd(&g_wave_prof[k], wp_n - wp_t); wp_t = wp_n; } while (0)
+#else
+#define WPROF_T0 do { } while (0)
+#define WPROF(k) do { } while (0)
+#endif
 
 __constant__ int8_t c_bsx[8] = {16, 16, 16, 8, 8, 8, 4, 4};
 __constant__ int8_t c_bsy[8] = {16, 16, 8, 16, 8, 4, 8, 4};
@@ -67,36 +102,97 @@ __device__ __forceinline__ int imin3(int a, int b, int c) { return min(a, min(b,
 // L.dist[k] = distortion of the bsx x bsy block at (bx, by) of the macroblock against the reference block whose origin is the padded
 // quarter-pel position (L.cx[k], L.cy[k]), k < n. metric 0: computeSAD(WP) (me_distortion.c:351/413), one origin clamp per block; metric 2:
 // computeSATD(WP) (:657/:734), origin clamp per 4x4 (t8: 8x8) sub-block. umv: ref_access_method.
-__device__ void eval_dist(const WaveDev &D, Lds &L, const uint8_t *planes, int metric, int t8, int umv, int wp, int wpw, int wpo,
+__device__ void eval_dist(const uint8_t *planes, int metric, int t8, int umv, int wp, int wpw, int wpo,
                           int bx, int by, int bsx, int bsy, int n)
 {
   const int lane = threadIdx.x;
   const size_t psz = (size_t)D.Wp * D.Hp;
   const int wpad = D.Wp - 17, hpad = D.Hp - 17;           // size_x_pad / size_y_pad, mbuffer.c:421-422
+  const uint8_t *lwin = nullptr;                          // this reference's LDS window (stage_windows), if it has one
+  for (int r = 0; r < WR; r++) if (L.rw_planes[r] == planes) lwin = L.rwin[r];
+  const int rwx0 = L.rw_x0, rwy0 = L.rw_y0;
+#ifdef JMHIP_WAVE_PROF
+  const unsigned long long ev_t0 = __builtin_amdgcn_s_memtime();
+#endif
   __syncthreads();
   if (metric == 0) {
     const int rowdw = bsx >> 2, seg = rowdw * bsy, cpb = 64 / seg;
     const int d = lane % seg, row = d / rowdw, c4 = d - row * rowdw;
     const uint32_t curv = *reinterpret_cast<const uint32_t *>(&L.cur[by + row][bx + 4 * c4]);
-    for (int base = 0; base < n; base += cpb) {
-      const int k = base + lane / seg;
-      int v = 0;
-      if (k < n) {
-        const int cx = L.cx[k], cy = L.cy[k];
-        int ix = cx >> 2, iy = cy >> 2;
-        if (umv) { ix = clampi(ix, 0, wpad); iy = clampi(iy, 0, hpad); }
-        const uint8_t *p = planes + psz * ((cy & 3) * 4 + (cx & 3)) + (size_t)(iy + row) * D.Wp + ix + 4 * c4;
-        uint32_t r, hi;
-        fetch_row(p, 4, &r, &hi);
-        if (wp) r = wp_apply4(r, wpw, wpo, D.p.wp_round, D.p.wp_denom);
-        v = (int)__builtin_amdgcn_sad_u8(r, curv, 0u);
+    for (int base = 0; base < n; base += 4 * cpb) {          // four passes' loads in flight before the first is consumed
+      uint32_t rr[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int k = base + u * cpb + lane / seg;
+        rr[u] = 0;
+        if (k < n) {
+          const int cx = L.cx[k], cy = L.cy[k];
+          int ix = cx >> 2, iy = cy >> 2;
+          if (umv) { ix = clampi(ix, 0, wpad); iy = clampi(iy, 0, hpad); }
+          const int lx = ix - rwx0, ly = iy - rwy0;
+          uint32_t hi;
+          if (lwin && !((cx | cy) & 3) && lx >= 0 && ly >= 0 && lx + bsx <= WIN_MAX - 4 && ly + bsy <= WIN_MAX) win_row(lwin, (ly + row) * WIN_MAX + lx + 4 * c4, 4, &rr[u], &hi);
+          else fetch_row(planes + psz * ((cy & 3) * 4 + (cx & 3)) + (size_t)(iy + row) * D.Wp + ix + 4 * c4, 4, &rr[u], &hi);
+        }
       }
-      for (int o = 1; o < seg; o <<= 1) v += __shfl_xor(v, o);
-      if (k < n && d == 0) L.dist[k] = v;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int k = base + u * cpb + lane / seg;
+        if (base + u * cpb >= n) break;
+        uint32_t r = rr[u];
+        if (wp) r = wp_apply4(r, wpw, wpo, D.p.wp_round, D.p.wp_denom);
+        int v = k < n ? (int)__builtin_amdgcn_sad_u8(r, curv, 0u) : 0;
+        for (int o = 1; o < seg; o <<= 1) v += __shfl_xor(v, o);
+        if (k < n && d == 0) L.dist[k] = v;
+      }
     }
   } else {
     const int bs = t8 ? 8 : 4, nsx = bsx / bs, nsub = nsx * (bsy / bs), cpb = 64 / nsub;
     const int s = lane % nsub, sy = s / nsx, sx = s - sy * nsx;
+    if (!t8) {
+      for (int base = 0; base < n; base += 4 * cpb) {        // four passes' loads in flight before the first is consumed
+        uint32_t rv[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int k = base + u * cpb + lane / nsub;
+#pragma unroll
+          for (int r = 0; r < 4; r++) rv[u][r] = 0;
+          if (k < n) {
+            const int ox = L.cx[k] + sx * 16, oy = L.cy[k] + sy * 16;
+            int ix = ox >> 2, iy = oy >> 2;
+            if (umv) { ix = clampi(ix, 0, wpad); iy = clampi(iy, 0, hpad); }
+            const uint8_t *p = planes + psz * ((oy & 3) * 4 + (ox & 3)) + (size_t)iy * D.Wp + ix;
+            const int lx = ix - rwx0, ly = iy - rwy0;
+            const bool inw = lwin && !((ox | oy) & 3) && lx >= 0 && ly >= 0 && lx + 4 <= WIN_MAX - 4 && ly + 4 <= WIN_MAX;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              uint32_t hi;
+              if (inw) win_row(lwin, (ly + r) * WIN_MAX + lx, 4, &rv[u][r], &hi); else fetch_row(p + (size_t)r * D.Wp, 4, &rv[u][r], &hi);
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int k = base + u * cpb + lane / nsub;
+          if (base + u * cpb >= n) break;
+          int v = 0;
+          if (k < n) {
+            int df[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              uint32_t q = rv[u][r];
+              if (wp) q = wp_apply4(q, wpw, wpo, D.p.wp_round, D.p.wp_denom);
+              const uint32_t cv = *reinterpret_cast<const uint32_t *>(&L.cur[by + sy * 4 + r][bx + sx * 4]);
+#pragma unroll
+              for (int c = 0; c < 4; c++) df[r][c] = (int)((cv >> (8 * c)) & 255u) - (int)((q >> (8 * c)) & 255u);
+            }
+            v = satd4x4(df);
+          }
+          for (int o = 1; o < nsub; o <<= 1) v += __shfl_xor(v, o);
+          if (k < n && s == 0) L.dist[k] = v;
+        }
+      }
+    } else
     for (int base = 0; base < n; base += cpb) {
       const int k = base + lane / nsub;
       int v = 0;
@@ -105,24 +201,14 @@ __device__ void eval_dist(const WaveDev &D, Lds &L, const uint8_t *planes, int m
         int ix = ox >> 2, iy = oy >> 2;
         if (umv) { ix = clampi(ix, 0, wpad); iy = clampi(iy, 0, hpad); }
         const uint8_t *p = planes + psz * ((oy & 3) * 4 + (ox & 3)) + (size_t)iy * D.Wp + ix;
-        if (!t8) {
-          int df[4][4];
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            uint32_t rv, hi;
-            fetch_row(p + (size_t)r * D.Wp, 4, &rv, &hi);
-            if (wp) rv = wp_apply4(rv, wpw, wpo, D.p.wp_round, D.p.wp_denom);
-            const uint32_t cv = *reinterpret_cast<const uint32_t *>(&L.cur[by + sy * 4 + r][bx + sx * 4]);
-#pragma unroll
-            for (int c = 0; c < 4; c++) df[r][c] = (int)((cv >> (8 * c)) & 255u) - (int)((rv >> (8 * c)) & 255u);
-          }
-          v = satd4x4(df);
-        } else {
+        const int lx = ix - rwx0, ly = iy - rwy0;
+        const bool inw = lwin && !((ox | oy) & 3) && lx >= 0 && ly >= 0 && lx + bs <= WIN_MAX - 4 && ly + bs <= WIN_MAX;
+        {
           int m[8][8];
 #pragma unroll
           for (int r = 0; r < 8; r++) {
             uint32_t lo, hi;
-            fetch_row(p + (size_t)r * D.Wp, 8, &lo, &hi);
+            if (inw) win_row(lwin, (ly + r) * WIN_MAX + lx, 8, &lo, &hi); else fetch_row(p + (size_t)r * D.Wp, 8, &lo, &hi);
             if (wp) { lo = wp_apply4(lo, wpw, wpo, D.p.wp_round, D.p.wp_denom); hi = wp_apply4(hi, wpw, wpo, D.p.wp_round, D.p.wp_denom); }
             const uint32_t c0 = *reinterpret_cast<const uint32_t *>(&L.cur[by + sy * 8 + r][bx + sx * 8]);
             const uint32_t c1 = *reinterpret_cast<const uint32_t *>(&L.cur[by + sy * 8 + r][bx + sx * 8 + 4]);
@@ -151,6 +237,9 @@ __device__ void eval_dist(const WaveDev &D, Lds &L, const uint8_t *planes, int m
     }
   }
   __syncthreads();
+#ifdef JMHIP_WAVE_PROF
+  if (threadIdx.x == 0) { atomicAdd(&g_wave_prof[10], __builtin_amdgcn_s_memtime() - ev_t0); atomicAdd(&g_wave_prof[11], 1ull); atomicAdd(&g_wave_prof[12], (unsigned long long)n); }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------- neighbours and the predictor
@@ -159,7 +248,7 @@ struct Nbr { int avail[4], ref[4], mvx[4], mvy[4], posx[4], posy[4]; };
 
 // getLuma4x4Neighbour for frame pictures (mb_access.c): luma offset (xN, yN) relative to macroblock (mbx, mby); available = inside the picture
 // and inside the slice (addresses [mb_first, mb_first + mb_count))
-__device__ __forceinline__ int nbr_pos(const WaveDev &D, int mbx, int mby, int xN, int yN, int *px, int *py)
+__device__ __forceinline__ int nbr_pos(int mbx, int mby, int xN, int yN, int *px, int *py)
 {
   int nx = mbx, ny = mby;
   if (xN < 0 && yN < 0) { nx--; ny--; }
@@ -175,12 +264,12 @@ __device__ __forceinline__ int nbr_pos(const WaveDev &D, int mbx, int mby, int x
   return 1;
 }
 
-__device__ void neighbours(const WaveDev &D, int mbx, int mby, int mb_x, int mb_y, int bsx, Nbr &nb)
+__device__ void neighbours(int mbx, int mby, int mb_x, int mb_y, int bsx, Nbr &nb)
 {
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const int xN = mb_x + (k == 1 ? 0 : (k == 2 ? bsx : -1)), yN = mb_y + (k == 0 ? 0 : -1);
-    nb.avail[k] = nbr_pos(D, mbx, mby, xN, yN, &nb.posx[k], &nb.posy[k]);
+    nb.avail[k] = nbr_pos(mbx, mby, xN, yN, &nb.posx[k], &nb.posy[k]);
     nb.ref[k] = -1; nb.mvx[k] = nb.mvy[k] = 0;
     if (nb.avail[k]) {
       const size_t at = (size_t)nb.posy[k] * D.w4 + nb.posx[k];
@@ -202,11 +291,11 @@ __device__ __forceinline__ void fix_block_c(int mb_x, int mb_y, int bsx, int *c_
 }
 
 // SetMotionVectorPredictor mv-search.c:87 / UMHEXSetMotionVectorPredictor me_umhex.c:1298 (dsr: also the dynamic search range)
-__device__ void mv_predictor(const WaveDev &D, int mbx, int mby, int ref_frame, int mb_x, int mb_y, int bsx, int bsy, int *pmx, int *pmy,
+__device__ void mv_predictor(int mbx, int mby, int ref_frame, int mb_x, int mb_y, int bsx, int bsy, int *pmx, int *pmy,
                              int dsr, int umhex_bt, int *search_range, int *sad_abc)
 {
   Nbr nb;
-  neighbours(D, mbx, mby, mb_x, mb_y, bsx, nb);
+  neighbours(mbx, mby, mb_x, mb_y, bsx, nb);
   fix_block_c(mb_x, mb_y, bsx, &nb.avail[2]);
   if (!nb.avail[2]) { nb.avail[2] = nb.avail[3]; nb.ref[2] = nb.ref[3]; nb.mvx[2] = nb.mvx[3]; nb.mvy[2] = nb.mvy[3]; nb.posx[2] = nb.posx[3]; nb.posy[2] = nb.posy[3]; }
   const int rL = nb.avail[0] ? nb.ref[0] : -1, rU = nb.avail[1] ? nb.ref[1] : -1, rUR = nb.avail[2] ? nb.ref[2] : -1;
@@ -265,12 +354,15 @@ struct Blk {
   int t8;                       // test8x8transform
 };
 
-__device__ __forceinline__ int mvc(int lam, int mvx_q, int mvy_q, const Blk &B) { return mv_cost(lam, mvx_q - B.pmx, mvy_q - B.pmy); }
+__shared__ Blk g_blk;
+#define B g_blk
+
+__device__ __forceinline__ int mvc(int lam, int mvx_q, int mvy_q) { return mv_cost(lam, mvx_q - B.pmx, mvy_q - B.pmy); }
 __device__ __forceinline__ int padq(int pic, int v_q) { return ((pic + JMHIP_PAD) << 2) + v_q; }
 
 // visited map of one search: (2R+1)^2 bits, index relative to the search centre
-__device__ __forceinline__ void map_clear(Lds &L, int R) { const int n = ((2 * R + 1) * (2 * R + 1) + 31) >> 5; for (int i = 0; i < n; i++) L.map[i] = 0u; }
-__device__ __forceinline__ int map_test_set(Lds &L, int R, int dx, int dy)
+__device__ __forceinline__ void map_clear(int R) { const int n = ((2 * R + 1) * (2 * R + 1) + 31) >> 5; __syncthreads(); for (int i = threadIdx.x; i < n; i += 64) L.map[i] = 0u; __syncthreads(); }
+__device__ __forceinline__ int map_test_set(int R, int dx, int dy)
 {
   const int i = (dy + R) * (2 * R + 1) + (dx + R);
   const uint32_t w = L.map[i >> 5], b = 1u << (i & 31);
@@ -278,12 +370,12 @@ __device__ __forceinline__ int map_test_set(Lds &L, int R, int dx, int dy)
   L.map[i >> 5] = w | b;
   return 0;
 }
-__device__ __forceinline__ int map_test(const Lds &L, int R, int dx, int dy) { const int i = (dy + R) * (2 * R + 1) + (dx + R); return (L.map[i >> 5] >> (i & 31)) & 1u; }
-__device__ __forceinline__ void map_set(Lds &L, int R, int dx, int dy) { const int i = (dy + R) * (2 * R + 1) + (dx + R); L.map[i >> 5] |= 1u << (i & 31); }
+__device__ __forceinline__ int map_test(int R, int dx, int dy) { const int i = (dy + R) * (2 * R + 1) + (dx + R); return (L.map[i >> 5] >> (i & 31)) & 1u; }
+__device__ __forceinline__ void map_set(int R, int dx, int dy) { const int i = (dy + R) * (2 * R + 1) + (dx + R); L.map[i >> 5] |= 1u << (i & 31); }
 
 // ---------------------------------------------------------------------------------------------- SubPelBlockMotionSearch (me_fullsearch.c:341)
 
-__device__ int subpel_full(const WaveDev &D, Lds &L, const Blk &B, int *mvx, int *mvy, int min_mcost)
+__device__ int subpel_full(int *mvx, int *mvy, int min_mcost)
 {
   const int start_hp = D.p.metric[0] != D.p.metric[1] ? 0 : 1, start_qp = D.p.metric[1] != D.p.metric[2] ? 0 : 1;
   const int max_x4 = (D.W - B.bsx + 2 * JMHIP_PAD) << 2, max_y4 = (D.H - B.bsy + 2 * JMHIP_PAD) << 2;
@@ -295,10 +387,10 @@ __device__ int subpel_full(const WaveDev &D, Lds &L, const Blk &B, int *mvx, int
     if (phase && !start_qp) min_mcost = INT_MAX;
     int n = 0;
     for (int pos = first; pos < 9; pos++) { L.cx[n] = p4x + c_s9x[pos] * step; L.cy[n] = p4y + c_s9y[pos] * step; n++; }
-    eval_dist(D, L, B.planes, D.p.metric[phase ? 2 : 1], B.t8, umv, B.wp, B.wpw, B.wpo, B.mb_x, B.mb_y, B.bsx, B.bsy, n);
+    eval_dist(B.planes, D.p.metric[phase ? 2 : 1], B.t8, umv, B.wp, B.wpw, B.wpo, B.mb_x, B.mb_y, B.bsx, B.bsy, n);
     int best = 0;
     for (int pos = first, k = 0; pos < 9; pos++, k++) {
-      int mcost = mvc(lam, *mvx + c_s9x[pos] * step, *mvy + c_s9y[pos] * step, B);
+      int mcost = mvc(lam, *mvx + c_s9x[pos] * step, *mvy + c_s9y[pos] * step);
       if (mcost >= min_mcost) continue;
       mcost += L.dist[k];
       if (phase == 0 && pos == 0 && check0) mcost -= (lam * 16) >> 16;
@@ -314,7 +406,7 @@ __device__ int subpel_full(const WaveDev &D, Lds &L, const Blk &B, int *mvx, int
 // argmin over the (2R+1)^2 window round (cx, cy) [pels] of SAD + mv cost with JM's order of preference (lowest spiral index on ties).
 // ffs: FastFullPelBlockMotionSearch (me_fullfast.c:833: the zero vector is tried first when !rdopt and then keeps ties);
 // else FullPelBlockMotionSearch (me_fullsearch.c:47: check_for_00 bonus :129-132 incl. the wrapped first-row bound, see me_int.hip).
-__device__ int full_window(const WaveDev &D, Lds &L, const Blk &B, int cx, int cy, int R, int ffs, int *mvx, int *mvy)
+__device__ int full_window(int cx, int cy, int R, int ffs, int *mvx, int *mvy)
 {
   const int lane = threadIdx.x, side = 2 * R + 1, npos = side * side, lam = D.p.lambda_mf[0];
   const size_t psz = (size_t)D.Wp * D.Hp;
@@ -371,7 +463,7 @@ __device__ int full_window(const WaveDev &D, Lds &L, const Blk &B, int cx, int c
 // SAD is independent of the predictor: once per (macroblock, reference) the SADs of the sixteen 4x4 blocks (and their 8x8 sums) are computed
 // for every displacement in a window round (scx, scy) and kept; every partition then finds its own argmin of (SAD + its own mv cost) over its
 // own window -- SetupFastFullPelSearch / SetupLargerBlocks (me_fullfast.c:491, :210) made macroblock-wide. lane <-> displacement.
-__device__ void surface_build(const WaveDev &D, Lds &L, const Blk &B, int scx, int scy, int Rs)
+__device__ void surface_build(int scx, int scy, int Rs)
 {
   const int lane = threadIdx.x, side = 2 * Rs + 1, wside = side + 15, n = side * side;
   const int ox = B.mbx * 16 + scx - Rs + JMHIP_PAD, oy = B.mby * 16 + scy - Rs + JMHIP_PAD;     // window origin in the padded integer plane
@@ -419,7 +511,7 @@ __device__ void surface_build(const WaveDev &D, Lds &L, const Blk &B, int scx, i
 }
 
 // argmin of SAD + mv cost over the (2R+1)^2 window round (cx, cy) from the surface of B.ref. Returns INT_MIN when the window is not covered.
-__device__ int surface_search(const WaveDev &D, Lds &L, const Blk &B, int cx, int cy, int R, int ffs, int *mvx, int *mvy)
+__device__ int surface_search(int cx, int cy, int R, int ffs, int *mvx, int *mvy)
 {
   const int scx = L.surf_c[B.ref][0], scy = L.surf_c[B.ref][1], Rs = L.surf_c[B.ref][2];
   if (!L.surf_c[B.ref][3] || cx - R < scx - Rs || cx + R > scx + Rs || cy - R < scy - Rs || cy + R > scy + Rs) return INT_MIN;
@@ -467,7 +559,7 @@ __device__ int surface_search(const WaveDev &D, Lds &L, const Blk &B, int cx, in
     const int mc = mv_cost(lam, (cx << 2) - B.pmx, (cy << 2) - B.pmy) - w16;
     if (mc < 0) {                                                      // me_fullsearch.c:138 with min_mcost = INT_MAX: computeSAD leaves after row 0
       L.cx[0] = padq(B.pic_x, cx << 2); L.cy[0] = padq(B.pic_y, cy << 2);
-      eval_dist(D, L, B.planes, 0, 0, 1, B.wp, B.wpw, B.wpo, 0, 0, 16, 1, 1);
+      eval_dist(B.planes, 0, 0, 1, B.wp, B.wpw, B.wpo, 0, 0, 16, 1, 1);
       best = min(best, ((unsigned)(mc + L.dist[0] + 4096) << TIE_BITS) | 1u);
     }
   }
@@ -496,7 +588,7 @@ __constant__ int8_t c_sp_qp[10][2] = {{0, 0}, {-1, 0}, {0, 1}, {1, 0}, {0, -1}, 
 struct EpState { int tmx, tmy, t2x, t2y, min_mcost, second; };
 
 // one pass of candidates (vectors L.qx/qy[0..n), pels) through the visited map, the evaluation and the caller's replay
-__device__ __forceinline__ int ep_access_umv(const WaveDev &D, const Blk &B, int vx, int vy)
+__device__ __forceinline__ int ep_access_umv(int vx, int vy)
 {
   // CHECK_RANGE (me_epzs.h:23) compares the QUARTER-pel candidate with pel-unit picture sizes, as JM does
   const int cx = (B.pic_x + vx) << 2, cy = (B.pic_y + vy) << 2;
@@ -504,16 +596,16 @@ __device__ __forceinline__ int ep_access_umv(const WaveDev &D, const Blk &B, int
 }
 
 // evaluates the candidates L.qx/qy[0..n) (integer vectors): EPZS picks the access method per candidate, so they go in two batches
-__device__ void ep_eval(const WaveDev &D, Lds &L, const Blk &B, int n)
+__device__ void ep_eval(int n)
 {
   // EPZS picks FAST or UMV access per candidate (CHECK_RANGE, me_epzs.h:23), and FAST only for blocks that lie inside the picture, where the
   // origin clamp of UMV access is the identity: every candidate is evaluated with UMV access.
   for (int k = 0; k < n; k++) { L.cx[k] = padq(B.pic_x, L.qx[k] << 2); L.cy[k] = padq(B.pic_y, L.qy[k] << 2); }
-  eval_dist(D, L, B.planes, D.p.metric[0], B.t8, 1, B.wp, B.wpw, B.wpo, B.mb_x, B.mb_y, B.bsx, B.bsy, n);
+  eval_dist(B.planes, D.p.metric[0], B.t8, 1, B.wp, B.wpw, B.wpo, B.mb_x, B.mb_y, B.bsx, B.bsy, n);
 }
 
 // EPZSPelBlockMotionSearch, me_epzs.c:1500. mvx/mvy: search centre in, result out (pels). all_mv: this block's img->all_mv row [ref][blocktype].
-__device__ int epzs_pel(const WaveDev &D, Lds &L, const Blk &B, int mb_nr, int R, int *mvx, int *mvy)
+__device__ int epzs_pel(int mb_nr, int R, int *mvx, int *mvy)
 {
   const jmhip_slice_params &P = D.p;
   const int lam = P.lambda_mf[0], bt = B.bt, ref = B.ref;
@@ -524,11 +616,12 @@ __device__ int epzs_pel(const WaveDev &D, Lds &L, const Blk &B, int mb_nr, int R
   const int medthres = P.epzs_thres[1][bt];
   int stop = medthres;
   EpState S{cx0, cy0, 0, 0, 0, INT_MAX};
-  map_clear(L, R);
-  map_set(L, R, 0, 0);
+  map_clear(R);
+  map_set(R, 0, 0);
   L.qx[0] = cx0; L.qy[0] = cy0;
-  ep_eval(D, L, B, 1);
-  S.min_mcost = mvc(lam, cx0 << 2, cy0 << 2, B) + L.dist[0];
+  ep_eval(1);
+  S.min_mcost = mvc(lam, cx0 << 2, cy0 << 2) + L.dist[0];
+  WPROF_T0;
   const int psad = prev_sad[px2];
   if (ref > 0 && psad < medthres && psad < S.min_mcost) {                      // :1608-1623
     if (motion && threadIdx.x == 0) { motion[0] = (short)S.tmx; motion[1] = (short)S.tmy; }
@@ -536,7 +629,7 @@ __device__ int epzs_pel(const WaveDev &D, Lds &L, const Blk &B, int mb_nr, int R
   }
   if (S.min_mcost > stop) {
     Nbr nb;
-    neighbours(D, B.mbx, B.mby, B.mb_x, B.mb_y, B.bsx, nb);
+    neighbours(B.mbx, B.mby, B.mb_x, B.mb_y, B.bsx, nb);
     const int mb_avail_right = B.mbx < D.mbw - 1, mb_avail_below = B.mby < D.mbh - 1;
     int c_avail = nb.avail[2], blk_right;
     if (B.mb_y > 0) {                                                          // :1660-1687
@@ -613,24 +706,26 @@ __device__ int epzs_pel(const WaveDev &D, Lds &L, const Blk &B, int mb_nr, int R
 #undef RR
     }
 #undef ADDP
+    WPROF(4);
     // ---- scan :1746-1795: the map is marked whatever the costs are, so the survivors are known before anything is evaluated
     int n = 0;
     for (int k = 0; k < np; k++) {
       const int tx = L.px[k], ty = L.py[k];
       if (iabs(tx - cx0) > R || iabs(ty - cy0) > R) continue;
-      if (map_test_set(L, R, tx - cx0, ty - cy0)) continue;
+      if (map_test_set(R, tx - cx0, ty - cy0)) continue;
       L.qx[n] = tx; L.qy[n] = ty; n++;
     }
-    ep_eval(D, L, B, n);
+    ep_eval(n);
     int check_median = 0;
     for (int k = 0; k < n; k++) {
       const int tx = L.qx[k], ty = L.qy[k];
-      int mcost = mvc(lam, tx << 2, ty << 2, B);
+      int mcost = mvc(lam, tx << 2, ty << 2);
       if (mcost >= S.second) continue;
       mcost += L.dist[k];
       if (mcost < S.min_mcost) { S.t2x = S.tmx; S.t2y = S.tmy; S.tmx = tx; S.tmy = ty; S.second = S.min_mcost; S.min_mcost = mcost; check_median = 1; }
       else if (mcost < S.second) { S.t2x = tx; S.t2y = ty; S.second = mcost; check_median = 1; }
     }
+    WPROF(5);
     // ---- refinement :1801-1942
     if (S.min_mcost > stop) {
       const int search_pattern = (P.epzs_pattern >= 1 && P.epzs_pattern <= 5) ? P.epzs_pattern : 0;       // :410-431
@@ -650,12 +745,12 @@ __device__ int epzs_pel(const WaveDev &D, Lds &L, const Blk &B, int mb_nr, int R
           int pidx[12];
           for (int c = 0, pt = point; c < total; c++) {
             const int tx = center_x + c_pat[pf].mvx[pt], ty = center_y + c_pat[pf].mvy[pt];
-            if (iabs(tx - cx0) <= R && iabs(ty - cy0) <= R && !map_test_set(L, R, tx - cx0, ty - cy0)) { L.qx[cnt] = tx; L.qy[cnt] = ty; pidx[cnt] = pt; cnt++; }
+            if (iabs(tx - cx0) <= R && iabs(ty - cy0) <= R && !map_test_set(R, tx - cx0, ty - cy0)) { L.qx[cnt] = tx; L.qy[cnt] = ty; pidx[cnt] = pt; cnt++; }
             if (++pt >= c_pat[pf].n) pt -= c_pat[pf].n;
           }
-          ep_eval(D, L, B, cnt);
+          ep_eval(cnt);
           for (int k = 0; k < cnt; k++) {
-            int mcost = mvc(lam, L.qx[k] << 2, L.qy[k] << 2, B);
+            int mcost = mvc(lam, L.qx[k] << 2, L.qy[k] << 2);
             if (mcost < S.min_mcost) {
               mcost += L.dist[k];
               if (mcost < S.min_mcost) { S.min_mcost = mcost; S.tmx = L.qx[k]; S.tmy = L.qy[k]; dir = pidx[k]; }
@@ -683,6 +778,7 @@ __device__ int epzs_pel(const WaveDev &D, Lds &L, const Blk &B, int mb_nr, int R
       }
     }
   }
+  WPROF(6);
   if (threadIdx.x == 0) {
     if (ref == 0 || prev_sad[px2] > S.min_mcost) prev_sad[px2] = S.min_mcost;                           // :1945
     if (motion) { motion[0] = (short)S.tmx; motion[1] = (short)S.tmy; }
@@ -692,16 +788,16 @@ __device__ int epzs_pel(const WaveDev &D, Lds &L, const Blk &B, int mb_nr, int R
 }
 
 // one level of EPZSSubPelBlockMotionSearch (me_epzs.c:2472-2579 / :2605-2715). Returns 1 on the sub-threshold early return.
-__device__ int epzs_sub_level(const WaveDev &D, Lds &L, const Blk &B, int half, int start, int lam, int metric, int umv, int *mvx, int *mvy, int *min_mcost, int subthres)
+__device__ int epzs_sub_level(int half, int start, int lam, int metric, int umv, int *mvx, int *mvy, int *min_mcost, int subthres)
 {
   const int8_t (*pts)[2] = half ? c_sp_hp : c_sp_qp;
   const int p4x = padq(B.pic_x, 0), p4y = padq(B.pic_y, 0);
   int n = 0;
   for (int pos = start; pos < 5; pos++) { L.cx[n] = p4x + *mvx + pts[pos][0]; L.cy[n] = p4y + *mvy + pts[pos][1]; n++; }
-  eval_dist(D, L, B.planes, metric, B.t8, umv, B.wp, B.wpw, B.wpo, B.mb_x, B.mb_y, B.bsx, B.bsy, n);
+  eval_dist(B.planes, metric, B.t8, umv, B.wp, B.wpw, B.wpo, B.mb_x, B.mb_y, B.bsx, B.bsy, n);
   int best = 0, second_pos = 0, second = INT_MAX;
   for (int pos = start, k = 0; pos < 5; pos++, k++) {
-    const int mcost = mvc(lam, *mvx + pts[pos][0], *mvy + pts[pos][1], B) + L.dist[k];
+    const int mcost = mvc(lam, *mvx + pts[pos][0], *mvy + pts[pos][1]) + L.dist[k];
     if (mcost < *min_mcost) { second = *min_mcost; second_pos = best; *min_mcost = mcost; best = pos; }
     else if (mcost < second) { second = mcost; second_pos = pos; }
   }
@@ -715,9 +811,9 @@ __device__ int epzs_sub_level(const WaveDev &D, Lds &L, const Blk &B, int half, 
   if (best != 0 || (iabs(B.pmx - *mvx) + iabs(B.pmy - *mvy))) {
     n = 0;
     for (int pos = sp; pos < ep; pos++) { L.cx[n] = p4x + *mvx + pts[pos][0]; L.cy[n] = p4y + *mvy + pts[pos][1]; n++; }
-    if (n) eval_dist(D, L, B.planes, metric, B.t8, umv, B.wp, B.wpw, B.wpo, B.mb_x, B.mb_y, B.bsx, B.bsy, n);
+    if (n) eval_dist(B.planes, metric, B.t8, umv, B.wp, B.wpw, B.wpo, B.mb_x, B.mb_y, B.bsx, B.bsy, n);
     for (int pos = sp, k = 0; pos < ep; pos++, k++) {
-      int mcost = mvc(lam, *mvx + pts[pos][0], *mvy + pts[pos][1], B);
+      int mcost = mvc(lam, *mvx + pts[pos][0], *mvy + pts[pos][1]);
       if (mcost >= *min_mcost) continue;
       mcost += L.dist[k];
       if (mcost < *min_mcost) { *min_mcost = mcost; best = pos; }
@@ -728,17 +824,17 @@ __device__ int epzs_sub_level(const WaveDev &D, Lds &L, const Blk &B, int half, 
 }
 
 // EPZSSubPelBlockMotionSearch, me_epzs.c:2390
-__device__ int epzs_subpel(const WaveDev &D, Lds &L, const Blk &B, int *mvx, int *mvy, int min_mcost)
+__device__ int epzs_subpel(int *mvx, int *mvy, int min_mcost)
 {
   const int start_hp = D.p.metric[0] != D.p.metric[1] ? 0 : 1, start_qp = D.p.metric[1] != D.p.metric[2] ? 0 : 1;
   const int max_x4 = (D.W - B.bsx + 2 * JMHIP_PAD) << 2, max_y4 = (D.H - B.bsy + 2 * JMHIP_PAD) << 2;
   int p4x = padq(B.pic_x, *mvx), p4y = padq(B.pic_y, *mvy);
   int umv = !((p4x > 1) && (p4x < max_x4 - 1) && (p4y > 1) && (p4y < max_y4 - 1));
-  if (epzs_sub_level(D, L, B, 1, start_hp, D.p.lambda_mf[1], D.p.metric[1], umv, mvx, mvy, &min_mcost, D.p.epzs_thres[3][B.bt])) return min_mcost;
+  if (epzs_sub_level(1, start_hp, D.p.lambda_mf[1], D.p.metric[1], umv, mvx, mvy, &min_mcost, D.p.epzs_thres[3][B.bt])) return min_mcost;
   if (!start_qp) min_mcost = INT_MAX;
   p4x = padq(B.pic_x, *mvx); p4y = padq(B.pic_y, *mvy);
   umv = !((p4x > 0) && (p4x < max_x4) && (p4y > 0) && (p4y < max_y4));
-  (void)epzs_sub_level(D, L, B, 0, start_qp, D.p.lambda_mf[2], D.p.metric[2], umv, mvx, mvy, &min_mcost, D.p.epzs_thres[3][B.bt]);
+  (void)epzs_sub_level(0, start_qp, D.p.lambda_mf[2], D.p.metric[2], umv, mvx, mvy, &min_mcost, D.p.epzs_thres[3][B.bt]);
   return min_mcost;
 }
 
@@ -753,43 +849,43 @@ struct UmState { int cx, cy, R, best_x, best_y, min_mcost, umv; };     // centre
 
 // a group of candidates L.qx/qy[0..n) through SEARCH_ONE_PIXEL (me_umhex.h:32-51): in range, not visited, mv cost below the minimum -> evaluated,
 // marked visited, accepted on strict <. The positions of a group never depend on the outcome inside the group.
-__device__ void um_group(const WaveDev &D, Lds &L, const Blk &B, UmState &U, int n)
+__device__ void um_group(UmState &U, int n)
 {
   int m = 0;
   for (int k = 0; k < n; k++) {
     const int vx = L.qx[k], vy = L.qy[k];
     if (iabs(vx - U.cx) > U.R || iabs(vy - U.cy) > U.R) continue;
-    if (map_test(L, U.R, vx - U.cx, vy - U.cy)) continue;
+    if (map_test(U.R, vx - U.cx, vy - U.cy)) continue;
     bool dup = false;                                      // the same position twice in one group: the second sees what the first left
     for (int j = 0; j < m; j++) dup |= (L.px[j] == vx && L.py[j] == vy);
     if (dup) continue;
     L.px[m] = vx; L.py[m] = vy; m++;
   }
   for (int k = 0; k < m; k++) { L.cx[k] = padq(B.pic_x, L.px[k] << 2); L.cy[k] = padq(B.pic_y, L.py[k] << 2); }
-  if (m) eval_dist(D, L, B.planes, D.p.metric[0], B.t8, U.umv, B.wp, B.wpw, B.wpo, B.mb_x, B.mb_y, B.bsx, B.bsy, m);
+  if (m) eval_dist(B.planes, D.p.metric[0], B.t8, U.umv, B.wp, B.wpw, B.wpo, B.mb_x, B.mb_y, B.bsx, B.bsy, m);
   // replay in the group's own order (duplicates re-tested against the map as it evolves)
   for (int k = 0; k < n; k++) {
     const int vx = L.qx[k], vy = L.qy[k];
     if (iabs(vx - U.cx) > U.R || iabs(vy - U.cy) > U.R) continue;
-    if (map_test(L, U.R, vx - U.cx, vy - U.cy)) continue;
-    int mcost = mvc(D.p.lambda_mf[0], vx << 2, vy << 2, B);
+    if (map_test(U.R, vx - U.cx, vy - U.cy)) continue;
+    int mcost = mvc(D.p.lambda_mf[0], vx << 2, vy << 2);
     if (mcost < U.min_mcost) {
       int j = 0;
       while (!(L.px[j] == vx && L.py[j] == vy)) j++;
       mcost += L.dist[j];
-      map_set(L, U.R, vx - U.cx, vy - U.cy);
+      map_set(U.R, vx - U.cx, vy - U.cy);
       if (mcost < U.min_mcost) { U.best_x = vx; U.best_y = vy; U.min_mcost = mcost; }
     }
   }
 }
-__device__ __forceinline__ void um_diamond(const WaveDev &D, Lds &L, const Blk &B, UmState &U)
+__device__ __forceinline__ void um_diamond(UmState &U)
 {
   for (int m = 0; m < 4; m++) { L.qx[m] = U.best_x + c_dia_x[m]; L.qy[m] = U.best_y + c_dia_y[m]; }
-  um_group(D, L, B, U, 4);
+  um_group(U, 4);
 }
 
 // UMHEXIntegerPelBlockMotionSearch, me_umhex.c:229. mvx/mvy: centre in, result out (pels). R: the (dynamic) search range of this block.
-__device__ int umhex_pel(const WaveDev &D, Lds &L, const Blk &B, int R, int *mvx, int *mvy, int min_mcost)
+__device__ int umhex_pel(int R, int *mvx, int *mvy, int min_mcost)
 {
   const jmhip_slice_params &P = D.p;
   const int bt = B.bt, ref = B.ref, block_x = B.mb_x >> 2, block_y = B.mb_y >> 2, px2l = block_x;
@@ -799,16 +895,16 @@ __device__ int umhex_pel(const WaveDev &D, Lds &L, const Blk &B, int R, int *mvx
     U.umv = !((center_x > R) && (center_x < D.W - 1 - R - B.bsx) && (center_y > R) && (center_y < D.H - 1 - R - B.bsy));
   }
   int et = P.umhex_thres[0][bt];
-  map_clear(L, R);
+  map_clear(R);
   {                                                                              // the centre :324-337 (always evaluated)
     L.cx[0] = padq(B.pic_x, U.cx << 2); L.cy[0] = padq(B.pic_y, U.cy << 2);
-    eval_dist(D, L, B.planes, P.metric[0], B.t8, U.umv, B.wp, B.wpw, B.wpo, B.mb_x, B.mb_y, B.bsx, B.bsy, 1);
-    const int mcost = mvc(P.lambda_mf[0], U.cx << 2, U.cy << 2, B) + L.dist[0];
-    map_set(L, R, 0, 0);
+    eval_dist(B.planes, P.metric[0], B.t8, U.umv, B.wp, B.wpw, B.wpo, B.mb_x, B.mb_y, B.bsx, B.bsy, 1);
+    const int mcost = mvc(P.lambda_mf[0], U.cx << 2, U.cy << 2) + L.dist[0];
+    map_set(R, 0, 0);
     if (mcost < U.min_mcost) { U.min_mcost = mcost; U.best_x = U.cx; U.best_y = U.cy; }
   }
-  um_diamond(D, L, B, U);
-  if (U.cx != 0 || U.cy != 0) { L.qx[0] = 0; L.qy[0] = 0; um_group(D, L, B, U, 1); um_diamond(D, L, B, U); }
+  um_diamond(U);
+  if (U.cx != 0 || U.cy != 0) { L.qx[0] = 0; L.qy[0] = 0; um_group(U, 1); um_diamond(U); }
   int pred_sad = 0;
   bool done = false;
   if (ref > 0 && U.min_mcost > et && L.um_best_cost[bt][px2l] < P.umhex_thres[2][bt]) done = true;     // :365
@@ -839,9 +935,9 @@ __device__ int umhex_pel(const WaveDev &D, Lds &L, const Blk &B, int R, int *mvx
       // the minimum, which the replay handles
       if (bt > 1) { L.qx[n] = upx / 4; L.qy[n] = upy / 4; n++; }
       if (pred_ref_flag) { L.qx[n] = prx / 4; L.qy[n] = pry / 4; n++; }
-      if (n) um_group(D, L, B, U, n);
+      if (n) um_group(U, n);
     }
-    um_diamond(D, L, B, U);
+    um_diamond(U);
     EARLY(fourth_2, fourth_1)
     if (bt > 6) goto fourth_1;
     {                                                                            // unsymmetrical cross :430-453
@@ -849,17 +945,17 @@ __device__ int umhex_pel(const WaveDev &D, Lds &L, const Blk &B, int R, int *mvx
       int n = 0;
       for (int i = 1; i < R; i += 2) { L.qx[n] = ix + i; L.qy[n] = iy; n++; L.qx[n] = ix - i; L.qy[n] = iy; n++; }
       for (int i = 1; i < (R / 2); i += 2) { L.qx[n] = ix; L.qy[n] = iy + i; n++; L.qx[n] = ix; L.qy[n] = iy - i; n++; }
-      um_group(D, L, B, U, n);
+      um_group(U, n);
     }
     EARLY(fourth_2, fourth_1)
     {
       const int ix = U.best_x, iy = U.best_y;
       for (int pos = 1; pos < 25; pos++) { int dx, dy; spiral_offset(pos, &dx, &dy); L.qx[pos - 1] = ix + dx; L.qy[pos - 1] = iy + dy; }
-      um_group(D, L, B, U, 24);
+      um_group(U, 24);
       EARLY(fourth_2, fourth_1)
       for (int i = 1; i <= (R / 4); i++) {                                       // multi-hexagon grid :475-494
         for (int m = 0; m < 16; m++) { L.qx[m] = ix + c_bhx[m] * i; L.qy[m] = iy + c_bhy[m] * i; }
-        um_group(D, L, B, U, 16);
+        um_group(U, 16);
         if (U.min_mcost < et) goto terminate;
       }
     }
@@ -867,13 +963,13 @@ __device__ int umhex_pel(const WaveDev &D, Lds &L, const Blk &B, int R, int *mvx
     for (int i = 0; i < R; i++) {
       const int ix = U.best_x, iy = U.best_y;
       for (int m = 0; m < 6; m++) { L.qx[m] = ix + c_hex_x[m]; L.qy[m] = iy + c_hex_y[m]; }
-      um_group(D, L, B, U, 6);
+      um_group(U, 6);
       if (U.best_x == ix && U.best_y == iy) break;
     }
   fourth_2:
     for (int i = 0; i < R; i++) {
       const int ix = U.best_x, iy = U.best_y;
-      um_diamond(D, L, B, U);
+      um_diamond(U);
       if (U.best_x == ix && U.best_y == iy) break;
     }
 #undef EARLY
@@ -890,7 +986,7 @@ terminate:
 }
 
 // UMHEXSubPelBlockMotionSearch, me_umhex.c:562 (quarter-pel metric and lambda for every position)
-__device__ int umhex_subpel(const WaveDev &D, Lds &L, const Blk &B, int *mvx, int *mvy, int min_mcost)
+__device__ int umhex_subpel(int *mvx, int *mvy, int min_mcost)
 {
   const int start_hp = D.p.metric[0] != D.p.metric[1] ? 0 : 1, lam = D.p.lambda_mf[2], metric = D.p.metric[2];
   const int p4x = padq(B.pic_x, 0), p4y = padq(B.pic_y, 0);
@@ -904,15 +1000,15 @@ __device__ int umhex_subpel(const WaveDev &D, Lds &L, const Blk &B, int *mvx, in
     int n = 0;
     if (!start_hp) { L.cx[n] = p4x + cx0; L.cy[n] = p4y + cy0; n++; }
     if (pfx != 0 || pfy != 0) { L.cx[n] = p4x + cx0 + pfx; L.cy[n] = p4y + cy0 + pfy; n++; }
-    if (n) eval_dist(D, L, B.planes, metric, B.t8, umv, B.wp, B.wpw, B.wpo, B.mb_x, B.mb_y, B.bsx, B.bsy, n);
+    if (n) eval_dist(B.planes, metric, B.t8, umv, B.wp, B.wpw, B.wpo, B.mb_x, B.mb_y, B.bsx, B.bsy, n);
     int k = 0;
     if (!start_hp) {
-      const int mcost = mvc(lam, cx0, cy0, B) + L.dist[k++];
+      const int mcost = mvc(lam, cx0, cy0) + L.dist[k++];
       SS(cx0, cy0) = 1;
       if (mcost < min_mcost) { min_mcost = mcost; cur_x = cx0; cur_y = cy0; }
     } else { SS(cx0, cy0) = 1; cur_x = cx0; cur_y = cy0; }
     if (pfx != 0 || pfy != 0) {
-      const int mcost = mvc(lam, cx0 + pfx, cy0 + pfy, B) + L.dist[k++];
+      const int mcost = mvc(lam, cx0 + pfx, cy0 + pfy) + L.dist[k++];
       SS(cx0 + pfx, cy0 + pfy) = 1;
       if (mcost < min_mcost) { min_mcost = mcost; cur_x = cx0 + pfx; cur_y = cy0 + pfy; }
     }
@@ -925,11 +1021,11 @@ __device__ int umhex_subpel(const WaveDev &D, Lds &L, const Blk &B, int *mvx, in
       idx[m] = -1;
       if (iabs(vx - cx0) <= 3 && iabs(vy - cy0) <= 3 && !SS(vx, vy)) { L.cx[n] = p4x + vx; L.cy[n] = p4y + vy; idx[m] = n++; }
     }
-    if (n) eval_dist(D, L, B.planes, metric, B.t8, umv, B.wp, B.wpw, B.wpo, B.mb_x, B.mb_y, B.bsx, B.bsy, n);
+    if (n) eval_dist(B.planes, metric, B.t8, umv, B.wp, B.wpw, B.wpo, B.mb_x, B.mb_y, B.bsx, B.bsy, n);
     int abort_search = 1;
     for (int m = 0; m < 4; m++) if (idx[m] >= 0) {
       const int vx = ix + c_dia_x[m], vy = iy + c_dia_y[m];
-      const int mcost = mvc(lam, vx, vy, B) + L.dist[idx[m]];
+      const int mcost = mvc(lam, vx, vy) + L.dist[idx[m]];
       SS(vx, vy) = 1;
       if (mcost < min_mcost) { min_mcost = mcost; cur_x = vx; cur_y = vy; abort_search = 0; }
     }
@@ -958,22 +1054,21 @@ __device__ __forceinline__ int part_index(int bt, int block_x, int block_y)
 }
 
 // FindSkipModeMotionVector, mv-search.c:1189
-__device__ void find_skip_mv(const WaveDev &D, Lds &L, int mbx, int mby)
+__device__ void find_skip_mv(int mbx, int mby)
 {
   int ax, ay, bx, by, pmx = 0, pmy = 0;
-  const int availA = nbr_pos(D, mbx, mby, -1, 0, &ax, &ay), availB = nbr_pos(D, mbx, mby, 0, -1, &bx, &by);
+  const int availA = nbr_pos(mbx, mby, -1, 0, &ax, &ay), availB = nbr_pos(mbx, mby, 0, -1, &bx, &by);
   int zl = 1, za = 1;
   if (availA) { const size_t at = (size_t)ay * D.w4 + ax; zl = (D.ref_idx[at] == 0 && D.mv[at * 2] == 0 && D.mv[at * 2 + 1] == 0); }
   if (availB) { const size_t at = (size_t)by * D.w4 + bx; za = (D.ref_idx[at] == 0 && D.mv[at * 2] == 0 && D.mv[at * 2 + 1] == 0); }
-  if (!(za || zl)) mv_predictor(D, mbx, mby, 0, 0, 0, 16, 16, &pmx, &pmy, 0, 0, nullptr, nullptr);
+  if (!(za || zl)) mv_predictor(mbx, mby, 0, 0, 0, 16, 16, &pmx, &pmy, 0, 0, nullptr, nullptr);
   for (int b = 0; b < 16; b++) { L.all_mv[b][0][0][0] = (short)pmx; L.all_mv[b][0][0][1] = (short)pmy; }
 }
 
 // BlockMotionSearch, mv-search.c:560 (P slice, rdopt 0)
-__device__ int block_motion_search(const WaveDev &D, Lds &L, int mbx, int mby, int ref, int mb_x, int mb_y, int bt, int search_range, jmhip_mb_inter *out)
+__device__ int block_motion_search(int mbx, int mby, int ref, int mb_x, int mb_y, int bt, int search_range, jmhip_mb_inter *out)
 {
   const jmhip_slice_params &P = D.p;
-  Blk B;
   B.mbx = mbx; B.mby = mby; B.mb_x = mb_x; B.mb_y = mb_y; B.bt = bt; B.bsx = c_bsx[bt]; B.bsy = c_bsy[bt]; B.ref = ref;
   B.pic_x = mbx * 16 + mb_x; B.pic_y = mby * 16 + mb_y;
   B.planes = D.ref_sub[P.ref_slot[ref]];
@@ -982,20 +1077,22 @@ __device__ int block_motion_search(const WaveDev &D, Lds &L, int mbx, int mby, i
   const int block_x = mb_x >> 2, block_y = mb_y >> 2, pi = part_index(bt, block_x, block_y);
   const int start_hp = P.metric[0] != P.metric[1] ? 0 : 1;
   int mvx, mvy, min_mcost = INT_MAX;
-  mv_predictor(D, mbx, mby, ref, mb_x, mb_y, B.bsx, B.bsy, &B.pmx, &B.pmy, P.search_mode == JMHIP_SEARCH_UMHEX && P.umhex_dsr, bt, &search_range, nullptr);
+  WPROF_T0;
+  mv_predictor(mbx, mby, ref, mb_x, mb_y, B.bsx, B.bsy, &B.pmx, &B.pmy, P.search_mode == JMHIP_SEARCH_UMHEX && P.umhex_dsr, bt, &search_range, nullptr);
+  WPROF(0);
   const int R = search_range;
   if (D.debug & 2) { mvx = clampi((B.pmx + 2) >> 2, -R, R); mvy = clampi((B.pmy + 2) >> 2, -R, R); min_mcost = 1000; }
   else if (P.search_mode == JMHIP_SEARCH_UMHEX) {
     mvx = B.pmx / 4; mvy = B.pmy / 4;
     mvx = clampi(mvx, -R, R); mvy = clampi(mvy, -R, R);
     mvx = clampi(mvx, -2047 + R, 2047 - R); mvy = clampi(mvy, P.level_mv_min + R, P.level_mv_max - R);
-    min_mcost = umhex_pel(D, L, B, R, &mvx, &mvy, min_mcost);
+    min_mcost = umhex_pel(R, &mvx, &mvy, min_mcost);
     __syncthreads();                                                           // lane 0 wrote the cost map
   } else if (P.search_mode == JMHIP_SEARCH_EPZS) {
     mvx = (B.pmx + 2) >> 2; mvy = (B.pmy + 2) >> 2;
     mvx = clampi(mvx, -R, R); mvy = clampi(mvy, -R, R);
     mvx = clampi(mvx, -2047 + R, 2047 - R); mvy = clampi(mvy, P.level_mv_min + R, P.level_mv_max - R);
-    min_mcost = epzs_pel(D, L, B, mby * D.mbw + mbx, R, &mvx, &mvy);
+    min_mcost = epzs_pel(mby * D.mbw + mbx, R, &mvx, &mvy);
     __syncthreads();                                                           // lane 0 wrote the row memories
   } else if (P.search_mode == JMHIP_SEARCH_FASTFULL) {
     // the window of SetupFastFullPelSearch (me_fullfast.c:550-566): centred on the 16x16 predictor of this reference, found when the reference's
@@ -1006,18 +1103,19 @@ __device__ int block_motion_search(const WaveDev &D, Lds &L, int mbx, int mby, i
       cx = clampi(cx, -Rf, Rf); cy = clampi(cy, -Rf, Rf);
       cx = clampi(cx, -2047 + Rf, 2047 - Rf); cy = clampi(cy, P.level_mv_min + Rf, P.level_mv_max - Rf);
       L.motion_cost[0][ref][0] = cx; L.motion_cost[0][ref][1] = cy; L.motion_cost[0][ref][2] = Rf;
-      surface_build(D, L, B, cx, cy, Rf);
+      surface_build(cx, cy, Rf);
     }
-    min_mcost = surface_search(D, L, B, L.motion_cost[0][ref][0], L.motion_cost[0][ref][1], L.motion_cost[0][ref][2], 1, &mvx, &mvy);
-    if (min_mcost == INT_MIN) min_mcost = full_window(D, L, B, L.motion_cost[0][ref][0], L.motion_cost[0][ref][1], L.motion_cost[0][ref][2], 1, &mvx, &mvy);
+    min_mcost = surface_search(L.motion_cost[0][ref][0], L.motion_cost[0][ref][1], L.motion_cost[0][ref][2], 1, &mvx, &mvy);
+    if (min_mcost == INT_MIN) min_mcost = full_window(L.motion_cost[0][ref][0], L.motion_cost[0][ref][1], L.motion_cost[0][ref][2], 1, &mvx, &mvy);
   } else {
     int cx = B.pmx / 4, cy = B.pmy / 4;
     cx = clampi(cx, -R, R); cy = clampi(cy, -R, R);
     cx = clampi(cx, -2047 + R, 2047 - R); cy = clampi(cy, P.level_mv_min + R, P.level_mv_max - R);
-    if (bt == 1) surface_build(D, L, B, cx, cy, min(R + SURF_MARGIN, 33 + SURF_MARGIN));     // the other partitions' centres are usually within the margin
-    min_mcost = surface_search(D, L, B, cx, cy, R, 0, &mvx, &mvy);
-    if (min_mcost == INT_MIN) min_mcost = full_window(D, L, B, cx, cy, R, 0, &mvx, &mvy);      // a centre the surface does not cover: direct evaluation
+    if (bt == 1) surface_build(cx, cy, min(R + SURF_MARGIN, 33 + SURF_MARGIN));     // the other partitions' centres are usually within the margin
+    min_mcost = surface_search(cx, cy, R, 0, &mvx, &mvy);
+    if (min_mcost == INT_MIN) min_mcost = full_window(cx, cy, R, 0, &mvx, &mvy);      // a centre the surface does not cover: direct evaluation
   }
+  WPROF(1);
   if (threadIdx.x == 0) { out->mv_int[ref][pi][0] = (int16_t)mvx; out->mv_int[ref][pi][1] = (int16_t)mvy; out->cost_int[ref][pi] = min_mcost; }
   mvx <<= 2; mvy <<= 2;
   // sub-pel :781-827
@@ -1025,30 +1123,32 @@ __device__ int block_motion_search(const WaveDev &D, Lds &L, int mbx, int mby, i
   if (P.search_mode == JMHIP_SEARCH_EPZS && ref > 0) do_sub = (2 * (long long)min_mcost < 7 * (long long)D.ep_dist[(size_t)(bt - 1) * D.w4 + (B.pic_x >> 2)]);   // min_mcost < 3.5 * prevSad
   if (do_sub && !(D.debug & 1)) {
     if (!start_hp) min_mcost = INT_MAX;
-    if (P.search_mode == JMHIP_SEARCH_UMHEX && bt > 3) min_mcost = umhex_subpel(D, L, B, &mvx, &mvy, min_mcost);
-    else if (P.search_mode == JMHIP_SEARCH_EPZS && P.epzs_subpel_me) min_mcost = epzs_subpel(D, L, B, &mvx, &mvy, min_mcost);
-    else min_mcost = subpel_full(D, L, B, &mvx, &mvy, min_mcost);
+    if (P.search_mode == JMHIP_SEARCH_UMHEX && bt > 3) min_mcost = umhex_subpel(&mvx, &mvy, min_mcost);
+    else if (P.search_mode == JMHIP_SEARCH_EPZS && P.epzs_subpel_me) min_mcost = epzs_subpel(&mvx, &mvy, min_mcost);
+    else min_mcost = subpel_full(&mvx, &mvy, min_mcost);
   }
+  WPROF(2);
   if (bt == 1 && !(D.debug & 4)) {                                             // skip shortcut :829-849, every reference
-    find_skip_mv(D, L, mbx, mby);
+    find_skip_mv(mbx, mby);
     const int smx = L.all_mv[0][0][0][0], smy = L.all_mv[0][0][0][1];
     int cost;
     const uint8_t *pl0 = D.ref_sub[P.ref_slot[0]];
     if (P.md_metric == 2) {
       L.cx[0] = padq(mbx * 16, smx); L.cy[0] = padq(mby * 16, smy);
-      eval_dist(D, L, pl0, 2, 0, 1, P.wp_pred, P.wp_weight[0], P.wp_offset[0], 0, 0, 16, 16, 1);
+      eval_dist(pl0, 2, 0, 1, P.wp_pred, P.wp_weight[0], P.wp_offset[0], 0, 0, 16, 16, 1);
       cost = L.dist[0];
     } else {                                                                   // SAD: LumaPrediction clamps per 4x4 block
       cost = 0;
       for (int b = 0; b < 16; b++) {
         L.cx[0] = padq(mbx * 16 + (b & 3) * 4, smx); L.cy[0] = padq(mby * 16 + (b >> 2) * 4, smy);
-        eval_dist(D, L, pl0, 0, 0, 1, P.wp_pred, P.wp_weight[0], P.wp_offset[0], (b & 3) * 4, (b >> 2) * 4, 4, 4, 1);
+        eval_dist(pl0, 0, 0, 1, P.wp_pred, P.wp_weight[0], P.wp_offset[0], (b & 3) * 4, (b >> 2) * 4, 4, 4, 1);
         cost += L.dist[0];
       }
     }
     cost -= (P.lambda_mf[2] + 4096) >> 13;
     if (cost < min_mcost) { min_mcost = cost; mvx = smx; mvy = smy; }
   }
+  WPROF(3);
   for (int j = block_y; j < block_y + (B.bsy >> 2); j++) for (int i = block_x; i < block_x + (B.bsx >> 2); i++) { L.all_mv[j * 4 + i][ref][bt][0] = (short)mvx; L.all_mv[j * 4 + i][ref][bt][1] = (short)mvy; }
   if (threadIdx.x == 0) {
     out->pred[ref][pi][0] = (int16_t)B.pmx; out->pred[ref][pi][1] = (int16_t)B.pmy;
@@ -1058,13 +1158,13 @@ __device__ int block_motion_search(const WaveDev &D, Lds &L, int mbx, int mby, i
 }
 
 // field writes: one lane writes, everyone reads back after the barrier
-__device__ __forceinline__ void field_set(const WaveDev &D, int by, int bx, int ref, int mvx, int mvy)
+__device__ __forceinline__ void field_set(int by, int bx, int ref, int mvx, int mvy)
 {
   if (threadIdx.x == 0) { const size_t at = (size_t)by * D.w4 + bx; D.ref_idx[at] = (int8_t)ref; D.mv[at * 2] = (short)mvx; D.mv[at * 2 + 1] = (short)mvy; }
 }
 
 // PartitionMotionSearch, mv-search.c:1378
-__device__ void partition_motion_search(const WaveDev &D, Lds &L, int mbx, int mby, int bt, int block8, jmhip_mb_inter *out)
+__device__ void partition_motion_search(int mbx, int mby, int bt, int block8, jmhip_mb_inter *out)
 {
   const int8_t bx0[5][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 2, 0, 0}, {0, 2, 0, 2}};
   const int8_t by0[5][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 2, 0, 0}, {0, 0, 0, 0}, {0, 0, 2, 2}};
@@ -1078,16 +1178,16 @@ __device__ void partition_motion_search(const WaveDev &D, Lds &L, int mbx, int m
     else range = P.search_range / ((min(ref, 1) + 1) * min(2, bt));
     int mc = 0;
     for (int v = by; v < by + sv0; v += sv) for (int h = bx; h < bx + sh0; h += sh) {
-      mc += block_motion_search(D, L, mbx, mby, ref, h << 2, v << 2, bt, range, out);
+      mc += block_motion_search(mbx, mby, ref, h << 2, v << 2, bt, range, out);
       const int mvx = L.all_mv[v * 4 + h][ref][bt][0], mvy = L.all_mv[v * 4 + h][ref][bt][1];
-      for (int j = 0; j < sv; j++) for (int i = 0; i < sh; i++) field_set(D, mby * 4 + v + j, mbx * 4 + h + i, ref, mvx, mvy);
+      for (int j = 0; j < sv; j++) for (int i = 0; i < sh; i++) field_set(mby * 4 + v + j, mbx * 4 + h + i, ref, mvx, mvy);
       __syncthreads();
     }
     L.motion_cost[bt][ref][block8] = mc;
   }
 }
 
-__device__ __forceinline__ int list0_cost(const WaveDev &D, const Lds &L, int mode, int block, int *best_ref)
+__device__ __forceinline__ int list0_cost(int mode, int block, int *best_ref)
 {
   int best = INT_MAX;
   for (int ref = 0; ref < D.p.num_refs; ref++) {
@@ -1099,7 +1199,7 @@ __device__ __forceinline__ int list0_cost(const WaveDev &D, const Lds &L, int mo
 __device__ __forceinline__ int refbits(int r) { return r == 0 ? 1 : (r < 3 ? 3 : 5); }       // mv-search.c:344-352, r <= 3
 
 // encode_one_macroblock_low (md_low.c:46), inter part, for one macroblock
-__device__ void macroblock_low(const WaveDev &D, Lds &L, int mbx, int mby, jmhip_mb_inter *out)
+__device__ void macroblock_low(int mbx, int mby, jmhip_mb_inter *out)
 {
   const jmhip_slice_params &P = D.p;
   const int8_t psz[8][2] = {{4, 4}, {4, 4}, {4, 2}, {2, 4}, {2, 2}, {2, 1}, {1, 2}, {1, 1}};
@@ -1112,16 +1212,16 @@ __device__ void macroblock_low(const WaveDev &D, Lds &L, int mbx, int mby, jmhip
     int cost = 0;
     for (int block = 0; block < (mode == 1 ? 1 : 2); block++) {
       int best_ref = 0;
-      partition_motion_search(D, L, mbx, mby, mode, block, out);
-      cost += list0_cost(D, L, mode, block, &best_ref);
+      partition_motion_search(mbx, mby, mode, block, out);
+      cost += list0_cost(mode, block, &best_ref);
       if (mode == 1) {
-        for (int b = 0; b < 16; b++) field_set(D, by0 + (b >> 2), bx0 + (b & 3), best_ref, L.all_mv[b][best_ref][1][0], L.all_mv[b][best_ref][1][1]);
+        for (int b = 0; b < 16; b++) field_set(by0 + (b >> 2), bx0 + (b & 3), best_ref, L.all_mv[b][best_ref][1][0], L.all_mv[b][best_ref][1][1]);
         for (int k = 0; k < 4; k++) l0ref[1][k] = best_ref;
       } else if (mode == 2) l0ref[2][2 * block] = l0ref[2][2 * block + 1] = best_ref;
       else l0ref[3][block] = l0ref[3][block + 2] = best_ref;
       if (mode > 1 && block == 0)
         for (int j = 0; j < psz[mode][1]; j++) for (int i = 0; i < psz[mode][0]; i++)
-          field_set(D, by0 + j, bx0 + i, best_ref, L.all_mv[j * 4 + i][best_ref][mode][0], L.all_mv[j * 4 + i][best_ref][mode][1]);
+          field_set(by0 + j, bx0 + i, best_ref, L.all_mv[j * 4 + i][best_ref][mode][0], L.all_mv[j * 4 + i][best_ref][mode][1]);
       __syncthreads();
     }
     if (cost < min_cost) { best_mode = mode; min_cost = cost; }
@@ -1134,8 +1234,8 @@ __device__ void macroblock_low(const WaveDev &D, Lds &L, int mbx, int mby, jmhip
       for (int mode = 4; mode < 8; mode++) {
         if (!P.valid[mode]) continue;
         int best_ref = 0;
-        partition_motion_search(D, L, mbx, mby, mode, block, out);
-        int cost = list0_cost(D, L, mode, block, &best_ref);
+        partition_motion_search(mbx, mby, mode, block, out);
+        int cost = list0_cost(mode, block, &best_ref);
         if (threadIdx.x == 0) for (int j = 0; j < 2; j++) for (int i = 0; i < 2; i++) D.ref_idx[(size_t)(by0 + j0 + j) * D.w4 + bx0 + i0 + i] = (int8_t)best_ref;
         __syncthreads();
         if (cost != INT_MAX) cost += ((P.lambda_mf[2] * (P.num_refs <= 1 ? 0 : refbits(mode - 4))) >> 16) - 1;
@@ -1143,15 +1243,15 @@ __device__ void macroblock_low(const WaveDev &D, Lds &L, int mbx, int mby, jmhip
       }
       cost8x8 += mc8;
       for (int j = j0; j < j0 + 2; j++) for (int i = i0; i < i0 + 2; i++)
-        field_set(D, by0 + j, bx0 + i, l0ref[4][block], L.all_mv[j * 4 + i][l0ref[4][block]][b8m[block]][0], L.all_mv[j * 4 + i][l0ref[4][block]][b8m[block]][1]);
+        field_set(by0 + j, bx0 + i, l0ref[4][block], L.all_mv[j * 4 + i][l0ref[4][block]][b8m[block]][0], L.all_mv[j * 4 + i][l0ref[4][block]][b8m[block]][1]);
       __syncthreads();
     }
     if (cost8x8 < min_cost) { best_mode = 8; min_cost = cost8x8; }
   }
-  find_skip_mv(D, L, mbx, mby);
+  find_skip_mv(mbx, mby);
   for (int b = 0; b < 16; b++) {
     const int k8 = 2 * (b >> 3) + ((b & 3) >> 1), m8 = best_mode == 8 ? b8m[k8] : best_mode, r = l0ref[best_mode == 8 ? 4 : best_mode][k8];
-    field_set(D, by0 + (b >> 2), bx0 + (b & 3), r, L.all_mv[b][r][m8][0], L.all_mv[b][r][m8][1]);
+    field_set(by0 + (b >> 2), bx0 + (b & 3), r, L.all_mv[b][r][m8][0], L.all_mv[b][r][m8][1]);
     if (threadIdx.x == 0) { out->final_mv[b][0] = L.all_mv[b][r][m8][0]; out->final_mv[b][1] = L.all_mv[b][r][m8][1]; }
   }
   if (threadIdx.x == 0) {
@@ -1162,9 +1262,8 @@ __device__ void macroblock_low(const WaveDev &D, Lds &L, int mbx, int mby, jmhip
   __syncthreads();
 }
 
-__global__ __launch_bounds__(64) void p_slice_kernel(WaveDev D, const short *carry_slice_in, short *carry_slice_out)
+__global__ __launch_bounds__(64) void p_slice_kernel(const short *carry_slice_in, short *carry_slice_out)
 {
-  __shared__ Lds L;
   const int lane = threadIdx.x;
   const int row0 = D.p.mb_first / D.mbw, mby = row0 + blockIdx.x;
   const int last = D.p.mb_first + D.p.mb_count - 1;
@@ -1202,8 +1301,30 @@ __global__ __launch_bounds__(64) void p_slice_kernel(WaveDev D, const short *car
       const int r = lane >> 2, k = lane & 3;
       *reinterpret_cast<uint32_t *>(&L.cur[r][k * 4]) = *reinterpret_cast<const uint32_t *>(D.cur + (size_t)(mby * 16 + r) * D.W + mbx * 16 + k * 4);
     }
+    // the references' integer samples round the macroblock (EPZS / UMHexagonS candidates; the exhaustive modes build their own surface)
+    if ((D.p.search_mode == JMHIP_SEARCH_EPZS || D.p.search_mode == JMHIP_SEARCH_UMHEX) && !(D.debug & 8)) {
+      const int wx0 = mbx * 16 + JMHIP_PAD - (WIN_MAX - 16) / 2, wy0 = mby * 16 + JMHIP_PAD - (WIN_MAX - 16) / 2;      // multiples of 4
+      if (lane == 0) { L.rw_x0 = wx0; L.rw_y0 = wy0; }
+      for (int r = 0; r < WR; r++) {
+        const uint8_t *pl0 = r < D.p.num_refs ? D.ref_sub[D.p.ref_slot[r]] : nullptr;
+        if (lane == 0) L.rw_planes[r] = pl0;
+        if (!pl0) continue;
+        uint32_t *dst = reinterpret_cast<uint32_t *>(L.rwin[r]);
+        for (int e = lane; e < WIN_MAX * (WIN_MAX / 4); e += 64) {
+          const int y = e / (WIN_MAX / 4), xd = e - y * (WIN_MAX / 4);
+          // positions outside the padded plane are never asked for (block origins are clamped into it): keep the address legal
+          dst[e] = *reinterpret_cast<const uint32_t *>(pl0 + (size_t)clampi(wy0 + y, 0, D.Hp - 1) * D.Wp + clampi(wx0 + 4 * xd, 0, D.Wp - 4));
+        }
+      }
+    } else if (lane < WR) L.rw_planes[lane] = nullptr;
     __syncthreads();
-    macroblock_low(D, L, mbx, mby, D.out + (mby * D.mbw + mbx));
+#ifdef JMHIP_WAVE_PROF
+    const unsigned long long mb_t0 = __builtin_amdgcn_s_memtime();
+#endif
+    macroblock_low(mbx, mby, D.out + (mby * D.mbw + mbx));
+#ifdef JMHIP_WAVE_PROF
+    if (lane == 0) { atomicAdd(&g_wave_prof[8], __builtin_amdgcn_s_memtime() - mb_t0); atomicAdd(&g_wave_prof[9], 1ull); }
+#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     if (lane == 0) __hip_atomic_store(&D.prog[mby], mbx + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -1216,6 +1337,10 @@ __global__ __launch_bounds__(64) void p_slice_kernel(WaveDev D, const short *car
     }
   }
 }
+
+#undef D
+#undef B
+#undef L
 
 // rows whose speculated start differs from what the row above left: flag[1] = first such row (min), else untouched
 __global__ void carry_check_kernel(const short *carry_in, const short *carry_out, int row_first, int rows, int *flags)
@@ -1361,7 +1486,8 @@ extern "C" int jmhip_p_slice_search(jmhip_ctx *c, const jmhip_slice_params *prm,
     JM_HIP_CHECK(c, hipMemsetAsync(s->prog, 0, sizeof(int) * c->mbh, c->stream));
     const int init_flags[4] = {0, 1 << 30, 0, 0};
     JM_HIP_CHECK(c, hipMemcpyAsync(s->flags, init_flags, sizeof(init_flags), hipMemcpyHostToDevice, c->stream));
-    p_slice_kernel<<<rows, 64, 0, c->stream>>>(D, s->carry_slice, s->carry_slice_next);
+    JM_HIP_CHECK(c, hipMemcpyToSymbolAsync(HIP_SYMBOL(c_wave), &D, sizeof(D), 0, hipMemcpyHostToDevice, c->stream));
+    p_slice_kernel<<<rows, 64, 0, c->stream>>>(s->carry_slice, s->carry_slice_next);
     JM_HIP_CHECK(c, hipGetLastError());
     s->passes++;
     int flags[4] = {0, 1 << 30, 0, 0};
@@ -1378,6 +1504,18 @@ extern "C" int jmhip_p_slice_search(jmhip_ctx *c, const jmhip_slice_params *prm,
     JM_HIP_CHECK(c, hipMemcpyAsync(s->ep_motion, s->ep_motion_snap, sizeof(short) * WR * 7 * 4 * w4 * 2, hipMemcpyDeviceToDevice, c->stream));
   }
   jm_stage_end(c, JMHIP_STAGE_ME_INT);
+#ifdef JMHIP_WAVE_PROF
+  {
+    unsigned long long h[16];
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wave_prof), sizeof(h));
+    const double nmb = h[9] ? (double)h[9] : 1.0;
+    fprintf(stderr, "WAVE PROF cycles per macroblock (%.0f MBs): total %.0f | predictor %.0f integer %.0f subpel %.0f skip %.0f | epzs: lists %.0f scan+eval %.0f refine %.0f | eval_dist: %.0f cycles in %.1f calls, %.1f candidates\n", nmb, h[8] / nmb,
+            h[0] / nmb, h[1] / nmb, h[2] / nmb, h[3] / nmb, h[4] / nmb, h[5] / nmb, h[6] / nmb, h[10] / nmb, h[11] / nmb, h[12] / nmb);
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wave_prof), z, sizeof(z));
+  }
+#endif
   std::swap(s->carry_slice, s->carry_slice_next);
   s->searched_to = (prm->mb_first == 0 || prm->mb_first == s->searched_to) ? prm->mb_first + prm->mb_count : 0;
   if (results) return jmhip_slice_results_download(c, results, prm->mb_first, prm->mb_count);
