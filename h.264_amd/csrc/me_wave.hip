@@ -30,15 +30,23 @@ struct WaveDev {
   int *prog;                                   // [mbh]: macroblocks finished in the row (x + 1)
   int *flags;                                  // [0] abort (a wait timed out)
   jmhip_mb_inter *out;                         // by macroblock address
-  int *ep_dist;                                // EPZSDistortion[LIST_0] [7][w4]
-  short *ep_motion;                            // EPZSMotion[LIST_0] [WR][7][4][w4][2]
+  // EPZS row memories, one stored row per macroblock row of the slice (+ row 0: the state the slice started from): a macroblock reads, per
+  // 4x4 column, the row of the macroblock that wrote it last in coding order (state_row) -- which makes any schedule that respects, or
+  // iterates towards, the coding order see what JM's single-row arrays would hold
+  int *ep_dist;                                // EPZSDistortion[LIST_0] [rows + 1][7][w4]
+  short *ep_motion;                            // EPZSMotion[LIST_0] [rows + 1][WR][7][4][w4][2]
+  int row0;                                    // first macroblock row of the slice
   const short *ep_col;                         // EPZSCo_located->mv[LIST_0] [h4][w4][2]
   const short *carry_in;                       // [mbh][WR][CARRY][2]: img->all_mv the first macroblock of a row finds (speculated)
   short *carry_out;                            // [mbh][WR][CARRY][2]: what the last macroblock of a row leaves
   int *um_cost;                                // fastme_l0_cost [8][h4][w4]
+  const int *um_in;                            // ... as the slice found it (what a macroblock's own entries hold until it writes them)
+  short *carry_mb;                             // [nmb][WR][CARRY][2]: img->all_mv entries every macroblock leaves for the next one in coding order
+  // relaxation schedule (p_slice_relax_kernel): which macroblocks changed what they hand on, last sweep / this sweep
+  const uint8_t *chg_prev; uint8_t *chg_next; int *n_changed; int first_sweep;
   uint16_t *surf;                              // exhaustive searches: per row, per reference, SAD surfaces [SURF_PLANES][surf_n]
   int surf_n;                                  // candidates per plane (capacity)
-  int debug;                                   // JMHIP_WAVE_DEBUG (timing experiments only; results are wrong): 1 no sub-pel, 2 no integer search, 4 no skip cost, 8 no LDS reference windows (results stay right)
+  int debug;                                   // JMHIP_WAVE_DEBUG (timing experiments only; results are wrong): 1 no sub-pel, 2 no integer search, 4 no skip cost
 };
 
 // The slice's parameter block lives in constant memory and the block being searched in LDS, both named directly by every device function:
@@ -59,12 +67,17 @@ struct Lds {
   int um_best_cost[8][4];                      // fastme_best_cost[blocktype - 1][pic_pix_x >> 2] (only ever read after being written by the same block)
   uint8_t um_sstate[52];                       // SearchState 7x7
   int surf_c[WR][4];                           // per reference: surface centre (pels), half side, valid
-  __attribute__((aligned(16))) uint8_t win[WIN_MAX * WIN_MAX];     // reference window of the surface pass
-  // integer samples round the macroblock, one window per reference of the slice (plane 0 of its quarter-pel stack, padded coordinates
-  // [rw_x0, rw_x0 + WIN_MAX) x [rw_y0, rw_y0 + WIN_MAX)): candidates at integer positions whose block lies inside are evaluated out of LDS
-  const uint8_t *rw_planes[WR];
-  int rw_x0, rw_y0;
-  __attribute__((aligned(16))) uint8_t rwin[WR][WIN_MAX * WIN_MAX];
+  // the macroblock's view of the picture-level state: staged once by mb_stage, used and updated in LDS, handed on by mb_commit.
+  // Grid [y + 1][x + 1] of the 4x4 blocks x = -1..4, y = -1..3: the macroblock's own sixteen and the ring its predictors read (A, B, C, D)
+  int mbx, mby;
+  int8_t f_ref[5][6];                          // enc_picture->ref_idx[LIST_0]
+  short f_mv[5][6][2];                         // enc_picture->mv[LIST_0]
+  int um_loc[8][5][6];                         // fastme_l0_cost per block type
+  int ep_sad[7][12];                           // EPZSDistortion, 4x4 columns 4 * mbx - 4 .. 4 * mbx + 7
+  union {
+    __attribute__((aligned(16))) uint8_t win[WIN_MAX * WIN_MAX];   // exhaustive modes: reference window of the surface pass
+    short ep_mot[WR][7][4][12][2];                                   // EPZS: EPZSMotion, same columns as ep_sad
+  };
 };
 
 // ONE instance at file scope: every device function names it directly, so its accesses are LDS instructions (ds_read / ds_write) also where a
@@ -72,15 +85,19 @@ struct Lds {
 __shared__ Lds g_lds;
 #define L g_lds
 
-// 4 (8) samples of one window row at any byte offset
-__device__ __forceinline__ void win_row(const uint8_t *w, int off, int n, uint32_t *lo, uint32_t *hi)
+// which stored row of the EPZS memories holds, for macroblock (mbx, mby), the entry of 4x4 column col: the macroblock of that column in this
+// row if it comes earlier in the slice, else the one above it; 0 = the state the slice started from
+__device__ __forceinline__ int state_row(int col, int mbx, int mby)
 {
-  const uint32_t *q = reinterpret_cast<const uint32_t *>(w) + (off >> 2);
-  const unsigned sh = (unsigned)(off & 3);
-  const uint32_t d0 = q[0], d1 = q[1];
-  *lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
-  if (n == 8) { const uint32_t d2 = q[2]; *hi = __builtin_amdgcn_alignbyte(d2, d1, sh); }
+  const int cx = col >> 2, yy = cx < mbx ? mby : mby - 1;
+  if (yy < 0) return 0;
+  const int a = yy * D.mbw + cx;
+  if (a < D.p.mb_first || a >= D.p.mb_first + D.p.mb_count) return 0;
+  return yy - D.row0 + 1;
 }
+#define FREF(py, px) L.f_ref[(py) - 4 * L.mby + 1][(px) - 4 * L.mbx + 1]
+#define FMV(py, px, c) L.f_mv[(py) - 4 * L.mby + 1][(px) - 4 * L.mbx + 1][c]
+#define UMLOC(bt, py, px) L.um_loc[bt][(py) - 4 * L.mby + 1][(px) - 4 * L.mbx + 1]
 
 #ifdef JMHIP_WAVE_PROF
 __device__ unsigned long long g_wave_prof[16];
@@ -108,9 +125,6 @@ __device__ void eval_dist(const uint8_t *planes, int metric, int t8, int umv, in
   const int lane = threadIdx.x;
   const size_t psz = (size_t)D.Wp * D.Hp;
   const int wpad = D.Wp - 17, hpad = D.Hp - 17;           // size_x_pad / size_y_pad, mbuffer.c:421-422
-  const uint8_t *lwin = nullptr;                          // this reference's LDS window (stage_windows), if it has one
-  for (int r = 0; r < WR; r++) if (L.rw_planes[r] == planes) lwin = L.rwin[r];
-  const int rwx0 = L.rw_x0, rwy0 = L.rw_y0;
 #ifdef JMHIP_WAVE_PROF
   const unsigned long long ev_t0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -129,10 +143,8 @@ __device__ void eval_dist(const uint8_t *planes, int metric, int t8, int umv, in
           const int cx = L.cx[k], cy = L.cy[k];
           int ix = cx >> 2, iy = cy >> 2;
           if (umv) { ix = clampi(ix, 0, wpad); iy = clampi(iy, 0, hpad); }
-          const int lx = ix - rwx0, ly = iy - rwy0;
           uint32_t hi;
-          if (lwin && !((cx | cy) & 3) && lx >= 0 && ly >= 0 && lx + bsx <= WIN_MAX - 4 && ly + bsy <= WIN_MAX) win_row(lwin, (ly + row) * WIN_MAX + lx + 4 * c4, 4, &rr[u], &hi);
-          else fetch_row(planes + psz * ((cy & 3) * 4 + (cx & 3)) + (size_t)(iy + row) * D.Wp + ix + 4 * c4, 4, &rr[u], &hi);
+          fetch_row(planes + psz * ((cy & 3) * 4 + (cx & 3)) + (size_t)(iy + row) * D.Wp + ix + 4 * c4, 4, &rr[u], &hi);
         }
       }
 #pragma unroll
@@ -162,12 +174,10 @@ __device__ void eval_dist(const uint8_t *planes, int metric, int t8, int umv, in
             int ix = ox >> 2, iy = oy >> 2;
             if (umv) { ix = clampi(ix, 0, wpad); iy = clampi(iy, 0, hpad); }
             const uint8_t *p = planes + psz * ((oy & 3) * 4 + (ox & 3)) + (size_t)iy * D.Wp + ix;
-            const int lx = ix - rwx0, ly = iy - rwy0;
-            const bool inw = lwin && !((ox | oy) & 3) && lx >= 0 && ly >= 0 && lx + 4 <= WIN_MAX - 4 && ly + 4 <= WIN_MAX;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
               uint32_t hi;
-              if (inw) win_row(lwin, (ly + r) * WIN_MAX + lx, 4, &rv[u][r], &hi); else fetch_row(p + (size_t)r * D.Wp, 4, &rv[u][r], &hi);
+              fetch_row(p + (size_t)r * D.Wp, 4, &rv[u][r], &hi);
             }
           }
         }
@@ -201,14 +211,12 @@ __device__ void eval_dist(const uint8_t *planes, int metric, int t8, int umv, in
         int ix = ox >> 2, iy = oy >> 2;
         if (umv) { ix = clampi(ix, 0, wpad); iy = clampi(iy, 0, hpad); }
         const uint8_t *p = planes + psz * ((oy & 3) * 4 + (ox & 3)) + (size_t)iy * D.Wp + ix;
-        const int lx = ix - rwx0, ly = iy - rwy0;
-        const bool inw = lwin && !((ox | oy) & 3) && lx >= 0 && ly >= 0 && lx + bs <= WIN_MAX - 4 && ly + bs <= WIN_MAX;
         {
           int m[8][8];
 #pragma unroll
           for (int r = 0; r < 8; r++) {
             uint32_t lo, hi;
-            if (inw) win_row(lwin, (ly + r) * WIN_MAX + lx, 8, &lo, &hi); else fetch_row(p + (size_t)r * D.Wp, 8, &lo, &hi);
+            fetch_row(p + (size_t)r * D.Wp, 8, &lo, &hi);
             if (wp) { lo = wp_apply4(lo, wpw, wpo, D.p.wp_round, D.p.wp_denom); hi = wp_apply4(hi, wpw, wpo, D.p.wp_round, D.p.wp_denom); }
             const uint32_t c0 = *reinterpret_cast<const uint32_t *>(&L.cur[by + sy * 8 + r][bx + sx * 8]);
             const uint32_t c1 = *reinterpret_cast<const uint32_t *>(&L.cur[by + sy * 8 + r][bx + sx * 8 + 4]);
@@ -271,11 +279,7 @@ __device__ void neighbours(int mbx, int mby, int mb_x, int mb_y, int bsx, Nbr &n
     const int xN = mb_x + (k == 1 ? 0 : (k == 2 ? bsx : -1)), yN = mb_y + (k == 0 ? 0 : -1);
     nb.avail[k] = nbr_pos(mbx, mby, xN, yN, &nb.posx[k], &nb.posy[k]);
     nb.ref[k] = -1; nb.mvx[k] = nb.mvy[k] = 0;
-    if (nb.avail[k]) {
-      const size_t at = (size_t)nb.posy[k] * D.w4 + nb.posx[k];
-      nb.ref[k] = D.ref_idx[at];
-      nb.mvx[k] = D.mv[at * 2]; nb.mvy[k] = D.mv[at * 2 + 1];
-    }
+    if (nb.avail[k]) { nb.ref[k] = FREF(nb.posy[k], nb.posx[k]); nb.mvx[k] = FMV(nb.posy[k], nb.posx[k], 0); nb.mvy[k] = FMV(nb.posy[k], nb.posx[k], 1); }
   }
 }
 
@@ -307,11 +311,10 @@ __device__ void mv_predictor(int mbx, int mby, int ref_frame, int mb_x, int mb_y
   else if (bsx == 16 && bsy == 8) { if (mb_y == 0) { if (rU == ref_frame) type = 2; } else if (rL == ref_frame) type = 1; }
   int sa = 0, sb = 0, sc = 0, sd = 0;
   if (dsr) {                                                           // neighbourhood SAD prediction, me_umhex.c:1441-1448
-    const size_t pl = (size_t)umhex_bt * D.h4 * D.w4;
-    sa = nb.avail[0] ? D.um_cost[pl + (size_t)nb.posy[0] * D.w4 + nb.posx[0]] : 0;
-    sb = nb.avail[1] ? D.um_cost[pl + (size_t)nb.posy[1] * D.w4 + nb.posx[1]] : 0;
-    sd = nb.avail[3] ? D.um_cost[pl + (size_t)nb.posy[3] * D.w4 + nb.posx[3]] : 0;
-    sc = nb.avail[2] ? D.um_cost[pl + (size_t)nb.posy[2] * D.w4 + nb.posx[2]] : sd;
+    sa = nb.avail[0] ? UMLOC(umhex_bt, nb.posy[0], nb.posx[0]) : 0;
+    sb = nb.avail[1] ? UMLOC(umhex_bt, nb.posy[1], nb.posx[1]) : 0;
+    sd = nb.avail[3] ? UMLOC(umhex_bt, nb.posy[3], nb.posx[3]) : 0;
+    sc = nb.avail[2] ? UMLOC(umhex_bt, nb.posy[2], nb.posx[2]) : sd;
   }
   int tmp_range[2] = {0, 0};
   const int R = D.p.search_range;
@@ -476,7 +479,7 @@ __device__ void surface_build(int scx, int scy, int Rs)
     L.win[i] = (uint8_t)v;
   }
   __syncthreads();
-  uint16_t *sf = D.surf + ((size_t)blockIdx.x * WR + B.ref) * SURF_PLANES * D.surf_n;
+  uint16_t *sf = D.surf + ((size_t)blockIdx.x * D.p.num_refs + B.ref) * SURF_PLANES * D.surf_n;
   for (int k = lane; k < n; k += 64) {
     const int dy = k / side, dx = k - dy * side;
     unsigned s4[16];
@@ -516,7 +519,7 @@ __device__ int surface_search(int cx, int cy, int R, int ffs, int *mvx, int *mvy
   const int scx = L.surf_c[B.ref][0], scy = L.surf_c[B.ref][1], Rs = L.surf_c[B.ref][2];
   if (!L.surf_c[B.ref][3] || cx - R < scx - Rs || cx + R > scx + Rs || cy - R < scy - Rs || cy + R > scy + Rs) return INT_MIN;
   const int lane = threadIdx.x, side = 2 * R + 1, npos = side * side, sside = 2 * Rs + 1, lam = D.p.lambda_mf[0];
-  const uint16_t *sf = D.surf + ((size_t)blockIdx.x * WR + B.ref) * SURF_PLANES * D.surf_n;
+  const uint16_t *sf = D.surf + ((size_t)blockIdx.x * D.p.num_refs + B.ref) * SURF_PLANES * D.surf_n;
   const int x4 = B.mb_x >> 2, y4 = B.mb_y >> 2, w4 = B.bsx >> 2, h4 = B.bsy >> 2;
   // the planes this partition sums: whole 8x8 blocks where it covers them, 4x4 blocks otherwise
   int pl[4], npl = 0;
@@ -611,8 +614,9 @@ __device__ int epzs_pel(int mb_nr, int R, int *mvx, int *mvy)
   const int lam = P.lambda_mf[0], bt = B.bt, ref = B.ref;
   const int cx0 = *mvx, cy0 = *mvy;                       // the centre (mv on entry)
   const int px2 = B.pic_x >> 2, py2 = B.pic_y >> 2, bshx = B.bsx >> 2, bshy = B.bsy >> 2, block_y = B.mb_y >> 2, block_x = B.mb_x >> 2;
-  int *prev_sad = D.ep_dist + (size_t)(bt - 1) * D.w4;
-  short *motion = P.epzs_spatial_mem ? D.ep_motion + ((((size_t)ref * 7 + (bt - 1)) * 4 + block_y) * D.w4 + px2) * 2 : nullptr;
+  const int col0 = 4 * B.mbx - 4;                              // first column of the staged row memories
+  int *prev_sad = &L.ep_sad[bt - 1][0] - col0;                 // indexed by picture column, as JM's EPZSDistortion[list][blocktype - 1]
+  short *motion = P.epzs_spatial_mem ? &L.ep_mot[ref][bt - 1][block_y][px2 - col0][0] : nullptr;
   const int medthres = P.epzs_thres[1][bt];
   int stop = medthres;
   EpState S{cx0, cy0, 0, 0, 0, INT_MAX};
@@ -624,7 +628,7 @@ __device__ int epzs_pel(int mb_nr, int R, int *mvx, int *mvy)
   WPROF_T0;
   const int psad = prev_sad[px2];
   if (ref > 0 && psad < medthres && psad < S.min_mcost) {                      // :1608-1623
-    if (motion && threadIdx.x == 0) { motion[0] = (short)S.tmx; motion[1] = (short)S.tmy; }
+    if (motion) { motion[0] = (short)S.tmx; motion[1] = (short)S.tmy; }
     return S.min_mcost;
   }
   if (S.min_mcost > stop) {
@@ -659,8 +663,7 @@ __device__ int epzs_pel(int mb_nr, int R, int *mvx, int *mvy)
     const int invalid_refs = (refA == -1) + (refB == -1) + (refC == -1 && refD == -1);
 #define ADDP(X, Y) do { const int x_ = (X), y_ = (Y); L.px[np] = x_; L.py[np] = y_; np += ((x_ | y_) != 0); } while (0)
     if (P.epzs_spatial_mem) {
-      const short *m = D.ep_motion + (((size_t)ref * 7 + (bt - 1)) * 4) * D.w4 * 2;
-#define MOT(r, x, c) ((int)m[((size_t)(r) * D.w4 + (x)) * 2 + (c)])
+#define MOT(r, x, c) ((int)L.ep_mot[ref][bt - 1][r][(x) - col0][c])
       ADDP(px2 > 0 ? MOT(block_y, px2 - bshx, 0) : 0, px2 > 0 ? MOT(block_y, px2 - bshx, 1) : 0);
       ADDP(block_y > 0 ? MOT(block_y - bshy, px2, 0) : MOT(4 - bshy, px2, 0), block_y > 0 ? MOT(block_y - bshy, px2, 1) : MOT(4 - bshy, px2, 1));
       ADDP(px2 + bshx < D.w4 ? (block_y > 0 ? MOT(block_y - bshy, px2 + bshx, 0) : MOT(4 - bshy, px2 + bshx, 0)) : 0,
@@ -765,7 +768,7 @@ __device__ int epzs_pel(int mb_nr, int R, int *mvx, int *mvy)
         const int ps = prev_sad[px2];
         if (ref > 0 && ((4 * ps < S.min_mcost) || ((3 * ps < S.min_mcost) && (ps <= stop)))) {          // :1894-1911
           *mvx = S.tmx; *mvy = S.tmy;
-          if (motion && threadIdx.x == 0) { motion[0] = (short)S.tmx; motion[1] = (short)S.tmy; }
+          if (motion) { motion[0] = (short)S.tmx; motion[1] = (short)S.tmy; }
           return S.min_mcost;
         }
         if (!(check_median && S.min_mcost > stop && P.epzs_dual > 0)) break;     // P slice: (P_SLICE || blocktype < 5) is true
@@ -779,10 +782,8 @@ __device__ int epzs_pel(int mb_nr, int R, int *mvx, int *mvy)
     }
   }
   WPROF(6);
-  if (threadIdx.x == 0) {
-    if (ref == 0 || prev_sad[px2] > S.min_mcost) prev_sad[px2] = S.min_mcost;                           // :1945
-    if (motion) { motion[0] = (short)S.tmx; motion[1] = (short)S.tmy; }
-  }
+  if (ref == 0 || prev_sad[px2] > S.min_mcost) prev_sad[px2] = S.min_mcost;                             // :1945
+  if (motion) { motion[0] = (short)S.tmx; motion[1] = (short)S.tmy; }
   *mvx = S.tmx; *mvy = S.tmy;
   return S.min_mcost;
 }
@@ -920,7 +921,7 @@ __device__ int umhex_pel(int R, int *mvx, int *mvy, int min_mcost)
       pred_ref_flag = 1;
     }
     if (ref > 0) pred_sad = L.um_ref_cost[ref - 1][bt][block_y * 4 + block_x];
-    else if (bt > 1) pred_sad = D.um_cost[((size_t)tbt * D.h4 + (B.pic_y >> 2)) * D.w4 + (B.pic_x >> 2)] / 2;
+    else if (bt > 1) pred_sad = UMLOC(tbt, B.pic_y >> 2, B.pic_x >> 2) / 2;
     else pred_sad = 0;
     et = P.umhex_thres[1][bt];
     float b1 = 0.f, b2 = 0.f;
@@ -978,7 +979,7 @@ terminate:
   // :534-554
   for (int i = 0; i < (B.bsx >> 2); i++) for (int j = 0; j < (B.bsy >> 2); j++) {
     L.um_ref_cost[ref][bt][(block_y + j) * 4 + block_x + i] = U.min_mcost;
-    if (ref == 0 && threadIdx.x == 0) D.um_cost[((size_t)bt * D.h4 + (B.pic_y >> 2) + j) * D.w4 + (B.pic_x >> 2) + i] = U.min_mcost;
+    if (ref == 0) UMLOC(bt, (B.pic_y >> 2) + j, (B.pic_x >> 2) + i) = U.min_mcost;
   }
   if (ref == 0 || L.um_best_cost[bt][px2l] > U.min_mcost) L.um_best_cost[bt][px2l] = U.min_mcost;
   *mvx = U.best_x; *mvy = U.best_y;
@@ -1059,8 +1060,8 @@ __device__ void find_skip_mv(int mbx, int mby)
   int ax, ay, bx, by, pmx = 0, pmy = 0;
   const int availA = nbr_pos(mbx, mby, -1, 0, &ax, &ay), availB = nbr_pos(mbx, mby, 0, -1, &bx, &by);
   int zl = 1, za = 1;
-  if (availA) { const size_t at = (size_t)ay * D.w4 + ax; zl = (D.ref_idx[at] == 0 && D.mv[at * 2] == 0 && D.mv[at * 2 + 1] == 0); }
-  if (availB) { const size_t at = (size_t)by * D.w4 + bx; za = (D.ref_idx[at] == 0 && D.mv[at * 2] == 0 && D.mv[at * 2 + 1] == 0); }
+  if (availA) zl = (FREF(ay, ax) == 0 && FMV(ay, ax, 0) == 0 && FMV(ay, ax, 1) == 0);
+  if (availB) za = (FREF(by, bx) == 0 && FMV(by, bx, 0) == 0 && FMV(by, bx, 1) == 0);
   if (!(za || zl)) mv_predictor(mbx, mby, 0, 0, 0, 16, 16, &pmx, &pmy, 0, 0, nullptr, nullptr);
   for (int b = 0; b < 16; b++) { L.all_mv[b][0][0][0] = (short)pmx; L.all_mv[b][0][0][1] = (short)pmy; }
 }
@@ -1120,7 +1121,7 @@ __device__ int block_motion_search(int mbx, int mby, int ref, int mb_x, int mb_y
   mvx <<= 2; mvy <<= 2;
   // sub-pel :781-827
   bool do_sub = true;
-  if (P.search_mode == JMHIP_SEARCH_EPZS && ref > 0) do_sub = (2 * (long long)min_mcost < 7 * (long long)D.ep_dist[(size_t)(bt - 1) * D.w4 + (B.pic_x >> 2)]);   // min_mcost < 3.5 * prevSad
+  if (P.search_mode == JMHIP_SEARCH_EPZS && ref > 0) do_sub = (2 * (long long)min_mcost < 7 * (long long)L.ep_sad[bt - 1][(B.pic_x >> 2) - (4 * mbx - 4)]);   // min_mcost < 3.5 * prevSad
   if (do_sub && !(D.debug & 1)) {
     if (!start_hp) min_mcost = INT_MAX;
     if (P.search_mode == JMHIP_SEARCH_UMHEX && bt > 3) min_mcost = umhex_subpel(&mvx, &mvy, min_mcost);
@@ -1157,10 +1158,10 @@ __device__ int block_motion_search(int mbx, int mby, int ref, int mb_x, int mb_y
   return min_mcost;
 }
 
-// field writes: one lane writes, everyone reads back after the barrier
+// field writes: into the macroblock's LDS copy (every lane writes the same value); mb_commit hands the final sixteen on
 __device__ __forceinline__ void field_set(int by, int bx, int ref, int mvx, int mvy)
 {
-  if (threadIdx.x == 0) { const size_t at = (size_t)by * D.w4 + bx; D.ref_idx[at] = (int8_t)ref; D.mv[at * 2] = (short)mvx; D.mv[at * 2 + 1] = (short)mvy; }
+  FREF(by, bx) = (int8_t)ref; FMV(by, bx, 0) = (short)mvx; FMV(by, bx, 1) = (short)mvy;
 }
 
 // PartitionMotionSearch, mv-search.c:1378
@@ -1236,7 +1237,7 @@ __device__ void macroblock_low(int mbx, int mby, jmhip_mb_inter *out)
         int best_ref = 0;
         partition_motion_search(mbx, mby, mode, block, out);
         int cost = list0_cost(mode, block, &best_ref);
-        if (threadIdx.x == 0) for (int j = 0; j < 2; j++) for (int i = 0; i < 2; i++) D.ref_idx[(size_t)(by0 + j0 + j) * D.w4 + bx0 + i0 + i] = (int8_t)best_ref;
+        for (int j = 0; j < 2; j++) for (int i = 0; i < 2; i++) FREF(by0 + j0 + j, bx0 + i0 + i) = (int8_t)best_ref;
         __syncthreads();
         if (cost != INT_MAX) cost += ((P.lambda_mf[2] * (P.num_refs <= 1 ? 0 : refbits(mode - 4))) >> 16) - 1;
         if (cost < mc8) { mc8 = cost; b8m[block] = mode; l0ref[4][block] = best_ref; }
@@ -1262,6 +1263,118 @@ __device__ void macroblock_low(int mbx, int mby, jmhip_mb_inter *out)
   __syncthreads();
 }
 
+
+// ---------------------------------------------------------------------------------------------- a macroblock's view of the picture-level state
+
+__device__ void all_mv_from_carry(const short *cin)
+{
+  for (int i = threadIdx.x; i < (int)(sizeof(L.all_mv) / 4); i += 64) reinterpret_cast<uint32_t *>(L.all_mv)[i] = 0u;
+  __syncthreads();
+  for (int e = threadIdx.x; e < WR * 16; e += 64) {
+    const int r = e >> 4, b = e & 15, k8 = 2 * (b >> 3) + ((b & 3) >> 1);
+    L.all_mv[b][r][1][0] = cin[(r * CARRY) * 2]; L.all_mv[b][r][1][1] = cin[(r * CARRY) * 2 + 1];
+    L.all_mv[b][r][4][0] = cin[(r * CARRY + 1 + k8) * 2]; L.all_mv[b][r][4][1] = cin[(r * CARRY + 1 + k8) * 2 + 1];
+  }
+  __syncthreads();
+}
+
+// what the macroblock reads of its surroundings, once, into LDS: the source samples, the ring of the motion field (and of UMHexagonS's cost
+// maps) its predictors look at, the EPZS row memories of its own columns and of one macroblock either side
+__device__ void mb_stage(int mbx, int mby)
+{
+  const int lane = threadIdx.x;
+  const jmhip_slice_params &P = D.p;
+  if (lane == 0) { L.mbx = mbx; L.mby = mby; }
+  {
+    const int r = lane >> 2, k = lane & 3;
+    *reinterpret_cast<uint32_t *>(&L.cur[r][k * 4]) = *reinterpret_cast<const uint32_t *>(D.cur + (size_t)(mby * 16 + r) * D.W + mbx * 16 + k * 4);
+  }
+  if (lane < 30) {
+    const int gy = lane / 6, gx = lane - gy * 6, px = 4 * mbx - 1 + gx, py = 4 * mby - 1 + gy;
+    const bool own = gy >= 1 && gx >= 1 && gx <= 4;
+    int r = -1, vx = 0, vy = 0;
+    if (!own && px >= 0 && py >= 0 && px < D.w4) { const size_t at = (size_t)py * D.w4 + px; r = D.ref_idx[at]; vx = D.mv[at * 2]; vy = D.mv[at * 2 + 1]; }
+    L.f_ref[gy][gx] = (int8_t)r; L.f_mv[gy][gx][0] = (short)vx; L.f_mv[gy][gx][1] = (short)vy;
+  }
+  if (P.search_mode == JMHIP_SEARCH_UMHEX)
+    for (int e = lane; e < 8 * 30; e += 64) {
+      const int bt = e / 30, g = e - bt * 30, gy = g / 6, gx = g - gy * 6, px = 4 * mbx - 1 + gx, py = 4 * mby - 1 + gy;
+      const bool own = gy >= 1 && gx >= 1 && gx <= 4;
+      int v = 0;
+      // own entries: what the slice found there (JM's array still holds the previous picture's value until the macroblock writes it)
+      if (px >= 0 && py >= 0 && px < D.w4 && py < D.h4) v = (own ? D.um_in : D.um_cost)[((size_t)bt * D.h4 + py) * D.w4 + px];
+      L.um_loc[bt][gy][gx] = v;
+    }
+  if (P.search_mode == JMHIP_SEARCH_EPZS) {
+    const int col0 = 4 * mbx - 4;
+    for (int e = lane; e < 7 * 12; e += 64) {
+      const int t = e / 12, j = e - t * 12, col = clampi(col0 + j, 0, D.w4 - 1);
+      L.ep_sad[t][j] = D.ep_dist[((size_t)state_row(col, mbx, mby) * 7 + t) * D.w4 + col];
+    }
+    if (P.epzs_spatial_mem)
+      for (int e = lane; e < P.num_refs * 7 * 4 * 12; e += 64) {
+        const int j = e % 12, br = (e / 12) & 3, t = (e / 48) % 7, r = e / (48 * 7);
+        const int col = clampi(col0 + j, 0, D.w4 - 1);
+        const size_t at = ((((size_t)state_row(col, mbx, mby) * WR + r) * 7 + t) * 4 + br) * D.w4 + col;
+        *reinterpret_cast<uint32_t *>(L.ep_mot[r][t][br][j]) = *reinterpret_cast<const uint32_t *>(D.ep_motion + at * 2);
+      }
+  }
+  __syncthreads();
+}
+
+// hands the macroblock's results on: its sixteen field entries, its cost-map / row-memory entries, the img->all_mv entries the next macroblock
+// in coding order reads. Returns (wave-uniform) whether any of it differs from what was stored -- the relaxation schedule's signal.
+__device__ int mb_commit(int mbx, int mby)
+{
+  const int lane = threadIdx.x;
+  const jmhip_slice_params &P = D.p;
+  __syncthreads();
+  bool diff = false;
+  if (lane < 16) {
+    const int bx = lane & 3, by = lane >> 2;
+    const size_t at = (size_t)(4 * mby + by) * D.w4 + 4 * mbx + bx;
+    const int8_t r = L.f_ref[by + 1][bx + 1];
+    const short vx = L.f_mv[by + 1][bx + 1][0], vy = L.f_mv[by + 1][bx + 1][1];
+    diff = D.ref_idx[at] != r || D.mv[at * 2] != vx || D.mv[at * 2 + 1] != vy;
+    D.ref_idx[at] = r; D.mv[at * 2] = vx; D.mv[at * 2 + 1] = vy;
+  }
+  if (P.search_mode == JMHIP_SEARCH_UMHEX)
+    for (int e = lane; e < 128; e += 64) {
+      const int bt = e >> 4, by = (e >> 2) & 3, bx = e & 3;
+      const size_t at = ((size_t)bt * D.h4 + 4 * mby + by) * D.w4 + 4 * mbx + bx;
+      const int v = L.um_loc[bt][by + 1][bx + 1];
+      diff = diff || D.um_cost[at] != v;
+      D.um_cost[at] = v;
+    }
+  if (P.search_mode == JMHIP_SEARCH_EPZS) {
+    const size_t row = (size_t)(mby - D.row0 + 1);
+    if (lane < 28) {
+      const int t = lane >> 2, j = lane & 3;
+      const size_t at = (row * 7 + t) * D.w4 + 4 * mbx + j;
+      const int v = L.ep_sad[t][4 + j];
+      diff = diff || D.ep_dist[at] != v;
+      D.ep_dist[at] = v;
+    }
+    if (P.epzs_spatial_mem)
+      for (int e = lane; e < P.num_refs * 7 * 16; e += 64) {
+        const int j = e & 3, br = (e >> 2) & 3, t = (e >> 4) % 7, r = e / (16 * 7);
+        const size_t at = ((((row * WR + r) * 7 + t) * 4 + br) * D.w4 + 4 * mbx + j) * 2;
+        const uint32_t v = *reinterpret_cast<const uint32_t *>(L.ep_mot[r][t][br][4 + j]);
+        uint32_t *g = reinterpret_cast<uint32_t *>(D.ep_motion + at);
+        diff = diff || *g != v;
+        *g = v;
+      }
+  }
+  if (lane < WR * CARRY) {
+    const int r = lane / CARRY, k = lane - r * CARRY, b = k ? ((k - 1) >> 1) * 8 + ((k - 1) & 1) * 2 : 0;
+    const uint32_t v = *reinterpret_cast<const uint32_t *>(L.all_mv[b][r][k ? 4 : 1]);
+    uint32_t *g = reinterpret_cast<uint32_t *>(D.carry_mb + ((size_t)(mby * D.mbw + mbx) * WR * CARRY + lane) * 2);
+    diff = diff || *g != v;
+    *g = v;
+  }
+  return __ballot(diff) != 0ull;
+}
+
 __global__ __launch_bounds__(64) void p_slice_kernel(const short *carry_slice_in, short *carry_slice_out)
 {
   const int lane = threadIdx.x;
@@ -1271,15 +1384,7 @@ __global__ __launch_bounds__(64) void p_slice_kernel(const short *carry_slice_in
   if (x0 > x1) return;
   // img->all_mv as the previous macroblock in coding order left it: the slice's first macroblock takes the persistent carry, other row starts
   // the speculated one; inside a row the LDS array simply lives on
-  for (int i = lane; i < (int)(sizeof(L.all_mv) / 4); i += 64) reinterpret_cast<uint32_t *>(L.all_mv)[i] = 0u;
-  __syncthreads();
-  {
-    const short *cin = (mby * D.mbw + x0 == D.p.mb_first) ? carry_slice_in : D.carry_in + (size_t)mby * WR * CARRY * 2;
-    for (int r = 0; r < WR; r++) {
-      for (int b = 0; b < 16; b++) { L.all_mv[b][r][1][0] = cin[(r * CARRY) * 2]; L.all_mv[b][r][1][1] = cin[(r * CARRY) * 2 + 1]; }
-      for (int b = 0; b < 16; b++) { const int k8 = 2 * (b >> 3) + ((b & 3) >> 1); L.all_mv[b][r][4][0] = cin[(r * CARRY + 1 + k8) * 2]; L.all_mv[b][r][4][1] = cin[(r * CARRY + 1 + k8) * 2 + 1]; }
-    }
-  }
+  all_mv_from_carry((mby * D.mbw + x0 == D.p.mb_first) ? carry_slice_in : D.carry_in + (size_t)mby * WR * CARRY * 2);
   for (int mbx = x0; mbx <= x1; mbx++) {
     // wait for the row above: its macroblock mbx + 1 (or its last one) if that one belongs to the slice
     if (mby > 0) {
@@ -1296,28 +1401,7 @@ __global__ __launch_bounds__(64) void p_slice_kernel(const short *carry_slice_in
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       }
     }
-    // the source macroblock
-    {
-      const int r = lane >> 2, k = lane & 3;
-      *reinterpret_cast<uint32_t *>(&L.cur[r][k * 4]) = *reinterpret_cast<const uint32_t *>(D.cur + (size_t)(mby * 16 + r) * D.W + mbx * 16 + k * 4);
-    }
-    // the references' integer samples round the macroblock (EPZS / UMHexagonS candidates; the exhaustive modes build their own surface)
-    if ((D.p.search_mode == JMHIP_SEARCH_EPZS || D.p.search_mode == JMHIP_SEARCH_UMHEX) && !(D.debug & 8)) {
-      const int wx0 = mbx * 16 + JMHIP_PAD - (WIN_MAX - 16) / 2, wy0 = mby * 16 + JMHIP_PAD - (WIN_MAX - 16) / 2;      // multiples of 4
-      if (lane == 0) { L.rw_x0 = wx0; L.rw_y0 = wy0; }
-      for (int r = 0; r < WR; r++) {
-        const uint8_t *pl0 = r < D.p.num_refs ? D.ref_sub[D.p.ref_slot[r]] : nullptr;
-        if (lane == 0) L.rw_planes[r] = pl0;
-        if (!pl0) continue;
-        uint32_t *dst = reinterpret_cast<uint32_t *>(L.rwin[r]);
-        for (int e = lane; e < WIN_MAX * (WIN_MAX / 4); e += 64) {
-          const int y = e / (WIN_MAX / 4), xd = e - y * (WIN_MAX / 4);
-          // positions outside the padded plane are never asked for (block origins are clamped into it): keep the address legal
-          dst[e] = *reinterpret_cast<const uint32_t *>(pl0 + (size_t)clampi(wy0 + y, 0, D.Hp - 1) * D.Wp + clampi(wx0 + 4 * xd, 0, D.Wp - 4));
-        }
-      }
-    } else if (lane < WR) L.rw_planes[lane] = nullptr;
-    __syncthreads();
+    mb_stage(mbx, mby);
 #ifdef JMHIP_WAVE_PROF
     const unsigned long long mb_t0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1325,6 +1409,7 @@ __global__ __launch_bounds__(64) void p_slice_kernel(const short *carry_slice_in
 #ifdef JMHIP_WAVE_PROF
     if (lane == 0) { atomicAdd(&g_wave_prof[8], __builtin_amdgcn_s_memtime() - mb_t0); atomicAdd(&g_wave_prof[9], 1ull); }
 #endif
+    (void)mb_commit(mbx, mby);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     if (lane == 0) __hip_atomic_store(&D.prog[mby], mbx + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -1338,9 +1423,59 @@ __global__ __launch_bounds__(64) void p_slice_kernel(const short *carry_slice_in
   }
 }
 
+
+// The same macroblocks under a RELAXATION schedule: every macroblock of the slice at once, each reading whatever its predecessors in coding
+// order last handed on (mb_commit), sweep after sweep until a sweep changes nothing. The dependencies are acyclic (raster order), so the
+// fixpoint is unique and equals what the coding-order walk produces; what the walk does in mbw + 2 mbh serial steps of one macroblock each,
+// the sweeps do with the whole GPU busy. A macroblock is re-evaluated only when a predecessor -- left, up-left, up, up-right, or the one before
+// it in coding order (img->all_mv) -- changed what it hands on in the previous sweep; the state of the previous picture is the first guess.
+__global__ __launch_bounds__(64) void p_slice_relax_kernel(const short *carry_slice_in)
+{
+  const int lane = threadIdx.x, first = D.p.mb_first, last = first + D.p.mb_count - 1;
+  for (int addr = first + blockIdx.x; addr <= last; addr += gridDim.x) {
+    const int mbx = addr % D.mbw, mby = addr / D.mbw;
+    bool active = D.first_sweep != 0;
+    if (!active) {
+      auto chg = [&](int nx, int ny) {
+        if (nx < 0 || ny < 0 || nx >= D.mbw) return false;
+        const int a = ny * D.mbw + nx;
+        return a >= first && a <= last && D.chg_prev[a - first] != 0;
+      };
+      active = chg(mbx - 1, mby) || chg(mbx, mby - 1) || chg(mbx + 1, mby - 1) || chg(mbx - 1, mby - 1) || (addr > first && D.chg_prev[addr - 1 - first] != 0);
+    }
+    if (!active) { if (lane == 0) D.chg_next[addr - first] = 0; continue; }
+    all_mv_from_carry(addr == first ? carry_slice_in : D.carry_mb + (size_t)(addr - 1) * WR * CARRY * 2);
+    mb_stage(mbx, mby);
+    macroblock_low(mbx, mby, D.out + addr);
+    const int changed = mb_commit(mbx, mby);
+    if (lane == 0) { D.chg_next[addr - first] = (uint8_t)changed; if (changed) atomicAdd(D.n_changed, 1); }
+    __syncthreads();
+  }
+}
+
+// after the slice: the EPZS row memories as JM's single-row arrays would now hold them (stored row 0, what the next slice starts from)
+__global__ void epzs_rows_fold_kernel(int *ep_dist, short *ep_motion, int w4, int mbw, int mb_first, int mb_count, int row0, int spatial_mem)
+{
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= w4) return;
+  const int last = mb_first + mb_count - 1, ylast = last / mbw, cx = col >> 2;
+  int src = 0;
+  for (int yy = ylast; yy >= ylast - 1 && yy >= 0 && !src; yy--) { const int a = yy * mbw + cx; if (a >= mb_first && a <= last) src = yy - row0 + 1; }
+  if (!src) return;
+  for (int t = 0; t < 7; t++) ep_dist[(size_t)t * w4 + col] = ep_dist[((size_t)src * 7 + t) * w4 + col];
+  if (spatial_mem)
+    for (int e = 0; e < WR * 7 * 4; e++) {
+      const size_t to = ((size_t)e * w4 + col) * 2, from = (((size_t)src * WR * 7 * 4 + e) * w4 + col) * 2;
+      ep_motion[to] = ep_motion[from]; ep_motion[to + 1] = ep_motion[from + 1];
+    }
+}
+
 #undef D
 #undef B
 #undef L
+#undef FREF
+#undef FMV
+#undef UMLOC
 
 // rows whose speculated start differs from what the row above left: flag[1] = first such row (min), else untouched
 __global__ void carry_check_kernel(const short *carry_in, const short *carry_out, int row_first, int rows, int *flags)
@@ -1356,10 +1491,11 @@ struct SliceState {
   int8_t *ref_idx = nullptr; short *mv = nullptr;
   int *prog = nullptr, *flags = nullptr;
   jmhip_mb_inter *out = nullptr;
-  int *ep_dist = nullptr, *ep_dist_snap = nullptr; short *ep_motion = nullptr, *ep_motion_snap = nullptr; short *ep_col = nullptr;
+  int *ep_dist = nullptr; short *ep_motion = nullptr; short *ep_col = nullptr;        // row memories: [mbh + 1] stored rows (WaveDev)
+  short *carry_mb = nullptr; uint8_t *chg[2] = {nullptr, nullptr};
   short *carry_in = nullptr, *carry_out = nullptr, *carry_slice = nullptr, *carry_slice_next = nullptr;
   int *um_cost = nullptr, *um_cost_snap = nullptr;
-  uint16_t *surf = nullptr; size_t surf_rows = 0; int surf_n = 0;
+  uint16_t *surf = nullptr; size_t surf_rows = 0; int surf_n = 0, surf_refs = 0;
   int passes = 0;
   bool has_col = false;
   int searched_to = 0;                         // macroblocks [0, searched_to) of the current picture have been searched
@@ -1376,8 +1512,10 @@ static SliceState *slice_state(jmhip_ctx *c)
   bool ok = hipMalloc((void **)&s->ref_idx, w4 * h4) == hipSuccess && hipMalloc((void **)&s->mv, w4 * h4 * 4) == hipSuccess &&
             hipMalloc((void **)&s->prog, sizeof(int) * c->mbh) == hipSuccess && hipMalloc((void **)&s->flags, sizeof(int) * 4) == hipSuccess &&
             hipMalloc((void **)&s->out, sizeof(jmhip_mb_inter) * nmb) == hipSuccess &&
-            hipMalloc((void **)&s->ep_dist, sizeof(int) * 7 * w4) == hipSuccess && hipMalloc((void **)&s->ep_dist_snap, sizeof(int) * 7 * w4) == hipSuccess &&
-            hipMalloc((void **)&s->ep_motion, sizeof(short) * WR * 7 * 4 * w4 * 2) == hipSuccess && hipMalloc((void **)&s->ep_motion_snap, sizeof(short) * WR * 7 * 4 * w4 * 2) == hipSuccess &&
+            hipMalloc((void **)&s->ep_dist, sizeof(int) * (c->mbh + 1) * 7 * w4) == hipSuccess &&
+            hipMalloc((void **)&s->ep_motion, sizeof(short) * (c->mbh + 1) * WR * 7 * 4 * w4 * 2) == hipSuccess &&
+            hipMalloc((void **)&s->carry_mb, sizeof(short) * nmb * WR * CARRY * 2) == hipSuccess &&
+            hipMalloc((void **)&s->chg[0], nmb) == hipSuccess && hipMalloc((void **)&s->chg[1], nmb) == hipSuccess &&
             hipMalloc((void **)&s->ep_col, sizeof(short) * h4 * w4 * 2) == hipSuccess &&
             hipMalloc((void **)&s->carry_in, sizeof(short) * c->mbh * WR * CARRY * 2) == hipSuccess && hipMalloc((void **)&s->carry_out, sizeof(short) * c->mbh * WR * CARRY * 2) == hipSuccess &&
             hipMalloc((void **)&s->carry_slice, sizeof(short) * WR * CARRY * 2) == hipSuccess && hipMalloc((void **)&s->carry_slice_next, sizeof(short) * WR * CARRY * 2) == hipSuccess &&
@@ -1394,8 +1532,9 @@ extern "C" int jmhip_slice_state_reset(jmhip_ctx *c)
   SliceState *s = slice_state(c);
   if (!s) return jm_fail(c, JMHIP_ERR_NOMEM, "slice search state");
   const size_t w4 = c->W / 4, h4 = c->H / 4;
-  JM_HIP_CHECK(c, hipMemsetAsync(s->ep_dist, 0, sizeof(int) * 7 * w4, c->stream));
-  JM_HIP_CHECK(c, hipMemsetAsync(s->ep_motion, 0, sizeof(short) * WR * 7 * 4 * w4 * 2, c->stream));
+  JM_HIP_CHECK(c, hipMemsetAsync(s->ep_dist, 0, sizeof(int) * (c->mbh + 1) * 7 * w4, c->stream));
+  JM_HIP_CHECK(c, hipMemsetAsync(s->ep_motion, 0, sizeof(short) * (c->mbh + 1) * WR * 7 * 4 * w4 * 2, c->stream));
+  JM_HIP_CHECK(c, hipMemsetAsync(s->carry_mb, 0, sizeof(short) * (size_t)c->mbw * c->mbh * WR * CARRY * 2, c->stream));
   JM_HIP_CHECK(c, hipMemsetAsync(s->ep_col, 0, sizeof(short) * h4 * w4 * 2, c->stream));
   JM_HIP_CHECK(c, hipMemsetAsync(s->carry_slice, 0, sizeof(short) * WR * CARRY * 2, c->stream));
   JM_HIP_CHECK(c, hipMemsetAsync(s->carry_in, 0, sizeof(short) * c->mbh * WR * CARRY * 2, c->stream));
@@ -1450,18 +1589,24 @@ extern "C" int jmhip_p_slice_search(jmhip_ctx *c, const jmhip_slice_params *prm,
   if (rc) return rc;
   const size_t w4 = c->W / 4, h4 = c->H / 4;
   const int row_first = prm->mb_first / c->mbw, row_last = (prm->mb_first + prm->mb_count - 1) / c->mbw, rows = row_last - row_first + 1;
-  if (prm->mb_first == 0) {                                  // a new picture: enc_picture->ref_idx / mv start empty
-    JM_HIP_CHECK(c, hipMemsetAsync(s->ref_idx, 0xff, w4 * h4, c->stream));
-    JM_HIP_CHECK(c, hipMemsetAsync(s->mv, 0, w4 * h4 * 4, c->stream));
-  }
+  // (a new picture's enc_picture->ref_idx / mv need no reset: a macroblock only ever reads entries of macroblocks coded before it, and the
+  // previous picture's field is the relaxation schedule's first guess)
   const bool exhaustive = prm->search_mode == JMHIP_SEARCH_FULL || prm->search_mode == JMHIP_SEARCH_FASTFULL;
+  // schedule: relaxation sweeps over `relax_grid` resident workgroups (default), or JMHIP_SLICE_SCHED=wave: the coding-order wavefront only
+  int relax_grid = 0;
+  {
+    const char *e = getenv("JMHIP_SLICE_SCHED");
+    if (!(e && !strcmp(e, "wave"))) relax_grid = exhaustive ? 1024 : 2048;
+    if (const char *g = getenv("JMHIP_SLICE_GRID")) if (relax_grid) relax_grid = std::max(1, atoi(g));
+  }
   if (exhaustive) {
     const int rs = prm->search_range + SURF_MARGIN, n = ((2 * rs + 1) * (2 * rs + 1) + 63) & ~63;
-    if (s->surf_rows < (size_t)rows || s->surf_n < n) {
+    const size_t slots = (size_t)std::max(rows, relax_grid);      // one surface set per resident workgroup (blockIdx.x)
+    if (s->surf_rows < slots || s->surf_n < n || s->surf_refs < prm->num_refs) {
       if (s->surf) JM_HIP_CHECK(c, hipFree(s->surf));
       s->surf = nullptr; s->surf_rows = 0;
-      if (hipMalloc((void **)&s->surf, sizeof(uint16_t) * (size_t)rows * WR * SURF_PLANES * n) != hipSuccess) return jm_fail(c, JMHIP_ERR_NOMEM, "SAD surfaces of the slice search");
-      s->surf_rows = rows; s->surf_n = n;
+      if (hipMalloc((void **)&s->surf, sizeof(uint16_t) * slots * prm->num_refs * SURF_PLANES * n) != hipSuccess) return jm_fail(c, JMHIP_ERR_NOMEM, "SAD surfaces of the slice search");
+      s->surf_rows = slots; s->surf_n = n; s->surf_refs = prm->num_refs;
     }
   }
   WaveDev D{};
@@ -1472,17 +1617,35 @@ extern "C" int jmhip_p_slice_search(jmhip_ctx *c, const jmhip_slice_params *prm,
   D.cur = c->cur_y;
   D.ref_sub = reinterpret_cast<const uint8_t *const *>(c->ref_ptrs_dev) + 32;
   D.ref_idx = s->ref_idx; D.mv = s->mv; D.prog = s->prog; D.flags = s->flags; D.out = s->out;
-  D.ep_dist = s->ep_dist; D.ep_motion = s->ep_motion; D.ep_col = s->ep_col;
-  D.carry_in = s->carry_in; D.carry_out = s->carry_out; D.um_cost = s->um_cost;
+  D.ep_dist = s->ep_dist; D.ep_motion = s->ep_motion; D.ep_col = s->ep_col; D.row0 = row_first;
+  D.carry_in = s->carry_in; D.carry_out = s->carry_out; D.um_cost = s->um_cost; D.um_in = s->um_cost_snap; D.carry_mb = s->carry_mb;
+  D.n_changed = s->flags + 2;
   const bool epzs = prm->search_mode == JMHIP_SEARCH_EPZS;
-  // the row memories are read-modify-write: a re-run must start from what this call found
-  if (epzs) {
-    JM_HIP_CHECK(c, hipMemcpyAsync(s->ep_dist_snap, s->ep_dist, sizeof(int) * 7 * w4, hipMemcpyDeviceToDevice, c->stream));
-    JM_HIP_CHECK(c, hipMemcpyAsync(s->ep_motion_snap, s->ep_motion, sizeof(short) * WR * 7 * 4 * w4 * 2, hipMemcpyDeviceToDevice, c->stream));
-  }
+  // a macroblock's own cost-map entries start from what the slice found (mb_stage)
+  if (prm->search_mode == JMHIP_SEARCH_UMHEX) JM_HIP_CHECK(c, hipMemcpyAsync(s->um_cost_snap, s->um_cost, sizeof(int) * 8 * h4 * w4, hipMemcpyDeviceToDevice, c->stream));
   s->passes = 0;
   jm_stage_begin(c, JMHIP_STAGE_ME_INT);
-  for (;;) {
+  bool settled = false;
+  if (relax_grid) {
+    // relaxation sweeps (p_slice_relax_kernel); the coding-order walk below remains the fallback if they do not settle within the cap
+    const int cap = getenv("JMHIP_SLICE_SWEEPS") ? atoi(getenv("JMHIP_SLICE_SWEEPS")) : 160;      // a sweep costs >= one macroblock (1.2 ms), the walk 250+
+    const int grid = std::min(relax_grid, prm->mb_count);
+    for (int sweep = 0; sweep < cap && !settled; sweep++) {
+      JM_HIP_CHECK(c, hipMemsetAsync(s->flags, 0, sizeof(int) * 4, c->stream));
+      D.first_sweep = sweep == 0; D.chg_prev = s->chg[sweep & 1]; D.chg_next = s->chg[(sweep + 1) & 1];
+      JM_HIP_CHECK(c, hipMemcpyToSymbolAsync(HIP_SYMBOL(c_wave), &D, sizeof(D), 0, hipMemcpyHostToDevice, c->stream));
+      p_slice_relax_kernel<<<grid, 64, 0, c->stream>>>(s->carry_slice);
+      JM_HIP_CHECK(c, hipGetLastError());
+      s->passes++;
+      int flags[4] = {0, 0, 1, 0};
+      JM_HIP_CHECK(c, hipMemcpyAsync(flags, s->flags, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
+      JM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+      settled = flags[2] == 0;
+    }
+    if (settled)
+      JM_HIP_CHECK(c, hipMemcpyAsync(s->carry_slice_next, s->carry_mb + (size_t)(prm->mb_first + prm->mb_count - 1) * WR * CARRY * 2, sizeof(short) * WR * CARRY * 2, hipMemcpyDeviceToDevice, c->stream));
+  }
+  for (; !settled;) {
     JM_HIP_CHECK(c, hipMemsetAsync(s->prog, 0, sizeof(int) * c->mbh, c->stream));
     const int init_flags[4] = {0, 1 << 30, 0, 0};
     JM_HIP_CHECK(c, hipMemcpyAsync(s->flags, init_flags, sizeof(init_flags), hipMemcpyHostToDevice, c->stream));
@@ -1496,13 +1659,13 @@ extern "C" int jmhip_p_slice_search(jmhip_ctx *c, const jmhip_slice_params *prm,
     JM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     if (flags[0]) { jm_stage_end(c, JMHIP_STAGE_ME_INT); return jm_fail(c, JMHIP_ERR_DEVICE, "p_slice_kernel: a row waited too long for the row above (internal error)"); }
     if (!epzs || rows == 1 || flags[1] == (1 << 30)) break;
-    if (s->passes > rows + 1) { jm_stage_end(c, JMHIP_STAGE_ME_INT); return jm_fail(c, JMHIP_ERR_DEVICE, "p_slice_kernel: row-start speculation did not settle (internal error)"); }
-    // next pass: every row starts from what the row above left in this pass; rows up to the first wrong one were exact already
+    if (s->passes > rows + 80) { jm_stage_end(c, JMHIP_STAGE_ME_INT); return jm_fail(c, JMHIP_ERR_DEVICE, "p_slice_kernel: row-start speculation did not settle (internal error)"); }
+    // next pass: every row starts from what the row above left in this pass; rows up to the first wrong one were exact already. (The stored
+    // rows of the row memories are rewritten in coding order by every pass; row 0, what the slice found, is never written.)
     JM_HIP_CHECK(c, hipMemcpyAsync(s->carry_in + (size_t)(row_first + 1) * WR * CARRY * 2, s->carry_out + (size_t)row_first * WR * CARRY * 2,
                                    sizeof(short) * (size_t)(rows - 1) * WR * CARRY * 2, hipMemcpyDeviceToDevice, c->stream));
-    JM_HIP_CHECK(c, hipMemcpyAsync(s->ep_dist, s->ep_dist_snap, sizeof(int) * 7 * w4, hipMemcpyDeviceToDevice, c->stream));
-    JM_HIP_CHECK(c, hipMemcpyAsync(s->ep_motion, s->ep_motion_snap, sizeof(short) * WR * 7 * 4 * w4 * 2, hipMemcpyDeviceToDevice, c->stream));
   }
+  if (epzs) epzs_rows_fold_kernel<<<((int)w4 + 63) / 64, 64, 0, c->stream>>>(s->ep_dist, s->ep_motion, (int)w4, c->mbw, prm->mb_first, prm->mb_count, row_first, prm->epzs_spatial_mem);
   jm_stage_end(c, JMHIP_STAGE_ME_INT);
 #ifdef JMHIP_WAVE_PROF
   {
@@ -1615,7 +1778,7 @@ void jm_slice_state_free(jmhip_ctx *c)
 {
   SliceState *s = static_cast<SliceState *>(c->slice_state);
   if (!s) return;
-  void *bufs[] = {s->ref_idx, s->mv, s->prog, s->flags, s->out, s->ep_dist, s->ep_dist_snap, s->ep_motion, s->ep_motion_snap, s->ep_col, s->carry_in, s->carry_out,
+  void *bufs[] = {s->ref_idx, s->mv, s->prog, s->flags, s->out, s->ep_dist, s->ep_motion, s->carry_mb, s->chg[0], s->chg[1], s->ep_col, s->carry_in, s->carry_out,
                   s->carry_slice, s->carry_slice_next, s->um_cost, s->um_cost_snap, s->surf};
   for (void *b : bufs) if (b) (void)hipFree(b);
   delete s;

@@ -175,6 +175,19 @@ def test_synthetic_clip_matches_the_oracle(pkg, mode, W, H, R, nref, slices):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("sched,sweeps", [("wave", None), ("relax", "1"), ("relax", "3")])
+@pytest.mark.parametrize("mode,W,H,R,nref,slices", [(3, 320, 192, 32, 3, 3), (1, 176, 144, 16, 2, 1), (0, 96, 64, 8, 2, 1), (-1, 96, 64, 8, 2, 2)])
+def test_schedules_agree(pkg, mode, W, H, R, nref, slices, sched, sweeps, monkeypatch):
+    """The default schedule is relaxation (every macroblock of the slice at once, sweep after sweep until nothing changes; me_wave.hip
+    p_slice_relax_kernel). JMHIP_SLICE_SCHED=wave forces the coding-order wavefront; JMHIP_SLICE_SWEEPS caps the sweeps, after which the
+    wavefront takes over from whatever state the sweeps left (1: after a single sweep). Every combination must give JM's result."""
+    monkeypatch.setenv("JMHIP_SLICE_SCHED", sched)
+    if sweeps:
+        monkeypatch.setenv("JMHIP_SLICE_SWEEPS", sweeps)
+    run_synthetic(pkg, mode, W, H, R, nref, slices=slices, nframes=3)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode", [3, 1])
 def test_sad_everywhere_and_satd_everywhere(pkg, mode):
     run_synthetic(pkg, mode, 176, 144, 16, 2, metric=(0, 0, 0), nframes=2)

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Times jmhip_p_slice_search (the macroblock-wavefront P-slice kernel) on a synthetic 1080p picture for each search mode.
-usage: python tools/time_slice.py [--size 1080p|qcif|720p] [--refs N] [--modes 3,1,0,-1] [--range R]"""
+usage: python tools/time_slice.py [--size 1080p|qcif|720p] [--refs N] [--modes 3,1,0,-1] [--range R] [--frames F]
+Every timed call searches a NEW picture of a moving synthetic clip against the previous `refs` source frames (the first call starts from an
+empty state, the later ones from what the previous picture left -- the relaxation schedule's first guess); sweeps / passes per call are printed."""
 import argparse
 import ctypes as C
 import os
@@ -20,33 +22,37 @@ def main():
     ap.add_argument("--refs", type=int, default=1)
     ap.add_argument("--modes", default="3,1,0,-1")
     ap.add_argument("--range", type=int, default=32)
-    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=4)
     a = ap.parse_args()
     W, H = {"1080p": (1920, 1088), "720p": (1280, 720), "qcif": (176, 144), "2160p": (3840, 2160)}[a.size]
     pkg = ge._load_pkg()
     lib = pkg.load_library()
     rng = np.random.default_rng(3)
-    clip = synth_clip(rng, W, H, a.refs + 1)
+    nfr = a.frames
+    clip = synth_clip(rng, W, H, a.refs + nfr)
     ctx = pkg.Context(W, H, yuv_format=0, max_refs=a.refs, search_range=a.range)
-    for r in range(a.refs):
-        ctx.ref_upload(r, clip[a.refs - 1 - r])
-        ctx.interp_luma(r)
-    ctx.cur_upload(clip[a.refs])
     lam = int(65536 * np.sqrt(0.85 * 2 ** ((28 - 12) / 3.0)) + 0.5)
     for mode in [int(m) for m in a.modes.split(",")]:
         ctx.slice_state_reset()
-        ctx.epzs_colocated_upload(np.zeros((H // 4, W // 4, 2), np.int16))
-        p = slice_params(pkg, mode, a.range, a.refs, [lam] * 3, 10, W, H=H)
-        pocs = [2 * (a.refs - 1 - r) for r in range(a.refs)]
-        lib.jmhip_epzs_scales(p, 2 * a.refs, (C.c_int * a.refs)(*pocs), a.refs)
-        ts = []
-        for k in range(a.reps):
+        ts, sw = [], []
+        for f in range(a.refs, a.refs + nfr):
+            for r in range(a.refs):
+                ctx.ref_upload(r, clip[f - 1 - r])
+                ctx.interp_luma(r)
+            ctx.cur_upload(clip[f])
+            ctx.epzs_colocated_upload(np.zeros((H // 4, W // 4, 2), np.int16))
+            p = slice_params(pkg, mode, a.range, a.refs, [lam] * 3, 10, W, H=H)
+            pocs = [2 * (f - 1 - r) for r in range(a.refs)]
+            lib.jmhip_epzs_scales(p, 2 * f, (C.c_int * a.refs)(*pocs), a.refs)
+            ctx.sync()
             t0 = time.perf_counter()
             ctx.p_slice_search(p, download=False)
             ctx.sync()
             ts.append(time.perf_counter() - t0)
-        print("mode %2d  %s  refs %d  R %d:  %s ms per picture  (passes %d)  -> %.0f macroblocks/s" % (
-            mode, a.size, a.refs, a.range, " ".join("%.1f" % (t * 1e3) for t in ts), ctx.slice_passes(), (W // 16) * (H // 16) / min(ts)), flush=True)
+            sw.append(ctx.slice_passes())
+        print("mode %2d  %s  refs %d  R %d:  %s ms per picture  (sweeps/passes %s)  -> %.0f macroblocks/s (mean of pictures 2..)" % (
+            mode, a.size, a.refs, a.range, " ".join("%.1f" % (t * 1e3) for t in ts), " ".join(str(v) for v in sw),
+            (W // 16) * (H // 16) / (sum(ts[1:]) / max(1, len(ts) - 1))), flush=True)
     ctx.close()
 
 
