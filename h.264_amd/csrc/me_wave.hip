@@ -1375,7 +1375,7 @@ __device__ int mb_commit(int mbx, int mby)
   return __ballot(diff) != 0ull;
 }
 
-__global__ __launch_bounds__(64) void p_slice_kernel(const short *carry_slice_in, short *carry_slice_out)
+__global__ __launch_bounds__(64, 2) void p_slice_kernel(const short *carry_slice_in, short *carry_slice_out)
 {
   const int lane = threadIdx.x;
   const int row0 = D.p.mb_first / D.mbw, mby = row0 + blockIdx.x;
@@ -1429,7 +1429,7 @@ __global__ __launch_bounds__(64) void p_slice_kernel(const short *carry_slice_in
 // fixpoint is unique and equals what the coding-order walk produces; what the walk does in mbw + 2 mbh serial steps of one macroblock each,
 // the sweeps do with the whole GPU busy. A macroblock is re-evaluated only when a predecessor -- left, up-left, up, up-right, or the one before
 // it in coding order (img->all_mv) -- changed what it hands on in the previous sweep; the state of the previous picture is the first guess.
-__global__ __launch_bounds__(64) void p_slice_relax_kernel(const short *carry_slice_in)
+__global__ __launch_bounds__(64, 2) void p_slice_relax_kernel(const short *carry_slice_in)
 {
   const int lane = threadIdx.x, first = D.p.mb_first, last = first + D.p.mb_count - 1;
   for (int addr = first + blockIdx.x; addr <= last; addr += gridDim.x) {
@@ -1641,6 +1641,7 @@ extern "C" int jmhip_p_slice_search(jmhip_ctx *c, const jmhip_slice_params *prm,
       JM_HIP_CHECK(c, hipMemcpyAsync(flags, s->flags, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
       JM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
       settled = flags[2] == 0;
+      if (getenv("JMHIP_SLICE_TRACE")) fprintf(stderr, "sweep %d: %d macroblocks changed what they hand on\n", sweep, flags[2]);
     }
     if (settled)
       JM_HIP_CHECK(c, hipMemcpyAsync(s->carry_slice_next, s->carry_mb + (size_t)(prm->mb_first + prm->mb_count - 1) * WR * CARRY * 2, sizeof(short) * WR * CARRY * 2, hipMemcpyDeviceToDevice, c->stream));
