@@ -1445,9 +1445,15 @@ __global__ __launch_bounds__(64, 2) void p_slice_relax_kernel(const short *carry
     }
     if (!active) { if (lane == 0) D.chg_next[addr - first] = 0; continue; }
     all_mv_from_carry(addr == first ? carry_slice_in : D.carry_mb + (size_t)(addr - 1) * WR * CARRY * 2);
+#ifdef JMHIP_WAVE_PROF
+    const unsigned long long mb_t0 = __builtin_amdgcn_s_memtime();
+#endif
     mb_stage(mbx, mby);
     macroblock_low(mbx, mby, D.out + addr);
     const int changed = mb_commit(mbx, mby);
+#ifdef JMHIP_WAVE_PROF
+    if (lane == 0) { atomicAdd(&g_wave_prof[8], __builtin_amdgcn_s_memtime() - mb_t0); atomicAdd(&g_wave_prof[9], 1ull); }
+#endif
     if (lane == 0) { D.chg_next[addr - first] = (uint8_t)changed; if (changed) atomicAdd(D.n_changed, 1); }
     __syncthreads();
   }
@@ -1596,7 +1602,7 @@ extern "C" int jmhip_p_slice_search(jmhip_ctx *c, const jmhip_slice_params *prm,
   int relax_grid = 0;
   {
     const char *e = getenv("JMHIP_SLICE_SCHED");
-    if (!(e && !strcmp(e, "wave"))) relax_grid = exhaustive ? 1024 : 2048;
+    if (!(e && !strcmp(e, "wave"))) relax_grid = 2048;                                      // two waves per SIMD (256 VGPRs): all that can be resident
     if (const char *g = getenv("JMHIP_SLICE_GRID")) if (relax_grid) relax_grid = std::max(1, atoi(g));
   }
   if (exhaustive) {
