@@ -326,7 +326,7 @@ def per_partition_predictors(pkg, ctx, lam, prm, mbs):
     ctx.sync()
     return {"predictors": "JM's own, per partition (jmhip_p_slice_search, FullSearch)", "distinct_centres_per_mb": {"mean": round(float(distinct.mean()), 2), "max": int(distinct.max())},
             "me_int_ms": round(t["me_int"][0] / max(1, t["me_int"][1]), 4), "me_sub_ms": round(t["me_sub"][0] / max(1, t["me_sub"][1]), 4),
-            "note": "the fast kernel takes macroblocks with <= 8 distinct centres (one walk each), the union-window kernel the rest"}
+            "note": "one window walk per distinct centre (the union-window kernel only takes partial partition masks and ranges the fast kernel does not cover)"}
 
 
 def main():

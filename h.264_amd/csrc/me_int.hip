@@ -1380,7 +1380,7 @@ extern "C" void jmhip_partition_info(int p, int *blocktype, int *x4, int *y4, in
 }
 
 // host mirror of search_center (mv-search.c:752-762) to size the LDS window
-constexpr int FAST_MAX_CENTRES = 8;
+constexpr int FAST_MAX_CENTRES = JMHIP_NPART;  // one walk per distinct centre always: a single macroblock in the union-window kernel is a 0.5 ms serial chain
 
 // JMHIP_ME_KERNEL=single selects the one-lane-per-candidate kernel (2R+1 >= 64 only); default: the pair-lane kernel (2R+1 >= 32)
 static int me_use_pair_kernel()
