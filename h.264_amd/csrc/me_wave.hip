@@ -119,8 +119,10 @@ __device__ __forceinline__ int imin3(int a, int b, int c) { return min(a, min(b,
 // L.dist[k] = distortion of the bsx x bsy block at (bx, by) of the macroblock against the reference block whose origin is the padded
 // quarter-pel position (L.cx[k], L.cy[k]), k < n. metric 0: computeSAD(WP) (me_distortion.c:351/413), one origin clamp per block; metric 2:
 // computeSATD(WP) (:657/:734), origin clamp per 4x4 (t8: 8x8) sub-block. umv: ref_access_method.
-__device__ void eval_dist(const uint8_t *planes, int metric, int t8, int umv, int wp, int wpw, int wpo,
-                          int bx, int by, int bsx, int bsy, int n)
+// Three functions rather than one: a function that touches no callee-saved VGPR (v40 and up) has no save / restore frame, and the SAD path --
+// half of a macroblock's ~200 evaluation calls -- needs a dozen registers, the 8x8 Hadamard path over a hundred.
+#define EVAL_ARGS const uint8_t *planes, int umv, int wp, int wpw, int wpo, int bx, int by, int bsx, int bsy, int n
+__device__ __attribute__((noinline)) void eval_sad(EVAL_ARGS)
 {
   const int lane = threadIdx.x;
   const size_t psz = (size_t)D.Wp * D.Hp;
@@ -129,7 +131,7 @@ __device__ void eval_dist(const uint8_t *planes, int metric, int t8, int umv, in
   const unsigned long long ev_t0 = __builtin_amdgcn_s_memtime();
 #endif
   __syncthreads();
-  if (metric == 0) {
+
     const int rowdw = bsx >> 2, seg = rowdw * bsy, cpb = 64 / seg;
     const int d = lane % seg, row = d / rowdw, c4 = d - row * rowdw;
     const uint32_t curv = *reinterpret_cast<const uint32_t *>(&L.cur[by + row][bx + 4 * c4]);
@@ -158,10 +160,28 @@ __device__ void eval_dist(const uint8_t *planes, int metric, int t8, int umv, in
         if (k < n && d == 0) L.dist[k] = v;
       }
     }
-  } else {
+  __syncthreads();
+#ifdef JMHIP_WAVE_PROF
+  if (threadIdx.x == 0) { atomicAdd(&g_wave_prof[10], __builtin_amdgcn_s_memtime() - ev_t0); atomicAdd(&g_wave_prof[11], 1ull); atomicAdd(&g_wave_prof[12], (unsigned long long)n); }
+#endif
+}
+
+
+__device__ __attribute__((noinline)) void eval_satd4(EVAL_ARGS)
+{
+  const int lane = threadIdx.x;
+  const size_t psz = (size_t)D.Wp * D.Hp;
+  const int wpad = D.Wp - 17, hpad = D.Hp - 17;           // size_x_pad / size_y_pad, mbuffer.c:421-422
+#ifdef JMHIP_WAVE_PROF
+  const unsigned long long ev_t0 = __builtin_amdgcn_s_memtime();
+#endif
+  __syncthreads();
+  {
+    constexpr int t8 = 0;
+
     const int bs = t8 ? 8 : 4, nsx = bsx / bs, nsub = nsx * (bsy / bs), cpb = 64 / nsub;
     const int s = lane % nsub, sy = s / nsx, sx = s - sy * nsx;
-    if (!t8) {
+    {
       for (int base = 0; base < n; base += 4 * cpb) {        // four passes' loads in flight before the first is consumed
         uint32_t rv[4][4];
 #pragma unroll
@@ -202,7 +222,29 @@ __device__ void eval_dist(const uint8_t *planes, int metric, int t8, int umv, in
           if (k < n && s == 0) L.dist[k] = v;
         }
       }
-    } else
+    }
+  }
+  __syncthreads();
+#ifdef JMHIP_WAVE_PROF
+  if (threadIdx.x == 0) { atomicAdd(&g_wave_prof[10], __builtin_amdgcn_s_memtime() - ev_t0); atomicAdd(&g_wave_prof[11], 1ull); atomicAdd(&g_wave_prof[12], (unsigned long long)n); }
+#endif
+}
+
+
+__device__ __attribute__((noinline)) void eval_satd8(EVAL_ARGS)
+{
+  const int lane = threadIdx.x;
+  const size_t psz = (size_t)D.Wp * D.Hp;
+  const int wpad = D.Wp - 17, hpad = D.Hp - 17;           // size_x_pad / size_y_pad, mbuffer.c:421-422
+#ifdef JMHIP_WAVE_PROF
+  const unsigned long long ev_t0 = __builtin_amdgcn_s_memtime();
+#endif
+  __syncthreads();
+  {
+    constexpr int t8 = 1;
+
+    const int bs = t8 ? 8 : 4, nsx = bsx / bs, nsub = nsx * (bsy / bs), cpb = 64 / nsub;
+    const int s = lane % nsub, sy = s / nsx, sx = s - sy * nsx;
     for (int base = 0; base < n; base += cpb) {
       const int k = base + lane / nsub;
       int v = 0;
@@ -248,6 +290,14 @@ __device__ void eval_dist(const uint8_t *planes, int metric, int t8, int umv, in
 #ifdef JMHIP_WAVE_PROF
   if (threadIdx.x == 0) { atomicAdd(&g_wave_prof[10], __builtin_amdgcn_s_memtime() - ev_t0); atomicAdd(&g_wave_prof[11], 1ull); atomicAdd(&g_wave_prof[12], (unsigned long long)n); }
 #endif
+}
+
+
+__device__ __forceinline__ void eval_dist(const uint8_t *planes, int metric, int t8, int umv, int wp, int wpw, int wpo, int bx, int by, int bsx, int bsy, int n)
+{
+  if (metric == 0) eval_sad(planes, umv, wp, wpw, wpo, bx, by, bsx, bsy, n);
+  else if (!t8) eval_satd4(planes, umv, wp, wpw, wpo, bx, by, bsx, bsy, n);
+  else eval_satd8(planes, umv, wp, wpw, wpo, bx, by, bsx, bsy, n);
 }
 
 // ---------------------------------------------------------------------------------------------- neighbours and the predictor
