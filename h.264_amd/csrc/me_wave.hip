@@ -1117,7 +1117,9 @@ __device__ void find_skip_mv(int mbx, int mby)
 }
 
 // BlockMotionSearch, mv-search.c:560 (P slice, rdopt 0)
-__device__ int block_motion_search(int mbx, int mby, int ref, int mb_x, int mb_y, int bt, int search_range, jmhip_mb_inter *out)
+// SM: the slice's search mode as a compile-time constant -- one instantiation per mode keeps the other modes' walkers (and their registers)
+// out of this function, which is called 41 times per macroblock and reference
+template <int SM> __device__ int block_motion_search(int mbx, int mby, int ref, int mb_x, int mb_y, int bt, int search_range, jmhip_mb_inter *out)
 {
   const jmhip_slice_params &P = D.p;
   B.mbx = mbx; B.mby = mby; B.mb_x = mb_x; B.mb_y = mb_y; B.bt = bt; B.bsx = c_bsx[bt]; B.bsy = c_bsy[bt]; B.ref = ref;
@@ -1129,23 +1131,23 @@ __device__ int block_motion_search(int mbx, int mby, int ref, int mb_x, int mb_y
   const int start_hp = P.metric[0] != P.metric[1] ? 0 : 1;
   int mvx, mvy, min_mcost = INT_MAX;
   WPROF_T0;
-  mv_predictor(mbx, mby, ref, mb_x, mb_y, B.bsx, B.bsy, &B.pmx, &B.pmy, P.search_mode == JMHIP_SEARCH_UMHEX && P.umhex_dsr, bt, &search_range, nullptr);
+  mv_predictor(mbx, mby, ref, mb_x, mb_y, B.bsx, B.bsy, &B.pmx, &B.pmy, SM == JMHIP_SEARCH_UMHEX && P.umhex_dsr, bt, &search_range, nullptr);
   WPROF(0);
   const int R = search_range;
   if (D.debug & 2) { mvx = clampi((B.pmx + 2) >> 2, -R, R); mvy = clampi((B.pmy + 2) >> 2, -R, R); min_mcost = 1000; }
-  else if (P.search_mode == JMHIP_SEARCH_UMHEX) {
+  else if (SM == JMHIP_SEARCH_UMHEX) {
     mvx = B.pmx / 4; mvy = B.pmy / 4;
     mvx = clampi(mvx, -R, R); mvy = clampi(mvy, -R, R);
     mvx = clampi(mvx, -2047 + R, 2047 - R); mvy = clampi(mvy, P.level_mv_min + R, P.level_mv_max - R);
     min_mcost = umhex_pel(R, &mvx, &mvy, min_mcost);
     __syncthreads();                                                           // lane 0 wrote the cost map
-  } else if (P.search_mode == JMHIP_SEARCH_EPZS) {
+  } else if (SM == JMHIP_SEARCH_EPZS) {
     mvx = (B.pmx + 2) >> 2; mvy = (B.pmy + 2) >> 2;
     mvx = clampi(mvx, -R, R); mvy = clampi(mvy, -R, R);
     mvx = clampi(mvx, -2047 + R, 2047 - R); mvy = clampi(mvy, P.level_mv_min + R, P.level_mv_max - R);
     min_mcost = epzs_pel(mby * D.mbw + mbx, R, &mvx, &mvy);
     __syncthreads();                                                           // lane 0 wrote the row memories
-  } else if (P.search_mode == JMHIP_SEARCH_FASTFULL) {
+  } else if (SM == JMHIP_SEARCH_FASTFULL) {
     // the window of SetupFastFullPelSearch (me_fullfast.c:550-566): centred on the 16x16 predictor of this reference, found when the reference's
     // first block (the 16x16) was searched and kept in motion_cost[0][ref][0..2]
     if (bt == 1) {
@@ -1171,11 +1173,11 @@ __device__ int block_motion_search(int mbx, int mby, int ref, int mb_x, int mb_y
   mvx <<= 2; mvy <<= 2;
   // sub-pel :781-827
   bool do_sub = true;
-  if (P.search_mode == JMHIP_SEARCH_EPZS && ref > 0) do_sub = (2 * (long long)min_mcost < 7 * (long long)L.ep_sad[bt - 1][(B.pic_x >> 2) - (4 * mbx - 4)]);   // min_mcost < 3.5 * prevSad
+  if (SM == JMHIP_SEARCH_EPZS && ref > 0) do_sub = (2 * (long long)min_mcost < 7 * (long long)L.ep_sad[bt - 1][(B.pic_x >> 2) - (4 * mbx - 4)]);   // min_mcost < 3.5 * prevSad
   if (do_sub && !(D.debug & 1)) {
     if (!start_hp) min_mcost = INT_MAX;
-    if (P.search_mode == JMHIP_SEARCH_UMHEX && bt > 3) min_mcost = umhex_subpel(&mvx, &mvy, min_mcost);
-    else if (P.search_mode == JMHIP_SEARCH_EPZS && P.epzs_subpel_me) min_mcost = epzs_subpel(&mvx, &mvy, min_mcost);
+    if (SM == JMHIP_SEARCH_UMHEX && bt > 3) min_mcost = umhex_subpel(&mvx, &mvy, min_mcost);
+    else if (SM == JMHIP_SEARCH_EPZS && P.epzs_subpel_me) min_mcost = epzs_subpel(&mvx, &mvy, min_mcost);
     else min_mcost = subpel_full(&mvx, &mvy, min_mcost);
   }
   WPROF(2);
@@ -1215,7 +1217,7 @@ __device__ __forceinline__ void field_set(int by, int bx, int ref, int mvx, int 
 }
 
 // PartitionMotionSearch, mv-search.c:1378
-__device__ void partition_motion_search(int mbx, int mby, int bt, int block8, jmhip_mb_inter *out)
+template <int SM> __device__ void partition_motion_search(int mbx, int mby, int bt, int block8, jmhip_mb_inter *out)
 {
   const int8_t bx0[5][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 2, 0, 0}, {0, 2, 0, 2}};
   const int8_t by0[5][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 2, 0, 0}, {0, 0, 0, 0}, {0, 0, 2, 2}};
@@ -1229,7 +1231,7 @@ __device__ void partition_motion_search(int mbx, int mby, int bt, int block8, jm
     else range = P.search_range / ((min(ref, 1) + 1) * min(2, bt));
     int mc = 0;
     for (int v = by; v < by + sv0; v += sv) for (int h = bx; h < bx + sh0; h += sh) {
-      mc += block_motion_search(mbx, mby, ref, h << 2, v << 2, bt, range, out);
+      mc += block_motion_search<SM>(mbx, mby, ref, h << 2, v << 2, bt, range, out);
       const int mvx = L.all_mv[v * 4 + h][ref][bt][0], mvy = L.all_mv[v * 4 + h][ref][bt][1];
       for (int j = 0; j < sv; j++) for (int i = 0; i < sh; i++) field_set(mby * 4 + v + j, mbx * 4 + h + i, ref, mvx, mvy);
       __syncthreads();
@@ -1250,7 +1252,7 @@ __device__ __forceinline__ int list0_cost(int mode, int block, int *best_ref)
 __device__ __forceinline__ int refbits(int r) { return r == 0 ? 1 : (r < 3 ? 3 : 5); }       // mv-search.c:344-352, r <= 3
 
 // encode_one_macroblock_low (md_low.c:46), inter part, for one macroblock
-__device__ void macroblock_low(int mbx, int mby, jmhip_mb_inter *out)
+template <int SM> __device__ void macroblock_low(int mbx, int mby, jmhip_mb_inter *out)
 {
   const jmhip_slice_params &P = D.p;
   const int8_t psz[8][2] = {{4, 4}, {4, 4}, {4, 2}, {2, 4}, {2, 2}, {2, 1}, {1, 2}, {1, 1}};
@@ -1263,7 +1265,7 @@ __device__ void macroblock_low(int mbx, int mby, jmhip_mb_inter *out)
     int cost = 0;
     for (int block = 0; block < (mode == 1 ? 1 : 2); block++) {
       int best_ref = 0;
-      partition_motion_search(mbx, mby, mode, block, out);
+      partition_motion_search<SM>(mbx, mby, mode, block, out);
       cost += list0_cost(mode, block, &best_ref);
       if (mode == 1) {
         for (int b = 0; b < 16; b++) field_set(by0 + (b >> 2), bx0 + (b & 3), best_ref, L.all_mv[b][best_ref][1][0], L.all_mv[b][best_ref][1][1]);
@@ -1285,7 +1287,7 @@ __device__ void macroblock_low(int mbx, int mby, jmhip_mb_inter *out)
       for (int mode = 4; mode < 8; mode++) {
         if (!P.valid[mode]) continue;
         int best_ref = 0;
-        partition_motion_search(mbx, mby, mode, block, out);
+        partition_motion_search<SM>(mbx, mby, mode, block, out);
         int cost = list0_cost(mode, block, &best_ref);
         for (int j = 0; j < 2; j++) for (int i = 0; i < 2; i++) FREF(by0 + j0 + j, bx0 + i0 + i) = (int8_t)best_ref;
         __syncthreads();
@@ -1425,7 +1427,7 @@ __device__ int mb_commit(int mbx, int mby)
   return __ballot(diff) != 0ull;
 }
 
-__global__ __launch_bounds__(64, 2) void p_slice_kernel(const short *carry_slice_in, short *carry_slice_out)
+template <int SM> __global__ __launch_bounds__(64, 2) void p_slice_kernel(const short *carry_slice_in, short *carry_slice_out)
 {
   const int lane = threadIdx.x;
   const int row0 = D.p.mb_first / D.mbw, mby = row0 + blockIdx.x;
@@ -1455,7 +1457,7 @@ __global__ __launch_bounds__(64, 2) void p_slice_kernel(const short *carry_slice
 #ifdef JMHIP_WAVE_PROF
     const unsigned long long mb_t0 = __builtin_amdgcn_s_memtime();
 #endif
-    macroblock_low(mbx, mby, D.out + (mby * D.mbw + mbx));
+    macroblock_low<SM>(mbx, mby, D.out + (mby * D.mbw + mbx));
 #ifdef JMHIP_WAVE_PROF
     if (lane == 0) { atomicAdd(&g_wave_prof[8], __builtin_amdgcn_s_memtime() - mb_t0); atomicAdd(&g_wave_prof[9], 1ull); }
 #endif
@@ -1479,7 +1481,7 @@ __global__ __launch_bounds__(64, 2) void p_slice_kernel(const short *carry_slice
 // fixpoint is unique and equals what the coding-order walk produces; what the walk does in mbw + 2 mbh serial steps of one macroblock each,
 // the sweeps do with the whole GPU busy. A macroblock is re-evaluated only when a predecessor -- left, up-left, up, up-right, or the one before
 // it in coding order (img->all_mv) -- changed what it hands on in the previous sweep; the state of the previous picture is the first guess.
-__global__ __launch_bounds__(64, 2) void p_slice_relax_kernel(const short *carry_slice_in)
+template <int SM> __global__ __launch_bounds__(64, 2) void p_slice_relax_kernel(const short *carry_slice_in)
 {
   const int lane = threadIdx.x, first = D.p.mb_first, last = first + D.p.mb_count - 1;
   for (int addr = first + blockIdx.x; addr <= last; addr += gridDim.x) {
@@ -1499,7 +1501,7 @@ __global__ __launch_bounds__(64, 2) void p_slice_relax_kernel(const short *carry
     const unsigned long long mb_t0 = __builtin_amdgcn_s_memtime();
 #endif
     mb_stage(mbx, mby);
-    macroblock_low(mbx, mby, D.out + addr);
+    macroblock_low<SM>(mbx, mby, D.out + addr);
     const int changed = mb_commit(mbx, mby);
 #ifdef JMHIP_WAVE_PROF
     if (lane == 0) { atomicAdd(&g_wave_prof[8], __builtin_amdgcn_s_memtime() - mb_t0); atomicAdd(&g_wave_prof[9], 1ull); }
@@ -1690,7 +1692,12 @@ extern "C" int jmhip_p_slice_search(jmhip_ctx *c, const jmhip_slice_params *prm,
       JM_HIP_CHECK(c, hipMemsetAsync(s->flags, 0, sizeof(int) * 4, c->stream));
       D.first_sweep = sweep == 0; D.chg_prev = s->chg[sweep & 1]; D.chg_next = s->chg[(sweep + 1) & 1];
       JM_HIP_CHECK(c, hipMemcpyToSymbolAsync(HIP_SYMBOL(c_wave), &D, sizeof(D), 0, hipMemcpyHostToDevice, c->stream));
-      p_slice_relax_kernel<<<grid, 64, 0, c->stream>>>(s->carry_slice);
+      switch (prm->search_mode) {
+      case JMHIP_SEARCH_EPZS: p_slice_relax_kernel<JMHIP_SEARCH_EPZS><<<grid, 64, 0, c->stream>>>(s->carry_slice); break;
+      case JMHIP_SEARCH_UMHEX: p_slice_relax_kernel<JMHIP_SEARCH_UMHEX><<<grid, 64, 0, c->stream>>>(s->carry_slice); break;
+      case JMHIP_SEARCH_FASTFULL: p_slice_relax_kernel<JMHIP_SEARCH_FASTFULL><<<grid, 64, 0, c->stream>>>(s->carry_slice); break;
+      default: p_slice_relax_kernel<JMHIP_SEARCH_FULL><<<grid, 64, 0, c->stream>>>(s->carry_slice); break;
+      }
       JM_HIP_CHECK(c, hipGetLastError());
       s->passes++;
       int flags[4] = {0, 0, 1, 0};
@@ -1707,7 +1714,12 @@ extern "C" int jmhip_p_slice_search(jmhip_ctx *c, const jmhip_slice_params *prm,
     const int init_flags[4] = {0, 1 << 30, 0, 0};
     JM_HIP_CHECK(c, hipMemcpyAsync(s->flags, init_flags, sizeof(init_flags), hipMemcpyHostToDevice, c->stream));
     JM_HIP_CHECK(c, hipMemcpyToSymbolAsync(HIP_SYMBOL(c_wave), &D, sizeof(D), 0, hipMemcpyHostToDevice, c->stream));
-    p_slice_kernel<<<rows, 64, 0, c->stream>>>(s->carry_slice, s->carry_slice_next);
+    switch (prm->search_mode) {
+    case JMHIP_SEARCH_EPZS: p_slice_kernel<JMHIP_SEARCH_EPZS><<<rows, 64, 0, c->stream>>>(s->carry_slice, s->carry_slice_next); break;
+    case JMHIP_SEARCH_UMHEX: p_slice_kernel<JMHIP_SEARCH_UMHEX><<<rows, 64, 0, c->stream>>>(s->carry_slice, s->carry_slice_next); break;
+    case JMHIP_SEARCH_FASTFULL: p_slice_kernel<JMHIP_SEARCH_FASTFULL><<<rows, 64, 0, c->stream>>>(s->carry_slice, s->carry_slice_next); break;
+    default: p_slice_kernel<JMHIP_SEARCH_FULL><<<rows, 64, 0, c->stream>>>(s->carry_slice, s->carry_slice_next); break;
+    }
     JM_HIP_CHECK(c, hipGetLastError());
     s->passes++;
     int flags[4] = {0, 1 << 30, 0, 0};

@@ -321,18 +321,24 @@ void jmhip_umhex_setup(jmhip_slice_params *p, int dsr, int scale, int qp_n, int 
 
 /* State that outlives a slice (JM's file-static / global arrays): EPZSDistortion, EPZSMotion, img->all_mv of the last macroblock coded,
  * the UMHexagonS cost maps. jmhip_slice_state_reset zeroes it (start of a sequence). The picture-level LIST_0 arrays
- * (enc_picture->ref_idx / mv) are reset by the first slice of a picture (mb_first == 0). */
+ * (enc_picture->ref_idx / mv) are NOT reset between pictures: a macroblock only ever reads entries of macroblocks coded before it in the
+ * same slice, and the previous picture's field is the first guess of the relaxation schedule below. */
 int jmhip_slice_state_reset(jmhip_ctx *ctx);
 /* EPZS temporal predictors: the scaled co-located field EPZSSliceInit builds (EPZSCo_located->mv[LIST_0], src/me_epzs.c:986-1030),
  * [H/4][W/4][2] int16 quarter-pel, host array. Needed before jmhip_p_slice_search when epzs_temporal is set. */
 int jmhip_epzs_colocated_upload(jmhip_ctx *ctx, const int16_t *col_mv);
 /* Run one P slice on the current picture. results: host array of mb_count records (may be NULL: results stay on the device for
- * jmhip_slice_results_download / jmhip_slice_field_download). */
+ * jmhip_slice_results_download / jmhip_slice_field_download).
+ * Schedule: JM codes the macroblocks in raster order and each reads what its predecessors left (predictors, row memories). The device
+ * evaluates every macroblock of the slice at once and repeats until a sweep changes nothing; the dependencies are acyclic, so that fixpoint
+ * is unique and is JM's result. If the sweeps do not settle within a cap the coding-order wavefront finishes; environment
+ * JMHIP_SLICE_SCHED=wave uses the wavefront only, JMHIP_SLICE_SWEEPS=n sets the cap, JMHIP_SLICE_TRACE=1 prints the sweeps.
+ * One slice search at a time per device and process (the parameter block lives in __constant__ memory); the call synchronises. */
 int jmhip_p_slice_search(jmhip_ctx *ctx, const jmhip_slice_params *prm, jmhip_mb_inter *results);
 int jmhip_slice_results_download(jmhip_ctx *ctx, jmhip_mb_inter *results, int mb_first, int mb_count);
 /* The picture-level LIST_0 arrays: ref_idx [H/4][W/4] int8, mv [H/4][W/4][2] int16 (either may be NULL). */
 int jmhip_slice_field_download(jmhip_ctx *ctx, int8_t *ref_idx, int16_t *mv);
-/* passes the last jmhip_p_slice_search needed (1 unless EPZS row starts were mis-speculated) */
+/* sweeps (relaxation) plus passes (wavefront) the last jmhip_p_slice_search needed */
 int jmhip_slice_result_info(jmhip_ctx *ctx, int *passes);
 /* Hand the searched picture (every macroblock: all its slices searched) to the frame stage: the decided modes, the vector and the
  * reference slot of every 8x8 block become the inputs of jmhip_residual_frame(modes = NULL), which then runs LumaResidualCoding /
