@@ -18,8 +18,8 @@ constexpr int WR = JMHIP_SLICE_REFS;
 constexpr int MAXC = 128;                      // candidates per batch
 constexpr int CARRY = 5;
 constexpr int SURF_PLANES = 20;                // the sixteen 4x4 blocks + the four 8x8 blocks of a macroblock
-constexpr int SURF_MARGIN = 4;                 // FullSearch: the surface is built round the 16x16 centre, this much wider than the range
-constexpr int WIN_MAX = 96;                    // LDS reference window side: 2 * (33 + SURF_MARGIN) + 1 + 15 = 90                       // vectors of the previous macroblock EPZS may read per reference: 16x16 + four 8x8
+constexpr int SURF_MARGIN = 6;                 // FullSearch: the surface is built round the 16x16 centre, this much wider than the range
+constexpr int WIN_MAX = 96;                    // LDS reference window side: 2 * (33 + SURF_MARGIN) + 1 + 15 = 94                       // vectors of the previous macroblock EPZS may read per reference: 16x16 + four 8x8
 
 struct WaveDev {
   jmhip_slice_params p;
