@@ -11,6 +11,7 @@
 // predictor set, one pass of a refinement pattern, a hexagon ring, the cross, the 5 / 9 sub-pel points) is evaluated in full across the lanes
 // and the sequential accept / reject logic is replayed on the results.
 #include "me_common.h"
+#include <time.h>
 
 namespace {
 
@@ -66,7 +67,7 @@ struct Lds {
   int um_ref_cost[WR][8][16];                  // fastme_ref_cost[ref][blocktype][by][bx]
   int um_best_cost[8][4];                      // fastme_best_cost[blocktype - 1][pic_pix_x >> 2] (only ever read after being written by the same block)
   uint8_t um_sstate[52];                       // SearchState 7x7
-  int surf_c[WR][4];                           // per reference: surface centre (pels), half side, valid
+  int surf_c[2 * WR][5];                       // per surface slot (0: the macroblock's, 1: a partition's own) and reference: centre (pels), half side, valid, block rows
   // the macroblock's view of the picture-level state: staged once by mb_stage, used and updated in LDS, handed on by mb_commit.
   // Grid [y + 1][x + 1] of the 4x4 blocks x = -1..4, y = -1..3: the macroblock's own sixteen and the ring its predictors read (A, B, C, D)
   int mbx, mby;
@@ -473,33 +474,47 @@ __device__ int full_window(int cx, int cy, int R, int ffs, int *mvx, int *mvy)
   const int w16 = (lam * 16) >> 16;
   unsigned best = 0xffffffffu;
   __syncthreads();
-  for (int base = 0; base < npos; base += cpb) {
-    const int k = base + lane / seg;
-    int v = 0, dx = 0, dy = 0;
-    if (k < npos) {
-      dy = k / side - R; dx = k - (dy + R) * side - R;
-      int ix = B.pic_x + cx + dx + JMHIP_PAD, iy = B.pic_y + cy + dy + JMHIP_PAD;
-      ix = clampi(ix, 0, wpad); iy = clampi(iy, 0, hpad);
-      const uint8_t *p = B.planes + (size_t)(iy + row) * D.Wp + ix + 4 * c4;
-      uint32_t r, hi;
-      fetch_row(p, 4, &r, &hi);
-      if (B.wp) r = wp_apply4(r, B.wpw, B.wpo, D.p.wp_round, D.p.wp_denom);
-      v = (int)__builtin_amdgcn_sad_u8(r, curv, 0u);
-    }
-    int rowsum = v;                                                    // SAD of the first row (for the wrapped bound)
-    for (int o = 1; o < rowdw; o <<= 1) rowsum += __shfl_xor(rowsum, o);
-    for (int o = 1; o < seg; o <<= 1) v += __shfl_xor(v, o);
-    if (k < npos && d == 0) {
-      int mc = mv_cost(lam, ((cx + dx) << 2) - B.pmx, ((cy + dy) << 2) - B.pmy);
-      int tie = spiral_pos(dx, dy) + 1;
-      if (check00 && ((B.pic_x + cx + dx) << 2) == B.pic_x && ((B.pic_y + cy + dy) << 2) == B.pic_y) {
-        mc -= w16;
-        if (dx == 0 && dy == 0 && mc < 0) v = rowsum;                  // INT_MAX - (negative) wraps: computeSAD leaves after row 0
+  constexpr int NB = 8;                                                 // passes whose loads are in flight together (the loop is latency-bound)
+  for (int base = 0; base < npos; base += NB * cpb) {
+    uint32_t rr[NB];
+#pragma unroll
+    for (int u = 0; u < NB; u++) {
+      const int k = base + u * cpb + lane / seg;
+      rr[u] = 0;
+      if (k < npos) {
+        const int dy = k / side - R, dx = k - (dy + R) * side - R;
+        int ix = B.pic_x + cx + dx + JMHIP_PAD, iy = B.pic_y + cy + dy + JMHIP_PAD;
+        ix = clampi(ix, 0, wpad); iy = clampi(iy, 0, hpad);
+        uint32_t hi;
+        fetch_row(B.planes + (size_t)(iy + row) * D.Wp + ix + 4 * c4, 4, &rr[u], &hi);
       }
-      if (ffs && cx + dx == 0 && cy + dy == 0) tie = 0;                // pos_00 pre-check
-      const int cost = mc + v;                                          // may be slightly negative through the bonus
-      const unsigned key = ((unsigned)(cost + 4096) << TIE_BITS) | (unsigned)tie;
-      best = min(best, key);
+    }
+#pragma unroll
+    for (int u = 0; u < NB; u++) {
+      const int k = base + u * cpb + lane / seg;
+      if (base + u * cpb >= npos) break;
+      int v = 0, dx = 0, dy = 0;
+      if (k < npos) {
+        dy = k / side - R; dx = k - (dy + R) * side - R;
+        uint32_t r = rr[u];
+        if (B.wp) r = wp_apply4(r, B.wpw, B.wpo, D.p.wp_round, D.p.wp_denom);
+        v = (int)__builtin_amdgcn_sad_u8(r, curv, 0u);
+      }
+      int rowsum = v;                                                    // SAD of the first row (for the wrapped bound)
+      for (int o = 1; o < rowdw; o <<= 1) rowsum += __shfl_xor(rowsum, o);
+      for (int o = 1; o < seg; o <<= 1) v += __shfl_xor(v, o);
+      if (k < npos && d == 0) {
+        int mc = mv_cost(lam, ((cx + dx) << 2) - B.pmx, ((cy + dy) << 2) - B.pmy);
+        int tie = spiral_pos(dx, dy) + 1;
+        if (check00 && ((B.pic_x + cx + dx) << 2) == B.pic_x && ((B.pic_y + cy + dy) << 2) == B.pic_y) {
+          mc -= w16;
+          if (dx == 0 && dy == 0 && mc < 0) v = rowsum;                  // INT_MAX - (negative) wraps: computeSAD leaves after row 0
+        }
+        if (ffs && cx + dx == 0 && cy + dy == 0) tie = 0;                // pos_00 pre-check
+        const int cost = mc + v;                                          // may be slightly negative through the bonus
+        const unsigned key = ((unsigned)(cost + 4096) << TIE_BITS) | (unsigned)tie;
+        best = min(best, key);
+      }
     }
   }
   for (int o = 1; o < 64; o <<= 1) best = min(best, (unsigned)__shfl_xor((int)best, o));
@@ -516,12 +531,13 @@ __device__ int full_window(int cx, int cy, int R, int ffs, int *mvx, int *mvy)
 // SAD is independent of the predictor: once per (macroblock, reference) the SADs of the sixteen 4x4 blocks (and their 8x8 sums) are computed
 // for every displacement in a window round (scx, scy) and kept; every partition then finds its own argmin of (SAD + its own mv cost) over its
 // own window -- SetupFastFullPelSearch / SetupLargerBlocks (me_fullfast.c:491, :210) made macroblock-wide. lane <-> displacement.
-__device__ void surface_build(int scx, int scy, int Rs)
+// slot 1: the surface of ONE partition whose centre the macroblock's surface (slot 0) does not cover, block rows [y4lo, y4hi) only
+__device__ void surface_build(int scx, int scy, int Rs, int slot = 0, int y4lo = 0, int y4hi = 4)
 {
   const int lane = threadIdx.x, side = 2 * Rs + 1, wside = side + 15, n = side * side;
   const int ox = B.mbx * 16 + scx - Rs + JMHIP_PAD, oy = B.mby * 16 + scy - Rs + JMHIP_PAD;     // window origin in the padded integer plane
   __syncthreads();
-  for (int i = lane; i < wside * wside; i += 64) {
+  for (int i = lane + 4 * y4lo * wside; i < (4 * y4hi + side - 1) * wside; i += 64) {     // the window rows these block rows read
     const int wy = i / wside, wx = i - wy * wside;
     const int py = clampi(oy + wy, 0, D.Hp - 1), px = clampi(ox + wx, 0, D.Wp - 1);                // the ring replicates the edge: per-sample clamp == origin clamp
     int v = B.planes[(size_t)py * D.Wp + px];
@@ -529,13 +545,14 @@ __device__ void surface_build(int scx, int scy, int Rs)
     L.win[i] = (uint8_t)v;
   }
   __syncthreads();
-  uint16_t *sf = D.surf + ((size_t)blockIdx.x * D.p.num_refs + B.ref) * SURF_PLANES * D.surf_n;
+  uint16_t *sf = D.surf + (((size_t)blockIdx.x * 2 + slot) * D.p.num_refs + B.ref) * SURF_PLANES * D.surf_n;
   for (int k = lane; k < n; k += 64) {
     const int dy = k / side, dx = k - dy * side;
     unsigned s4[16];
 #pragma unroll
     for (int by = 0; by < 4; by++) {
       unsigned a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+      if (by < y4lo || by >= y4hi) { s4[by * 4] = s4[by * 4 + 1] = s4[by * 4 + 2] = s4[by * 4 + 3] = 0; continue; }
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const uint8_t *w = &L.win[(dy + by * 4 + r) * wside + dx];
@@ -560,16 +577,19 @@ __device__ void surface_build(int scx, int scy, int Rs)
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
-  L.surf_c[B.ref][0] = scx; L.surf_c[B.ref][1] = scy; L.surf_c[B.ref][2] = Rs; L.surf_c[B.ref][3] = 1;
+  int *sc = L.surf_c[slot * WR + B.ref];
+  sc[0] = scx; sc[1] = scy; sc[2] = Rs; sc[3] = 1; sc[4] = ((1 << y4hi) - 1) & ~((1 << y4lo) - 1);
 }
 
 // argmin of SAD + mv cost over the (2R+1)^2 window round (cx, cy) from the surface of B.ref. Returns INT_MIN when the window is not covered.
-__device__ int surface_search(int cx, int cy, int R, int ffs, int *mvx, int *mvy)
+__device__ int surface_search(int cx, int cy, int R, int ffs, int *mvx, int *mvy, int slot = 0)
 {
-  const int scx = L.surf_c[B.ref][0], scy = L.surf_c[B.ref][1], Rs = L.surf_c[B.ref][2];
-  if (!L.surf_c[B.ref][3] || cx - R < scx - Rs || cx + R > scx + Rs || cy - R < scy - Rs || cy + R > scy + Rs) return INT_MIN;
+  const int *sc = L.surf_c[slot * WR + B.ref];
+  const int scx = sc[0], scy = sc[1], Rs = sc[2];
+  const int rows = ((1 << ((B.mb_y + B.bsy) >> 2)) - 1) & ~((1 << (B.mb_y >> 2)) - 1);
+  if (!sc[3] || (sc[4] & rows) != rows || cx - R < scx - Rs || cx + R > scx + Rs || cy - R < scy - Rs || cy + R > scy + Rs) return INT_MIN;
   const int lane = threadIdx.x, side = 2 * R + 1, npos = side * side, sside = 2 * Rs + 1, lam = D.p.lambda_mf[0];
-  const uint16_t *sf = D.surf + ((size_t)blockIdx.x * D.p.num_refs + B.ref) * SURF_PLANES * D.surf_n;
+  const uint16_t *sf = D.surf + (((size_t)blockIdx.x * 2 + slot) * D.p.num_refs + B.ref) * SURF_PLANES * D.surf_n;
   const int x4 = B.mb_x >> 2, y4 = B.mb_y >> 2, w4 = B.bsx >> 2, h4 = B.bsy >> 2;
   // the planes this partition sums: whole 8x8 blocks where it covers them, 4x4 blocks otherwise
   int pl[4], npl = 0;
@@ -1166,7 +1186,11 @@ template <int SM> __device__ int block_motion_search(int mbx, int mby, int ref, 
     cx = clampi(cx, -2047 + R, 2047 - R); cy = clampi(cy, P.level_mv_min + R, P.level_mv_max - R);
     if (bt == 1) surface_build(cx, cy, min(R + SURF_MARGIN, 33 + SURF_MARGIN));     // the other partitions' centres are usually within the margin
     min_mcost = surface_search(cx, cy, R, 0, &mvx, &mvy);
-    if (min_mcost == INT_MIN) min_mcost = full_window(cx, cy, R, 0, &mvx, &mvy);      // a centre the surface does not cover: direct evaluation
+    if (min_mcost == INT_MIN) {                                          // a centre the macroblock's surface does not cover: the partition's own surface
+      min_mcost = surface_search(cx, cy, R, 0, &mvx, &mvy, 1);
+      if (min_mcost == INT_MIN) { surface_build(cx, cy, R, 1, mb_y >> 2, (mb_y + B.bsy) >> 2); min_mcost = surface_search(cx, cy, R, 0, &mvx, &mvy, 1); }
+      if (min_mcost == INT_MIN) min_mcost = full_window(cx, cy, R, 0, &mvx, &mvy);
+    }
   }
   WPROF(1);
   if (threadIdx.x == 0) { out->mv_int[ref][pi][0] = (int16_t)mvx; out->mv_int[ref][pi][1] = (int16_t)mvy; out->cost_int[ref][pi] = min_mcost; }
@@ -1259,7 +1283,7 @@ template <int SM> __device__ void macroblock_low(int mbx, int mby, jmhip_mb_inte
   const int bx0 = mbx * 4, by0 = mby * 4;
   int best_mode = 1, min_cost = INT_MAX;
   int l0ref[5][4] = {{0}}, b8m[4] = {0, 0, 0, 0};
-  for (int r = 0; r < WR; r++) L.surf_c[r][3] = 0;
+  for (int r = 0; r < 2 * WR; r++) L.surf_c[r][3] = 0;
   for (int mode = 1; mode < 4; mode++) {
     if (!P.valid[mode]) continue;
     int cost = 0;
@@ -1663,7 +1687,7 @@ extern "C" int jmhip_p_slice_search(jmhip_ctx *c, const jmhip_slice_params *prm,
     if (s->surf_rows < slots || s->surf_n < n || s->surf_refs < prm->num_refs) {
       if (s->surf) JM_HIP_CHECK(c, hipFree(s->surf));
       s->surf = nullptr; s->surf_rows = 0;
-      if (hipMalloc((void **)&s->surf, sizeof(uint16_t) * slots * prm->num_refs * SURF_PLANES * n) != hipSuccess) return jm_fail(c, JMHIP_ERR_NOMEM, "SAD surfaces of the slice search");
+      if (hipMalloc((void **)&s->surf, sizeof(uint16_t) * slots * 2 * prm->num_refs * SURF_PLANES * n) != hipSuccess) return jm_fail(c, JMHIP_ERR_NOMEM, "SAD surfaces of the slice search");
       s->surf_rows = slots; s->surf_n = n; s->surf_refs = prm->num_refs;
     }
   }
@@ -1704,7 +1728,13 @@ extern "C" int jmhip_p_slice_search(jmhip_ctx *c, const jmhip_slice_params *prm,
       JM_HIP_CHECK(c, hipMemcpyAsync(flags, s->flags, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
       JM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
       settled = flags[2] == 0;
-      if (getenv("JMHIP_SLICE_TRACE")) fprintf(stderr, "sweep %d: %d macroblocks changed what they hand on\n", sweep, flags[2]);
+      if (getenv("JMHIP_SLICE_TRACE")) {
+        static double t_last = 0.0;
+        struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+        const double t_now = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+        fprintf(stderr, "sweep %d: %d macroblocks changed what they hand on (%.2f ms since the previous line)\n", sweep, flags[2], t_now - t_last);
+        t_last = t_now;
+      }
     }
     if (settled)
       JM_HIP_CHECK(c, hipMemcpyAsync(s->carry_slice_next, s->carry_mb + (size_t)(prm->mb_first + prm->mb_count - 1) * WR * CARRY * 2, sizeof(short) * WR * CARRY * 2, hipMemcpyDeviceToDevice, c->stream));
