@@ -73,18 +73,20 @@ __global__ __launch_bounds__(64) void mc_kernel(FrameDev F, const jmhip_me_mb *_
     // with the 8x8 transform LumaPrediction is called per 8x8 block (macroblock.c:1143): the UMV clamp then applies to the
     // 8x8 block's origin and this 4x4 block sits at its offset inside it
     const int t8 = s_mode.pad[0] ? 1 : 0, ox4 = t8 ? (x4 & 1) * 4 : 0, oy4 = t8 ? (y4 & 1) * 4 : 0;
-    const int xq = ((mbx * 16 + 4 * x4 - ox4) << 2) + 4 * JMHIP_PAD + s_mv[tid][0];   // pic_opix_x + mv, macroblock.c:851
-    const int yq = ((mby * 16 + 4 * y4 - oy4) << 2) + 4 * JMHIP_PAD + s_mv[tid][1];
-    const int xpos = clampi(xq >> 2, 0, F.Wp - 1 - 16) + ox4, ypos = clampi(yq >> 2, 0, F.Hp - 1 - 16) + oy4;   // UMVLine4X, refbuf.c:37
-    const int slot = s_ref[2 * (y4 >> 1) + (x4 >> 1)];
-    const uint8_t *src = F.ref_sub[slot] + (size_t)((yq & 3) * 4 + (xq & 3)) * F.Wp * F.Hp + (size_t)ypos * F.Wp + xpos;
+    const int bqx = ((mbx * 16 + 4 * x4 - ox4) << 2) + 4 * JMHIP_PAD, bqy = ((mby * 16 + 4 * y4 - oy4) << 2) + 4 * JMHIP_PAD;
+    const int xq = bqx + s_mv[tid][0], yq = bqy + s_mv[tid][1];                            // pic_opix_x + mv, macroblock.c:851
+    const int b8 = 2 * (y4 >> 1) + (x4 >> 1), slot = s_ref[b8];
+    int pdir = 0, slot1 = 0, xq1 = 0, yq1 = 0;                                               // the second list of a B macroblock
+    if (F.bi) { const jmhip_mb_bipred &bm = F.bi[i]; pdir = bm.pdir[b8]; slot1 = bm.ref1[b8]; xq1 = bqx + bm.mv1[tid][0]; yq1 = bqy + bm.mv1[tid][1]; }
 #pragma unroll
     for (int rr = 0; rr < 4; rr++) {
-      uint32_t pv = fetch4(src + (size_t)rr * F.Wp);
-      if (F.wp_on) {
+      const uint32_t v0 = pdir != 1 ? luma_row4(F, slot, xq, yq, ox4, oy4, rr) : 0u;
+      const uint32_t v1 = pdir != 0 ? luma_row4(F, slot1, xq1, yq1, ox4, oy4, rr) : 0u;
+      uint32_t pv = v0;
+      if (F.wp_on || pdir) {
         uint32_t w = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) w |= (uint32_t)clampi((((int)F.wp_w[slot][0] * (int)((pv >> (8 * k)) & 255u) + F.wp_lround) >> F.wp_ldenom) + F.wp_o[slot][0], 0, 255) << (8 * k);
+        for (int k = 0; k < 4; k++) w |= (uint32_t)mix_pred(F, pdir, slot, slot1, 0, (int)((v0 >> (8 * k)) & 255u), (int)((v1 >> (8 * k)) & 255u)) << (8 * k);
         pv = w;
       }
       *reinterpret_cast<uint32_t *>(&jy.pred[4 * y4 + rr][4 * x4]) = pv;
@@ -103,35 +105,17 @@ __global__ __launch_bounds__(64) void mc_kernel(FrameDev F, const jmhip_me_mb *_
       const int j = q / (F.mb_cw / 2), ic = 2 * (q - j * (F.mb_cw / 2));
       const int by4 = j >> rsy, bx4 = ic >> rsx;                     // luma 4x4 block indices
       const short *mv = s_mv[by4 * 4 + bx4];
-      const int ii = ((ic + mbx * F.mb_cw) << F.shift_x) + 4 * JMHIP_PAD + mv[0];
-      const int jj = ((j + mby * F.mb_ch) << F.shift_y) + 4 * JMHIP_PAD + mv[1];
-      const int width_pad_cr = F.Wcp - 1 - F.mb_cw, height_pad_cr = F.Hcp - 1 - F.mb_ch;      // mbuffer.c:425-426
-      const int xpos = clampi(ii >> F.shift_x, 0, width_pad_cr), ypos = clampi(jj >> F.shift_y, 0, height_pad_cr);
+      const int bii = ((ic + mbx * F.mb_cw) << F.shift_x) + 4 * JMHIP_PAD, bjj = ((j + mby * F.mb_ch) << F.shift_y) + 4 * JMHIP_PAD;
       jmhip_tq_job &jc = jobs_c[2 * i + uv];
-      const int slot = s_ref[2 * (by4 >> 1) + (bx4 >> 1)];
-      int p0, p1;
-      if (F.fly) {
-        // The value plane (jj & mask_y, ii & mask_x) of getSubImagesChroma holds at padded position (ypos, xpos) and (ypos, xpos + 1)
-        // (img_chroma.c:412-420, interp_chroma.hip): weights (8-k)(8-l), (8-k)l, k(8-l), kl on the four neighbours with the source
-        // coordinates clamped to the picture. The clamp above keeps xpos + 1 and ypos off the plane's never-written last column / row,
-        // so the planes' zero cells cannot be asked for. Same integers as the planes, no 64x copy of the chroma picture in HBM.
-        const uint8_t *pic = uv ? F.ref_v[slot] : F.ref_u[slot];
-        const int k = (jj & F.mask_y) * F.mul_y, l = (ii & F.mask_x) * F.mul_x;
-        const uint8_t *r0 = pic + (size_t)clampi(ypos - F.pad_cy, 0, F.Hc - 1) * F.Wc;
-        const uint8_t *r1 = pic + (size_t)clampi(ypos - F.pad_cy + 1, 0, F.Hc - 1) * F.Wc;
-        const int xa = clampi(xpos - F.pad_cx, 0, F.Wc - 1), xb = clampi(xpos - F.pad_cx + 1, 0, F.Wc - 1), xc = clampi(xpos - F.pad_cx + 2, 0, F.Wc - 1);
-        const int a0 = r0[xa], a1 = r0[xb], a2 = r0[xc], b0 = r1[xa], b1 = r1[xb], b2 = r1[xc];
-        const int h00 = a0 * (8 - l) + a1 * l, h01 = a1 * (8 - l) + a2 * l, h10 = b0 * (8 - l) + b1 * l, h11 = b1 * (8 - l) + b2 * l;
-        p0 = (h00 * (8 - k) + h10 * k + 32) >> 6; p1 = (h01 * (8 - k) + h11 * k + 32) >> 6;
-      } else {
-        const uint8_t *planes = (uv ? F.ref_cr : F.ref_cb)[slot];
-        const uint8_t *src = planes + (size_t)((jj & F.mask_y) * F.sub_x + (ii & F.mask_x)) * F.Wcp * F.Hcp + (size_t)ypos * F.Wcp + xpos;
-        p0 = src[0]; p1 = src[1];
-      }
-      if (F.wp_on) {
-        p0 = clampi((((int)F.wp_w[slot][uv + 1] * p0 + F.wp_cround) >> F.wp_cdenom) + F.wp_o[slot][uv + 1], 0, 255);
-        p1 = clampi((((int)F.wp_w[slot][uv + 1] * p1 + F.wp_cround) >> F.wp_cdenom) + F.wp_o[slot][uv + 1], 0, 255);
-      }
+      const int b8 = 2 * (by4 >> 1) + (bx4 >> 1), slot = s_ref[b8];
+      int pdir = 0, slot1 = 0;
+      if (F.bi) { pdir = F.bi[i].pdir[b8]; slot1 = F.bi[i].ref1[b8]; }
+      // a sample of plane (jj & mask_y, ii & mask_x) of getSubImagesChroma at the clamped position: from the planes, or -- when they were not
+      // built -- the same value computed from the integer chroma picture (chroma_pair, frame_common.h; img_chroma.c:412-420)
+      int p0 = 0, p1 = 0, q0 = 0, q1 = 0;
+      if (pdir != 1) chroma_pair(F, slot, uv, bii + mv[0], bjj + mv[1], &p0, &p1);
+      if (pdir != 0) { const short *m1 = F.bi[i].mv1[by4 * 4 + bx4]; chroma_pair(F, slot1, uv, bii + m1[0], bjj + m1[1], &q0, &q1); }
+      if (F.wp_on || pdir) { p0 = mix_pred(F, pdir, slot, slot1, uv + 1, p0, q0); p1 = mix_pred(F, pdir, slot, slot1, uv + 1, p1, q1); }
       // ic is even: the two samples go out as one 16-bit store
       *reinterpret_cast<uint16_t *>(&jc.pred[j][ic]) = (uint16_t)(p0 | (p1 << 8));
       const uint8_t *cs = (uv ? F.cur_v : F.cur_u) + (size_t)(mby * F.mb_ch + j) * F.Wc + mbx * F.mb_cw + ic;
@@ -253,6 +237,32 @@ extern "C" int jmhip_frame_wp_set(jmhip_ctx *c, const jmhip_frame_wp *wp)
   return JMHIP_OK;
 }
 
+extern "C" int jmhip_frame_bipred_set(jmhip_ctx *c, const jmhip_mb_bipred *bi, int n, const jmhip_frame_bw *bw)
+{
+  if (!c) return JMHIP_ERR_ARG;
+  if (!bi) { c->fr_bi_n = 0; return JMHIP_OK; }
+  if (n <= 0) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_frame_bipred_set: n");
+  for (int i = 0; i < n; i++)
+    for (int k = 0; k < 4; k++) {
+      if (bi[i].pdir[k] < 0 || bi[i].pdir[k] > 2) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_frame_bipred_set: prediction direction 0..2");
+      if (bi[i].pdir[k] && (bi[i].ref1[k] < 0 || bi[i].ref1[k] >= 4 || bi[i].ref1[k] >= (int)c->refs.size() || !c->refs[bi[i].ref1[k]].has_luma_sub))
+        return jm_fail(c, JMHIP_ERR_ARG, "jmhip_frame_bipred_set: list-1 reference slot 0..3 with quarter-pel planes (jmhip_interp_luma)");
+    }
+  JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
+  if (c->fr_bi_capacity < n) {
+    if (c->fr_bi) JM_HIP_CHECK(c, hipFree(c->fr_bi));
+    c->fr_bi = nullptr; c->fr_bi_capacity = 0;
+    if (hipMalloc(&c->fr_bi, sizeof(jmhip_mb_bipred) * (size_t)n) != hipSuccess) return jm_fail(c, JMHIP_ERR_NOMEM, "second-list array of the frame stage");
+    c->fr_bi_capacity = n;
+  }
+  JM_HIP_CHECK(c, hipMemcpyAsync(c->fr_bi, bi, sizeof(jmhip_mb_bipred) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+  JM_HIP_CHECK(c, hipStreamSynchronize(c->stream));             // caller-owned array
+  c->fr_bi_n = n; c->fr_bi_mask = 0;
+  for (int i = 0; i < n; i++) for (int k = 0; k < 4; k++) if (bi[i].pdir[k]) c->fr_bi_mask |= 1u << bi[i].ref1[k];
+  if (bw) c->fr_bw = *bw; else memset(&c->fr_bw, 0, sizeof(c->fr_bw));
+  return JMHIP_OK;
+}
+
 extern "C" int jmhip_residual_frame(jmhip_ctx *c, const jmhip_mb_mode *modes, const jmhip_quant quants[3])
 {
   return jmhip_residual_frame_q(c, modes, quants, 3);
@@ -289,8 +299,9 @@ extern "C" int jmhip_residual_frame_q(jmhip_ctx *c, const jmhip_mb_mode *modes, 
   // chroma prediction reads the eighth-pel planes when every used reference has them (JM's ChromaMCBuffer = 1 layout); otherwise the
   // same sample values are computed in mc_kernel from the integer chroma pictures (reference slots 0..3)
   bool chroma_fly = false;
+  const unsigned used_refs = c->me_ref_mask | (c->fr_bi_n ? c->fr_bi_mask : 0u);      // list 0 of the search stage, list 1 of jmhip_frame_bipred_set
   for (size_t k = 0; k < c->refs.size(); k++)
-    if ((c->me_ref_mask >> k) & 1) {
+    if ((used_refs >> k) & 1) {
       if (!c->refs[k].has_luma_sub) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_residual_frame: quarter-pel planes of a used reference not built (jmhip_interp_luma)");
       if (c->Wc && !c->refs[k].has_cr_sub) {
         if (k >= 4 || !c->refs[k].has_pic) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_residual_frame: chroma planes of a used reference not built (jmhip_interp_chroma)");
@@ -321,6 +332,15 @@ extern "C" int jmhip_residual_frame_q(jmhip_ctx *c, const jmhip_mb_mode *modes, 
   F.fly = chroma_fly ? 1 : 0; F.mul_x = c->cg.mul_x; F.mul_y = c->cg.mul_y; F.pad_cx = c->cg.pad_x; F.pad_cy = c->cg.pad_y;
   for (int k = 0; k < 4; k++) { F.ref_u[k] = k < (int)c->refs.size() ? c->refs[k].u : nullptr; F.ref_v[k] = k < (int)c->refs.size() ? c->refs[k].v : nullptr; }
   F.blk_ref = c->fr_from_slices ? (const int8_t *)c->fr_blk_ref : nullptr;
+  F.bi = nullptr;
+  if (c->fr_bi_n) {
+    if (c->fr_bi_n != n) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_residual_frame: jmhip_frame_bipred_set was given another number of macroblocks");
+    F.bi = (const jmhip_mb_bipred *)c->fr_bi;
+    for (int a = 0; a < 4; a++) for (int q = 0; q < 3; q++) {
+      F.bu1[a][q] = c->fr_bw.weight1[a][q]; F.bo1[a][q] = c->fr_bw.offset1[a][q];
+      for (int b = 0; b < 4; b++) { F.bw0[a][b][q] = c->fr_bw.w0[a][b][q]; F.bw1[a][b][q] = c->fr_bw.w1[a][b][q]; }
+    }
+  }
   F.wp_on = c->fr_wp.enable ? 1 : 0; F.wp_lround = c->fr_wp.luma_round; F.wp_ldenom = c->fr_wp.luma_denom; F.wp_cround = c->fr_wp.chroma_round; F.wp_cdenom = c->fr_wp.chroma_denom;
   for (int k = 0; k < 16; k++) for (int q = 0; q < 3; q++) { F.wp_w[k][q] = c->fr_wp.weight[k][q]; F.wp_o[k][q] = c->fr_wp.offset[k][q]; }
 

@@ -34,6 +34,8 @@ extern "C" int jmhip_sizeof(int which)
   case 17: return (int)sizeof(jmhip_slice_params);
   case 18: return (int)sizeof(jmhip_mb_inter);
   case 19: return (int)sizeof(jmhip_frame_wp);
+  case 20: return (int)sizeof(jmhip_mb_bipred);
+  case 21: return (int)sizeof(jmhip_frame_bw);
   default: return -1;
   }
 }
@@ -116,7 +118,7 @@ extern "C" void jmhip_ctx_destroy(jmhip_ctx *c)
   (void)hipFree(c->cur_own[0]); (void)hipFree(c->cur_own[1]); (void)hipFree(c->cur_own[2]);
   (void)hipFree(c->stage_dev); (void)hipFree(c->me_jobs_dev); (void)hipFree(c->me_res_dev); (void)hipFree(c->ref_ptrs_dev); (void)hipFree(c->me_idx_dev); (void)hipFree(c->surf_dev); (void)hipFree(c->surf_jobs_dev);
   (void)hipFree(c->tq_jobs_dev); (void)hipFree(c->tq_res_dev); (void)hipFree(c->tq_quant_dev);
-  (void)hipFree(c->fr_rec); (void)hipFree(c->fr_blk_ref); (void)hipFree(c->fr_jobs_y); (void)hipFree(c->fr_jobs_c); (void)hipFree(c->fr_res_y); (void)hipFree(c->fr_res_c);
+  (void)hipFree(c->fr_bi); (void)hipFree(c->fr_rec); (void)hipFree(c->fr_blk_ref); (void)hipFree(c->fr_jobs_y); (void)hipFree(c->fr_jobs_c); (void)hipFree(c->fr_res_y); (void)hipFree(c->fr_res_c);
   jm_slice_state_free(c);
   (void)hipFree(c->dbk_dev); (void)hipFree(c->fr_quant); (void)hipFree(c->fr_modes); (void)hipFree(c->rec_y); (void)hipFree(c->rec_u); (void)hipFree(c->rec_v);
   for (auto &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }

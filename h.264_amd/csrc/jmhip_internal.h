@@ -55,6 +55,8 @@ struct jmhip_ctx {
   bool fr_fused = false;                              // the last jmhip_residual_frame took the fused kernel: results live in fr_rec
   void *fr_blk_ref = nullptr;                         // [n][4] reference slot per 8x8 block (frame stage fed from the slice search)
   bool fr_from_slices = false;                        // modes + per-block references of the frame stage were left on the device by jmhip_slice_to_frame
+  void *fr_bi = nullptr; int fr_bi_n = 0, fr_bi_capacity = 0; unsigned fr_bi_mask = 0;   // second list of B macroblocks (jmhip_frame_bipred_set), device array
+  jmhip_frame_bw fr_bw{};
   jmhip_frame_wp fr_wp{};                             // explicit weighted prediction of the frame stage (enable = 0: off)
   jmhip_quant fr_quant_host[4];
   uint8_t *rec_y = nullptr, *rec_u = nullptr, *rec_v = nullptr;

@@ -738,29 +738,14 @@ __global__ __launch_bounds__(64) void frame_fused_kernel(FrameDev F, const jmhip
     const int uv = tt >> 5, q = tt & 31, j = q >> 2, ic = 2 * (q & 3);
     const int by4 = j >> 1, bx4 = ic >> 1;
     const short *mv = s_mv[h][by4 * 4 + bx4];
-    const int ii = ((ic + mbx * 8) << 3) + 4 * JMHIP_PAD + mv[0];
-    const int jj = ((j + mby * 8) << 3) + 4 * JMHIP_PAD + mv[1];
-    const int xpos = clampi(ii >> 3, 0, F.Wcp - 1 - 8), ypos = clampi(jj >> 3, 0, F.Hcp - 1 - 8);
-    const int slot = s_ref[h][2 * (by4 >> 1) + (bx4 >> 1)];
-    int p0, p1;
-    if (F.fly) {
-      const uint8_t *pic = uv ? F.ref_v[slot] : F.ref_u[slot];
-      const int k = (jj & 7) * F.mul_y, lx = (ii & 7) * F.mul_x;
-      const uint8_t *r0 = pic + (size_t)clampi(ypos - F.pad_cy, 0, F.Hc - 1) * F.Wc;
-      const uint8_t *r1 = pic + (size_t)clampi(ypos - F.pad_cy + 1, 0, F.Hc - 1) * F.Wc;
-      const int xa = clampi(xpos - F.pad_cx, 0, F.Wc - 1), xb = clampi(xpos - F.pad_cx + 1, 0, F.Wc - 1), xc = clampi(xpos - F.pad_cx + 2, 0, F.Wc - 1);
-      const int a0 = r0[xa], a1 = r0[xb], a2 = r0[xc], b0 = r1[xa], b1 = r1[xb], b2 = r1[xc];
-      const int h00 = a0 * (8 - lx) + a1 * lx, h01 = a1 * (8 - lx) + a2 * lx, h10 = b0 * (8 - lx) + b1 * lx, h11 = b1 * (8 - lx) + b2 * lx;
-      p0 = (h00 * (8 - k) + h10 * k + 32) >> 6; p1 = (h01 * (8 - k) + h11 * k + 32) >> 6;
-    } else {
-      const uint8_t *planes = (uv ? F.ref_cr : F.ref_cb)[slot];
-      const uint8_t *src = planes + (size_t)((jj & 7) * F.sub_x + (ii & 7)) * F.Wcp * F.Hcp + (size_t)ypos * F.Wcp + xpos;
-      p0 = src[0]; p1 = src[1];
-    }
-    if (F.wp_on) {
-      p0 = clampi((((int)F.wp_w[slot][uv + 1] * p0 + F.wp_cround) >> F.wp_cdenom) + F.wp_o[slot][uv + 1], 0, 255);
-      p1 = clampi((((int)F.wp_w[slot][uv + 1] * p1 + F.wp_cround) >> F.wp_cdenom) + F.wp_o[slot][uv + 1], 0, 255);
-    }
+    const int bii = ((ic + mbx * 8) << 3) + 4 * JMHIP_PAD, bjj = ((j + mby * 8) << 3) + 4 * JMHIP_PAD;
+    const int b8 = 2 * (by4 >> 1) + (bx4 >> 1), slot = s_ref[h][b8];
+    int pdir = 0, slot1 = 0;
+    if (F.bi) { const jmhip_mb_bipred &bm = F.bi[mb_of(h)]; pdir = bm.pdir[b8]; slot1 = bm.ref1[b8]; }
+    int p0 = 0, p1 = 0, q0 = 0, q1 = 0;
+    if (pdir != 1) chroma_pair(F, slot, uv, bii + mv[0], bjj + mv[1], &p0, &p1);
+    if (pdir != 0) { const short *m1 = F.bi[mb_of(h)].mv1[by4 * 4 + bx4]; chroma_pair(F, slot1, uv, bii + m1[0], bjj + m1[1], &q0, &q1); }
+    if (F.wp_on || pdir) { p0 = mix_pred(F, pdir, slot, slot1, uv + 1, p0, q0); p1 = mix_pred(F, pdir, slot, slot1, uv + 1, p1, q1); }
     *reinterpret_cast<uint16_t *>(&s_pc[h][uv][j][ic]) = (uint16_t)(p0 | (p1 << 8));
     const uint8_t *cs = (uv ? F.cur_v : F.cur_u) + (size_t)(mby * 8 + j) * F.Wc + mbx * 8 + ic;
     *reinterpret_cast<uint16_t *>(&s_sc[h][uv][j][ic]) = *reinterpret_cast<const uint16_t *>(cs);
@@ -780,18 +765,19 @@ __global__ __launch_bounds__(64) void frame_fused_kernel(FrameDev F, const jmhip
     int m[4][4], pr[4][4];
     {
       const short *mv = s_mv[h][y4 * 4 + x4];
-      const int xq = ((mbx * 16 + bx) << 2) + 4 * JMHIP_PAD + mv[0], yq = ((mby * 16 + by) << 2) + 4 * JMHIP_PAD + mv[1];
-      const int xpos = clampi(xq >> 2, 0, F.Wp - 1 - 16), ypos = clampi(yq >> 2, 0, F.Hp - 1 - 16);      // UMVLine4X, refbuf.c:37
-      const int slot = s_ref[h][b8];
-      const uint8_t *src = F.ref_sub[slot] + (size_t)((yq & 3) * 4 + (xq & 3)) * F.Wp * F.Hp + (size_t)ypos * F.Wp + xpos;
+      const int bqx = ((mbx * 16 + bx) << 2) + 4 * JMHIP_PAD, bqy = ((mby * 16 + by) << 2) + 4 * JMHIP_PAD;
+      const int xq = bqx + mv[0], yq = bqy + mv[1], slot = s_ref[h][b8];
+      int pdir = 0, slot1 = 0, xq1 = 0, yq1 = 0;                                             // the second list of a B macroblock
+      if (F.bi) { const jmhip_mb_bipred &bm = F.bi[mb_of(h)]; pdir = bm.pdir[b8]; slot1 = bm.ref1[b8]; xq1 = bqx + bm.mv1[y4 * 4 + x4][0]; yq1 = bqy + bm.mv1[y4 * 4 + x4][1]; }
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        const uint32_t pv = fetch4(src + (size_t)j * F.Wp);
+        const uint32_t v0 = pdir != 1 ? luma_row4(F, slot, xq, yq, 0, 0, j) : 0u;
+        const uint32_t v1 = pdir != 0 ? luma_row4(F, slot1, xq1, yq1, 0, 0, j) : 0u;
         const uint32_t sv = *reinterpret_cast<const uint32_t *>(F.cur_y + (size_t)(mby * 16 + by + j) * F.W + mbx * 16 + bx);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          int p = (int)((pv >> (8 * k)) & 255u);
-          if (F.wp_on) p = clampi((((int)F.wp_w[slot][0] * p + F.wp_lround) >> F.wp_ldenom) + F.wp_o[slot][0], 0, 255);
+          int p = (int)((v0 >> (8 * k)) & 255u);
+          if (F.wp_on || pdir) p = mix_pred(F, pdir, slot, slot1, 0, p, (int)((v1 >> (8 * k)) & 255u));
           pr[j][k] = p; m[j][k] = (int)((sv >> (8 * k)) & 255u) - p;                                     // img->m7, macroblock.c:1059-1068
         }
       }

@@ -78,6 +78,13 @@ class FrameWp(C.Structure):
                 ("weight", (C.c_int16 * 3) * 16), ("offset", (C.c_int16 * 3) * 16)]
 
 
+class FrameBw(C.Structure):
+    _fields_ = [("w0", ((C.c_int16 * 3) * 4) * 4), ("w1", ((C.c_int16 * 3) * 4) * 4), ("weight1", (C.c_int16 * 3) * 4), ("offset1", (C.c_int16 * 3) * 4)]
+
+
+MB_BIPRED_DTYPE = np.dtype([("pdir", "i1", (4,)), ("ref1", "i1", (4,)), ("mv1", "<i2", (16, 2))])
+
+
 class SliceParams(C.Structure):
     """jmhip_slice_params (include/jmhip.h)."""
     _fields_ = [("search_mode", C.c_int32), ("search_range", C.c_int32), ("full_search", C.c_int32), ("num_refs", C.c_int32),
@@ -200,13 +207,14 @@ def load_library():
     lib.jmhip_slice_result_info.argtypes = [vp, C.POINTER(ip)]
     lib.jmhip_slice_to_frame.argtypes = [vp, vp, ip]
     lib.jmhip_frame_wp_set.argtypes = [vp, vp]
+    lib.jmhip_frame_bipred_set.argtypes = [vp, vp, ip, vp]
     for which, dt in ((0, ME_MB_DTYPE), (1, ME_RESULT_DTYPE), (2, QUANT_DTYPE), (3, TQ_JOB_DTYPE), (4, TQ_RESULT_DTYPE),
                       (5, DIST_JOB_DTYPE), (8, MB_MODE_DTYPE), (9, SURFACE_JOB_DTYPE), (10, BIPRED_JOB_DTYPE), (11, BIPRED_RESULT_DTYPE), (13, PREDCOST_JOB_DTYPE),
                       (14, DEBLOCK_MB_DTYPE), (15, DEBLOCK_BLK_DTYPE), (18, MB_INTER_DTYPE)):
         if lib.jmhip_sizeof(which) != dt.itemsize:
             raise JmhipError("binding layout mismatch for struct %d: C %d vs numpy %d" % (which, lib.jmhip_sizeof(which), dt.itemsize))
     if lib.jmhip_sizeof(6) != C.sizeof(MeParams) or lib.jmhip_sizeof(7) != C.sizeof(Config) or lib.jmhip_sizeof(12) != C.sizeof(BipredParams) or \
-            lib.jmhip_sizeof(16) != C.sizeof(DeblockParams) or lib.jmhip_sizeof(17) != C.sizeof(SliceParams) or lib.jmhip_sizeof(19) != C.sizeof(FrameWp):
+            lib.jmhip_sizeof(16) != C.sizeof(DeblockParams) or lib.jmhip_sizeof(17) != C.sizeof(SliceParams) or lib.jmhip_sizeof(19) != C.sizeof(FrameWp) or lib.jmhip_sizeof(20) != MB_BIPRED_DTYPE.itemsize or lib.jmhip_sizeof(21) != C.sizeof(FrameBw):
         raise JmhipError("binding layout mismatch for jmhip_me_params / jmhip_config")
     _lib = lib
     return lib
@@ -398,6 +406,23 @@ class Context:
             for q in range(3):
                 s.weight[k][q] = int(w[k, q]); s.offset[k][q] = int(o[k, q])
         self._chk(self.lib.jmhip_frame_wp_set(self.h, C.byref(s)), "jmhip_frame_wp_set")
+
+    def frame_bipred_set(self, bi=None, bw=None):
+        """bi: MB_BIPRED_DTYPE array (second list of B macroblocks) or None (P macroblocks again); bw: dict(w0, w1 as (4,4,3), weight1,
+        offset1 as (4,3)) by reference slot, used when frame_wp_set has weighting on."""
+        if bi is None:
+            self._chk(self.lib.jmhip_frame_bipred_set(self.h, None, 0, None), "jmhip_frame_bipred_set")
+            return
+        bi = np.ascontiguousarray(bi, dtype=MB_BIPRED_DTYPE)
+        s = None
+        if bw is not None:
+            s = FrameBw()
+            for a in range(4):
+                for q in range(3):
+                    s.weight1[a][q] = int(bw["weight1"][a][q]); s.offset1[a][q] = int(bw["offset1"][a][q])
+                    for b in range(4):
+                        s.w0[a][b][q] = int(bw["w0"][a][b][q]); s.w1[a][b][q] = int(bw["w1"][a][b][q])
+        self._chk(self.lib.jmhip_frame_bipred_set(self.h, _ptr(bi), len(bi), C.byref(s) if s is not None else None), "jmhip_frame_bipred_set")
 
     def slice_passes(self):
         n = C.c_int()

@@ -433,6 +433,18 @@ typedef struct jmhip_frame_wp {
 } jmhip_frame_wp;
 int jmhip_frame_wp_set(jmhip_ctx *ctx, const jmhip_frame_wp *wp);
 
+/* B macroblocks in the frame stage: the second list of LumaPrediction (src/macroblock.c:836: p_dir 0 / 1 / 2 at :862-876, the mixes
+ * :880-940) and ChromaPrediction4x4 (:1768-1830). Per macroblock of the job list: per 8x8 block the prediction direction (0 list 0 only --
+ * the P case --, 1 list 1 only, 2 both), the list-1 reference SLOT, and per 4x4 block (raster) the list-1 vector in quarter-pel units. List 0
+ * stays what the search stage / jmhip_slice_to_frame left. bi == NULL switches back to P macroblocks. Host array, copied. */
+typedef struct jmhip_mb_bipred { int8_t pdir[4]; int8_t ref1[4]; int16_t mv1[16][2]; } jmhip_mb_bipred;
+/* Weights of the second list, used when jmhip_frame_wp_set has weighting on (its rounding / denominators apply; JM's weighted_bipred_idc):
+ * by reference SLOT (0..3) and component (Y, Cb, Cr): bi-predictive pair weights wbp_weight[0 / 1][ref0][ref1][c], list-1 uni-directional
+ * weight wp_weight[1][ref1][c] and offset wp_offset[1][ref1][c]. JM quirk mirrored: the bi-predictive chroma mix shifts by the LUMA
+ * denominator + 1 (src/macroblock.c:1781). */
+typedef struct jmhip_frame_bw { int16_t w0[4][4][3], w1[4][4][3], weight1[4][3], offset1[4][3]; } jmhip_frame_bw;
+int jmhip_frame_bipred_set(jmhip_ctx *ctx, const jmhip_mb_bipred *bi, int n, const jmhip_frame_bw *bw);
+
 /* Inter mode of one macroblock as JM's mode decision fixed it (the decision itself stays on the host):
  * mode 1 = 16x16, 2 = 16x8, 3 = 8x16, 8 = P8x8 with b8mode[b] in {4,5,6,7} (8x8, 8x4, 4x8, 4x4). */
 typedef struct { int8_t mode; int8_t b8mode[4]; int8_t pad[3]; } jmhip_mb_mode;   /* pad[0] = luma_transform_size_8x8_flag (0/1) */

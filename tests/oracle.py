@@ -364,14 +364,29 @@ def covering_partition(m, x4, y4):
     return 25 + 4 * b8 + 2 * (y4 & 1) + (x4 & 1)
 
 
-def residual_frame(refpic, cur, mbs, mv, modes, quants3, job_dtype, yuv_format=1, blk_ref=None, wp=None):
+def residual_frame(refpic, cur, mbs, mv, modes, quants3, job_dtype, yuv_format=1, blk_ref=None, wp=None, bi=None, bw=None):
     """Reference for jmhip_residual_frame. refpic: RefPic with chroma planes; cur = (Y,U,V); mv: (n,41,2) quarter-pel.
     blk_ref (n,4): refpic is then a LIST of RefPic and each 8x8 block predicts from refpic[blk_ref[i][b8]] (LumaPrediction's l0_ref_idx,
-    macroblock.c:836). wp: explicit weighted uni-prediction (macroblock.c:899-903 luma, :1895-1898 chroma), the dict Context.frame_wp_set takes."""
+    macroblock.c:836). wp: explicit weighted uni-prediction (macroblock.c:899-903 luma, :1895-1898 chroma), the dict Context.frame_wp_set takes.
+    bi (MB_BIPRED_DTYPE, n): B macroblocks -- per 8x8 block p_dir 0 / 1 / 2, the list-1 reference slot, list-1 vectors per 4x4 block; bw: the
+    second list's weights (Context.frame_bipred_set). Mixes: macroblock.c:880-940 (luma), :1768-1830 (chroma, incl. the luma denominator in
+    the bi-predictive chroma shift :1781)."""
     Y, U, V = cur
     n = len(mbs)
-    refs = refpic if blk_ref is not None else [refpic]
+    refs = refpic if isinstance(refpic, (list, tuple)) else [refpic]
     refpic = refs[0]
+
+    def mix(pdir, s0, s1, comp, v0, v1):
+        """LumaPrediction / ChromaPrediction4x4's combination of the list-0 fetch v0 and the list-1 fetch v1 (arrays)."""
+        if wp is None:
+            return ((v0.astype(np.int64) + v1 + 1) >> 1) if pdir == 2 else (v1 if pdir else v0)
+        rnd, den = (wp["luma_round"], wp["luma_denom"]) if comp == 0 else (wp["chroma_round"], wp["chroma_denom"])
+        if pdir == 2:
+            off = (int(wp["offset"][s0][comp]) + int(bw["offset1"][s1][comp]) + 1) >> 1
+            return np.clip(((int(bw["w0"][s0][s1][comp]) * v0.astype(np.int64) + int(bw["w1"][s0][s1][comp]) * v1.astype(np.int64) + 2 * rnd) >> (wp["luma_denom"] + 1)) + off, 0, 255)
+        if pdir == 0:
+            return np.clip(((int(wp["weight"][s0][comp]) * v0.astype(np.int64) + rnd) >> den) + int(wp["offset"][s0][comp]), 0, 255)
+        return np.clip(((int(bw["weight1"][s1][comp]) * v1.astype(np.int64) + rnd) >> den) + int(bw["offset1"][s1][comp]), 0, 255)
 
     def weigh(v, slot, comp):
         if wp is None:
@@ -400,8 +415,19 @@ def residual_frame(refpic, cur, mbs, mv, modes, quants3, job_dtype, yuv_format=1
                 yq = ((mby * 16 + 4 * y4 - oy4) << 2) + 80 + int(mv[i, p, 1])
                 xpos = min(max(xq >> 2, 0), Wp - 17) + ox4
                 ypos = min(max(yq >> 2, 0), Hp - 17) + oy4
-                slot = int(blk_ref[i][2 * (y4 >> 1) + (x4 >> 1)]) if blk_ref is not None else 0
-                jobs_y[i]["pred"][4 * y4:4 * y4 + 4, 4 * x4:4 * x4 + 4] = weigh(refs[slot].luma[yq & 3, xq & 3, ypos:ypos + 4, xpos:xpos + 4], slot, 0)
+                b8 = 2 * (y4 >> 1) + (x4 >> 1)
+                slot = int(blk_ref[i][b8]) if blk_ref is not None else 0
+                v0 = refs[slot].luma[yq & 3, xq & 3, ypos:ypos + 4, xpos:xpos + 4]
+                if bi is None:
+                    jobs_y[i]["pred"][4 * y4:4 * y4 + 4, 4 * x4:4 * x4 + 4] = weigh(v0, slot, 0)
+                else:
+                    pdir, s1 = int(bi[i]["pdir"][b8]), int(bi[i]["ref1"][b8])
+                    xq1 = ((mbx * 16 + 4 * x4 - ox4) << 2) + 80 + int(bi[i]["mv1"][4 * y4 + x4][0])
+                    yq1 = ((mby * 16 + 4 * y4 - oy4) << 2) + 80 + int(bi[i]["mv1"][4 * y4 + x4][1])
+                    xp1 = min(max(xq1 >> 2, 0), Wp - 17) + ox4
+                    yp1 = min(max(yq1 >> 2, 0), Hp - 17) + oy4
+                    v1 = refs[s1].luma[yq1 & 3, xq1 & 3, yp1:yp1 + 4, xp1:xp1 + 4] if pdir else v0
+                    jobs_y[i]["pred"][4 * y4:4 * y4 + 4, 4 * x4:4 * x4 + 4] = mix(pdir, slot, s1, 0, v0, v1)
         jobs_y[i]["src"] = Y[mby * 16:mby * 16 + 16, mbx * 16:mbx * 16 + 16]
         for uv, C_ in enumerate((U, V)):
             jc = jobs_c[2 * i + uv]
@@ -413,9 +439,22 @@ def residual_frame(refpic, cur, mbs, mv, modes, quants3, job_dtype, yuv_format=1
                     jj = ((j + mby * mch) << shift_y) + 80 + int(mv4[by4, bx4, 1])
                     xpos = min(max(ii >> shift_x, 0), Wcp - 1 - mcw)
                     ypos = min(max(jj >> shift_y, 0), Hcp - 1 - mch)
-                    slot = int(blk_ref[i][2 * (by4 >> 1) + (bx4 >> 1)]) if blk_ref is not None else 0
+                    b8 = 2 * (by4 >> 1) + (bx4 >> 1)
+                    slot = int(blk_ref[i][b8]) if blk_ref is not None else 0
                     planes = refs[slot].cr if uv else refs[slot].cb
-                    jc["pred"][j, ic:ic + 2] = weigh(planes[jj & ((1 << shift_y) - 1), ii & ((1 << shift_x) - 1), ypos, xpos:xpos + 2], slot, uv + 1)
+                    v0 = planes[jj & ((1 << shift_y) - 1), ii & ((1 << shift_x) - 1), ypos, xpos:xpos + 2]
+                    if bi is None:
+                        jc["pred"][j, ic:ic + 2] = weigh(v0, slot, uv + 1)
+                    else:
+                        pdir, s1 = int(bi[i]["pdir"][b8]), int(bi[i]["ref1"][b8])
+                        m1 = bi[i]["mv1"][4 * by4 + bx4]
+                        ii1 = ((ic + mbx * mcw) << shift_x) + 80 + int(m1[0])
+                        jj1 = ((j + mby * mch) << shift_y) + 80 + int(m1[1])
+                        xp1 = min(max(ii1 >> shift_x, 0), Wcp - 1 - mcw)
+                        yp1 = min(max(jj1 >> shift_y, 0), Hcp - 1 - mch)
+                        pl1 = refs[s1].cr if uv else refs[s1].cb
+                        v1 = pl1[jj1 & ((1 << shift_y) - 1), ii1 & ((1 << shift_x) - 1), yp1, xp1:xp1 + 2] if pdir else v0
+                        jc["pred"][j, ic:ic + 2] = mix(pdir, slot, s1, uv + 1, v0, v1)
             jc["src"][:mch, :mcw] = C_[mby * mch:mby * mch + mch, mbx * mcw:mbx * mcw + mcw]
     ry = tq_reference("luma4x4", quants3, jobs_y)
     t8 = np.array([int(m["pad"][0]) for m in modes], bool)

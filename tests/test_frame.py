@@ -131,3 +131,69 @@ def test_residual_frame_with_8x8_transform_macroblocks(pkg, cavlc, qp, far, chro
     for g, wv, name in zip(recon, want["recon"], "YUV"):
         assert np.array_equal(g, wv), "recon %s" % name
     assert (got["cbp"][t8] & 15).max() > 0 or qp >= 34
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("weighted,planes,fused", [(False, False, True), (True, True, True), (True, False, False), (False, True, False)])
+def test_b_macroblocks_second_list(pkg, weighted, planes, fused, monkeypatch):
+    """jmhip_frame_bipred_set: per 8x8 block list 0 only / list 1 only / both, list-1 vectors per 4x4 block from a second reference slot,
+    plain average or JM's weighted mixes (incl. the luma denominator in the bi-predictive chroma shift) -- reconstruction and cbp of every
+    macroblock against the oracle, through the fused kernel and through the separate kernels, chroma from planes and computed."""
+    if not fused:
+        monkeypatch.setenv("JMHIP_FRAME_FUSED", "0")
+    rng = np.random.default_rng(31 + weighted + 2 * planes)
+    W, H, R = 96, 64, 8
+    n = (W // 16) * (H // 16)
+    base = rng.integers(0, 256, (H + 32, W + 32)).astype(np.float64)
+    for _ in range(2):
+        base = (base + np.roll(base, 1, 0) + np.roll(base, 1, 1) + np.roll(base, -1, 0)) / 4
+    def frame(dx, dy):
+        Y = np.clip(base[16 + dy:16 + dy + H, 16 + dx:16 + dx + W] + rng.normal(0, 2, (H, W)), 0, 255).astype(np.uint8)
+        U = np.clip(Y[::2, ::2].astype(int) // 2 + 60, 0, 255).astype(np.uint8)
+        V = np.clip(220 - Y[1::2, 1::2].astype(int) // 2, 0, 255).astype(np.uint8)
+        return Y, U, V
+    ref0, ref1, cur = frame(0, 0), frame(4, -3), frame(2, -1)
+    ctx = pkg.Context(W, H, yuv_format=1, max_refs=2, search_range=R)
+    for slot, ref in ((0, ref0), (1, ref1)):
+        ctx.ref_upload(slot, *ref)
+        ctx.interp_luma(slot)
+        if planes:
+            ctx.interp_chroma(slot)
+    ctx.cur_upload(*cur)
+    mbs = np.zeros(n, dtype=pkg.ME_MB_DTYPE)
+    for i in range(n):
+        mbs[i]["mb_x"], mbs[i]["mb_y"], mbs[i]["ref"], mbs[i]["ref_is_0"] = i % (W // 16), i // (W // 16), 0, 1
+        mbs[i]["pred_mv"][:] = rng.integers(-6, 7, 2)
+    prm = pkg.MeParams()
+    prm.search_mode, prm.search_range, prm.rdopt = 0, R, 1
+    prm.level_mv_min, prm.level_mv_max = -511, 511
+    prm.lambda_[0] = prm.lambda_[1] = prm.lambda_[2] = 30000
+    prm.subpel, prm.partition_mask = 1, (1 << 41) - 1
+    me = ctx.me_frame(prm, mbs)
+    bi = np.zeros(n, dtype=pkg.MB_BIPRED_DTYPE)
+    bi["pdir"] = rng.integers(0, 3, (n, 4))
+    bi["ref1"] = 1
+    bi["mv1"] = rng.integers(-40, 41, (n, 16, 2))
+    bi["mv1"][0] = [[-300, -200]] * 16                     # far outside the picture: the UMV clamps
+    wp = bw = None
+    if weighted:
+        wp = {"luma_round": 16, "luma_denom": 5, "chroma_round": 4, "chroma_denom": 3, "weight": np.zeros((16, 3), int), "offset": np.zeros((16, 3), int)}
+        wp["weight"][0], wp["offset"][0] = (30, 9, 7), (3, -2, 1)
+        bw = {"w0": rng.integers(10, 40, (4, 4, 3)), "w1": rng.integers(10, 40, (4, 4, 3)), "weight1": rng.integers(5, 12, (4, 3)), "offset1": rng.integers(-4, 5, (4, 3))}
+        bw["weight1"][:, 0] += 22
+    ctx.frame_wp_set(wp)
+    ctx.frame_bipred_set(bi, bw)
+    quants = np.array([pkg.flat_quant(26 + d, 342, adaptive_rounding=1, adapt_rnd_weight=4, cavlc=1) for d in (0, 0, 3)], dtype=pkg.QUANT_DTYPE)
+    ctx.residual_frame(quants, None)
+    got = ctx.residual_download(n)
+    recon = ctx.recon_download()
+    ctx.frame_bipred_set(None)
+    ctx.frame_wp_set(None)
+    ctx.close()
+    assert (bi["pdir"] == 0).any() and (bi["pdir"] == 1).any() and (bi["pdir"] == 2).any()
+    rps = [oracle.RefPic(*ref0, yuv_format=1), oracle.RefPic(*ref1, yuv_format=1)]
+    want = oracle.residual_frame(rps, cur, mbs, me["mv"], got["modes"], quants, pkg.TQ_JOB_DTYPE, yuv_format=1, blk_ref=np.zeros((n, 4), int), wp=wp, bi=bi, bw=bw)
+    assert np.array_equal(got["cbp"], want["cbp"]) and np.array_equal(got["cbp_blk"], want["cbp_blk"])
+    for k in range(3):
+        assert np.array_equal(recon[k], want["recon"][k]), "plane %d" % k
+    assert (got["cbp"] != 0).any()
