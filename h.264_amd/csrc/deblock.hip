@@ -514,6 +514,136 @@ __global__ __launch_bounds__(1024) void deblock_lds_kernel(DeblockDev D, int S)
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------- relaxation schedule (4:2:0)
+//
+// JM filters macroblock k's vertical edges, then its horizontal edges, in place and in raster order. Written as a data flow, step D_k reads
+//   the unfiltered samples of macroblock k, the four right-most columns of its left neighbour AFTER D_(k-1) (call that A_(k-1)), and the four
+//   bottom rows of its upper neighbour after D_(up) AND after D_(up+1) has filtered the up neighbour's right edge (A_up overlaid with R_(up+1)),
+// and produces A_k (its own 16x16 + chroma after both passes), R_k (what its left edge made of the left neighbour's columns 12..15) and
+// T_k (what its top edge made of the upper neighbour's rows 12..15). The final picture is A_k overlaid with R_(k+1), then with T_(k+mbw).
+// The dependencies are acyclic, so -- exactly as for the slice search (me_wave.hip) -- every macroblock can be evaluated at once from whatever its
+// predecessors last produced, sweep after sweep, until a sweep changes nothing: that fixpoint is the raster-order result. A change only
+// travels as far as a filter carries it (a few samples), so a handful of sweeps of ~10 us replace the 254 + serial steps of the wavefront.
+// Layout of one macroblock's record in `st`: A.Y[16][16] A.U[8][8] A.V[8][8] | R.Y[16][4] R.U[8][4] R.V[8][4] | T.Y[4][16] T.U[4][8] T.V[4][8].
+constexpr int DBR_A = 384, DBR_R = 64 + 32 + 32, DBR_T = 64 + 32 + 32, DBR_REC = DBR_A + DBR_R + DBR_T;     // 640 bytes
+
+struct DbkRelax {
+  const uint8_t *y, *u, *v;     // the unfiltered picture (read only during the sweeps)
+  uint8_t *st;                  // [nmb][DBR_REC]
+  const EdgeInfo *edges;
+  const uint8_t *chg_prev; uint8_t *chg_next; int *n_changed;
+  int W, Wc, mbw, mbh, first_sweep;
+};
+
+__global__ __launch_bounds__(64) void deblock_relax_kernel(DbkRelax D)
+{
+  __shared__ __attribute__((aligned(16))) uint8_t tY[4][20 * 20], tC[4][2][12 * 12];
+  const int h = threadIdx.x >> 4, l = threadIdx.x & 15;
+  const int nmb = D.mbw * D.mbh, k = min(blockIdx.x * 4 + h, nmb - 1);
+  const bool live = blockIdx.x * 4 + h < nmb;
+  const int mbx = k % D.mbw, mby = k / D.mbw;
+  const bool has_left = mbx > 0, has_up = mby > 0, has_ur = mby > 0 && mbx + 1 < D.mbw;
+  bool active = D.first_sweep != 0;
+  if (!active) active = (has_left && D.chg_prev[k - 1]) || (has_up && D.chg_prev[k - D.mbw]) || (has_ur && D.chg_prev[k - D.mbw + 1]);
+  active = active && live;
+  uint8_t *Y = tY[h], *U = tC[h][0], *V = tC[h][1];
+  const uint8_t *rec = D.st + (size_t)k * DBR_REC;
+  if (active) {
+    // ---- stage: own samples (unfiltered), left margin = A_left columns 12..15, top margin = A_up rows 12..15 overlaid with R_(up+1)
+    {
+      const uint4 v = *reinterpret_cast<const uint4 *>(D.y + (size_t)(mby * 16 + l) * D.W + mbx * 16);
+      uint32_t *d = reinterpret_cast<uint32_t *>(Y + (l + 4) * 20 + 4);
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      const uint8_t *cp = (l >> 3) ? D.v : D.u;
+      const uint2 c2 = *reinterpret_cast<const uint2 *>(cp + (size_t)(mby * 8 + (l & 7)) * D.Wc + mbx * 8);
+      uint32_t *dc = reinterpret_cast<uint32_t *>(((l >> 3) ? V : U) + ((l & 7) + 4) * 12 + 4);
+      dc[0] = c2.x; dc[1] = c2.y;
+    }
+    if (has_left) {
+      const uint8_t *a = rec - DBR_REC;
+      *reinterpret_cast<uint32_t *>(Y + (l + 4) * 20) = *reinterpret_cast<const uint32_t *>(a + l * 16 + 12);
+      *reinterpret_cast<uint32_t *>(((l >> 3) ? V : U) + ((l & 7) + 4) * 12) = *reinterpret_cast<const uint32_t *>(a + 256 + (l >> 3) * 64 + (l & 7) * 8 + 4);
+    }
+    if (has_up) {
+      const uint8_t *a = rec - (size_t)D.mbw * DBR_REC;
+      const int r = l >> 2, q = l & 3;                       // luma: 4 rows x 4 dwords
+      uint32_t v = *reinterpret_cast<const uint32_t *>(a + (12 + r) * 16 + q * 4);
+      if (q == 3 && has_ur) v = *reinterpret_cast<const uint32_t *>(a + DBR_REC + DBR_A + (12 + r) * 4);            // R_(up+1).Y rows 12..15
+      *reinterpret_cast<uint32_t *>(Y + r * 20 + 4 + q * 4) = v;
+      // chroma: per plane 4 rows (4..7) x 2 dwords
+      const int pl = l >> 3, cr = (l >> 1) & 3, cq = l & 1;
+      uint32_t w = *reinterpret_cast<const uint32_t *>(a + 256 + pl * 64 + (4 + cr) * 8 + cq * 4);
+      if (cq == 1 && has_ur) w = *reinterpret_cast<const uint32_t *>(a + DBR_REC + DBR_A + 64 + pl * 32 + (4 + cr) * 4);  // R_(up+1).U/V rows 4..7
+      *reinterpret_cast<uint32_t *>((pl ? V : U) + cr * 12 + 4 + cq * 4) = w;
+    }
+  }
+  __syncthreads();
+  if (active) {
+    const Edges4 e0 = load_edges(D.edges + ((size_t)k * 2 + 0) * 4);
+    luma_type_line<true>(Y + (l + 4) * 20 + 4, 20, has_left, e0, 0, l >> 2);
+    chroma_type_line<true, 8>(((l >> 3) ? V : U) + ((l & 7) + 4) * 12 + 4, 12, has_left, e0, 1 + (l >> 3), (l & 7) >> 1, 0, -1, 4, -1);
+  }
+  __syncthreads();
+  if (active) {
+    const Edges4 e1 = load_edges(D.edges + ((size_t)k * 2 + 1) * 4);
+    luma_type_line<false>(Y + 4 * 20 + 4 + l, 20, has_up, e1, 0, l >> 2);
+    chroma_type_line<false, 8>(((l >> 3) ? V : U) + 4 * 12 + 4 + (l & 7), 12, has_up, e1, 1 + (l >> 3), (l & 7) >> 1, 0, -1, 4, -1);
+  }
+  __syncthreads();
+  bool diff = false;
+  if (active) {
+    // ---- hand on: A (own), R (left margin), T (top margin); compare with what was stored
+    uint8_t *o = D.st + (size_t)k * DBR_REC;
+    auto put = [&](uint32_t *g, uint32_t v) { diff = diff || *g != v; *g = v; };
+    for (int q = 0; q < 4; q++) put(reinterpret_cast<uint32_t *>(o + l * 16 + q * 4), *reinterpret_cast<const uint32_t *>(Y + (l + 4) * 20 + 4 + q * 4));
+    {
+      const uint8_t *cs = ((l >> 3) ? V : U) + ((l & 7) + 4) * 12;
+      put(reinterpret_cast<uint32_t *>(o + 256 + (l >> 3) * 64 + (l & 7) * 8), *reinterpret_cast<const uint32_t *>(cs + 4));
+      put(reinterpret_cast<uint32_t *>(o + 256 + (l >> 3) * 64 + (l & 7) * 8 + 4), *reinterpret_cast<const uint32_t *>(cs + 8));
+      if (has_left) {
+        put(reinterpret_cast<uint32_t *>(o + DBR_A + l * 4), *reinterpret_cast<const uint32_t *>(Y + (l + 4) * 20));                    // R.Y
+        put(reinterpret_cast<uint32_t *>(o + DBR_A + 64 + (l >> 3) * 32 + (l & 7) * 4), *reinterpret_cast<const uint32_t *>(cs));      // R.U / R.V
+      }
+    }
+    if (has_up) {
+      const int r = l >> 2, q = l & 3;
+      put(reinterpret_cast<uint32_t *>(o + DBR_A + DBR_R + r * 16 + q * 4), *reinterpret_cast<const uint32_t *>(Y + r * 20 + 4 + q * 4));   // T.Y
+      const int pl = l >> 3, cr = (l >> 1) & 3, cq = l & 1;
+      put(reinterpret_cast<uint32_t *>(o + DBR_A + DBR_R + 64 + pl * 32 + cr * 8 + cq * 4), *reinterpret_cast<const uint32_t *>((pl ? V : U) + cr * 12 + 4 + cq * 4));
+    }
+  }
+  const unsigned long long m = __ballot(diff);
+  if (l == 0 && live) {
+    const int changed = ((m >> (16 * h)) & 0xffffull) != 0;
+    D.chg_next[k] = (uint8_t)changed;
+    if (changed) atomicAdd(D.n_changed, 1);
+  }
+}
+
+// the filtered picture from the records: A_k, columns 12..15 from R_(k+1), then rows 12..15 from T_(k+mbw)
+__global__ __launch_bounds__(64) void deblock_compose_kernel(const uint8_t *st, uint8_t *y, uint8_t *u, uint8_t *v, int W, int Wc, int mbw, int mbh)
+{
+  const int h = threadIdx.x >> 4, l = threadIdx.x & 15, nmb = mbw * mbh, k = blockIdx.x * 4 + h;
+  if (k >= nmb) return;
+  const int mbx = k % mbw, mby = k / mbw;
+  const uint8_t *a = st + (size_t)k * DBR_REC;
+  const bool has_r = mbx + 1 < mbw, has_b = mby + 1 < mbh;
+  {                                                          // luma row l
+    uint4 o = *reinterpret_cast<const uint4 *>(a + l * 16);
+    if (has_r) o.w = *reinterpret_cast<const uint32_t *>(a + DBR_REC + DBR_A + l * 4);
+    if (has_b && l >= 12) o = *reinterpret_cast<const uint4 *>(a + (size_t)mbw * DBR_REC + DBR_A + DBR_R + (l - 12) * 16);
+    *reinterpret_cast<uint4 *>(y + (size_t)(mby * 16 + l) * W + mbx * 16) = o;
+  }
+  {                                                          // chroma: plane l >> 3, row l & 7
+    const int pl = l >> 3, r = l & 7;
+    uint2 o = *reinterpret_cast<const uint2 *>(a + 256 + pl * 64 + r * 8);
+    if (has_r) o.y = *reinterpret_cast<const uint32_t *>(a + DBR_REC + DBR_A + 64 + pl * 32 + r * 4);
+    if (has_b && r >= 4) o = *reinterpret_cast<const uint2 *>(a + (size_t)mbw * DBR_REC + DBR_A + DBR_R + 64 + pl * 32 + (r - 4) * 8);
+    *reinterpret_cast<uint2 *>((pl ? v : u) + (size_t)(mby * 8 + r) * Wc + mbx * 8) = o;
+  }
+}
+
 int ensure_recon(jmhip_ctx *c) { return jm_ensure_recon(c); }
 
 }  // namespace
@@ -561,6 +691,47 @@ int dbk_run(jmhip_ctx *c, const DbkArrays &a, int mvlimit, int mb_row0, int mb_r
   deblock_strength_kernel<<<(nmb * 8 + 255) / 256, 256, 0, c->stream>>>((const jmhip_deblock_mb *)a.mbs, (const jmhip_deblock_blk *)a.blks,
                                                                          (EdgeInfo *)a.edges, c->mbw, c->mbh, mvlimit);
   JM_HIP_CHECK(c, hipGetLastError());
+  // relaxation schedule (deblock_relax_kernel): whole 4:2:0 pictures; JMHIP_DEBLOCK_SCHED=wave keeps the wavefront kernels below, which also
+  // take the other chroma formats and row bands, and finish if the sweeps have not settled within the cap
+  {
+    const char *sched = getenv("JMHIP_DEBLOCK_SCHED");
+    if (c->cfg.yuv_format == JMHIP_YUV420 && mb_row0 == 0 && mb_rows == c->mbh && !(sched && !strcmp(sched, "wave"))) {
+      const size_t st_bytes = (size_t)nmb * DBR_REC, need = st_bytes + 2 * (size_t)nmb + 64 * sizeof(int);
+      if (c->dbr_cap < need) {
+        if (c->dbr_dev) JM_HIP_CHECK(c, hipFree(c->dbr_dev));
+        c->dbr_dev = nullptr; c->dbr_cap = 0;
+        if (hipMalloc(&c->dbr_dev, need) != hipSuccess) return jm_fail(c, JMHIP_ERR_NOMEM, "deblocking records");
+        c->dbr_cap = need;
+      }
+      uint8_t *st = (uint8_t *)c->dbr_dev, *chg = st + st_bytes;
+      int *counters = reinterpret_cast<int *>(st + ((st_bytes + 2 * (size_t)nmb + 3) & ~(size_t)3));
+      DbkRelax R;
+      R.y = c->rec_y; R.u = c->rec_u; R.v = c->rec_v; R.st = st; R.edges = (const EdgeInfo *)a.edges;
+      R.W = c->W; R.Wc = c->Wc; R.mbw = c->mbw; R.mbh = c->mbh;
+      const int cap = getenv("JMHIP_DEBLOCK_SWEEPS") ? atoi(getenv("JMHIP_DEBLOCK_SWEEPS")) : 48, group = 4;     // sweeps per host check
+      bool settled = false;
+      int sweep = 0;
+      while (sweep < cap && !settled) {
+        JM_HIP_CHECK(c, hipMemsetAsync(counters, 0, sizeof(int) * group, c->stream));
+        for (int g = 0; g < group; g++, sweep++) {
+          R.first_sweep = sweep == 0; R.chg_prev = chg + (size_t)(sweep & 1) * nmb; R.chg_next = chg + (size_t)((sweep + 1) & 1) * nmb; R.n_changed = counters + g;
+          deblock_relax_kernel<<<(nmb + 3) / 4, 64, 0, c->stream>>>(R);
+        }
+        JM_HIP_CHECK(c, hipGetLastError());
+        int last[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+        JM_HIP_CHECK(c, hipMemcpyAsync(last, counters, sizeof(int) * group, hipMemcpyDeviceToHost, c->stream));
+        JM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+        settled = last[group - 1] == 0;
+        if (getenv("JMHIP_DEBLOCK_TRACE")) fprintf(stderr, "deblock sweeps %d..%d: %d %d %d %d macroblocks changed\n", sweep - group, sweep - 1, last[0], last[1], last[2], last[3]);
+      }
+      c->dbk_sweeps = sweep;
+      if (settled) {
+        deblock_compose_kernel<<<(nmb + 3) / 4, 64, 0, c->stream>>>(st, c->rec_y, c->rec_u, c->rec_v, c->W, c->Wc, c->mbw, c->mbh);
+        JM_HIP_CHECK(c, hipGetLastError());
+        return JMHIP_OK;
+      }
+    }
+  }
   DeblockDev D;
   D.y = c->rec_y; D.u = c->rec_u; D.v = c->rec_v;
   D.edges = (const EdgeInfo *)a.edges;

@@ -63,6 +63,7 @@ struct jmhip_ctx {
   bool rec_valid = false;                             // the recon planes hold a reconstruction (cleared by jmhip_recon_to_ref's plane swap)
   bool rec_has_pic = false;                           // recon planes loaded by jmhip_recon_upload
   void *dbk_dev = nullptr; size_t dbk_cap = 0;        // deblocking: macroblock / block / edge arrays
+  void *dbr_dev = nullptr; size_t dbr_cap = 0; int dbk_sweeps = 0;   // deblocking, relaxation schedule: per-macroblock records, change flags, counters
   // TQ arrays
   void *tq_jobs_dev = nullptr, *tq_res_dev = nullptr, *tq_quant_dev = nullptr; int tq_capacity = 0, tq_qcap = 0;
   void *slice_state = nullptr;                         // me_wave.hip: the P-slice search state (field arrays, EPZS / UMHexagonS memories)

@@ -157,9 +157,25 @@ def test_deblock_bands_in_sequence_cross_their_borders(pkg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("sched,sweeps", [("wave", None), ("relax", "4"), ("relax", None)])
+def test_deblock_schedules_agree(pkg, sched, sweeps, monkeypatch):
+    """4:2:0 pictures are filtered by RELAXATION by default (deblock.hip deblock_relax_kernel: every macroblock from what its left / up /
+    up-right neighbours last produced, sweep after sweep until nothing changes, then one compose pass); JMHIP_DEBLOCK_SCHED=wave forces the
+    2:1 wavefront kernels, JMHIP_DEBLOCK_SWEEPS caps the sweeps (4 = one group: pictures that need more fall through to the wavefront with
+    the picture untouched). All three against the oracle: worst case (every edge filtered, strong intra edges), slices, 1080p."""
+    monkeypatch.setenv("JMHIP_DEBLOCK_SCHED", sched)
+    if sweeps:
+        monkeypatch.setenv("JMHIP_DEBLOCK_SWEEPS", sweeps)
+    run(pkg, 176, 144, 1, seed=41, idc_mode="zero", intra_frac=1.0, qp_lo=40, qp_hi=51)
+    run(pkg, 320, 192, 1, seed=42, idc_mode="two", intra_frac=0.3)
+    run(pkg, 1920, 1088, 1, seed=43, smooth=False, qp_lo=44, qp_hi=51, idc_mode="zero")
+
+
+@pytest.mark.gpu
 def test_deblock_global_memory_kernel_on_420(pkg, monkeypatch):
     """4:0:0 / 4:2:0 / 4:2:2 normally take the LDS-ring kernel; the global-memory wavefront kernel (4:4:4 / oversized pictures) must agree."""
     monkeypatch.setenv("JMHIP_DEBLOCK_KERNEL", "global")
+    monkeypatch.setenv("JMHIP_DEBLOCK_SCHED", "wave")
     run(pkg, 176, 144, 1, seed=21)
     run(pkg, 320, 64, 0, seed=22)
     run(pkg, 176, 144, 2, seed=23)
