@@ -525,92 +525,113 @@ __global__ __launch_bounds__(1024) void deblock_lds_kernel(DeblockDev D, int S)
 // The dependencies are acyclic, so -- exactly as for the slice search (me_wave.hip) -- every macroblock can be evaluated at once from whatever its
 // predecessors last produced, sweep after sweep, until a sweep changes nothing: that fixpoint is the raster-order result. A change only
 // travels as far as a filter carries it (a few samples), so a handful of sweeps of ~10 us replace the 254 + serial steps of the wavefront.
-// Layout of one macroblock's record in `st`: A.Y[16][16] A.U[8][8] A.V[8][8] | R.Y[16][4] R.U[8][4] R.V[8][4] | T.Y[4][16] T.U[4][8] T.V[4][8].
-constexpr int DBR_A = 384, DBR_R = 64 + 32 + 32, DBR_T = 64 + 32 + 32, DBR_REC = DBR_A + DBR_R + DBR_T;     // 640 bytes
+// Layout of one macroblock's record in `st` (4:2:0; 4:2:2 has 16 chroma rows, 4:0:0 none): A.Y[16][16] A.U[8][8] A.V[8][8] | R.Y[16][4] R.U[8][4]
+// R.V[8][4] | T.Y[4][16] T.U[4][8] T.V[4][8]. 4:4:4 stays with the wavefront kernels.
+// chroma rows per macroblock / record geometry by chroma format (CF: 0 = 4:0:0, 1 = 4:2:0, 2 = 4:2:2)
+template <int CF> struct DbrGeo {
+  static constexpr int CH = CF == 2 ? 16 : CF == 1 ? 8 : 0;                  // chroma rows of a macroblock (8 columns)
+  static constexpr int A = 256 + 2 * CH * 8, R = 64 + 2 * CH * 4, T = 64 + (CF ? 64 : 0), REC = A + R + T;
+};
 
 struct DbkRelax {
   const uint8_t *y, *u, *v;     // the unfiltered picture (read only during the sweeps)
-  uint8_t *st;                  // [nmb][DBR_REC]
+  uint8_t *st;                  // [nmb][REC]
   const EdgeInfo *edges;
   const uint8_t *chg_prev; uint8_t *chg_next; int *n_changed;
   int W, Wc, mbw, mbh, first_sweep;
 };
 
+template <int CF>
 __global__ __launch_bounds__(64) void deblock_relax_kernel(DbkRelax D)
 {
-  __shared__ __attribute__((aligned(16))) uint8_t tY[4][20 * 20], tC[4][2][12 * 12];
+  using G = DbrGeo<CF>;
+  constexpr int CH = G::CH, CT = (CH + 4) * 12;               // chroma tile: rows -4 .. CH-1, columns -4 .. 7
+  __shared__ __attribute__((aligned(16))) uint8_t tY[4][20 * 20], tC[4][2][CF ? CT : 16];
   const int h = threadIdx.x >> 4, l = threadIdx.x & 15;
-  const int nmb = D.mbw * D.mbh, k = min(blockIdx.x * 4 + h, nmb - 1);
-  const bool live = blockIdx.x * 4 + h < nmb;
+  const int nmb = D.mbw * D.mbh, k = min((int)blockIdx.x * 4 + h, nmb - 1);
+  const bool live = (int)blockIdx.x * 4 + h < nmb;
   const int mbx = k % D.mbw, mby = k / D.mbw;
   const bool has_left = mbx > 0, has_up = mby > 0, has_ur = mby > 0 && mbx + 1 < D.mbw;
   bool active = D.first_sweep != 0;
   if (!active) active = (has_left && D.chg_prev[k - 1]) || (has_up && D.chg_prev[k - D.mbw]) || (has_ur && D.chg_prev[k - D.mbw + 1]);
   active = active && live;
-  uint8_t *Y = tY[h], *U = tC[h][0], *V = tC[h][1];
-  const uint8_t *rec = D.st + (size_t)k * DBR_REC;
+  uint8_t *Y = tY[h];
+  uint8_t *const C2[2] = {tC[h][0], tC[h][1]};
+  const uint8_t *rec = D.st + (size_t)k * G::REC;
   if (active) {
     // ---- stage: own samples (unfiltered), left margin = A_left columns 12..15, top margin = A_up rows 12..15 overlaid with R_(up+1)
     {
       const uint4 v = *reinterpret_cast<const uint4 *>(D.y + (size_t)(mby * 16 + l) * D.W + mbx * 16);
       uint32_t *d = reinterpret_cast<uint32_t *>(Y + (l + 4) * 20 + 4);
       d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-      const uint8_t *cp = (l >> 3) ? D.v : D.u;
-      const uint2 c2 = *reinterpret_cast<const uint2 *>(cp + (size_t)(mby * 8 + (l & 7)) * D.Wc + mbx * 8);
-      uint32_t *dc = reinterpret_cast<uint32_t *>(((l >> 3) ? V : U) + ((l & 7) + 4) * 12 + 4);
-      dc[0] = c2.x; dc[1] = c2.y;
+      for (int t = l; t < 2 * CH; t += 16) {
+        const int pl = t / (CH ? CH : 1), r = t - pl * CH;
+        const uint2 c2 = *reinterpret_cast<const uint2 *>((pl ? D.v : D.u) + (size_t)(mby * CH + r) * D.Wc + mbx * 8);
+        uint32_t *dc = reinterpret_cast<uint32_t *>(C2[pl] + (r + 4) * 12 + 4);
+        dc[0] = c2.x; dc[1] = c2.y;
+      }
     }
     if (has_left) {
-      const uint8_t *a = rec - DBR_REC;
+      const uint8_t *a = rec - G::REC;
       *reinterpret_cast<uint32_t *>(Y + (l + 4) * 20) = *reinterpret_cast<const uint32_t *>(a + l * 16 + 12);
-      *reinterpret_cast<uint32_t *>(((l >> 3) ? V : U) + ((l & 7) + 4) * 12) = *reinterpret_cast<const uint32_t *>(a + 256 + (l >> 3) * 64 + (l & 7) * 8 + 4);
+      for (int t = l; t < 2 * CH; t += 16) {
+        const int pl = t / (CH ? CH : 1), r = t - pl * CH;
+        *reinterpret_cast<uint32_t *>(C2[pl] + (r + 4) * 12) = *reinterpret_cast<const uint32_t *>(a + 256 + pl * CH * 8 + r * 8 + 4);
+      }
     }
     if (has_up) {
-      const uint8_t *a = rec - (size_t)D.mbw * DBR_REC;
+      const uint8_t *a = rec - (size_t)D.mbw * G::REC;
       const int r = l >> 2, q = l & 3;                       // luma: 4 rows x 4 dwords
       uint32_t v = *reinterpret_cast<const uint32_t *>(a + (12 + r) * 16 + q * 4);
-      if (q == 3 && has_ur) v = *reinterpret_cast<const uint32_t *>(a + DBR_REC + DBR_A + (12 + r) * 4);            // R_(up+1).Y rows 12..15
+      if (q == 3 && has_ur) v = *reinterpret_cast<const uint32_t *>(a + G::REC + G::A + (12 + r) * 4);            // R_(up+1).Y rows 12..15
       *reinterpret_cast<uint32_t *>(Y + r * 20 + 4 + q * 4) = v;
-      // chroma: per plane 4 rows (4..7) x 2 dwords
-      const int pl = l >> 3, cr = (l >> 1) & 3, cq = l & 1;
-      uint32_t w = *reinterpret_cast<const uint32_t *>(a + 256 + pl * 64 + (4 + cr) * 8 + cq * 4);
-      if (cq == 1 && has_ur) w = *reinterpret_cast<const uint32_t *>(a + DBR_REC + DBR_A + 64 + pl * 32 + (4 + cr) * 4);  // R_(up+1).U/V rows 4..7
-      *reinterpret_cast<uint32_t *>((pl ? V : U) + cr * 12 + 4 + cq * 4) = w;
+      if (CF) {                                              // chroma: per plane the last 4 rows x 2 dwords
+        const int pl = l >> 3, cr = (l >> 1) & 3, cq = l & 1;
+        uint32_t w = *reinterpret_cast<const uint32_t *>(a + 256 + pl * CH * 8 + (CH - 4 + cr) * 8 + cq * 4);
+        if (cq == 1 && has_ur) w = *reinterpret_cast<const uint32_t *>(a + G::REC + G::A + 64 + pl * CH * 4 + (CH - 4 + cr) * 4);
+        *reinterpret_cast<uint32_t *>(C2[pl] + cr * 12 + 4 + cq * 4) = w;
+      }
     }
   }
   __syncthreads();
   if (active) {
     const Edges4 e0 = load_edges(D.edges + ((size_t)k * 2 + 0) * 4);
     luma_type_line<true>(Y + (l + 4) * 20 + 4, 20, has_left, e0, 0, l >> 2);
-    chroma_type_line<true, 8>(((l >> 3) ? V : U) + ((l & 7) + 4) * 12 + 4, 12, has_left, e0, 1 + (l >> 3), (l & 7) >> 1, 0, -1, 4, -1);
+    if (CF == 1) chroma_type_line<true, 8>(C2[l >> 3] + ((l & 7) + 4) * 12 + 4, 12, has_left, e0, 1 + (l >> 3), (l & 7) >> 1, 0, -1, 4, -1);
+    if (CF == 2) {                                           // 16 rows per plane: StrengthIdx = row -> group row >> 2
+      chroma_type_line<true, 8>(C2[0] + (l + 4) * 12 + 4, 12, has_left, e0, 1, l >> 2, 0, -1, 4, -1);
+      chroma_type_line<true, 8>(C2[1] + (l + 4) * 12 + 4, 12, has_left, e0, 2, l >> 2, 0, -1, 4, -1);
+    }
   }
   __syncthreads();
   if (active) {
     const Edges4 e1 = load_edges(D.edges + ((size_t)k * 2 + 1) * 4);
     luma_type_line<false>(Y + 4 * 20 + 4 + l, 20, has_up, e1, 0, l >> 2);
-    chroma_type_line<false, 8>(((l >> 3) ? V : U) + 4 * 12 + 4 + (l & 7), 12, has_up, e1, 1 + (l >> 3), (l & 7) >> 1, 0, -1, 4, -1);
+    if (CF == 1) chroma_type_line<false, 8>(C2[l >> 3] + 4 * 12 + 4 + (l & 7), 12, has_up, e1, 1 + (l >> 3), (l & 7) >> 1, 0, -1, 4, -1);
+    if (CF == 2) chroma_type_line<false, 16>(C2[l >> 3] + 4 * 12 + 4 + (l & 7), 12, has_up, e1, 1 + (l >> 3), (l & 7) >> 1, 0, 4, 8, 12);
   }
   __syncthreads();
   bool diff = false;
   if (active) {
     // ---- hand on: A (own), R (left margin), T (top margin); compare with what was stored
-    uint8_t *o = D.st + (size_t)k * DBR_REC;
+    uint8_t *o = D.st + (size_t)k * G::REC;
     auto put = [&](uint32_t *g, uint32_t v) { diff = diff || *g != v; *g = v; };
     for (int q = 0; q < 4; q++) put(reinterpret_cast<uint32_t *>(o + l * 16 + q * 4), *reinterpret_cast<const uint32_t *>(Y + (l + 4) * 20 + 4 + q * 4));
-    {
-      const uint8_t *cs = ((l >> 3) ? V : U) + ((l & 7) + 4) * 12;
-      put(reinterpret_cast<uint32_t *>(o + 256 + (l >> 3) * 64 + (l & 7) * 8), *reinterpret_cast<const uint32_t *>(cs + 4));
-      put(reinterpret_cast<uint32_t *>(o + 256 + (l >> 3) * 64 + (l & 7) * 8 + 4), *reinterpret_cast<const uint32_t *>(cs + 8));
-      if (has_left) {
-        put(reinterpret_cast<uint32_t *>(o + DBR_A + l * 4), *reinterpret_cast<const uint32_t *>(Y + (l + 4) * 20));                    // R.Y
-        put(reinterpret_cast<uint32_t *>(o + DBR_A + 64 + (l >> 3) * 32 + (l & 7) * 4), *reinterpret_cast<const uint32_t *>(cs));      // R.U / R.V
-      }
+    if (has_left) put(reinterpret_cast<uint32_t *>(o + G::A + l * 4), *reinterpret_cast<const uint32_t *>(Y + (l + 4) * 20));              // R.Y
+    for (int t = l; t < 2 * CH; t += 16) {
+      const int pl = t / (CH ? CH : 1), r = t - pl * CH;
+      const uint8_t *cs = C2[pl] + (r + 4) * 12;
+      put(reinterpret_cast<uint32_t *>(o + 256 + pl * CH * 8 + r * 8), *reinterpret_cast<const uint32_t *>(cs + 4));
+      put(reinterpret_cast<uint32_t *>(o + 256 + pl * CH * 8 + r * 8 + 4), *reinterpret_cast<const uint32_t *>(cs + 8));
+      if (has_left) put(reinterpret_cast<uint32_t *>(o + G::A + 64 + pl * CH * 4 + r * 4), *reinterpret_cast<const uint32_t *>(cs));            // R.U / R.V
     }
     if (has_up) {
       const int r = l >> 2, q = l & 3;
-      put(reinterpret_cast<uint32_t *>(o + DBR_A + DBR_R + r * 16 + q * 4), *reinterpret_cast<const uint32_t *>(Y + r * 20 + 4 + q * 4));   // T.Y
-      const int pl = l >> 3, cr = (l >> 1) & 3, cq = l & 1;
-      put(reinterpret_cast<uint32_t *>(o + DBR_A + DBR_R + 64 + pl * 32 + cr * 8 + cq * 4), *reinterpret_cast<const uint32_t *>((pl ? V : U) + cr * 12 + 4 + cq * 4));
+      put(reinterpret_cast<uint32_t *>(o + G::A + G::R + r * 16 + q * 4), *reinterpret_cast<const uint32_t *>(Y + r * 20 + 4 + q * 4));   // T.Y
+      if (CF) {
+        const int pl = l >> 3, cr = (l >> 1) & 3, cq = l & 1;
+        put(reinterpret_cast<uint32_t *>(o + G::A + G::R + 64 + pl * 32 + cr * 8 + cq * 4), *reinterpret_cast<const uint32_t *>(C2[pl] + cr * 12 + 4 + cq * 4));
+      }
     }
   }
   const unsigned long long m = __ballot(diff);
@@ -622,25 +643,28 @@ __global__ __launch_bounds__(64) void deblock_relax_kernel(DbkRelax D)
 }
 
 // the filtered picture from the records: A_k, columns 12..15 from R_(k+1), then rows 12..15 from T_(k+mbw)
+template <int CF>
 __global__ __launch_bounds__(64) void deblock_compose_kernel(const uint8_t *st, uint8_t *y, uint8_t *u, uint8_t *v, int W, int Wc, int mbw, int mbh)
 {
+  using G = DbrGeo<CF>;
+  constexpr int CH = G::CH;
   const int h = threadIdx.x >> 4, l = threadIdx.x & 15, nmb = mbw * mbh, k = blockIdx.x * 4 + h;
   if (k >= nmb) return;
   const int mbx = k % mbw, mby = k / mbw;
-  const uint8_t *a = st + (size_t)k * DBR_REC;
+  const uint8_t *a = st + (size_t)k * G::REC;
   const bool has_r = mbx + 1 < mbw, has_b = mby + 1 < mbh;
   {                                                          // luma row l
     uint4 o = *reinterpret_cast<const uint4 *>(a + l * 16);
-    if (has_r) o.w = *reinterpret_cast<const uint32_t *>(a + DBR_REC + DBR_A + l * 4);
-    if (has_b && l >= 12) o = *reinterpret_cast<const uint4 *>(a + (size_t)mbw * DBR_REC + DBR_A + DBR_R + (l - 12) * 16);
+    if (has_r) o.w = *reinterpret_cast<const uint32_t *>(a + G::REC + G::A + l * 4);
+    if (has_b && l >= 12) o = *reinterpret_cast<const uint4 *>(a + (size_t)mbw * G::REC + G::A + G::R + (l - 12) * 16);
     *reinterpret_cast<uint4 *>(y + (size_t)(mby * 16 + l) * W + mbx * 16) = o;
   }
-  {                                                          // chroma: plane l >> 3, row l & 7
-    const int pl = l >> 3, r = l & 7;
-    uint2 o = *reinterpret_cast<const uint2 *>(a + 256 + pl * 64 + r * 8);
-    if (has_r) o.y = *reinterpret_cast<const uint32_t *>(a + DBR_REC + DBR_A + 64 + pl * 32 + r * 4);
-    if (has_b && r >= 4) o = *reinterpret_cast<const uint2 *>(a + (size_t)mbw * DBR_REC + DBR_A + DBR_R + 64 + pl * 32 + (r - 4) * 8);
-    *reinterpret_cast<uint2 *>((pl ? v : u) + (size_t)(mby * 8 + r) * Wc + mbx * 8) = o;
+  for (int t = l; t < 2 * CH; t += 16) {                     // chroma rows
+    const int pl = t / (CH ? CH : 1), r = t - pl * CH;
+    uint2 o = *reinterpret_cast<const uint2 *>(a + 256 + pl * CH * 8 + r * 8);
+    if (has_r) o.y = *reinterpret_cast<const uint32_t *>(a + G::REC + G::A + 64 + pl * CH * 4 + r * 4);
+    if (has_b && r >= CH - 4) o = *reinterpret_cast<const uint2 *>(a + (size_t)mbw * G::REC + G::A + G::R + 64 + pl * 32 + (r - (CH - 4)) * 8);
+    *reinterpret_cast<uint2 *>((pl ? v : u) + (size_t)(mby * CH + r) * Wc + mbx * 8) = o;
   }
 }
 
@@ -695,8 +719,10 @@ int dbk_run(jmhip_ctx *c, const DbkArrays &a, int mvlimit, int mb_row0, int mb_r
   // take the other chroma formats and row bands, and finish if the sweeps have not settled within the cap
   {
     const char *sched = getenv("JMHIP_DEBLOCK_SCHED");
-    if (c->cfg.yuv_format == JMHIP_YUV420 && mb_row0 == 0 && mb_rows == c->mbh && !(sched && !strcmp(sched, "wave"))) {
-      const size_t st_bytes = (size_t)nmb * DBR_REC, need = st_bytes + 2 * (size_t)nmb + 64 * sizeof(int);
+    const int rcf = c->cfg.yuv_format == JMHIP_YUV420 ? 1 : c->cfg.yuv_format == JMHIP_YUV422 ? 2 : c->cfg.yuv_format == JMHIP_YUV400 ? 0 : -1;
+    if (rcf >= 0 && mb_row0 == 0 && mb_rows == c->mbh && !(sched && !strcmp(sched, "wave"))) {
+      const size_t rec_bytes = rcf == 2 ? DbrGeo<2>::REC : rcf == 1 ? DbrGeo<1>::REC : DbrGeo<0>::REC;
+      const size_t st_bytes = (size_t)nmb * rec_bytes, need = st_bytes + 2 * (size_t)nmb + 64 * sizeof(int);
       if (c->dbr_cap < need) {
         if (c->dbr_dev) JM_HIP_CHECK(c, hipFree(c->dbr_dev));
         c->dbr_dev = nullptr; c->dbr_cap = 0;
@@ -715,7 +741,9 @@ int dbk_run(jmhip_ctx *c, const DbkArrays &a, int mvlimit, int mb_row0, int mb_r
         JM_HIP_CHECK(c, hipMemsetAsync(counters, 0, sizeof(int) * group, c->stream));
         for (int g = 0; g < group; g++, sweep++) {
           R.first_sweep = sweep == 0; R.chg_prev = chg + (size_t)(sweep & 1) * nmb; R.chg_next = chg + (size_t)((sweep + 1) & 1) * nmb; R.n_changed = counters + g;
-          deblock_relax_kernel<<<(nmb + 3) / 4, 64, 0, c->stream>>>(R);
+          if (rcf == 2) deblock_relax_kernel<2><<<(nmb + 3) / 4, 64, 0, c->stream>>>(R);
+          else if (rcf == 1) deblock_relax_kernel<1><<<(nmb + 3) / 4, 64, 0, c->stream>>>(R);
+          else deblock_relax_kernel<0><<<(nmb + 3) / 4, 64, 0, c->stream>>>(R);
         }
         JM_HIP_CHECK(c, hipGetLastError());
         int last[8] = {1, 1, 1, 1, 1, 1, 1, 1};
@@ -726,7 +754,9 @@ int dbk_run(jmhip_ctx *c, const DbkArrays &a, int mvlimit, int mb_row0, int mb_r
       }
       c->dbk_sweeps = sweep;
       if (settled) {
-        deblock_compose_kernel<<<(nmb + 3) / 4, 64, 0, c->stream>>>(st, c->rec_y, c->rec_u, c->rec_v, c->W, c->Wc, c->mbw, c->mbh);
+        if (rcf == 2) deblock_compose_kernel<2><<<(nmb + 3) / 4, 64, 0, c->stream>>>(st, c->rec_y, c->rec_u, c->rec_v, c->W, c->Wc, c->mbw, c->mbh);
+        else if (rcf == 1) deblock_compose_kernel<1><<<(nmb + 3) / 4, 64, 0, c->stream>>>(st, c->rec_y, c->rec_u, c->rec_v, c->W, c->Wc, c->mbw, c->mbh);
+        else deblock_compose_kernel<0><<<(nmb + 3) / 4, 64, 0, c->stream>>>(st, c->rec_y, c->rec_u, c->rec_v, c->W, c->Wc, c->mbw, c->mbh);
         JM_HIP_CHECK(c, hipGetLastError());
         return JMHIP_OK;
       }

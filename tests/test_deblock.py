@@ -169,6 +169,8 @@ def test_deblock_schedules_agree(pkg, sched, sweeps, monkeypatch):
     run(pkg, 176, 144, 1, seed=41, idc_mode="zero", intra_frac=1.0, qp_lo=40, qp_hi=51)
     run(pkg, 320, 192, 1, seed=42, idc_mode="two", intra_frac=0.3)
     run(pkg, 1920, 1088, 1, seed=43, smooth=False, qp_lo=44, qp_hi=51, idc_mode="zero")
+    run(pkg, 176, 144, 2, seed=44)
+    run(pkg, 320, 64, 0, seed=45)
 
 
 @pytest.mark.gpu
