@@ -539,6 +539,7 @@ struct DbkRelax {
   const EdgeInfo *edges;
   const uint8_t *chg_prev; uint8_t *chg_next; int *n_changed;
   int W, Wc, mbw, mbh, first_sweep;
+  int row0, rows;               // macroblock rows [row0, row0 + rows) are filtered; the row above row0 is read (and its bottom rows written) in the picture itself
 };
 
 template <int CF>
@@ -548,12 +549,13 @@ __global__ __launch_bounds__(64) void deblock_relax_kernel(DbkRelax D)
   constexpr int CH = G::CH, CT = (CH + 4) * 12;               // chroma tile: rows -4 .. CH-1, columns -4 .. 7
   __shared__ __attribute__((aligned(16))) uint8_t tY[4][20 * 20], tC[4][2][CF ? CT : 16];
   const int h = threadIdx.x >> 4, l = threadIdx.x & 15;
-  const int nmb = D.mbw * D.mbh, k = min((int)blockIdx.x * 4 + h, nmb - 1);
+  const int nmb = D.mbw * D.rows, k = D.row0 * D.mbw + min((int)blockIdx.x * 4 + h, nmb - 1);
   const bool live = (int)blockIdx.x * 4 + h < nmb;
   const int mbx = k % D.mbw, mby = k / D.mbw;
-  const bool has_left = mbx > 0, has_up = mby > 0, has_ur = mby > 0 && mbx + 1 < D.mbw;
+  const bool up_rec = mby > D.row0;                            // the upper neighbour is part of this call (has a record); else the picture holds it
+  const bool has_left = mbx > 0, has_up = mby > 0, has_ur = up_rec && mbx + 1 < D.mbw;
   bool active = D.first_sweep != 0;
-  if (!active) active = (has_left && D.chg_prev[k - 1]) || (has_up && D.chg_prev[k - D.mbw]) || (has_ur && D.chg_prev[k - D.mbw + 1]);
+  if (!active) active = (has_left && D.chg_prev[k - 1]) || (up_rec && D.chg_prev[k - D.mbw]) || (has_ur && D.chg_prev[k - D.mbw + 1]);
   active = active && live;
   uint8_t *Y = tY[h];
   uint8_t *const C2[2] = {tC[h][0], tC[h][1]};
@@ -579,7 +581,15 @@ __global__ __launch_bounds__(64) void deblock_relax_kernel(DbkRelax D)
         *reinterpret_cast<uint32_t *>(C2[pl] + (r + 4) * 12) = *reinterpret_cast<const uint32_t *>(a + 256 + pl * CH * 8 + r * 8 + 4);
       }
     }
-    if (has_up) {
+    if (has_up && !up_rec) {                                 // first row of a band: the rows above as the picture holds them
+      const int r = l >> 2, q = l & 3;
+      *reinterpret_cast<uint32_t *>(Y + r * 20 + 4 + q * 4) = *reinterpret_cast<const uint32_t *>(D.y + (size_t)(mby * 16 - 4 + r) * D.W + mbx * 16 + q * 4);
+      if (CF) {
+        const int pl = l >> 3, cr = (l >> 1) & 3, cq = l & 1;
+        *reinterpret_cast<uint32_t *>(C2[pl] + cr * 12 + 4 + cq * 4) = *reinterpret_cast<const uint32_t *>((pl ? D.v : D.u) + (size_t)(mby * CH - 4 + cr) * D.Wc + mbx * 8 + cq * 4);
+      }
+    }
+    if (up_rec) {
       const uint8_t *a = rec - (size_t)D.mbw * G::REC;
       const int r = l >> 2, q = l & 3;                       // luma: 4 rows x 4 dwords
       uint32_t v = *reinterpret_cast<const uint32_t *>(a + (12 + r) * 16 + q * 4);
@@ -644,15 +654,24 @@ __global__ __launch_bounds__(64) void deblock_relax_kernel(DbkRelax D)
 
 // the filtered picture from the records: A_k, columns 12..15 from R_(k+1), then rows 12..15 from T_(k+mbw)
 template <int CF>
-__global__ __launch_bounds__(64) void deblock_compose_kernel(const uint8_t *st, uint8_t *y, uint8_t *u, uint8_t *v, int W, int Wc, int mbw, int mbh)
+__global__ __launch_bounds__(64) void deblock_compose_kernel(const uint8_t *st, uint8_t *y, uint8_t *u, uint8_t *v, int W, int Wc, int mbw, int row0, int rows)
 {
   using G = DbrGeo<CF>;
   constexpr int CH = G::CH;
-  const int h = threadIdx.x >> 4, l = threadIdx.x & 15, nmb = mbw * mbh, k = blockIdx.x * 4 + h;
-  if (k >= nmb) return;
+  const int h = threadIdx.x >> 4, l = threadIdx.x & 15, nmb = mbw * rows;
+  if ((int)blockIdx.x * 4 + h >= nmb) return;
+  const int k = row0 * mbw + blockIdx.x * 4 + h;
   const int mbx = k % mbw, mby = k / mbw;
   const uint8_t *a = st + (size_t)k * G::REC;
-  const bool has_r = mbx + 1 < mbw, has_b = mby + 1 < mbh;
+  const bool has_r = mbx + 1 < mbw, has_b = mby + 1 < row0 + rows;
+  if (mby == row0 && row0 > 0) {                             // the band's top edges changed the bottom rows of the row above: T straight into the picture
+    const int r = l >> 2, q = l & 3;
+    *reinterpret_cast<uint32_t *>(y + (size_t)(mby * 16 - 4 + r) * W + mbx * 16 + q * 4) = *reinterpret_cast<const uint32_t *>(a + G::A + G::R + r * 16 + q * 4);
+    if (CF) {
+      const int pl = l >> 3, cr = (l >> 1) & 3, cq = l & 1;
+      *reinterpret_cast<uint32_t *>((pl ? v : u) + (size_t)(mby * CH - 4 + cr) * Wc + mbx * 8 + cq * 4) = *reinterpret_cast<const uint32_t *>(a + G::A + G::R + 64 + pl * 32 + cr * 8 + cq * 4);
+    }
+  }
   {                                                          // luma row l
     uint4 o = *reinterpret_cast<const uint4 *>(a + l * 16);
     if (has_r) o.w = *reinterpret_cast<const uint32_t *>(a + G::REC + G::A + l * 4);
@@ -720,8 +739,9 @@ int dbk_run(jmhip_ctx *c, const DbkArrays &a, int mvlimit, int mb_row0, int mb_r
   {
     const char *sched = getenv("JMHIP_DEBLOCK_SCHED");
     const int rcf = c->cfg.yuv_format == JMHIP_YUV420 ? 1 : c->cfg.yuv_format == JMHIP_YUV422 ? 2 : c->cfg.yuv_format == JMHIP_YUV400 ? 0 : -1;
-    if (rcf >= 0 && mb_row0 == 0 && mb_rows == c->mbh && !(sched && !strcmp(sched, "wave"))) {
+    if (rcf >= 0 && mb_rows > 0 && !(sched && !strcmp(sched, "wave"))) {
       const size_t rec_bytes = rcf == 2 ? DbrGeo<2>::REC : rcf == 1 ? DbrGeo<1>::REC : DbrGeo<0>::REC;
+      const int nrange = c->mbw * mb_rows;
       const size_t st_bytes = (size_t)nmb * rec_bytes, need = st_bytes + 2 * (size_t)nmb + 64 * sizeof(int);
       if (c->dbr_cap < need) {
         if (c->dbr_dev) JM_HIP_CHECK(c, hipFree(c->dbr_dev));
@@ -733,7 +753,7 @@ int dbk_run(jmhip_ctx *c, const DbkArrays &a, int mvlimit, int mb_row0, int mb_r
       int *counters = reinterpret_cast<int *>(st + ((st_bytes + 2 * (size_t)nmb + 3) & ~(size_t)3));
       DbkRelax R;
       R.y = c->rec_y; R.u = c->rec_u; R.v = c->rec_v; R.st = st; R.edges = (const EdgeInfo *)a.edges;
-      R.W = c->W; R.Wc = c->Wc; R.mbw = c->mbw; R.mbh = c->mbh;
+      R.W = c->W; R.Wc = c->Wc; R.mbw = c->mbw; R.mbh = c->mbh; R.row0 = mb_row0; R.rows = mb_rows;
       const int cap = getenv("JMHIP_DEBLOCK_SWEEPS") ? atoi(getenv("JMHIP_DEBLOCK_SWEEPS")) : 48, group = 4;     // sweeps per host check
       bool settled = false;
       int sweep = 0;
@@ -741,9 +761,9 @@ int dbk_run(jmhip_ctx *c, const DbkArrays &a, int mvlimit, int mb_row0, int mb_r
         JM_HIP_CHECK(c, hipMemsetAsync(counters, 0, sizeof(int) * group, c->stream));
         for (int g = 0; g < group; g++, sweep++) {
           R.first_sweep = sweep == 0; R.chg_prev = chg + (size_t)(sweep & 1) * nmb; R.chg_next = chg + (size_t)((sweep + 1) & 1) * nmb; R.n_changed = counters + g;
-          if (rcf == 2) deblock_relax_kernel<2><<<(nmb + 3) / 4, 64, 0, c->stream>>>(R);
-          else if (rcf == 1) deblock_relax_kernel<1><<<(nmb + 3) / 4, 64, 0, c->stream>>>(R);
-          else deblock_relax_kernel<0><<<(nmb + 3) / 4, 64, 0, c->stream>>>(R);
+          if (rcf == 2) deblock_relax_kernel<2><<<(nrange + 3) / 4, 64, 0, c->stream>>>(R);
+          else if (rcf == 1) deblock_relax_kernel<1><<<(nrange + 3) / 4, 64, 0, c->stream>>>(R);
+          else deblock_relax_kernel<0><<<(nrange + 3) / 4, 64, 0, c->stream>>>(R);
         }
         JM_HIP_CHECK(c, hipGetLastError());
         int last[8] = {1, 1, 1, 1, 1, 1, 1, 1};
@@ -754,9 +774,9 @@ int dbk_run(jmhip_ctx *c, const DbkArrays &a, int mvlimit, int mb_row0, int mb_r
       }
       c->dbk_sweeps = sweep;
       if (settled) {
-        if (rcf == 2) deblock_compose_kernel<2><<<(nmb + 3) / 4, 64, 0, c->stream>>>(st, c->rec_y, c->rec_u, c->rec_v, c->W, c->Wc, c->mbw, c->mbh);
-        else if (rcf == 1) deblock_compose_kernel<1><<<(nmb + 3) / 4, 64, 0, c->stream>>>(st, c->rec_y, c->rec_u, c->rec_v, c->W, c->Wc, c->mbw, c->mbh);
-        else deblock_compose_kernel<0><<<(nmb + 3) / 4, 64, 0, c->stream>>>(st, c->rec_y, c->rec_u, c->rec_v, c->W, c->Wc, c->mbw, c->mbh);
+        if (rcf == 2) deblock_compose_kernel<2><<<(nrange + 3) / 4, 64, 0, c->stream>>>(st, c->rec_y, c->rec_u, c->rec_v, c->W, c->Wc, c->mbw, mb_row0, mb_rows);
+        else if (rcf == 1) deblock_compose_kernel<1><<<(nrange + 3) / 4, 64, 0, c->stream>>>(st, c->rec_y, c->rec_u, c->rec_v, c->W, c->Wc, c->mbw, mb_row0, mb_rows);
+        else deblock_compose_kernel<0><<<(nrange + 3) / 4, 64, 0, c->stream>>>(st, c->rec_y, c->rec_u, c->rec_v, c->W, c->Wc, c->mbw, mb_row0, mb_rows);
         JM_HIP_CHECK(c, hipGetLastError());
         return JMHIP_OK;
       }
