@@ -420,7 +420,10 @@ def main():
     # N > 1: the all-gather is enqueued on the context's own stream (stream-ordered with the kernels round it, no host sync)
     ext = torch.cuda.ExternalStream(ctx.stream_ptr(), device=dev) if world > 1 else None
 
+    done = [0]                                          # steps run so far (the clip position of the resident reference)
+
     def step(k):
+        done[0] = k + 1
         Y, U, V = src[1 + (k % (nframes - 1))]
         ctx.cur_bind(Y.data_ptr(), U.data_ptr(), V.data_ptr())          # the source frame is resident: no copy
         # luma: the 16 quarter-pel planes (search + sub-pel refinement + MC read them all over). Chroma: MC is their only reader and takes
@@ -572,8 +575,23 @@ def main():
             out["speedup_vs_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         if world == 1 and args.cpu_mbs > 0:
             out["parity_check"] = parity_check(pkg, ctx, frames, mbs, prm, last_src=1 + ((args.warmup + args.steps + 2) % (nframes - 1)), prev_ref=prev_ref_host)
+            if not args.deblock:
+                # for information: the same step with JM's default in-loop deblocking filter in the loop (jmhip_deblock_recon, relaxation schedule)
+                args.deblock = True
+                k0 = done[0]
+                for k in range(3):
+                    step(k0 + k)
+                fence()
+                t0 = time.perf_counter()
+                for k in range(10):
+                    step(k0 + 3 + k)
+                fence()
+                dt = (time.perf_counter() - t0) / 10
+                args.deblock = False
+                out["with_loop_filter"] = {"ms_per_step": round(dt * 1e3, 4), "macroblocks_per_s": round(MBW * MBH / dt, 1),
+                                           "note": "LoopFilterDisable = 0: every reference picture is deblocked on the device before it is interpolated; not the metric's path"}
             # the clip's pictures that follow the reference the last step left, in display order
-            order = [1 + ((args.warmup + args.steps + 3 + j) % (nframes - 1)) for j in range(nframes - 1)]
+            order = [1 + ((done[0] + j) % (nframes - 1)) for j in range(nframes - 1)]
             out["slice_search"] = slice_search_times(pkg, ctx, lam, src, order)
             out["per_partition_pred"] = per_partition_predictors(pkg, ctx, lam, prm, mbs)
             e2e = jm_end_to_end(frames)
