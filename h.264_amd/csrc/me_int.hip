@@ -712,6 +712,7 @@ __global__ __launch_bounds__(256, 3) void me_int_pair_kernel(MeDev P, const jmhi
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   STAMP(0);
   const int mbi = job_index[item] & 0xffffff, rep = (job_index[item] >> 24) & 63;
+  const int uni = __builtin_amdgcn_readfirstlane((job_index[item] >> 30) & 1);      // one predictor for all 41 partitions
   const jmhip_me_mb &job = jobs[mbi];
   const int mbx = job.mb_x, mby = job.mb_y;
   const int R = P.R, UW = 2 * R + 1, UH = UW;
@@ -754,10 +755,16 @@ __global__ __launch_bounds__(256, 3) void me_int_pair_kernel(MeDev P, const jmhi
     const int v4 = 4 * ((isx ? umin_x : umin_y) + line);
     const int *sp = isx ? S.spx : S.spy;
     uint32_t w = 0;
+    if (uni) {                                          // every used slot holds the same count
+      const uint32_t b = (uint32_t)mvbits(v4 - sp[0]) * 0x01010101u;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int p = sp[4 * q + k];
-      w |= (p == SLOT_UNUSED ? 0u : (uint32_t)mvbits(v4 - p)) << (8 * k);
+      for (int k = 0; k < 4; k++) w |= sp[4 * q + k] == SLOT_UNUSED ? 0u : (b & (0xffu << (8 * k)));
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int p = sp[4 * q + k];
+        w |= (p == SLOT_UNUSED ? 0u : (uint32_t)mvbits(v4 - p)) << (8 * k);
+      }
     }
     reinterpret_cast<uint32_t *>(isx ? S.bxtab[line] : S.bytab[line])[q] = w;
   }
@@ -865,6 +872,14 @@ __global__ __launch_bounds__(256, 3) void me_int_pair_kernel(MeDev P, const jmhi
     }
   };
   auto load_mvc = [&](int colx, int row) __attribute__((always_inline)) {
+    if (uni) {                                          // slot 0 of a half is a 4x4 leaf, always used
+      const unsigned prod = __umul24((unsigned)lam, (unsigned)S.bytab[row][half * 24] + (unsigned)S.bxtab[colx][half * 24]);
+      const unsigned hi = prod & 0xffff0000u;
+#pragma unroll
+      for (int j = 0; j < PAIR_NK - 1; j++) mvc[j] = hi;
+      mvc[PAIR_NK - 1] = (prod >> 16) + (unsigned)w16;
+      return;
+    }
     const uint2 *bt = reinterpret_cast<const uint2 *>(&S.bytab[row][half * 24]), *bxq = reinterpret_cast<const uint2 *>(&S.bxtab[colx][half * 24]);
     const uint2 b0 = bt[0], b1 = bt[1], b2 = bt[2], x0 = bxq[0], x1 = bxq[1], x2 = bxq[2];
     const uint32_t byp[6] = {b0.x, b0.y, b1.x, b1.y, b2.x, b2.y}, bxp[6] = {x0.x, x0.y, x1.x, x1.y, x2.x, x2.y};
@@ -1488,7 +1503,12 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
       if (ng == FAST_MAX_CENTRES) { fast = false; break; }
       reps[ng] = p; rcx[ng] = cx; rcy[ng] = cy; ng++;
     }
-    if (fast) for (int g = 0; g < ng; g++) c->me_fast_idx.push_back(i | (reps[g] << 24));
+    if (fast) {
+      // bit 30: all 41 predictors of the macroblock are equal (the metric's workload; smooth motion in JM's own fields): one mv cost serves every partition
+      bool uni = true;
+      for (int p = 1; p < JMHIP_NPART && uni; p++) uni = m.pred_mv[p][0] == m.pred_mv[0][0] && m.pred_mv[p][1] == m.pred_mv[0][1];
+      for (int g = 0; g < ng; g++) c->me_fast_idx.push_back(i | (reps[g] << 24) | (uni ? 1 << 30 : 0));
+    }
     else {
       c->me_gen_idx.push_back(i);
       max_uw = uw > max_uw ? uw : max_uw; max_uh = uh > max_uh ? uh : max_uh;
