@@ -667,7 +667,7 @@ __global__ __launch_bounds__(256) void tq_chroma420_kernel(const jmhip_tq_job *_
 // b8*4+b4, so a DPP quad is an 8x8 block), in the chroma phase lanes 0..31 own the four Cb / four Cr blocks of each macroblock (a quad per
 // component, as tq_chroma420_kernel); all 64 lanes fetch the chroma prediction.
 // Same arithmetic, line for line, as the kernels it replaces (they stay for 4:2:2, 4:0:0, 8x8-transform macroblocks and jmhip_tq_batch).
-__global__ __launch_bounds__(64) void frame_fused_kernel(FrameDev F, const jmhip_me_mb *__restrict__ mbs, const jmhip_me_result *__restrict__ me,
+__global__ __launch_bounds__(128) void frame_fused_kernel(FrameDev F, const jmhip_me_mb *__restrict__ mbs, const jmhip_me_result *__restrict__ me,
                                                         const jmhip_mb_mode *__restrict__ modes_in, jmhip_mb_mode *__restrict__ modes_out,
                                                         const jmhip_quant *__restrict__ quants, JmMbRes *__restrict__ out, JmMbCoded *__restrict__ coded, int n)
 {
@@ -682,11 +682,14 @@ __global__ __launch_bounds__(64) void frame_fused_kernel(FrameDev F, const jmhip
   __shared__ __attribute__((aligned(4))) uint8_t s_pc[NMB][2][8][8], s_sc[NMB][2][8][8];      // chroma prediction / source tiles
   const int vb = jm_xcd_item((n + NMB - 1) / NMB);
   if (vb < 0) return;
-  const int tid = threadIdx.x, i0 = vb * NMB;
+  // two waves: wave 0 stages and then owns the luma blocks, wave 1 owns chroma (prediction, then dct_chroma) -- the two transform paths run
+  // side by side instead of one after the other (the kernel is bound by one wave's latency)
+  const int wv = threadIdx.x >> 6, tid = threadIdx.x & 63, i0 = vb * NMB;
   const int nlive = min(NMB, n - i0);                  // the last wave repeats macroblock n-1 in its spare groups and stores nothing for them
   auto mb_of = [&](int hh) { return min(i0 + hh, n - 1); };
 
   // the 41 vectors and costs of each macroblock arrive in one round trip (the mode picks among them afterwards, out of LDS)
+  if (wv == 0)
   for (int e = tid; e < NMB * JMHIP_NPART; e += 64) {
     const int hh = e / JMHIP_NPART, p = e - hh * JMHIP_NPART;
     const jmhip_me_result &r = me[mb_of(hh)];
@@ -694,11 +697,11 @@ __global__ __launch_bounds__(64) void frame_fused_kernel(FrameDev F, const jmhip
     s_cost[hh][p] = r.cost[p];
   }
   jmhip_mb_mode m_in;
-  if (tid < NMB && modes_in) m_in = modes_in[mb_of(tid)];
-  if (tid >= 8 && tid < 8 + NMB) { const jmhip_me_mb &mb = mbs[mb_of(tid - 8)]; s_pos[tid - 8][0] = mb.mb_x; s_pos[tid - 8][1] = mb.mb_y; }
-  if (tid >= 16 && tid < 16 + 4 * NMB) { const int hh = (tid - 16) >> 2, k = tid & 3; s_ref[hh][k] = F.blk_ref ? F.blk_ref[(size_t)mb_of(hh) * 4 + k] : mbs[mb_of(hh)].ref; }
+  if (wv == 0 && tid < NMB && modes_in) m_in = modes_in[mb_of(tid)];
+  if (wv == 0 && tid >= 8 && tid < 8 + NMB) { const jmhip_me_mb &mb = mbs[mb_of(tid - 8)]; s_pos[tid - 8][0] = mb.mb_x; s_pos[tid - 8][1] = mb.mb_y; }
+  if (wv == 0 && tid >= 16 && tid < 16 + 4 * NMB) { const int hh = (tid - 16) >> 2, k = tid & 3; s_ref[hh][k] = F.blk_ref ? F.blk_ref[(size_t)mb_of(hh) * 4 + k] : mbs[mb_of(hh)].ref; }
   __syncthreads();
-  if (tid < NMB) {
+  if (wv == 0 && tid < NMB) {
     jmhip_mb_mode m;
     if (modes_in) m = m_in;
     else {                                             // smallest summed motion cost; ties go to the lower mode number (as mc_kernel)
@@ -723,7 +726,7 @@ __global__ __launch_bounds__(64) void frame_fused_kernel(FrameDev F, const jmhip
     if (tid < nlive) modes_out[i0 + tid] = m;
   }
   __syncthreads();
-  {
+  if (wv == 0) {
     const int hh = tid >> 4, l = tid & 15;
     const uint32_t v = s_mvall[hh][covering_partition(s_mode[hh], l & 3, l >> 2)];
     s_mv[hh][l][0] = (short)(v & 0xffff); s_mv[hh][l][1] = (short)(v >> 16);
@@ -731,6 +734,7 @@ __global__ __launch_bounds__(64) void frame_fused_kernel(FrameDev F, const jmhip
   __syncthreads();
 
   // ---- chroma prediction and source into LDS: four sample pairs per lane (mc_kernel's chroma loop, macroblock.c:1626-1650)
+  if (wv == 1)
 #pragma unroll
   for (int t = tid; t < NMB * 64; t += 64) {
     const int h = t >> 6, tt = t & 63;
@@ -752,7 +756,7 @@ __global__ __launch_bounds__(64) void frame_fused_kernel(FrameDev F, const jmhip
   }
 
   int cbp_luma = 0, cbp_blk_luma = 0;                  // after the coefficient-cost thresholds (every luma lane ends up holding them)
-  {
+  if (wv == 0) {
     // ---- luma block: prediction (LumaPrediction per 4x4 block, macroblock.c:836), residual, dct_4x4 (block.c:843)
     const int h = tid >> 4, l = tid & 15;
     const int mbx = s_pos[h][0], mby = s_pos[h][1];
@@ -847,9 +851,9 @@ __global__ __launch_bounds__(64) void frame_fused_kernel(FrameDev F, const jmhip
         *reinterpret_cast<uint32_t *>(F.rec_y + (size_t)(mby * 16 + by + j) * F.W + mbx * 16 + bx) = keep ? rec[j] : prd[j];
     }
   }
-  __syncthreads();                                     // the chroma tiles are complete
+  if (wv == 1) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }   // the chroma tiles are this wave's own
 
-  if (tid < 8 * NMB) {
+  if (wv == 1 && tid < 8 * NMB) {
     // ---- chroma block: dct_chroma for 4:2:0 on a quad of lanes (tq_chroma420_kernel), block.c:1051-1495
     const int h = tid >> 3, uv = (tid >> 2) & 1, b4 = tid & 3, cb = 16 + 4 * uv + b4;
     const int mbx = s_pos[h][0], mby = s_pos[h][1];
@@ -962,7 +966,7 @@ __global__ __launch_bounds__(64) void frame_fused_kernel(FrameDev F, const jmhip
   }
   __syncthreads();
 
-  if ((tid & 15) == 0 && (tid >> 4) < nlive) {         // macroblock.c:2028-2040
+  if (wv == 0 && (tid & 15) == 0 && (tid >> 4) < nlive) {         // macroblock.c:2028-2040
     const JmMbRes &R = s_rec[tid >> 4];
     const int i = i0 + (tid >> 4);
     long long cb = cbp_blk_luma;
@@ -973,7 +977,7 @@ __global__ __launch_bounds__(64) void frame_fused_kernel(FrameDev F, const jmhip
   {
     const uint4 *src = reinterpret_cast<const uint4 *>(s_rec);
     uint4 *dst = reinterpret_cast<uint4 *>(out + i0);
-    for (int k = tid; k < nlive * (int)(sizeof(JmMbRes) / 16); k += 64) dst[k] = src[k];
+    for (int k = threadIdx.x; k < nlive * (int)(sizeof(JmMbRes) / 16); k += 128) dst[k] = src[k];
   }
 }
 
@@ -983,7 +987,7 @@ int jm_launch_frame_fused(jmhip_ctx *c, const void *frame_dev, const void *mbs, 
                           const void *quants, void *records, void *coded, int n)
 {
   const FrameDev &F = *static_cast<const FrameDev *>(frame_dev);
-  frame_fused_kernel<<<jm_xcd_grid((n + 3) / 4), 64, 0, c->stream>>>(F, (const jmhip_me_mb *)mbs, (const jmhip_me_result *)me, (const jmhip_mb_mode *)modes_in, (jmhip_mb_mode *)modes_out,
+  frame_fused_kernel<<<jm_xcd_grid((n + 3) / 4), 128, 0, c->stream>>>(F, (const jmhip_me_mb *)mbs, (const jmhip_me_result *)me, (const jmhip_mb_mode *)modes_in, (jmhip_mb_mode *)modes_out,
                                                                      (const jmhip_quant *)quants, (JmMbRes *)records, (JmMbCoded *)coded, n);
   if (hipGetLastError() != hipSuccess) return jm_fail(c, JMHIP_ERR_DEVICE, "frame_fused_kernel launch");
   return JMHIP_OK;
