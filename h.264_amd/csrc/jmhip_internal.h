@@ -40,6 +40,7 @@ struct jmhip_ctx {
   void *me_jobs_dev = nullptr; void *me_res_dev = nullptr; int me_capacity = 0; int me_n = 0;
   int me_max_uw = 0, me_max_uh = 0, me_last_mode = 0, me_last_R = 0, me_last_rdopt = 0, me_last_lvl[2] = {0, 0};
   unsigned long long me_last_mask = 0;
+  bool me_last_metric_path = false;
   unsigned me_ref_mask = 0;
   void *me_idx_dev = nullptr;                         // macroblock indices: fast-path list then generic list
   std::vector<int> me_fast_idx, me_gen_idx;                           // reference slots used by the last ME call
@@ -114,6 +115,12 @@ int jm_frame_buffers_ensure(jmhip_ctx *ctx, int n);                             
 struct MeDev;
 int jm_me_sub_tables(jmhip_ctx *ctx);                                                   // me_sub.hip
 void jm_launch_me_sub(jmhip_ctx *ctx, const MeDev &P, const jmhip_me_mb *jobs_dev, jmhip_me_result *res_dev, int n);
+// me_metric.hip: the search chain for every error metric / the chroma term (jmhip_me_params.metric_set)
+static inline bool jm_me_metric_path(const jmhip_me_params *prm)
+{ return prm->metric_set && (prm->metric[0] != 0 || prm->metric[1] != 2 || prm->metric[2] != 2 || prm->chroma_me != 0); }
+int jm_me_metric_check(jmhip_ctx *ctx, const jmhip_me_params *prm, unsigned ref_mask, const char *who);
+int jm_launch_me_metric(jmhip_ctx *ctx, const jmhip_me_params *prm, const MeDev &P, const jmhip_me_mb *jobs_dev, const int *idx_dev,
+                        jmhip_me_result *res_dev, int n, size_t lds, int skip_int);
 
 // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8) and every XCD has its own L2. Kernels whose neighbouring
 // work items share data (adjacent macroblocks: overlapping reference windows) take their item through this mapping, which

@@ -1475,6 +1475,11 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
     max_uw = max_uh = 0; ref_mask = 0; c->me_fast_idx.clear(); c->me_gen_idx.clear();
   }
   const bool full_mask = (prm->partition_mask & ((1ull << JMHIP_NPART) - 1)) == ((1ull << JMHIP_NPART) - 1);
+  const bool metric_any = jm_me_metric_path(prm);       // other metrics / chroma term: me_metric.hip
+  // its integer stage is only needed when the integer level itself differs from JM's default (SAD, luma only): otherwise the fast
+  // kernels search and me_metric.hip refines
+  const bool metric_path = metric_any && (prm->metric[0] != 0 || prm->chroma_me != 0);
+  if (resident && metric_path != c->me_last_metric_path) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_frame: resident jobs need the metric path of the call that uploaded them");
   for (int i = 0; i < n && !resident; i++) {
     const jmhip_me_mb &m = mbs[i];
     if (m.mb_x < 0 || m.mb_x >= c->mbw || m.mb_y < 0 || m.mb_y >= c->mbh) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_frame: macroblock outside the picture");
@@ -1493,7 +1498,7 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
     // distinct centre (FastFull and single-predictor macroblocks have one; JM's FullSearch typically a handful, the
     // neighbouring predictors being close). Beyond FAST_MAX_CENTRES the union-window kernel is cheaper.
     int reps[FAST_MAX_CENTRES], rcx[FAST_MAX_CENTRES], rcy[FAST_MAX_CENTRES], ng = 0;
-    bool fast = full_mask && (2 * R + 1 >= (me_use_pair_kernel() ? 32 : 64)) && (2 * R + 1 + 15 <= 96) && i < (1 << 24);
+    bool fast = !metric_path && full_mask && (2 * R + 1 >= (me_use_pair_kernel() ? 32 : 64)) && (2 * R + 1 + 15 <= 96) && i < (1 << 24);
     for (int p = 0; p < JMHIP_NPART && fast; p++) {
       int cx, cy, g;
       const int s = prm->search_mode == JMHIP_SEARCH_FASTFULL ? 0 : p;
@@ -1539,6 +1544,8 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
   c->me_n = n; c->me_ref_mask = ref_mask; c->me_max_uw = max_uw; c->me_max_uh = max_uh;
   c->me_last_mode = prm->search_mode; c->me_last_R = prm->search_range; c->me_last_rdopt = prm->rdopt; c->me_last_mask = prm->partition_mask;
   c->me_last_lvl[0] = prm->level_mv_min; c->me_last_lvl[1] = prm->level_mv_max;
+  c->me_last_metric_path = metric_path;
+  if (metric_any && (rc = jm_me_metric_check(c, prm, ref_mask, "jmhip_me_frame"))) return rc;
 
   MeDev P{};
   P.mode = prm->search_mode; P.R = R; P.rdopt = prm->rdopt; P.is_b = prm->is_b_slice;
@@ -1561,6 +1568,13 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
   (void)hipMemsetAsync(stamps_dev, 0, 512 * 4 * 8 * 8, c->stream);
   P.stamps = stamps_dev;
 #endif
+  if (metric_path) {                                    // integer and sub-pel stage in one kernel
+    jm_stage_begin(c, JMHIP_STAGE_ME_INT);
+    rc = jm_launch_me_metric(c, prm, P, (const jmhip_me_mb *)c->me_jobs_dev, (const int *)c->me_idx_dev, (jmhip_me_result *)c->me_res_dev, ngen, lds, 0);
+    jm_stage_end(c, JMHIP_STAGE_ME_INT);
+    JM_HIP_CHECK(c, hipGetLastError());
+    return rc;
+  }
   jm_stage_begin(c, JMHIP_STAGE_ME_INT);
   if (nfast) {
     MeDev PF = P;
@@ -1612,6 +1626,13 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
     }
   }
 #endif
+  if (P.subpel && metric_any) {                        // the refinement with the configured metrics, from the integer vectors and costs just left
+    jm_stage_begin(c, JMHIP_STAGE_ME_SUB);
+    rc = jm_launch_me_metric(c, prm, P, (const jmhip_me_mb *)c->me_jobs_dev, nullptr, (jmhip_me_result *)c->me_res_dev, n, 0, 1);
+    jm_stage_end(c, JMHIP_STAGE_ME_SUB);
+    JM_HIP_CHECK(c, hipGetLastError());
+    return rc;
+  }
   if (P.subpel) {
 #ifdef JMHIP_STAMPS
     (void)hipMemsetAsync(P.stamps, 0, 512 * 4 * 8 * 8, c->stream);

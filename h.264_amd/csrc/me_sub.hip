@@ -287,6 +287,12 @@ extern "C" int jmhip_me_subpel(jmhip_ctx *c, const jmhip_me_params *prm, const j
   int rc = jm_me_sub_tables(c);
   if (rc) return rc;
   if ((rc = jm_ensure_ref_table(c))) return rc;
+  const bool metric_path = jm_me_metric_path(prm);
+  if (metric_path) {
+    unsigned ref_mask = 0;
+    for (int i = 0; i < n; i++) ref_mask |= 1u << mbs[i].ref;
+    if ((rc = jm_me_metric_check(c, prm, ref_mask, "jmhip_me_subpel"))) return rc;
+  }
   void *dj = nullptr, *dr = nullptr;
   if (hipMalloc(&dj, sizeof(jmhip_me_mb) * (size_t)n) != hipSuccess || hipMalloc(&dr, sizeof(jmhip_me_result) * (size_t)n) != hipSuccess) {
     (void)hipFree(dj); return jm_fail(c, JMHIP_ERR_NOMEM, "sub-pel arrays");
@@ -305,7 +311,8 @@ extern "C" int jmhip_me_subpel(jmhip_ctx *c, const jmhip_me_params *prm, const j
   if (e == hipSuccess) e = hipMemcpyAsync(dr, results, sizeof(jmhip_me_result) * (size_t)n, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) {
     jm_stage_begin(c, JMHIP_STAGE_ME_SUB);
-    jm_launch_me_sub(c, P, (const jmhip_me_mb *)dj, (jmhip_me_result *)dr, n);
+    if (metric_path) jm_launch_me_metric(c, prm, P, (const jmhip_me_mb *)dj, nullptr, (jmhip_me_result *)dr, n, 0, 1);
+    else jm_launch_me_sub(c, P, (const jmhip_me_mb *)dj, (jmhip_me_result *)dr, n);
     jm_stage_end(c, JMHIP_STAGE_ME_SUB);
     e = hipGetLastError();
   }

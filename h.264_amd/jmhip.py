@@ -53,7 +53,10 @@ class MeParams(C.Structure):
     _fields_ = [("search_mode", C.c_int), ("search_range", C.c_int), ("rdopt", C.c_int), ("is_b_slice", C.c_int),
                 ("level_mv_min", C.c_int), ("level_mv_max", C.c_int), ("lambda_", C.c_int * 3),
                 ("transform8x8_mode", C.c_int), ("subpel", C.c_int), ("partition_mask", C.c_uint64),
-                ("wp_enable", C.c_int32), ("wp_round", C.c_int32), ("wp_denom", C.c_int32), ("wp_weight", C.c_int16 * 16), ("wp_offset", C.c_int16 * 16)]
+                ("wp_enable", C.c_int32), ("wp_round", C.c_int32), ("wp_denom", C.c_int32), ("wp_weight", C.c_int16 * 16), ("wp_offset", C.c_int16 * 16),
+                ("metric_set", C.c_int32), ("metric", C.c_int32 * 3), ("chroma_me", C.c_int32), ("chroma_me_weight", C.c_int32),
+                ("wp_chroma_round", C.c_int32), ("wp_chroma_denom", C.c_int32),
+                ("wp_weight_cr", (C.c_int16 * 2) * 16), ("wp_offset_cr", (C.c_int16 * 2) * 16)]
 
 
 ME_MB_DTYPE = np.dtype([("mb_x", "<i2"), ("mb_y", "<i2"), ("ref", "<i2"), ("ref_is_0", "<i2"),

@@ -155,6 +155,17 @@ typedef struct {
    * wp_offset[0] of JM's [list][ref][0] entry for the picture in that slot. wp_enable = 0: plain search. */
   int32_t wp_enable, wp_round, wp_denom;
   int16_t wp_weight[16], wp_offset[16];
+  /* Error metrics and the chroma term. metric_set = 0: JM's defaults -- MEDistortionFPel / HPel / QPel = SAD / Hadamard SAD / Hadamard
+   * SAD, luma only -- the fields below are ignored (the fast kernels). metric_set = 1: metric[F_PEL, H_PEL, Q_PEL] =
+   * input->MEErrorMetric[] (0 SAD, 1 SSE, 2 Hadamard SAD; the computeUniPred dispatch of src/mv-search.c:400-424, incl. the carried
+   * minimum when two levels share a metric, :396-397, and SetupFastFullPelSearch's squared error for every metric but SAD,
+   * src/me_fullfast.c:512); chroma_me = input->ChromaMEEnable (0; 1: Cb / Cr term at integer positions; 2: at sub-pel positions
+   * too; src/me_distortion.c:376-402, :1072-1098), chroma_me_weight = input->ChromaMEWeight: needs the current picture's chroma
+   * planes and jmhip_interp_chroma on every reference used. With wp_enable the chroma term is weighted per slot and component
+   * (wp_weight_cr[slot][uv], computeSADWP :443-470); SSE has no weighted form here. */
+  int32_t metric_set, metric[3], chroma_me, chroma_me_weight;
+  int32_t wp_chroma_round, wp_chroma_denom;
+  int16_t wp_weight_cr[16][2], wp_offset_cr[16][2];
 } jmhip_me_params;
 
 /* Per-macroblock inputs. pred_mv: motion-vector predictor per partition in quarter-pel units, what
@@ -244,7 +255,9 @@ typedef struct {
 int jmhip_bipred_search(jmhip_ctx *ctx, const jmhip_bipred_params *prm, const jmhip_bipred_job *jobs, int n, jmhip_bipred_result *results);
 
 /* SubPelBlockMotionSearch alone (src/me_fullsearch.c:341): results[i].mv_int[p] is the INPUT (integer vector in pel
- * units, as FullPel/FastFull left it), results[i].mv/cost[p] the output. Same params/jobs as jmhip_me_frame. */
+ * units, as FullPel/FastFull left it), results[i].mv/cost[p] the output. Same params/jobs as jmhip_me_frame. With
+ * metric_set and equal metrics at the integer and half-pel level, results[i].cost_int[p] is an input too: the min_mcost the
+ * refinement starts from (src/mv-search.c:785-788). */
 int jmhip_me_subpel(jmhip_ctx *ctx, const jmhip_me_params *prm, const jmhip_me_mb *mbs, int n, jmhip_me_result *results);
 
 

@@ -238,20 +238,28 @@ static int partition_of(int blocktype, int x, int y)     /* (x, y): block origin
 
 /* what the device search covers: luma-only SAD (integer) / SATD (sub-pel), plain or weighted reference, frame pictures */
 /* weighted reference ME of the search just admitted by me_ok(): wp_weight / wp_offset [list][ref][0] (src/me_fullsearch.c:76-91) */
-static struct { int on, weight, offset; } me_wp;
+static struct { int on, weight, offset, weight_cr[2], offset_cr[2]; } me_wp;
 
+/* fixed_metrics: 0 = the caller serves luma distortions of whatever metric (the walkers' surfaces); 1 = every MEErrorMetric[] and
+ * ChromaMEEnable setting the device search has (FullPel / SubPel / FastFull through jmhip_me_frame: JM's defaults on the fast kernels,
+ * everything else through metric_set) */
 static int me_ok_metric(short ref, int list, StorablePicture **rp, int *slot, int fixed_metrics)
 {
-  int list_offset = img->mb_data[img->current_mb_nr].list_offset;
+  int list_offset = img->mb_data[img->current_mb_nr].list_offset, m;
   int weighted = ((active_pps->weighted_pred_flag && (img->type == P_SLICE || img->type == SP_SLICE)) ||
                   (active_pps->weighted_bipred_idc && (img->type == B_SLICE))) && input->UseWeightedReferenceME;
-  if (input->ChromaMEEnable || list_offset) return 0;
+  if (list_offset) return 0;
+  if (input->ChromaMEEnable && !fixed_metrics) return 0;
   me_wp.on = weighted;
-  if (weighted) { me_wp.weight = wp_weight[list + list_offset][ref][0]; me_wp.offset = wp_offset[list + list_offset][ref][0]; }
-  if (fixed_metrics && (input->MEErrorMetric[F_PEL] != ERROR_SAD || input->MEErrorMetric[H_PEL] != ERROR_SATD || input->MEErrorMetric[Q_PEL] != ERROR_SATD)) return 0;
+  if (weighted) {
+    me_wp.weight = wp_weight[list + list_offset][ref][0]; me_wp.offset = wp_offset[list + list_offset][ref][0];
+    for (m = 0; m < 2; m++) { me_wp.weight_cr[m] = wp_weight[list + list_offset][ref][1 + m]; me_wp.offset_cr[m] = wp_offset[list + list_offset][ref][1 + m]; }
+    if (fixed_metrics) for (m = 0; m < 3; m++) if (input->MEErrorMetric[m] == ERROR_SSE) return 0;      /* computeSSEWP is not on the device */
+  }
   if (!cur_ready()) return 0;
   *rp = listX[list][ref];
   *slot = slot_find(*rp);
+  if (*slot >= 0 && input->ChromaMEEnable && !slots[*slot].has_chroma) return 0;
   return *slot >= 0;
 }
 
@@ -270,6 +278,25 @@ static void me_params(jmhip_me_params *prm, int mode, int range, int lam_f, int 
   prm->lambda[0] = lam_f; prm->lambda[1] = lam_h; prm->lambda[2] = lam_q;
   prm->transform8x8_mode = input->Transform8x8Mode; prm->subpel = 0;
   prm->partition_mask = 1ull << p;
+  /* input->MEErrorMetric[] / ChromaMEEnable: anything but JM's defaults goes to the general search (me_metric.hip) */
+  prm->metric_set = 1;
+  for (k = 0; k < 3; k++) prm->metric[k] = input->MEErrorMetric[k];
+  prm->chroma_me = input->ChromaMEEnable; prm->chroma_me_weight = input->ChromaMEWeight;
+  if (me_wp.on && input->ChromaMEEnable) {
+    prm->wp_chroma_round = wp_chroma_round; prm->wp_chroma_denom = chroma_log_weight_denom;
+    for (k = 0; k < 16; k++) {
+      prm->wp_weight_cr[k][0] = (int16_t)me_wp.weight_cr[0]; prm->wp_weight_cr[k][1] = (int16_t)me_wp.weight_cr[1];
+      prm->wp_offset_cr[k][0] = (int16_t)me_wp.offset_cr[0]; prm->wp_offset_cr[k][1] = (int16_t)me_wp.offset_cr[1];
+    }
+  }
+}
+
+/* the reference-picture globals JM's search functions leave behind when the chroma term is on (me_fullsearch.c:93-108) */
+static void jm_side_effects_chroma(StorablePicture *rp)
+{
+  if (!input->ChromaMEEnable) return;
+  ref_pic_sub.crcb[0] = rp->imgUV_sub[0]; ref_pic_sub.crcb[1] = rp->imgUV_sub[1];
+  width_pad_cr = rp->size_x_cr_pad; height_pad_cr = rp->size_y_cr_pad;
 }
 
 int FullPelBlockMotionSearch(imgpel *orig_pic, short ref, int list, int pic_pix_x, int pic_pix_y, int blocktype,
@@ -300,7 +327,7 @@ int FullPelBlockMotionSearch(imgpel *orig_pic, short ref, int list, int pic_pix_
     memset(&mb, 0, sizeof(mb));
     mb.mb_x = img->opix_x >> 4; mb.mb_y = img->opix_y >> 4; mb.ref = slot; mb.ref_is_0 = (ref == 0);
     mb.pred_mv[p][0] = pred_mv_x; mb.pred_mv[p][1] = pred_mv_y;
-    jm_side_effects(rp);
+    jm_side_effects(rp); jm_side_effects_chroma(rp);
     OK(jmhip_me_frame(g, &prm, &mb, 1, &r));
     if (verify) {
       short jx = *mv_x, jy = *mv_y; int c;
@@ -323,7 +350,9 @@ int SubPelBlockMotionSearch(imgpel *orig_pic, short ref, int list, int pic_pix_x
 {
   static int (*orig)(imgpel *, short, int, int, int, int, short, short, short *, short *, int, int, int, int *);
   StorablePicture *rp; int slot, p = -1, ok;
-  ok = (shim_mask & 0x04) && min_mcost == INT_MAX && search_pos2 == 9 && search_pos4 == 9 && !((*mv_x | *mv_y) & 3) &&
+  /* mv-search.c:396, :785-788: with equal metrics at the integer and half-pel level the refinement starts from the integer minimum */
+  const int start_hp = !(input->ChromaMEEnable == 1 || input->MEErrorMetric[F_PEL] != input->MEErrorMetric[H_PEL]);
+  ok = (shim_mask & 0x04) && (min_mcost == INT_MAX || start_hp) && search_pos2 == 9 && search_pos4 == 9 && !((*mv_x | *mv_y) & 3) &&
        me_ok(ref, list, &rp, &slot) && (p = partition_of(blocktype, pic_pix_x - img->opix_x, pic_pix_y - img->opix_y)) >= 0 &&
        test8x8transform == (input->Transform8x8Mode && blocktype <= 4);
   if (!ok) {
@@ -338,8 +367,8 @@ int SubPelBlockMotionSearch(imgpel *orig_pic, short ref, int list, int pic_pix_x
     memset(&mb, 0, sizeof(mb)); memset(&r, 0, sizeof(r));
     mb.mb_x = img->opix_x >> 4; mb.mb_y = img->opix_y >> 4; mb.ref = slot; mb.ref_is_0 = (ref == 0);
     mb.pred_mv[p][0] = pred_mv_x; mb.pred_mv[p][1] = pred_mv_y;
-    r.mv_int[p][0] = *mv_x >> 2; r.mv_int[p][1] = *mv_y >> 2;
-    jm_side_effects(rp);
+    r.mv_int[p][0] = *mv_x >> 2; r.mv_int[p][1] = *mv_y >> 2; r.cost_int[p] = min_mcost;
+    jm_side_effects(rp); jm_side_effects_chroma(rp);
     OK(jmhip_me_subpel(g, &prm, &mb, 1, &r));
     if (verify) {
       short jx = *mv_x, jy = *mv_y; int c;
@@ -396,7 +425,7 @@ int FastFullPelBlockMotionSearch(imgpel *orig_pic, short ref, int list, int pic_
     mb.mb_x = img->opix_x >> 4; mb.mb_y = img->opix_y >> 4; mb.ref = slot; mb.ref_is_0 = (ref == 0);
     mb.pred_mv[0][0] = ff_state[list][ref].pmv[0]; mb.pred_mv[0][1] = ff_state[list][ref].pmv[1];   /* the window centre */
     mb.pred_mv[p][0] = pred_mv_x; mb.pred_mv[p][1] = pred_mv_y;
-    jm_side_effects(rp);
+    jm_side_effects(rp); jm_side_effects_chroma(rp);
     OK(jmhip_me_frame(g, &prm, &mb, 1, &r));
     if (verify) {
       short jx = *mv_x, jy = *mv_y; int c;

@@ -110,10 +110,11 @@ class RefPic:
                            self.cr.ctypes.data if self.cr is not None else None)
 
 
-def me_params(rdopt=1, is_b_slice=0, transform8x8_mode=0, metric=(0, 2, 2), level_mv=(-511, 511)):
+def me_params(rdopt=1, is_b_slice=0, transform8x8_mode=0, metric=(0, 2, 2), level_mv=(-511, 511), chroma_me=0, chroma_me_weight=1):
     p = MeParams()
     p.rdopt, p.is_b_slice, p.transform8x8_mode = rdopt, is_b_slice, transform8x8_mode
     p.metric[0], p.metric[1], p.metric[2] = metric
+    p.chroma_me, p.chroma_me_weight = chroma_me, chroma_me_weight
     p.max_val = p.max_val_uv = 255
     p.level_mv_min, p.level_mv_max = level_mv
     return p
@@ -122,11 +123,27 @@ def me_params(rdopt=1, is_b_slice=0, transform8x8_mode=0, metric=(0, 2, 2), leve
 BLOCK_SIZE = {1: (16, 16), 2: (16, 8), 3: (8, 16), 4: (8, 8), 5: (8, 4), 6: (4, 8), 7: (4, 4)}
 
 
-def block_search_full(p, refpic, cur, pic_x, pic_y, blocktype, pred, R, lam, ref_is_0=1):
-    """BlockMotionSearch chain for SearchMode=-1 -> (mv_qpel, cost, mv_int, cost_int)."""
-    bsx, bsy = BLOCK_SIZE[blocktype]
+def chroma_shifts(yuv_format):
+    """luma -> chroma block size shifts (x, y)"""
+    return (1 if yuv_format in (1, 2) else 0), (1 if yuv_format == 1 else 0)
+
+
+def orig_block(cur, pic_x, pic_y, bsx, bsy, cur_uv=None, yuv_format=1):
+    """orig_pic of BlockMotionSearch (mv-search.c:605-630): the luma block, then the Cb block at 256 and the Cr block at 512."""
     orig = np.zeros(768, dtype=np.uint16)
     orig[: bsx * bsy] = np.asarray(cur[pic_y:pic_y + bsy, pic_x:pic_x + bsx], dtype=np.uint16).reshape(-1)
+    if cur_uv is not None:
+        sx, sy = chroma_shifts(yuv_format)
+        for k in range(2):
+            blk = np.asarray(cur_uv[k][pic_y >> sy:(pic_y + bsy) >> sy, pic_x >> sx:(pic_x + bsx) >> sx], dtype=np.uint16).reshape(-1)
+            orig[256 << k:(256 << k) + blk.size] = blk
+    return orig
+
+
+def block_search_full(p, refpic, cur, pic_x, pic_y, blocktype, pred, R, lam, ref_is_0=1, cur_uv=None):
+    """BlockMotionSearch chain for SearchMode=-1 -> (mv_qpel, cost, mv_int, cost_int)."""
+    bsx, bsy = BLOCK_SIZE[blocktype]
+    orig = orig_block(cur, pic_x, pic_y, bsx, bsy, cur_uv, refpic.yuv_format)
     lam_a = (C.c_int * 3)(*lam)
     mv = np.zeros(2, dtype=np.int16)
     mvi = np.zeros(2, dtype=np.int16)
@@ -160,9 +177,13 @@ def _setup_search_protos():
     return L
 
 
-def me_frame(p, refpics, cur, mbs, mode, R, lam, subpel=True, mask=(1 << 41) - 1):
-    """Reference for jmhip_me_frame: returns dict of arrays mv, cost, mv_int, cost_int shaped like the ABI result."""
+def me_frame(p, refpics, cur, mbs, mode, R, lam, subpel=True, mask=(1 << 41) - 1, cur_uv=None):
+    """Reference for jmhip_me_frame: returns dict of arrays mv, cost, mv_int, cost_int shaped like the ABI result.
+    cur_uv: (U, V) of the current picture when p.chroma_me is set."""
     L = _setup_search_protos()
+    start_hp = 0 if (p.chroma_me == 1 or p.metric[0] != p.metric[1]) else 1          # mv-search.c:396
+    if cur_uv is not None:
+        cur_uv = [np.ascontiguousarray(c, dtype=np.uint16) for c in cur_uv]
     n = len(mbs)
     out = {"mv": np.zeros((n, 41, 2), np.int16), "cost": np.full((n, 41), -1, np.int32),
            "mv_int": np.zeros((n, 41, 2), np.int16), "cost_int": np.full((n, 41), -1, np.int32)}
@@ -175,6 +196,13 @@ def me_frame(p, refpics, cur, mbs, mode, R, lam, subpel=True, mask=(1 << 41) - 1
         if mode == 0:
             mbpix = np.zeros(768, np.uint16)
             mbpix[:256] = cur16[oy:oy + 16, ox:ox + 16].reshape(-1)
+            if cur_uv is not None:                      # me_fullfast.c:577-587: Cb rows, then Cr rows, right behind the luma block
+                sx, sy = chroma_shifts(rp.yuv_format)
+                o = 256
+                for k in range(2):
+                    blk = cur_uv[k][oy >> sy:(oy + 16) >> sy, ox >> sx:(ox + 16) >> sx].reshape(-1)
+                    mbpix[o:o + blk.size] = blk
+                    o += blk.size
             ff = FastFull()
             buf = np.zeros(8 * 16 * (2 * R + 1) ** 2, np.int32)
             ff.block_sad = buf.ctypes.data_as(C.POINTER(C.c_int))
@@ -186,11 +214,10 @@ def me_frame(p, refpics, cur, mbs, mode, R, lam, subpel=True, mask=(1 << 41) - 1
             px, py = ox + 4 * x4, oy + 4 * y4
             pred = (int(mb["pred_mv"][q][0]), int(mb["pred_mv"][q][1]))
             if mode == -1 and subpel:
-                mv, cost, mvi, ci = block_search_full(p, rp, cur16, px, py, bt, pred, R, lam, int(mb["ref_is_0"]))
+                mv, cost, mvi, ci = block_search_full(p, rp, cur16, px, py, bt, pred, R, lam, int(mb["ref_is_0"]), cur_uv)
             else:
                 bsx, bsy = 4 * w4, 4 * h4
-                orig = np.zeros(768, np.uint16)
-                orig[: bsx * bsy] = cur16[py:py + bsy, px:px + bsx].reshape(-1)
+                orig = orig_block(cur16, px, py, bsx, bsy, cur_uv, rp.yuv_format)
                 mvs = np.zeros(2, np.int16)
                 if mode == 0:
                     ci = L.jmo_fastfull_search(C.byref(p), C.byref(ff), ox, oy, px, py, bt, pred[0], pred[1],
@@ -205,7 +232,8 @@ def me_frame(p, refpics, cur, mbs, mode, R, lam, subpel=True, mask=(1 << 41) - 1
                 if subpel:
                     mvq = np.array([mvi[0] << 2, mvi[1] << 2], np.int16)
                     cost = L.jmo_subpel_search(C.byref(p), C.byref(rp.ref), orig.ctypes.data, int(mb["ref_is_0"]), px, py, bt,
-                                               pred[0], pred[1], mvq.ctypes.data, mvq[1:].ctypes.data, 9, 9, 2147483647, lam_a)
+                                               pred[0], pred[1], mvq.ctypes.data, mvq[1:].ctypes.data, 9, 9,
+                                               ci if start_hp else 2147483647, lam_a)       # mv-search.c:785-788
                     mv = (int(mvq[0]), int(mvq[1]))
                 else:
                     mv, cost = (mvi[0] << 2, mvi[1] << 2), ci

@@ -49,11 +49,12 @@ SymbolMode = {cabac}
 SearchMode = {search}
 RDOptimization = {rdopt}
 MEDistortionFPel = {fpel}
-MEDistortionHPel = 2
-MEDistortionQPel = 2
+MEDistortionHPel = {hpel}
+MEDistortionQPel = {qpel}
 MDDistortion = 2
 ChromaMCBuffer = 1
-ChromaMEEnable = 0
+ChromaMEEnable = {cme}
+ChromaMEWeight = {cmw}
 RestrictSearchRange = 2
 AdaptiveRounding = {adrnd}
 Transform8x8Mode = {t8x8}
@@ -94,6 +95,14 @@ CASES = {
     "slices_deblock_across_422": dict(search=0, profile=122, cabac=0, t8x8=1, bframes=0, refs=1, rdopt=1, adrnd=0, yuv=2, qp=36, lfflag=1, lfidc=0, lfa=-2, lfb=3, slicemode=1),
     # 4:4:4 (High 4:4:4 Predictive): chroma planes take the luma filter in the loop filter, quarter-pel chroma planes, dct_4x4 on all three planes
     "fastfull_444": dict(search=0, profile=244, cabac=1, t8x8=1, bframes=0, refs=1, rdopt=1, adrnd=0, yuv=3, qp=34),
+    # every error metric of computeUniPred and the chroma term through the general search (me_metric.hip): SSE everywhere with Cb / Cr at
+    # integer and sub-pel positions; Hadamard SAD at integer positions too (8x8 for block types 1..4; the refinements start from the carried
+    # minimum); FastFullSearch with the unweighted chroma term of SetupFastFullPelSearch and SAD half-pel; weighted reference ME with chroma
+    "full_sse_chroma2": dict(search=-1, profile=77, cabac=1, t8x8=0, bframes=0, refs=2, rdopt=1, adrnd=0, yuv=1, fpel=1, hpel=1, qpel=1, cme=2, cmw=2),
+    "full_satd_all_t8": dict(search=-1, profile=100, cabac=1, t8x8=1, bframes=1, refs=2, rdopt=0, adrnd=0, yuv=1, fpel=2, hpel=2, qpel=2),
+    "fastfull_chroma1": dict(search=0, profile=66, cabac=0, t8x8=0, bframes=0, refs=2, rdopt=0, adrnd=1, yuv=1, fpel=0, hpel=0, qpel=2, cme=1, cmw=1),
+    "fastfull_satd_fpel_422": dict(search=0, profile=122, cabac=1, t8x8=1, bframes=0, refs=1, rdopt=1, adrnd=0, yuv=2, fpel=2, hpel=2, qpel=2, cme=2, cmw=1),
+    "full_wp_chroma": dict(search=-1, profile=77, cabac=1, t8x8=0, bframes=0, refs=2, rdopt=1, adrnd=0, yuv=1, wp=1, fade=1, fpel=0, hpel=0, qpel=2, cme=2, cmw=1),
     "full_lowcplx_422": dict(search=-1, profile=122, cabac=0, t8x8=1, bframes=0, refs=1, rdopt=0, adrnd=1, yuv=2),  # rdopt off centre rule, 4:2:2 chroma DC
 }
 
@@ -129,6 +138,10 @@ def run(exe, d, env=None):
 def prepare(tmp_path, name, w=176, h=144, frames=3, R=16, qp=28):
     v = dict(dict(w=w, h=h, frames=frames, R=R, qp=qp, lfflag=0, lfidc=0, lfa=0, lfb=0, slicemode=0, slicearg=33), **CASES[name])
     v.setdefault("fpel", 0)
+    v.setdefault("hpel", 2)
+    v.setdefault("qpel", 2)
+    v.setdefault("cme", 0)
+    v.setdefault("cmw", 1)
     v.setdefault("bipred", 0)
     v.setdefault("wbp", 0)
     v.setdefault("wp", 0)
