@@ -28,6 +28,14 @@ RUNS = {
     "yuv422_fs": (["-d", "encoder_yuv422.cfg", "-p", "SearchMode=-1", "-p", "SearchRange=16"], 40),
     "main_cavlc8x8_rdopt0": (["-d", "encoder_main.cfg", "-p", "SearchMode=0", "-p", "RDOptimization=0", "-p", "SymbolMode=0",
                               "-p", "Transform8x8Mode=1", "-p", "ProfileIDC=100"], 40),
+    # the other error metrics of computeUniPred (mv-search.c:400-424): Hadamard SAD at every level (the refinements start from the carried
+    # minimum), SSE at integer and half-pel positions with SAD quarter-pel; FastFullSearch with a non-SAD metric (squared error surfaces)
+    "baseline_fs16_satd": (["-d", "encoder_baseline.cfg", "-p", "SearchMode=-1", "-p", "SearchRange=16", "-p", "MEDistortionFPel=2",
+                            "-p", "MEDistortionHPel=2", "-p", "MEDistortionQPel=2", "-p", "FramesToBeEncoded=2"], 40),
+    "baseline_fs16_sse": (["-d", "encoder_baseline.cfg", "-p", "SearchMode=-1", "-p", "SearchRange=16", "-p", "MEDistortionFPel=1",
+                           "-p", "MEDistortionHPel=1", "-p", "MEDistortionQPel=0", "-p", "FramesToBeEncoded=2"], 40),
+    "main_fastfull_satd_fpel": (["-d", "encoder_main.cfg", "-p", "SearchMode=0", "-p", "MEDistortionFPel=2", "-p", "MEDistortionHPel=2",
+                                 "-p", "MEDistortionQPel=2", "-p", "FramesToBeEncoded=2", "-p", "NumberBFrames=0"], 40),
 }
 KINDS = {1: "luma", 2: "chroma", 3: "fullpel", 4: "subpel", 5: "fastfull", 6: "dct4", 7: "dct8", 8: "dct16", 9: "dctc"}
 
@@ -65,7 +73,10 @@ def subsample(lst, n):
 def main():
     if not os.path.exists(TAP):
         sys.exit("build oracle/_ref first: make -C oracle ref")
+    only = sys.argv[1:]                                # optional: the runs to (re)generate; default all
     for name, (args, keep) in RUNS.items():
+        if only and name not in only:
+            continue
         with tempfile.TemporaryDirectory() as d:
             for f in os.listdir(REF):
                 if f.endswith(".cfg") or f.endswith(".yuv"):

@@ -55,7 +55,7 @@ def test_integer_search_matches_jm(pkg, path):
     done = 0
     for kind in ("fullpel", "fastfull"):
         for r in recs(z, kind):
-            if int(r[5]) != 0 or int(r[8]) != 0:          # SAD full-pel metric, no weighted ME: what this round builds
+            if int(r[3]) != 0 or (int(r[8]) != 0 and int(r[5]) == 1):      # records with the chroma term carry no chroma planes; computeSSEWP is not built
                 continue
             a = r[14:]
             if kind == "fullpel":
@@ -89,11 +89,63 @@ def test_integer_search_matches_jm(pkg, path):
             prm.lambda_[0] = prm.lambda_[1] = prm.lambda_[2] = lam
             prm.transform8x8_mode, prm.subpel = int(r[4]), 0
             prm.partition_mask = (1 << p) | (1 if mode == 0 else 0)
+            prm.metric_set = 1                              # MEErrorMetric[] of the record (SAD / SSE / Hadamard SAD at integer positions)
+            prm.metric[0], prm.metric[1], prm.metric[2] = int(r[5]), int(r[6]), int(r[7])
+            if int(r[8]):                                   # UseWeightedReferenceME: weight_luma, offset_luma, wp_luma_round, luma_log_weight_denom
+                prm.wp_enable, prm.wp_round, prm.wp_denom = 1, int(r[11]), int(r[12])
+                prm.wp_weight[0], prm.wp_offset[0] = int(r[9]), int(r[10])
             got = ctx.me_frame(prm, mbs)[0]
             ctx.close()
             assert (int(got["mv_int"][p][0]), int(got["mv_int"][p][1]), int(got["cost_int"][p])) == (ox, oy, ocost), (kind, px, py, bt)
             done += 1
     assert done > 0 or "fullpel" not in z
+
+
+@pytest.mark.parametrize("path", GOLD, ids=IDS)
+def test_subpel_search_matches_jm(pkg, path):
+    """SubPelBlockMotionSearch records of the real JM replayed through jmhip_me_subpel: every recorded metric triple, the carried minimum
+    (min_mcost of the record) when the integer and half-pel metric agree."""
+    z = np.load(path)
+    done = 0
+    for r in recs(z, "subpel"):
+        if int(r[3]) != 0 or (int(r[8]) != 0 and 1 in (int(r[5]), int(r[6]), int(r[7]))):
+            continue
+        a = r[14:]
+        ref0, px, py, bt, pmx, pmy, ix, iy, sp2, sp4, minc, l0, l1, l2, ox, oy, ocost = [int(v) for v in a[:17]]
+        start_hp = int(r[5]) == int(r[6])
+        if sp2 != 9 or sp4 != 9 or (ix | iy) & 3 or (minc != 2147483647 and not start_hp):
+            continue
+        lr = recs(z, "luma")[int(r[0])]
+        Y, w, h = luma_pic(lr)
+        ctx = pkg.Context(w, h, yuv_format=0, max_refs=1, search_range=16)
+        ctx.ref_upload(0, Y.astype(np.uint8))
+        ctx.interp_luma(0)
+        bsx, bsy = oracle.BLOCK_SIZE[bt]
+        cur = np.zeros((h, w), np.uint8)
+        cur[py:py + bsy, px:px + bsx] = a[17:17 + bsx * bsy].reshape(bsy, bsx)
+        ctx.cur_upload(cur)
+        p = _partition_of(pkg, bt, (px & 15) >> 2, (py & 15) >> 2)
+        mbs = np.zeros(1, dtype=pkg.ME_MB_DTYPE)
+        mbs[0]["mb_x"], mbs[0]["mb_y"], mbs[0]["ref"], mbs[0]["ref_is_0"] = px >> 4, py >> 4, 0, ref0
+        mbs[0]["pred_mv"][p] = (pmx, pmy)
+        prm = pkg.MeParams()
+        prm.search_mode, prm.search_range, prm.rdopt, prm.is_b_slice = -1, 16, int(r[1]), int(r[2])
+        prm.level_mv_min, prm.level_mv_max = -511, 511
+        prm.lambda_[0], prm.lambda_[1], prm.lambda_[2] = l0, l1, l2
+        prm.transform8x8_mode, prm.subpel, prm.partition_mask = int(r[4]), 1, 1 << p
+        prm.metric_set = 1
+        prm.metric[0], prm.metric[1], prm.metric[2] = int(r[5]), int(r[6]), int(r[7])
+        if int(r[8]):
+            prm.wp_enable, prm.wp_round, prm.wp_denom = 1, int(r[11]), int(r[12])
+            prm.wp_weight[0], prm.wp_offset[0] = int(r[9]), int(r[10])
+        res = np.zeros(1, dtype=pkg.ME_RESULT_DTYPE)
+        res[0]["mv_int"][p] = (ix >> 2, iy >> 2)
+        res[0]["cost_int"][p] = minc
+        got = ctx.me_subpel(prm, mbs, res)[0]
+        ctx.close()
+        assert (int(got["mv"][p][0]), int(got["mv"][p][1]), int(got["cost"][p])) == (ox, oy, ocost), (px, py, bt, tuple(int(v) for v in r[5:8]))
+        done += 1
+    assert done > 0 or len(recs(z, "subpel")) == 0
 
 
 def _tile_job(pkg, m7, mpr):
