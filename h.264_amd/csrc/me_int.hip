@@ -1446,8 +1446,11 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
     return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_me_frame: search_mode must be -1 (FullSearch) or 0 (FastFullSearch); EPZS/UMHex run on the host over jmhip_distortion_batch");
   const int R = prm->search_range;
   if (R < 0 || R > c->cfg.search_range) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_frame: search_range exceeds the context's");
-  if ((2 * R + 1) * (2 * R + 1) + 1 >= (1 << TIE_BITS))
-    return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_me_frame: search_range > 44 does not fit the packed argmin key");
+  // search_range > 44: the spiral index does not fit the 13-bit tie field of the fast kernels' packed 32-bit keys; the general kernel
+  // (me_metric.hip, 64-bit keys) searches instead
+  const bool wide = (2 * R + 1) * (2 * R + 1) + 1 >= (1 << TIE_BITS);
+  jmhip_me_params eff = *prm;
+  if (!eff.metric_set) { eff.metric[0] = 0; eff.metric[1] = eff.metric[2] = 2; eff.chroma_me = 0; eff.metric_set = 1; }
   for (int k = 0; k < 3; k++)
     if (prm->lambda[k] < 0 || prm->lambda[k] >= (1 << 24)) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_me_frame: lambda factor must be below 2^24 (the kernels multiply it with __umul24; JM's largest, QP 51, is 5.5e6)");
   if (!c->has_cur) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_frame: current picture not uploaded");
@@ -1475,10 +1478,10 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
     max_uw = max_uh = 0; ref_mask = 0; c->me_fast_idx.clear(); c->me_gen_idx.clear();
   }
   const bool full_mask = (prm->partition_mask & ((1ull << JMHIP_NPART) - 1)) == ((1ull << JMHIP_NPART) - 1);
-  const bool metric_any = jm_me_metric_path(prm);       // other metrics / chroma term: me_metric.hip
+  const bool metric_any = jm_me_metric_path(prm) || wide;      // other metrics / chroma term: me_metric.hip
   // its integer stage is only needed when the integer level itself differs from JM's default (SAD, luma only): otherwise the fast
   // kernels search and me_metric.hip refines
-  const bool metric_path = metric_any && (prm->metric[0] != 0 || prm->chroma_me != 0);
+  const bool metric_path = metric_any && (eff.metric[0] != 0 || eff.chroma_me != 0 || wide);
   if (resident && metric_path != c->me_last_metric_path) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_me_frame: resident jobs need the metric path of the call that uploaded them");
   for (int i = 0; i < n && !resident; i++) {
     const jmhip_me_mb &m = mbs[i];
@@ -1545,7 +1548,7 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
   c->me_last_mode = prm->search_mode; c->me_last_R = prm->search_range; c->me_last_rdopt = prm->rdopt; c->me_last_mask = prm->partition_mask;
   c->me_last_lvl[0] = prm->level_mv_min; c->me_last_lvl[1] = prm->level_mv_max;
   c->me_last_metric_path = metric_path;
-  if (metric_any && (rc = jm_me_metric_check(c, prm, ref_mask, "jmhip_me_frame"))) return rc;
+  if (metric_any && (rc = jm_me_metric_check(c, &eff, ref_mask, "jmhip_me_frame"))) return rc;
 
   MeDev P{};
   P.mode = prm->search_mode; P.R = R; P.rdopt = prm->rdopt; P.is_b = prm->is_b_slice;
@@ -1570,7 +1573,7 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
 #endif
   if (metric_path) {                                    // integer and sub-pel stage in one kernel
     jm_stage_begin(c, JMHIP_STAGE_ME_INT);
-    rc = jm_launch_me_metric(c, prm, P, (const jmhip_me_mb *)c->me_jobs_dev, (const int *)c->me_idx_dev, (jmhip_me_result *)c->me_res_dev, ngen, lds, 0);
+    rc = jm_launch_me_metric(c, &eff, P, (const jmhip_me_mb *)c->me_jobs_dev, (const int *)c->me_idx_dev, (jmhip_me_result *)c->me_res_dev, ngen, lds, 0);
     jm_stage_end(c, JMHIP_STAGE_ME_INT);
     JM_HIP_CHECK(c, hipGetLastError());
     return rc;
@@ -1628,7 +1631,7 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
 #endif
   if (P.subpel && metric_any) {                        // the refinement with the configured metrics, from the integer vectors and costs just left
     jm_stage_begin(c, JMHIP_STAGE_ME_SUB);
-    rc = jm_launch_me_metric(c, prm, P, (const jmhip_me_mb *)c->me_jobs_dev, nullptr, (jmhip_me_result *)c->me_res_dev, n, 0, 1);
+    rc = jm_launch_me_metric(c, &eff, P, (const jmhip_me_mb *)c->me_jobs_dev, nullptr, (jmhip_me_result *)c->me_res_dev, n, 0, 1);
     jm_stage_end(c, JMHIP_STAGE_ME_SUB);
     JM_HIP_CHECK(c, hipGetLastError());
     return rc;

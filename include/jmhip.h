@@ -141,7 +141,7 @@ typedef struct {
                               partition from its own predictor (src/mv-search.c:752-762);
                               JMHIP_SEARCH_FASTFULL: FastFullPelBlockMotionSearch (src/me_fullfast.c:833), one
                               centre per MB from the 16x16 predictor (:550-566)                        */
-  int search_range;        /* <= cfg.search_range                                                    */
+  int search_range;        /* <= cfg.search_range (<= 64); beyond 44 the general kernel searches (64-bit keys) */
   int rdopt;               /* input->rdopt                                                           */
   int is_b_slice;          /* img->type == B_SLICE                                                   */
   int level_mv_min, level_mv_max;   /* LEVELMVLIMIT[img->LevelIndex][0..1], inc/mv-search.h:35-54    */

@@ -175,3 +175,12 @@ def test_rejections(pkg):
     with pytest.raises(pkg.JmhipError, match="SSE"):
         ctx.me_frame(prm, mbs)
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,R", [(-1, 48), (0, 64)])
+def test_search_ranges_beyond_the_packed_keys(pkg, mode, R):
+    """search_range > 44: the spiral index no longer fits the fast kernels' 13-bit tie field; the general kernel (64-bit keys) takes the
+    search, with JM's default metrics (metric_set = 0)."""
+    from tests.test_me import run_case as run_default
+    run_default(pkg, 96, 64, "shift", mode, R, 0, 3, per_partition=False, seed=R)
