@@ -30,6 +30,7 @@ struct MetricDev {
   const uint8_t *const *ref_c[2];      // [slot] eighth-pel plane stacks of Cb / Cr
   int wpc_round, wpc_denom;
   short wpc_w[16][2], wpc_o[16][2];
+  int c_off, c_cw, c_ch, nfx, nfy;     // chroma windows in LDS behind the luma window: [uv][fy][fx][c_ch][c_cw]
 };
 
 // partition table (JM's PartitionMotionSearch order, include/jmhip.h): blocktype, x4, y4, w4, h4
@@ -152,7 +153,8 @@ __global__ __launch_bounds__(256) void me_metric_kernel(MeDev P, MetricDev M, co
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ int s_cx[JMHIP_NPART], s_cy[JMHIP_NPART], s_px[JMHIP_NPART], s_py[JMHIP_NPART];
   __shared__ int s_u[8];
-  __shared__ uint8_t s_cur[256];
+  __shared__ __attribute__((aligned(16))) uint8_t s_cur[256];
+  __shared__ uint8_t s_cuc[2][256];
   __shared__ unsigned long long s_key[JMHIP_NPART];
   __shared__ int s_mv[JMHIP_NPART][2], s_cost[JMHIP_NPART];
 
@@ -198,6 +200,23 @@ __global__ __launch_bounds__(256) void me_metric_kernel(MeDev P, MetricDev M, co
         smem[(size_t)y * pitch + x] = (uint8_t)v;
       }
     }
+    if (M.chroma_int) {
+      // chroma windows: the planes an integer luma displacement can address (fraction 0 or 4 eighths per axis in 4:2:0), per-sample
+      // clamp one short of the planes' last row / column -- JM never writes those (img_chroma.c:63, :129) and its origin clamp never reads them
+      const int cxo = ((mbx * 16 + umin_x + 20) << 2) >> M.shift_x, cyo = ((mby * 16 + umin_y + 20) << 2) >> M.shift_y;
+      const int per = M.c_cw * M.c_ch, total = 2 * M.nfy * M.nfx * per;
+      for (int d = tid; d < total; d += 256) {
+        const int pl = d / per, e = d - pl * per, y = e / M.c_cw, x = e - y * M.c_cw;
+        const int k = pl / (M.nfy * M.nfx), f = pl - k * (M.nfy * M.nfx), fy = (f / M.nfx) * 4, fx = (f % M.nfx) * 4;
+        int v = M.ref_c[k][slot][(size_t)(fy * M.sub_x + fx) * ((size_t)M.Wcp * M.Hcp) + (size_t)clampi(cyo + y, 0, M.Hcp - 2) * M.Wcp + clampi(cxo + x, 0, M.Wcp - 2)];
+        if (P.wp_on) v = wp1(v, M.wpc_w[slot][k], M.wpc_o[slot][k], M.wpc_round, M.wpc_denom);
+        smem[M.c_off + d] = (uint8_t)v;
+      }
+      for (int d = tid; d < 2 * M.mbc_w * M.mbc_h; d += 256) {
+        const int k = d / (M.mbc_w * M.mbc_h), e = d - k * (M.mbc_w * M.mbc_h), y = e / M.mbc_w, x = e - y * M.mbc_w;
+        s_cuc[k][y * 16 + x] = M.cur_c[k][(size_t)(mby * M.mbc_h + y) * M.Wc + mbx * M.mbc_w + x];
+      }
+    }
     __syncthreads();
 
     // FastFullSearch builds its distortions as SAD or squared error (dist_method, me_fullfast.c:512), with the chroma term unweighted
@@ -216,35 +235,45 @@ __global__ __launch_bounds__(256) void me_metric_kernel(MeDev P, MetricDev M, co
       const int mvx = umin_x + ax, mvy = umin_y + ay;
       int leaf[16], leaf8[4] = {0, 0, 0, 0};
       if (mf != 2) {
+        // rows as dwords: five aligned window dwords per row, shifted into place (the row pitch leaves room for the fifth)
 #pragma unroll
-        for (int b = 0; b < 16; b++) {
-          const int ox = (b & 3) * 4, oy = (b >> 2) * 4;
-          int s = 0;
+        for (int b = 0; b < 16; b++) leaf[b] = 0;
+        const uint32_t *cur32 = reinterpret_cast<const uint32_t *>(s_cur);
+        const uint8_t *wrow = smem + (size_t)ay * pitch + (ax & ~3);
+        const unsigned sh = ax & 3;
 #pragma unroll
-          for (int r = 0; r < 4; r++)
+        for (int r = 0; r < 16; r++) {
+          const uint32_t *wp = reinterpret_cast<const uint32_t *>(wrow + (size_t)r * pitch);
+          const uint32_t d0 = wp[0], d1 = wp[1], d2 = wp[2], d3 = wp[3], d4 = wp[4];
+          const uint32_t rr[4] = {__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
+                                  __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh)};
 #pragma unroll
-            for (int x = 0; x < 4; x++) s += pel_err(mf == 1, (int)s_cur[(oy + r) * 16 + ox + x] - (int)smem[(size_t)(ay + oy + r) * pitch + ax + ox + x]);
-          leaf[b] = s;
+          for (int g = 0; g < 4; g++) {
+            const uint32_t cv = cur32[r * 4 + g];
+            if (mf == 0) leaf[(r >> 2) * 4 + g] = (int)__builtin_amdgcn_sad_u8(rr[g], cv, (unsigned)leaf[(r >> 2) * 4 + g]);
+            else {
+#pragma unroll
+              for (int k = 0; k < 4; k++) { const int d = (int)((rr[g] >> (8 * k)) & 255u) - (int)((cv >> (8 * k)) & 255u); leaf[(r >> 2) * 4 + g] += d * d; }
+            }
+          }
         }
         if (M.chroma_int) {
           // chroma block of the leaf: UMVLine8X_chroma at the candidate of the leaf's own origin (the partition's chroma block is the
           // union of its leaves' blocks; the origin clamp equals a per-sample clamp on the padded plane, whose ring is flat)
           const int X4 = (mbx * 16 + mvx + 20) << 2, Y4 = (mby * 16 + mvy + 20) << 2;
-          const int fx = X4 & M.mask_x, fy = Y4 & M.mask_y;
+          const int fxi = (X4 & M.mask_x) >> 2, fyi = (Y4 & M.mask_y) >> 2;
+          const int cxo = ((mbx * 16 + umin_x + 20) << 2) >> M.shift_x, cyo = ((mby * 16 + umin_y + 20) << 2) >> M.shift_y;
           const int lw = 4 >> M.csx, lh = 4 >> M.csy;
           for (int k = 0; k < 2; k++) {
-            const uint8_t *pl = M.ref_c[k][slot] + (size_t)(fy * M.sub_x + fx) * ((size_t)M.Wcp * M.Hcp);
-            const uint8_t *cu = M.cur_c[k] + (size_t)(mby * M.mbc_h) * M.Wc + mbx * M.mbc_w;
-            for (int b = 0; b < 16; b++) {
+            const uint8_t *pl = smem + M.c_off + ((k * M.nfy + fyi) * M.nfx + fxi) * (M.c_cw * M.c_ch);
+#pragma unroll
+            for (int b = 0; b < 16; b++) {                  // static leaf index: the array stays in registers
               const int ox = (b & 3) * 4, oy = (b >> 2) * 4;
-              const int cx0 = (X4 + (ox << 2)) >> M.shift_x, cy0 = (Y4 + (oy << 2)) >> M.shift_y;
+              const int cx0 = ((X4 + (ox << 2)) >> M.shift_x) - cxo, cy0 = ((Y4 + (oy << 2)) >> M.shift_y) - cyo;
               int s = 0;
               for (int r = 0; r < lh; r++)
-                for (int x = 0; x < lw; x++) {
-                  int rv = pl[(size_t)clampi(cy0 + r, 0, M.Hcp - 2) * M.Wcp + clampi(cx0 + x, 0, M.Wcp - 2)];      // the last padded row / column is never written by JM (img_chroma.c:63, :129) and never read (origin clamp)
-                  if (P.wp_on) rv = wp1(rv, M.wpc_w[slot][k], M.wpc_o[slot][k], M.wpc_round, M.wpc_denom);
-                  s += pel_err(mf == 1, (int)cu[(size_t)((oy >> M.csy) + r) * M.Wc + (ox >> M.csx) + x] - rv);
-                }
+                for (int x = 0; x < lw; x++)
+                  s += pel_err(mf == 1, (int)s_cuc[k][((oy >> M.csy) + r) * 16 + (ox >> M.csx) + x] - (int)pl[(cy0 + r) * M.c_cw + cx0 + x]);
               leaf[b] += cw * s;
             }
           }
@@ -428,6 +457,13 @@ int jm_launch_me_metric(jmhip_ctx *c, const jmhip_me_params *prm, const MeDev &P
   M.ref_c[1] = reinterpret_cast<const uint8_t *const *>(c->ref_ptrs_dev) + 96;
   M.wpc_round = prm->wp_chroma_round; M.wpc_denom = prm->wp_chroma_denom;
   for (int k = 0; k < 16; k++) for (int j = 0; j < 2; j++) { M.wpc_w[k][j] = prm->wp_weight_cr[k][j]; M.wpc_o[k][j] = prm->wp_offset_cr[k][j]; }
+  if (M.chroma_int && !skip_int) {                      // chroma windows behind the luma window
+    M.c_off = (int)((lds + 15) & ~(size_t)15);
+    M.c_cw = ((P.win_pitch << 2) >> M.shift_x) + 2; M.c_ch = ((P.win_rows << 2) >> M.shift_y) + 2;
+    M.nfx = M.shift_x == 3 ? 2 : 1; M.nfy = M.shift_y == 3 ? 2 : 1;
+    lds = (size_t)M.c_off + (size_t)2 * M.nfx * M.nfy * M.c_cw * M.c_ch;
+    if (lds > 63 * 1024) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_me_frame: search window with the chroma term does not fit LDS (search range / spread of the predictors)");
+  }
   me_metric_kernel<<<jm_xcd_grid(n), 256, lds, c->stream>>>(P, M, jobs_dev, idx_dev, res_dev, n);
   return JMHIP_OK;
 }

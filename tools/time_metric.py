@@ -28,7 +28,7 @@ mbs = np.zeros(n, dtype=ME_MB_DTYPE)
 mbs["mb_x"], mbs["mb_y"] = np.arange(n) % (W // 16), np.arange(n) // (W // 16)
 mbs["ref_is_0"] = 1
 mbs["pred_mv"][:] = rng.integers(-8, 9, (n, 1, 2))
-for metric, cme in (((0, 2, 2), 0), ((0, 2, 2), 2), ((0, 0, 0), 0), ((1, 1, 1), 2), ((2, 2, 2), 0)):
+for metric, cme in (((0, 2, 2), 0), ((0, 2, 2), 2), ((0, 0, 0), 0), ((1, 1, 1), 0), ((1, 1, 1), 2), ((2, 2, 2), 0)):
     prm = pkg.MeParams()
     prm.search_mode, prm.search_range, prm.rdopt = -1, R, 1
     prm.level_mv_min, prm.level_mv_max = -511, 511
