@@ -379,7 +379,15 @@ def main():
     rehearsal = os.environ.get("JMHIP_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
-    if world > 1 and not solo:
+    # JMHIP_BENCH_RCCL1=1: take the N > 1 code path (bands, one-chunk all-gather over RCCL on the context's stream, scatter) with a process
+    # group of ONE rank: what a one-GPU box can exercise of the RCCL transport (tests/test_bench_ranks.py). Not a bench result.
+    rccl1 = os.environ.get("JMHIP_BENCH_RCCL1") == "1" and world == 1 and not solo
+    multi = world > 1 or rccl1
+    if rccl1:
+        args.cpu_mbs = 0
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+    if multi and not solo:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("gloo" if rehearsal else "nccl", rank=rank, world_size=world)
@@ -409,7 +417,7 @@ def main():
                        pkg.flat_quant(QP, 342, adaptive_rounding=1, adapt_rnd_weight=4, cavlc=1),
                        pkg.flat_quant(QP + 3, 342, adaptive_rounding=1, adapt_rnd_weight=4, cavlc=1)], dtype=pkg.QUANT_DTYPE)
     # N > 1: one exchange buffer per rank -- its band as a single chunk [Y | U | V] -- and one gather buffer of `world` chunks
-    chunk = ctx.band_chunk_bytes(band) if world > 1 else 0
+    chunk = ctx.band_chunk_bytes(band) if multi else 0
     sbuf = torch.zeros(max(chunk, 4), dtype=torch.uint8, device=dev)
     gbuf = torch.zeros(max(chunk * world, 4), dtype=torch.uint8, device=dev)
 
@@ -418,7 +426,7 @@ def main():
     torch.cuda.synchronize()
     first = [True]
     # N > 1: the all-gather is enqueued on the context's own stream (stream-ordered with the kernels round it, no host sync)
-    ext = torch.cuda.ExternalStream(ctx.stream_ptr(), device=dev) if world > 1 else None
+    ext = torch.cuda.ExternalStream(ctx.stream_ptr(), device=dev) if multi else None
 
     done = [0]                                          # steps run so far (the clip position of the resident reference)
 
@@ -429,7 +437,7 @@ def main():
         # luma: the 16 quarter-pel planes (search + sub-pel refinement + MC read them all over). Chroma: MC is their only reader and takes
         # 2 x 64 samples per macroblock, so the frame stage computes those eighth-pel samples itself (jmhip_residual_frame) instead of
         # materialising 64 planes per component -- --chroma-planes builds them as JM's ChromaMCBuffer = 1 does (identical results)
-        if world == 1:
+        if not multi:
             ctx.interp_luma(0)
             if args.chroma_planes:
                 ctx.interp_chroma(0)
@@ -444,13 +452,13 @@ def main():
                 ctx.me_frame_async(prm, None, n)
             ctx.residual_frame(quants)
             if args.deblock:
-                if world == 1 and args.deblock_slices > 1:
+                if not multi and args.deblock_slices > 1:
                     ctx.deblock_recon(QP, (QP, QP), disable_idc=2, slice_rows=(MBH + args.deblock_slices - 1) // args.deblock_slices)
-                elif world == 1:
+                elif not multi:
                     ctx.deblock_recon(QP, (QP, QP))
                 else:
                     ctx.deblock_recon(QP, (QP, QP), disable_idc=2, slice_rows=band, mb_row0=row0, mb_rows=row1 - row0)
-        if world == 1:
+        if not multi:
             ctx.recon_to_ref(0)
         else:
             if n:                                           # a rank without rows (world > picture rows / band) only receives

@@ -45,3 +45,15 @@ def test_two_ranks_with_the_loop_filter_inside_their_slices():
     plain = run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--cpu-mbs", "0"])
     assert one["ref_checksum"] == two["ref_checksum"]
     assert one["ref_checksum"] != plain["ref_checksum"], "the filter changed nothing"
+
+
+@pytest.mark.gpu
+def test_rccl_transport_with_a_process_group_of_one():
+    """What a one-GPU box can exercise of the RCCL path: JMHIP_BENCH_RCCL1=1 takes bench.py's N > 1 code -- band interpolation, one-chunk
+    pack, dist.all_gather_into_tensor over the nccl (= RCCL) backend enqueued on the library's own HIP stream, scatter -- with a process
+    group of a single rank. Same reference picture as the plain run."""
+    one = run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--cpu-mbs", "0"])
+    r1 = run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--cpu-mbs", "0"],
+             {"JMHIP_BENCH_RCCL1": "1", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29561"})
+    assert one["ref_checksum"] == r1["ref_checksum"]
+    assert r1["n_gpus"] == 1
