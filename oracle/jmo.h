@@ -299,6 +299,10 @@ typedef struct {
   int blocktype_lut[4][4];       /* input->blocktype_lut */
   short *all_mv_state;           /* img->all_mv[4][4][LIST_0][JMO_MAX_REFS][9][2] as the previous macroblock in coding order left it (in/out; JM
                                     never resets it, and EPZS reads it: me_epzs.c:1433). NULL: zeros. */
+  int transform8x8_mode;         /* input->Transform8x8Mode: 0; 1 = both transform sizes compete (md_low.c:183-188, :203-326, :547-551); 2 = 8x8 only.
+                                    me.transform8x8_mode must carry the same value (the 8x8 Hadamard of block types 1..4, mv-search.c:640) */
+  const void *q8;                /* (const jmo_quant *) mode 1: the inter 8x8 luma quantiser of the slice (transform8x8_flag = 1): the coded-block pattern of the 8x8-transform
+                                    P8x8 pass decides between the two passes' partitionings (md_low.c:547). AdaptiveRounding must be off. */
 } jmo_lowcplx_params;
 
 /* what JM knows of one macroblock after encode_one_macroblock_low, plus every BlockMotionSearch call's outcome (41 partitions per reference) */
@@ -310,6 +314,11 @@ typedef struct {
   short skip_mv[2];              /* all_mv[..][0][0][0] */
   short pred[JMO_LC_REFS][41][2], mv_int[JMO_LC_REFS][41][2], mv[JMO_LC_REFS][41][2];
   int cost_int[JMO_LC_REFS][41], cost[JMO_LC_REFS][41];
+  /* Transform8x8Mode: the 8x8 blocks' searches of the 8x8-transform P8x8 pass (the 4x4-transform pass searches them again: those calls are
+   * in the arrays above), the transform decision of the chosen mode and the coded-block pattern of that pass (when it was needed, else -1) */
+  short pred8ts[JMO_LC_REFS][4][2], mv_int8ts[JMO_LC_REFS][4][2], mv8ts[JMO_LC_REFS][4][2];
+  int cost_int8ts[JMO_LC_REFS][4], cost8ts[JMO_LC_REFS][4];
+  int transform8x8_flag, cbp8ts;
 } jmo_mb_inter;
 
 void jmo_lowcplx_p_slice(const jmo_lowcplx_params *q, const jmo_ref *refs, const jmo_pel *cur, int cur_stride,

@@ -37,6 +37,7 @@ typedef struct {
   int motion_cost[8][JMO_MAX_REFS][4];        /* motion_cost[blocktype][LIST_0][ref][block8x8] */
   jmo_fastfull ff[JMO_MAX_REFS]; int ff_done[JMO_MAX_REFS];
   jmo_mb_inter *out;
+  int pass8ts;                     /* inside the 8x8-transform P8x8 pass: the call records go to the *8ts arrays */
 } lc_ctx;
 
 #define REFIDX(c, y, x) (c)->ref_idx[(size_t)(y) * (c)->w4 + (x)]
@@ -114,6 +115,27 @@ static void me_params_for_ref(const lc_ctx *c, int ref, jmo_me_params *p)
   if (p->apply_weights) { p->weight_luma = c->q->wp_weight[ref]; p->offset_luma = c->q->wp_offset[ref]; }
 }
 
+/* LumaPrediction (macroblock.c:836) of the whole macroblock for a per-4x4 assignment of list-0 reference and vector: one fetch per bs x bs
+ * block (bs = 4, or 8 for the 8x8-transform residual of LumaResidualCoding8x8 :1142) with its origin clamped (UMV), explicit weights when
+ * the picture parameter set has them */
+static void predict_mb(const lc_ctx *c, const int ref4[16], const short (*mv4)[2], jmo_pel mpr[16][16], int bs)
+{
+  const jmo_lowcplx_params *q = c->q;
+  int bx, by, x, y;
+  for (by = 0; by < 16; by += bs) for (bx = 0; bx < 16; bx += bs) {
+    const int b = (by >> 2) * 4 + (bx >> 2), r = ref4[b];
+    const jmo_ref *rp = &c->refs[r];
+    const int xq = ((c->mb_x * 16 + bx) << 2) + JMO_PAD4 + mv4[b][0], yq = ((c->mb_y * 16 + by) << 2) + JMO_PAD4 + mv4[b][1];
+    const int xpos = clip3(0, rp->width_pad, xq >> 2), ypos = clip3(0, rp->height_pad, yq >> 2);
+    const jmo_pel *src = rp->luma[(yq & 3) * 4 + (xq & 3)] + (long)ypos * rp->Wp + xpos;
+    for (y = 0; y < bs; y++) for (x = 0; x < bs; x++) {
+      int v = src[(long)y * rp->Wp + x];
+      if (q->wp_pred) v = clip3(0, q->me.max_val, ((q->wp_weight[r] * v + q->me.wp_luma_round) >> q->me.luma_log_weight_denom) + q->wp_offset[r]);
+      mpr[by + y][bx + x] = (jmo_pel)v;
+    }
+  }
+}
+
 /* FindSkipModeMotionVector, mv-search.c:1189 -> all_mv[..][0][0] */
 static void find_skip_mv(lc_ctx *c)
 {
@@ -138,6 +160,15 @@ static int skip_cost(const lc_ctx *c, const jmo_pel *mb /*packed 16x16*/)
   p.chroma_me = 0;
   jmo_dist_from_params(&p, &c->refs[0], &d);
   d.umv = 1; d.test8x8 = 0; d.chroma_me = 0;
+  if (c->q->transform8x8_mode) {       /* rdopt 0 with the 8x8 transform: distortion8x8 of each 8x8 block, predicted per 4x4 block (mv-search.c:1171-1176) */
+    jmo_pel mpr[16][16];
+    int ref4[16], b, c4, c8;
+    short mv4[16][2];
+    for (b = 0; b < 16; b++) { ref4[b] = 0; mv4[b][0] = c->all_mv[0][0][0][0][0]; mv4[b][1] = c->all_mv[0][0][0][0][1]; }
+    predict_mb(c, ref4, (const short (*)[2])mv4, mpr, 4);
+    jmo_pred_costs(mb, &mpr[0][0], c->q->md_metric, 1, &c4, &c8);
+    return c8;
+  }
   if (c->q->md_metric == JMO_ERR_SATD)
     return jmo_uni_pred(&p, JMO_Q_PEL, &d, mb, 16, 16, JMO_INT_MAX, ((c->mb_x * 16) << 2) + JMO_PAD4 + c->all_mv[0][0][0][0][0],
                         ((c->mb_y * 16) << 2) + JMO_PAD4 + c->all_mv[0][0][0][0][1]);
@@ -231,7 +262,10 @@ static int block_motion_search(lc_ctx *c, int ref, int mb_x, int mb_y, int block
     min_mcost = jmo_fullpel_search(&p, rp, orig, ref == 0, pic_pix_x, pic_pix_y, blocktype, pred_mv[0], pred_mv[1], &mv[0], &mv[1], search_range,
                                    min_mcost, q->lambda_mf[JMO_F_PEL]);
   }
-  {
+  if (c->pass8ts) {
+    const int b8 = (block_y >> 1) * 2 + (block_x >> 1);
+    c->out->mv_int8ts[ref][b8][0] = mv[0]; c->out->mv_int8ts[ref][b8][1] = mv[1]; c->out->cost_int8ts[ref][b8] = min_mcost;
+  } else {
     const int pi = part_index(blocktype, block_x, block_y);
     c->out->mv_int[ref][pi][0] = mv[0]; c->out->mv_int[ref][pi][1] = mv[1]; c->out->cost_int[ref][pi] = min_mcost;
   }
@@ -257,7 +291,11 @@ static int block_motion_search(lc_ctx *c, int ref, int mb_x, int mb_y, int block
   for (j = block_y; j < block_y + (bsy >> 2); j++) for (i = block_x; i < block_x + (bsx >> 2); i++) {
     c->all_mv[j][i][ref][blocktype][0] = mv[0]; c->all_mv[j][i][ref][blocktype][1] = mv[1];
   }
-  {
+  if (c->pass8ts) {
+    const int b8 = (block_y >> 1) * 2 + (block_x >> 1);
+    c->out->pred8ts[ref][b8][0] = pred_mv[0]; c->out->pred8ts[ref][b8][1] = pred_mv[1];
+    c->out->mv8ts[ref][b8][0] = mv[0]; c->out->mv8ts[ref][b8][1] = mv[1]; c->out->cost8ts[ref][b8] = min_mcost;
+  } else {
     const int pi = part_index(blocktype, block_x, block_y);
     c->out->pred[ref][pi][0] = pred_mv[0]; c->out->pred[ref][pi][1] = pred_mv[1];
     c->out->mv[ref][pi][0] = mv[0]; c->out->mv[ref][pi][1] = mv[1]; c->out->cost[ref][pi] = min_mcost;
@@ -318,6 +356,12 @@ static void macroblock_low(lc_ctx *c)
   const jmo_lowcplx_params *q = c->q;
   int mode, block, best_mode = 1, min_cost = JMO_INT_MAX, cost, i, j, k, r;
   int best8x8l0ref[5][4], best8x8mode[4] = {0, 0, 0, 0};            /* [1..3] and [4] = P8x8 */
+  const int T8 = q->transform8x8_mode;
+  int t8_flag = 0, best_transform_flag = 0, cbp8ts = -1;
+  int ref8ts[4] = {0, 0, 0, 0}; short mv8ts[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};       /* StoreNewMotionVectorsBlock8x8 of the 8x8-transform pass */
+  int tr8_cost = JMO_INT_MAX, tr4_cost = JMO_INT_MAX;
+  jmo_pel curmb[256];
+  for (j = 0; j < 16; j++) memcpy(curmb + 16 * j, c->cur + (size_t)(c->mb_y * 16 + j) * c->cur_stride + c->mb_x * 16, 16 * sizeof(jmo_pel));
   const int bx0 = c->mb_x * 4, by0 = c->mb_y * 4;
   /* img->all_mv is NOT reset per macroblock (nor per slice or picture): EPZSBlockTypePredictors (me_epzs.c:1433) reads the 16x16 and
    * 8x8 vectors of the PREVIOUS macroblock in coding order before this one has searched those types -- for the first macroblock
@@ -349,11 +393,48 @@ static void macroblock_low(lc_ctx *c)
         }
       }
     }
-    if (cost < min_cost) { best_mode = mode; min_cost = cost; }
+    if (T8) {                                                 /* TransformDecision(currMB, -1, &cost), md_low.c:183-188, macroblock.c:1458 */
+      jmo_pel mpr[16][16];
+      int ref4[16], c4, c8;
+      short mv4[16][2];
+      /* SetModesAndRefframeForBlocks(currMB, mode) (md_low.c:186, rdopt.c:1470-1500) writes the mode's best references into enc_picture->ref_idx --
+       * a side effect only Transform8x8Mode has: without it the second block of modes 2 / 3 leaves the last reference searched there --
+       * and SetModesAndRefframe (macroblock.c:1301) reads them back for the prediction */
+      for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) {
+        const int rr = best8x8l0ref[mode][2 * (j >> 1) + (i >> 1)];
+        REFIDX(c, by0 + j, bx0 + i) = (signed char)rr;
+        ref4[j * 4 + i] = rr; mv4[j * 4 + i][0] = c->all_mv[j][i][rr][mode][0]; mv4[j * 4 + i][1] = c->all_mv[j][i][rr][mode][1];
+      }
+      predict_mb(c, ref4, (const short (*)[2])mv4, mpr, 4);
+      jmo_pred_costs(curmb, &mpr[0][0], q->md_metric, 0, &c4, &c8);
+      if (T8 == 2 || c8 < c4) t8_flag = 1;
+      else { cost = cost - c8 + c4; t8_flag = 0; }
+    }
+    if (cost < min_cost) { best_mode = mode; min_cost = cost; best_transform_flag = t8_flag; }
   }
 
-  if (q->valid[4] || q->valid[5] || q->valid[6] || q->valid[7]) {       /* P8x8, 4x4 transform: md_low.c:190-330 */
+  if (q->valid[4] || q->valid[5] || q->valid[6] || q->valid[7]) {       /* P8x8: md_low.c:190-330 */
     int cost8x8 = 0;
+    if (T8) {                                                 /* the 8x8 partition with the 8x8 transform: sub-mode 4 only (mode_decision.c:556) */
+      tr8_cost = 0;
+      c->pass8ts = 1;
+      for (block = 0; block < 4; block++) {
+        const int pbx = bx0 + (block & 1) * 2, pby = by0 + (block & 2), j0 = block & 2, i0 = (block & 1) * 2;
+        int best_ref = 0;
+        partition_motion_search(c, 4, block);
+        cost = list0_cost(c, 4, block, &best_ref);
+        for (j = pby; j < pby + 2; j++) for (i = pbx; i < pbx + 2; i++) REFIDX(c, j, i) = (signed char)best_ref;
+        if (cost != JMO_INT_MAX) cost += ((q->lambda_mf[JMO_Q_PEL] * (q->num_refs <= 1 ? 0 : refbits_(0))) >> 16) - 1;
+        tr8_cost += cost;
+        ref8ts[block] = best_ref; mv8ts[block][0] = c->all_mv[j0][i0][best_ref][4][0]; mv8ts[block][1] = c->all_mv[j0][i0][best_ref][4][1];
+        for (j = j0; j < j0 + 2; j++) for (i = i0; i < i0 + 2; i++) {          /* SetRefAndMotionVectors, mode_decision.c:965 */
+          REFIDX(c, by0 + j, bx0 + i) = (signed char)best_ref;
+          MVAT(c, by0 + j, bx0 + i)[0] = mv8ts[block][0]; MVAT(c, by0 + j, bx0 + i)[1] = mv8ts[block][1];
+        }
+      }
+      c->pass8ts = 0;
+    }
+    if (T8 != 2) {
     for (block = 0; block < 4; block++) {
       int min_cost8x8 = JMO_INT_MAX;
       const int pbx = bx0 + (block & 1) * 2, pby = by0 + (block & 2);
@@ -376,9 +457,56 @@ static void macroblock_low(lc_ctx *c)
         }
       }
     }
-    if (cost8x8 < min_cost) { best_mode = 8; min_cost = cost8x8; }
+    tr4_cost = cost8x8;
+    }
+    if (tr4_cost < min_cost || tr8_cost < min_cost) {         /* md_low.c:281-326 */
+      best_mode = 8;
+      if (T8 == 2) { min_cost = tr8_cost; t8_flag = 1; }
+      else if (T8) {
+        if (tr8_cost < tr4_cost) { min_cost = tr8_cost; t8_flag = 1; }
+        else if (tr4_cost < tr8_cost) { min_cost = tr4_cost; t8_flag = 0; }
+        else {                                                /* GetBestTransformP8x8, rdopt.c:3262: the two passes' predictions */
+          jmo_pel mpr[16][16];
+          int ref4[16], c4, c8, dummy;
+          short mv4[16][2];
+          for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) {
+            const int k8 = 2 * (j >> 1) + (i >> 1), rr = best8x8l0ref[4][k8], m8 = best8x8mode[k8];
+            ref4[j * 4 + i] = rr; mv4[j * 4 + i][0] = c->all_mv[j][i][rr][m8][0]; mv4[j * 4 + i][1] = c->all_mv[j][i][rr][m8][1];
+          }
+          predict_mb(c, ref4, (const short (*)[2])mv4, mpr, 4);
+          jmo_pred_costs(curmb, &mpr[0][0], q->md_metric, 0, &c4, &dummy);
+          for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) { const int k8 = 2 * (j >> 1) + (i >> 1); ref4[j * 4 + i] = ref8ts[k8]; mv4[j * 4 + i][0] = mv8ts[k8][0]; mv4[j * 4 + i][1] = mv8ts[k8][1]; }
+          predict_mb(c, ref4, (const short (*)[2])mv4, mpr, 8);
+          jmo_pred_costs(curmb, &mpr[0][0], q->md_metric, 0, &dummy, &c8);
+          if (c8 < c4) { min_cost = tr8_cost; t8_flag = 1; } else { min_cost = tr4_cost; t8_flag = 0; }
+        }
+      } else { min_cost = tr4_cost; t8_flag = 0; }
+    }
   }
   find_skip_mv(c);                                            /* md_low.c:332-333 */
+  if (best_mode != 8) t8_flag = best_transform_flag;          /* :596-597 */
+  else if (t8_flag && T8 != 2) {
+    /* md_low.c:547-548: the 8x8-transform pass wins only if its residual has a coded 8x8 block: LumaResidualCoding8x8 (macroblock.c:1009) of
+     * its four blocks -- one 8x8 prediction each, dct_8x8, a block whose coefficient cost is <= _LUMA_COEFF_COST_ (4) counts as empty */
+    jmo_pel mpr[16][16], recon[16][16];
+    int ref4[16], m7[16][16], levels[4][65], runs[4][65], fadj[16][16];
+    short mv4[16][2];
+    for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) { const int k8 = 2 * (j >> 1) + (i >> 1); ref4[j * 4 + i] = ref8ts[k8]; mv4[j * 4 + i][0] = mv8ts[k8][0]; mv4[j * 4 + i][1] = mv8ts[k8][1]; }
+    predict_mb(c, ref4, (const short (*)[2])mv4, mpr, 8);
+    for (j = 0; j < 16; j++) for (i = 0; i < 16; i++) m7[j][i] = (int)curmb[j * 16 + i] - (int)mpr[j][i];
+    cbp8ts = 0;
+    for (block = 0; block < 4; block++) {
+      int coeff_cost = 0;
+      const int nonzero = jmo_dct_8x8((const jmo_quant *)q->q8, m7, (const jmo_pel (*)[16])mpr, block, &coeff_cost, levels, runs, recon, fadj);
+      if (nonzero && coeff_cost > 4) cbp8ts |= 1 << block;
+    }
+    if (cbp8ts == 0) t8_flag = 0;
+  }
+  if (best_mode == 8 && t8_flag) {                            /* SetCoeffAndReconstruction8x8, rdopt.c:1595: the 8x8-transform pass's partitioning */
+    for (k = 0; k < 4; k++) { best8x8mode[k] = 4; best8x8l0ref[4][k] = ref8ts[k]; }
+    for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) { const int k8 = 2 * (j >> 1) + (i >> 1); c->all_mv[j][i][ref8ts[k8]][4][0] = mv8ts[k8][0]; c->all_mv[j][i][ref8ts[k8]][4][1] = mv8ts[k8][1]; }
+  }
+  c->out->transform8x8_flag = t8_flag; c->out->cbp8ts = cbp8ts;
 
   /* SetModesAndRefframeForBlocks + SetMotionVectorsMB (rdopt.c:1262, :1845) */
   c->out->best_mode = best_mode; c->out->min_cost = min_cost;

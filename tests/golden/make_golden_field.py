@@ -26,6 +26,16 @@ RUNS = {
     "field_fastfull_r16_2ref": COMMON + ["-p", "SearchMode=0", "-p", "NumberReferenceFrames=2"],
     "field_epzs_r16_2ref": COMMON + ["-p", "SearchMode=3", "-p", "NumberReferenceFrames=2"],
     "field_umhex_r16_2ref": COMMON + ["-p", "SearchMode=1", "-p", "NumberReferenceFrames=2"],
+    # Transform8x8Mode (High profile, AdaptiveRounding off): 1 = both transform sizes compete in every mode and the P8x8 partitioning depends on the
+    # coded-block pattern of the 8x8-transform pass (coarse quantiser: the pattern is often empty); 2 = 8x8 only
+    "field_epzs_t8_r16_2ref": COMMON + ["-p", "SearchMode=3", "-p", "NumberReferenceFrames=2", "-p", "Transform8x8Mode=1", "-p", "ProfileIDC=100",
+                                        "-p", "AdaptiveRounding=0", "-p", "QPPSlice=36"],
+    "field_full_t8only_r16_1ref": COMMON + ["-p", "SearchMode=-1", "-p", "NumberReferenceFrames=1", "-p", "Transform8x8Mode=2", "-p", "ProfileIDC=100",
+                                            "-p", "AdaptiveRounding=0"],
+    "field_umhex_t8_cabac_r16_2ref": COMMON + ["-p", "SearchMode=1", "-p", "NumberReferenceFrames=2", "-p", "Transform8x8Mode=1", "-p", "ProfileIDC=100",
+                                               "-p", "AdaptiveRounding=0", "-p", "QPPSlice=32", "-p", "SymbolMode=1"],
+    "field_fastfull_t8_r16_2ref": COMMON + ["-p", "SearchMode=0", "-p", "NumberReferenceFrames=2", "-p", "Transform8x8Mode=1", "-p", "ProfileIDC=100",
+                                            "-p", "AdaptiveRounding=0", "-p", "QPPSlice=40"],
 }
 
 
@@ -52,7 +62,10 @@ def parse(path):
 def main():
     if not os.path.exists(TAP):
         sys.exit("build oracle/_ref first: make -C oracle ref")
+    only = sys.argv[1:]
     for name, args in RUNS.items():
+        if only and name not in only:
+            continue
         with tempfile.TemporaryDirectory() as d:
             for f in os.listdir(REF):
                 if f.endswith(".cfg") or f.endswith(".yuv"):

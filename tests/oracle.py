@@ -576,13 +576,17 @@ class LowcplxParams(C.Structure):
                 ("lambda_mf", C.c_int * 3), ("ref_cost1", C.c_int), ("md_metric", C.c_int), ("wp_pred", C.c_int),
                 ("wp_weight", C.c_int * MAX_REFS), ("wp_offset", C.c_int * MAX_REFS), ("me", MeParams), ("epzs_subpel_me", C.c_int),
                 ("W", C.c_int), ("H", C.c_int), ("slice_id", C.c_void_p), ("epzs", C.c_void_p), ("umhex", C.c_void_p),
-                ("frame_ctr_b", C.c_int), ("img_number", C.c_int), ("blocktype_lut", (C.c_int * 4) * 4), ("all_mv_state", C.c_void_p)]
+                ("frame_ctr_b", C.c_int), ("img_number", C.c_int), ("blocktype_lut", (C.c_int * 4) * 4), ("all_mv_state", C.c_void_p),
+                ("transform8x8_mode", C.c_int), ("q8", C.c_void_p)]
 
 
 MB_INTER_DTYPE = np.dtype([("best_mode", "<i4"), ("min_cost", "<i4"), ("b8mode", "<i4", (4,)), ("b8ref", "<i4", (4,)),
                            ("final_mv", "<i2", (16, 2)), ("skip_mv", "<i2", (2,)),
                            ("pred", "<i2", (LC_REFS, 41, 2)), ("mv_int", "<i2", (LC_REFS, 41, 2)), ("mv", "<i2", (LC_REFS, 41, 2)),
-                           ("cost_int", "<i4", (LC_REFS, 41)), ("cost", "<i4", (LC_REFS, 41))], align=True)
+                           ("cost_int", "<i4", (LC_REFS, 41)), ("cost", "<i4", (LC_REFS, 41)),
+                           ("pred8ts", "<i2", (LC_REFS, 4, 2)), ("mv_int8ts", "<i2", (LC_REFS, 4, 2)), ("mv8ts", "<i2", (LC_REFS, 4, 2)),
+                           ("cost_int8ts", "<i4", (LC_REFS, 4)), ("cost8ts", "<i4", (LC_REFS, 4)),
+                           ("transform8x8_flag", "<i4"), ("cbp8ts", "<i4")], align=True)
 
 # JM's shipped defaults (bin/encoder_*.cfg: EPZSPattern 2, Dual 3, Fixed 2, Temporal 1, SpatialMem 1, thresholds 0/1/2, sub-pel 2; UMHexDSR 1, UMHexScale 3)
 EPZS_DEFAULTS = dict(pattern=2, dual=3, fixed=2, temporal=1, spatial_mem=1, min_scale=0, med_scale=1, max_scale=2, subpel_scale=2)
@@ -657,14 +661,21 @@ BLOCKTYPE_LUT = {(0, 0): 7, (0, 1): 6, (1, 0): 5, (1, 1): 4, (1, 3): 3, (3, 1): 
 
 
 def lowcplx_params(search_mode, search_range, num_refs, lambda_mf, ref_cost1, W, H, epzs=None, umhex=None, full_search=2, metric=(0, 2, 2),
-                   md_metric=2, valid=(1, 1, 1, 1, 1, 1, 1), frame_ctr_b=0, img_number=1, level_mv=(-511, 511), all_mv_state=None):
+                   md_metric=2, valid=(1, 1, 1, 1, 1, 1, 1), frame_ctr_b=0, img_number=1, level_mv=(-511, 511), all_mv_state=None,
+                   transform8x8_mode=0, qp=28, cavlc=1):
     q = LowcplxParams()
     q.search_mode, q.search_range, q.num_refs, q.full_search = search_mode, search_range, num_refs, full_search
     for m in range(1, 8):
         q.valid[m] = valid[m - 1]
     q.lambda_mf[0], q.lambda_mf[1], q.lambda_mf[2] = lambda_mf
     q.ref_cost1, q.md_metric = ref_cost1, md_metric
-    q.me = me_params(rdopt=0, metric=metric, level_mv=level_mv)
+    q.me = me_params(rdopt=0, metric=metric, level_mv=level_mv, transform8x8_mode=transform8x8_mode)
+    q.transform8x8_mode = transform8x8_mode
+    if transform8x8_mode:                    # the inter 8x8 luma quantiser of the slice: flat matrices, default offset (342 / 2048), no adaptive rounding
+        ls, ils, lo, _ = flat_tables(qp, 342, True)
+        q._keep_q8 = QuantHolder(dict(levelscale=ls, invlevelscale=ils, leveloffset=lo, qp=qp, adaptive_rounding=0, adapt_rnd_weight=0, field_scan=0,
+                                      disthres=0, max_val=255, cavlc=cavlc, img_qp=qp, transform8x8_flag=1))
+        q.q8 = C.addressof(q._keep_q8.c)
     q.epzs_subpel_me = 1
     q.W, q.H = W, H
     q.epzs = epzs.h if epzs else None

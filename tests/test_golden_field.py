@@ -10,7 +10,10 @@ import pytest
 from tests import oracle
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = {"field_full_r16_1ref": -1, "field_fastfull_r16_2ref": 0, "field_epzs_r16_2ref": 3, "field_umhex_r16_2ref": 1}
+CASES = {"field_full_r16_1ref": -1, "field_fastfull_r16_2ref": 0, "field_epzs_r16_2ref": 3, "field_umhex_r16_2ref": 1,
+         # Transform8x8Mode 1 / 2 (tests/golden/make_golden_field.py): (search mode, Transform8x8Mode, CAVLC)
+         "field_epzs_t8_r16_2ref": (3, 1, 1), "field_full_t8only_r16_1ref": (-1, 2, 1), "field_umhex_t8_cabac_r16_2ref": (1, 1, 0),
+         "field_fastfull_t8_r16_2ref": (0, 1, 1)}
 QP_N = 28          # QPPSlice of bin/encoder_baseline.cfg (UMHEX thresholds, me_umhex.c:110)
 
 
@@ -21,6 +24,9 @@ def part_index(bt, bx, by):
 
 
 def replay(name, mode, on_frame=None):
+    t8, cavlc = 0, 1
+    if isinstance(mode, tuple):
+        mode, t8, cavlc = mode
     """Runs every P picture of a fixture through the oracle driver (state carried across pictures like JM's) and yields per picture
     (fixture arrays, driver records, final ref_idx, final mv)."""
     z = np.load(os.path.join(GOLD, name + ".npz"))
@@ -29,7 +35,7 @@ def replay(name, mode, on_frame=None):
     W, H = int(head0[0]), int(head0[1])
     R, max_refs = 16, 2
     epzs = oracle.Epzs(W, H, R, max_refs) if mode == 3 else None
-    umhex = oracle.Umhex(W, H, R, max_refs, QP_N) if mode == 1 else None
+    umhex = oracle.Umhex(W, H, R, max_refs, int(head0[2]) if t8 else QP_N) if mode == 1 else None
     out = []
     all_mv_state = np.zeros((4, 4, oracle.MAX_REFS, 9, 2), np.int16)
     for k in range(n):
@@ -42,7 +48,8 @@ def replay(name, mode, on_frame=None):
             epzs.slice_init(int(head[10]), [int(v) for v in refinfo[:, 0]], ids, z["f%d_col_mv" % k], z["f%d_col_ref_id" % k],
                             num_ref_idx_l0_active=int(head[11]))
         q = oracle.lowcplx_params(mode, R, nref, [int(v) for v in head[6:9]], int(head[9]), W, H, epzs=epzs, umhex=umhex,
-                                  frame_ctr_b=int(head[5]), img_number=int(head[4]), all_mv_state=all_mv_state)
+                                  frame_ctr_b=int(head[5]), img_number=int(head[4]), all_mv_state=all_mv_state,
+                                  transform8x8_mode=t8, qp=int(head[2]), cavlc=cavlc)
         rec, ref_idx, mv = oracle.lowcplx_p_slice(q, refs, z["f%d_cur" % k])
         out.append((dict(calls=z["f%d_calls" % k], mb=z["f%d_mb" % k], field=z["f%d_field" % k], nref=nref), rec, ref_idx, mv))
     if epzs:
@@ -56,10 +63,19 @@ def replay(name, mode, on_frame=None):
 def test_every_block_motion_search_call_and_the_final_field_match_jm(name):
     for k, (fx, rec, ref_idx, mv) in enumerate(replay(name, CASES[name])):
         bad = 0
+        t8 = CASES[name][1] if isinstance(CASES[name], tuple) else 0
+        seen = set()
         for (mb, ref, bt, bx, by, px, py, mx, my, cost, rng, lam) in fx["calls"]:
             p = part_index(int(bt), int(bx), int(by))
             r = rec[int(mb)]
-            got = (r["pred"][ref, p, 0], r["pred"][ref, p, 1], r["mv"][ref, p, 0], r["mv"][ref, p, 1], r["cost"][ref, p])
+            # Transform8x8Mode: the 8x8 blocks are searched in the 8x8-transform P8x8 pass first (and, mode 1, again in the 4x4-transform pass)
+            first8 = t8 and int(bt) == 4 and (int(mb), int(ref), p) not in seen
+            seen.add((int(mb), int(ref), p))
+            if first8:
+                b8 = p - 5
+                got = (r["pred8ts"][ref, b8, 0], r["pred8ts"][ref, b8, 1], r["mv8ts"][ref, b8, 0], r["mv8ts"][ref, b8, 1], r["cost8ts"][ref, b8])
+            else:
+                got = (r["pred"][ref, p, 0], r["pred"][ref, p, 1], r["mv"][ref, p, 0], r["mv"][ref, p, 1], r["cost"][ref, p])
             if got != (px, py, mx, my, cost):
                 if not bad:
                     first = "picture %d mb %d ref %d blocktype %d block (%d,%d): JM pred (%d,%d) mv (%d,%d) cost %d, oracle %s" % (
