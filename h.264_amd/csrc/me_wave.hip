@@ -71,6 +71,7 @@ struct Lds {
   // the macroblock's view of the picture-level state: staged once by mb_stage, used and updated in LDS, handed on by mb_commit.
   // Grid [y + 1][x + 1] of the 4x4 blocks x = -1..4, y = -1..3: the macroblock's own sixteen and the ring its predictors read (A, B, C, D)
   int mbx, mby;
+  int pass8ts;                                 // inside the 8x8-transform P8x8 pass (Transform8x8Mode): the call records go to the *8ts arrays
   int8_t f_ref[5][6];                          // enc_picture->ref_idx[LIST_0]
   short f_mv[5][6][2];                         // enc_picture->mv[LIST_0]
   int um_loc[8][5][6];                         // fastme_l0_cost per block type
@@ -1146,7 +1147,7 @@ template <int SM> __device__ int block_motion_search(int mbx, int mby, int ref, 
   B.pic_x = mbx * 16 + mb_x; B.pic_y = mby * 16 + mb_y;
   B.planes = D.ref_sub[P.ref_slot[ref]];
   B.wp = P.wp_me; B.wpw = P.wp_weight[ref]; B.wpo = P.wp_offset[ref];
-  B.t8 = 0;
+  B.t8 = P.transform8x8_mode && bt <= 4;                                       // test8x8transform, mv-search.c:640
   const int block_x = mb_x >> 2, block_y = mb_y >> 2, pi = part_index(bt, block_x, block_y);
   const int start_hp = P.metric[0] != P.metric[1] ? 0 : 1;
   int mvx, mvy, min_mcost = INT_MAX;
@@ -1193,7 +1194,11 @@ template <int SM> __device__ int block_motion_search(int mbx, int mby, int ref, 
     }
   }
   WPROF(1);
-  if (threadIdx.x == 0) { out->mv_int[ref][pi][0] = (int16_t)mvx; out->mv_int[ref][pi][1] = (int16_t)mvy; out->cost_int[ref][pi] = min_mcost; }
+  const int b8i = (block_y >> 1) * 2 + (block_x >> 1), to8ts = L.pass8ts;
+  if (threadIdx.x == 0) {
+    if (to8ts) { out->mv_int8ts[ref][b8i][0] = (int16_t)mvx; out->mv_int8ts[ref][b8i][1] = (int16_t)mvy; out->cost_int8ts[ref][b8i] = min_mcost; }
+    else { out->mv_int[ref][pi][0] = (int16_t)mvx; out->mv_int[ref][pi][1] = (int16_t)mvy; out->cost_int[ref][pi] = min_mcost; }
+  }
   mvx <<= 2; mvy <<= 2;
   // sub-pel :781-827
   bool do_sub = true;
@@ -1210,9 +1215,9 @@ template <int SM> __device__ int block_motion_search(int mbx, int mby, int ref, 
     const int smx = L.all_mv[0][0][0][0], smy = L.all_mv[0][0][0][1];
     int cost;
     const uint8_t *pl0 = D.ref_sub[P.ref_slot[0]];
-    if (P.md_metric == 2) {
+    if (P.md_metric == 2) {                                                    // with the 8x8 transform: distortion8x8 per 8x8 block, :1171-1176
       L.cx[0] = padq(mbx * 16, smx); L.cy[0] = padq(mby * 16, smy);
-      eval_dist(pl0, 2, 0, 1, P.wp_pred, P.wp_weight[0], P.wp_offset[0], 0, 0, 16, 16, 1);
+      eval_dist(pl0, 2, P.transform8x8_mode ? 1 : 0, 1, P.wp_pred, P.wp_weight[0], P.wp_offset[0], 0, 0, 16, 16, 1);
       cost = L.dist[0];
     } else {                                                                   // SAD: LumaPrediction clamps per 4x4 block
       cost = 0;
@@ -1228,8 +1233,13 @@ template <int SM> __device__ int block_motion_search(int mbx, int mby, int ref, 
   WPROF(3);
   for (int j = block_y; j < block_y + (B.bsy >> 2); j++) for (int i = block_x; i < block_x + (B.bsx >> 2); i++) { L.all_mv[j * 4 + i][ref][bt][0] = (short)mvx; L.all_mv[j * 4 + i][ref][bt][1] = (short)mvy; }
   if (threadIdx.x == 0) {
-    out->pred[ref][pi][0] = (int16_t)B.pmx; out->pred[ref][pi][1] = (int16_t)B.pmy;
-    out->mv[ref][pi][0] = (int16_t)mvx; out->mv[ref][pi][1] = (int16_t)mvy; out->cost[ref][pi] = min_mcost;
+    if (to8ts) {
+      out->pred8ts[ref][b8i][0] = (int16_t)B.pmx; out->pred8ts[ref][b8i][1] = (int16_t)B.pmy;
+      out->mv8ts[ref][b8i][0] = (int16_t)mvx; out->mv8ts[ref][b8i][1] = (int16_t)mvy; out->cost8ts[ref][b8i] = min_mcost;
+    } else {
+      out->pred[ref][pi][0] = (int16_t)B.pmx; out->pred[ref][pi][1] = (int16_t)B.pmy;
+      out->mv[ref][pi][0] = (int16_t)mvx; out->mv[ref][pi][1] = (int16_t)mvy; out->cost[ref][pi] = min_mcost;
+    }
   }
   return min_mcost;
 }
@@ -1264,6 +1274,96 @@ template <int SM> __device__ void partition_motion_search(int mbx, int mby, int 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------- Transform8x8Mode (md_low.c:183-188, :203-326, :547-548)
+
+// prediction-residual cost of a bs x bs block at (ox, oy) of the macroblock predicted from (ref, mv): the sum of distortion4x4 (t8 = 0) or the
+// distortion8x8 (t8 = 1, bs = 8) of the mode-decision metric, as TransformDecision (macroblock.c:1458) / GetBestTransformP8x8 (rdopt.c:3262)
+// form them. (LumaPrediction clamps per 4x4 block, the evaluation per 4x4 / 8x8 sub-block: the same samples, the padding ring is flat; the
+// sequential layout of JM's diff64 permutes the index bits of the 8x8 block, which the Hadamard magnitudes' sum is invariant under.)
+__device__ int pred_block_cost(int mbx, int mby, int ox, int oy, int bs, int ref, int mvx, int mvy, int t8)
+{
+  const jmhip_slice_params &P = D.p;
+  L.cx[0] = padq(mbx * 16 + ox, mvx); L.cy[0] = padq(mby * 16 + oy, mvy);
+  eval_dist(D.ref_sub[P.ref_slot[ref]], P.md_metric, t8, 1, P.wp_pred, P.wp_weight[ref], P.wp_offset[ref], ox, oy, bs, bs, 1);
+  return L.dist[0];
+}
+
+__constant__ uint8_t c_t8_scan[64][2] = {                                       // SNGL_SCAN8x8 (i, j), transform8x8.c:171
+  {0,0},{1,0},{0,1},{0,2},{1,1},{2,0},{3,0},{2,1},{1,2},{0,3},{0,4},{1,3},{2,2},{3,1},{4,0},{5,0},
+  {4,1},{3,2},{2,3},{1,4},{0,5},{0,6},{1,5},{2,4},{3,3},{4,2},{5,1},{6,0},{7,0},{6,1},{5,2},{4,3},
+  {3,4},{2,5},{1,6},{0,7},{1,7},{2,6},{3,5},{4,4},{5,3},{6,2},{7,1},{7,2},{6,3},{5,4},{4,5},{3,6},
+  {2,7},{3,7},{4,6},{5,5},{6,4},{7,3},{7,4},{6,5},{5,6},{4,7},{5,7},{6,6},{7,5},{7,6},{6,7},{7,7}};
+__constant__ uint8_t c_t8_cost[2][64] = {                                       // COEFF_COST8x8, transform8x8.c:197
+  {3,3,3,3,2,2,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0},
+  {9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9,9}};
+
+__device__ __forceinline__ void t8_fwd_1d(const int p[8], int o[8])            // forward8x8, transform.c:248-275
+{
+  int a0 = p[0] + p[7], a1 = p[1] + p[6], a2 = p[2] + p[5], a3 = p[3] + p[4];
+  const int b0 = a0 + a3, b1 = a1 + a2, b2 = a0 - a3, b3 = a1 - a2;
+  a0 = p[0] - p[7]; a1 = p[1] - p[6]; a2 = p[2] - p[5]; a3 = p[3] - p[4];
+  const int b4 = a1 + a2 + ((a0 >> 1) + a0), b5 = a0 - a3 - ((a2 >> 1) + a2);
+  const int b6 = a0 + a3 - ((a1 >> 1) + a1), b7 = a1 - a2 + ((a3 >> 1) + a3);
+  o[0] = b0 + b1; o[1] = b4 + (b7 >> 2); o[2] = b2 + (b3 >> 1); o[3] = b5 + (b6 >> 2);
+  o[4] = b0 - b1; o[5] = b6 - (b5 >> 2); o[6] = (b2 >> 1) - b3; o[7] = (b4 >> 2) - b7;
+}
+
+// cbp8_8x8ts: which 8x8 blocks of the 8x8-transform P8x8 pass keep coefficients -- LumaResidualCoding8x8 (macroblock.c:1009) of each block: one
+// 8x8 prediction (origin clamp, explicit weights), dct_8x8 (transform8x8.c:1452: forward transform, quantisation, coefficient cost with the
+// CAVLC four-way interleave), a block whose cost is <= _LUMA_COEFF_COST_ (4) is dropped (:1223). Lanes 0..3, one block each; rare (only when
+// that pass wins the macroblock), so nothing is shared.
+__device__ int t8_pass_cbp(int mbx, int mby, const int *ref8, const short (*mv8)[2])
+{
+  const jmhip_slice_params &P = D.p;
+  const int lane = threadIdx.x;
+  int keep = 0;
+  __syncthreads();
+  if (lane < 4) {
+    const int ox = 8 * (lane & 1), oy = 8 * (lane >> 1), ref = ref8[lane];
+    const int cx = padq(mbx * 16 + ox, mv8[lane][0]), cy = padq(mby * 16 + oy, mv8[lane][1]);
+    const int ix = clampi(cx >> 2, 0, D.Wp - 17), iy = clampi(cy >> 2, 0, D.Hp - 17);
+    const uint8_t *src = D.ref_sub[P.ref_slot[ref]] + (size_t)D.Wp * D.Hp * ((cy & 3) * 4 + (cx & 3)) + (size_t)iy * D.Wp + ix;
+    int t[8][8];
+    for (int j = 0; j < 8; j++) {
+      int p[8], o[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        int v = src[(size_t)j * D.Wp + i];
+        if (P.wp_pred) v = min(max((((int)P.wp_weight[ref] * v + P.wp_round) >> P.wp_denom) + (int)P.wp_offset[ref], 0), 255);
+        p[i] = (int)L.cur[oy + j][ox + i] - v;
+      }
+      t8_fwd_1d(p, o);
+#pragma unroll
+      for (int i = 0; i < 8; i++) t[j][i] = o[i];
+    }
+    for (int i = 0; i < 8; i++) {
+      int p[8], o[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) p[j] = t[j][i];
+      t8_fwd_1d(p, o);
+#pragma unroll
+      for (int j = 0; j < 8; j++) t[j][i] = o[j];
+    }
+    const int q_bits = 16 + P.t8_qp / 6;
+    int run = -1, runs4[4] = {-1, -1, -1, -1}, cost = 0, nonzero = 0;
+    for (int k = 0; k < 64; k++) {
+      const int i = c_t8_scan[k][0], j = c_t8_scan[k][1];
+      run++; runs4[k & 3]++;
+      const int level = (iabs(t[j][i]) * P.t8_levelscale[j * 8 + i] + P.t8_leveloffset[j * 8 + i]) >> q_bits;
+      if (level != 0) {
+        nonzero = 1;
+        if (P.t8_cavlc) { cost += level > 1 ? 999999 : c_t8_cost[P.t8_disthres][runs4[k & 3]]; runs4[k & 3] = -1; }
+        else { cost += level > 1 ? 999999 : c_t8_cost[P.t8_disthres][run]; run = -1; }
+      }
+    }
+    keep = nonzero && cost > 4;
+  }
+  const int cbp = (int)(__ballot(keep) & 15ull);
+  __syncthreads();
+  return cbp;
+}
+
 __device__ __forceinline__ int list0_cost(int mode, int block, int *best_ref)
 {
   int best = INT_MAX;
@@ -1283,6 +1383,22 @@ template <int SM> __device__ void macroblock_low(int mbx, int mby, jmhip_mb_inte
   const int bx0 = mbx * 4, by0 = mby * 4;
   int best_mode = 1, min_cost = INT_MAX;
   int l0ref[5][4] = {{0}}, b8m[4] = {0, 0, 0, 0};
+  const int T8 = P.transform8x8_mode;
+  int t8_flag = 0, best_tflag = 0, cbp8ts = -1, tr8_cost = INT_MAX, tr4_cost = INT_MAX;
+  int ref8ts[4] = {0, 0, 0, 0};
+  short mv8ts[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+  if (threadIdx.x == 0) L.pass8ts = 0;
+  for (int e = threadIdx.x; e < WR * 4; e += 64) {                             // the 8x8-transform pass's call records: zero unless that pass runs
+    const int r = e >> 2, k = e & 3;
+    out->pred8ts[r][k][0] = out->pred8ts[r][k][1] = out->mv_int8ts[r][k][0] = out->mv_int8ts[r][k][1] = out->mv8ts[r][k][0] = out->mv8ts[r][k][1] = 0;
+    out->cost_int8ts[r][k] = out->cost8ts[r][k] = 0;
+  }
+  if (T8 == 2)                                                                 // no 4x4-transform P8x8 pass: its call records stay empty
+    for (int e = threadIdx.x; e < WR * 36; e += 64) {
+      const int r = e / 36, k = 5 + e % 36;
+      out->pred[r][k][0] = out->pred[r][k][1] = out->mv_int[r][k][0] = out->mv_int[r][k][1] = out->mv[r][k][0] = out->mv[r][k][1] = 0;
+      out->cost_int[r][k] = out->cost[r][k] = 0;
+    }
   for (int r = 0; r < 2 * WR; r++) L.surf_c[r][3] = 0;
   for (int mode = 1; mode < 4; mode++) {
     if (!P.valid[mode]) continue;
@@ -1301,10 +1417,47 @@ template <int SM> __device__ void macroblock_low(int mbx, int mby, jmhip_mb_inte
           field_set(by0 + j, bx0 + i, best_ref, L.all_mv[j * 4 + i][best_ref][mode][0], L.all_mv[j * 4 + i][best_ref][mode][1]);
       __syncthreads();
     }
-    if (cost < min_cost) { best_mode = mode; min_cost = cost; }
+    if (T8) {
+      // SetModesAndRefframeForBlocks (md_low.c:186, rdopt.c:1470-1500) writes the mode's best references into the picture array -- a side effect only
+      // Transform8x8Mode has -- and TransformDecision predicts with them
+      for (int b = 0; b < 16; b++) FREF(by0 + (b >> 2), bx0 + (b & 3)) = (int8_t)l0ref[mode][2 * (b >> 3) + ((b & 3) >> 1)];
+      __syncthreads();
+      if (T8 == 2) t8_flag = 1;
+      else if (P.md_metric != 2) t8_flag = 0;            // SAD: cost8x8 == cost4x4, the cost stays
+      else {
+        int c4 = 0, c8 = 0;
+        for (int k8 = 0; k8 < 4; k8++) {
+          const int b = (k8 >> 1) * 8 + (k8 & 1) * 2, r = l0ref[mode][k8];
+          c4 += pred_block_cost(mbx, mby, 8 * (k8 & 1), 8 * (k8 >> 1), 8, r, L.all_mv[b][r][mode][0], L.all_mv[b][r][mode][1], 0);
+          c8 += pred_block_cost(mbx, mby, 8 * (k8 & 1), 8 * (k8 >> 1), 8, r, L.all_mv[b][r][mode][0], L.all_mv[b][r][mode][1], 1);
+        }
+        if (c8 < c4) t8_flag = 1; else { cost = cost - c8 + c4; t8_flag = 0; }
+      }
+    }
+    if (cost < min_cost) { best_mode = mode; min_cost = cost; best_tflag = t8_flag; }
   }
   if (P.valid[4] || P.valid[5] || P.valid[6] || P.valid[7]) {
     int cost8x8 = 0;
+    if (T8) {                                            // the 8x8 partition with the 8x8 transform: sub-mode 4 only (mode_decision.c:556)
+      tr8_cost = 0;
+      __syncthreads();
+      if (threadIdx.x == 0) L.pass8ts = 1;
+      __syncthreads();
+      for (int block = 0; block < 4; block++) {
+        const int j0 = block & 2, i0 = (block & 1) * 2;
+        int best_ref = 0;
+        partition_motion_search<SM>(mbx, mby, 4, block, out);
+        int cost = list0_cost(4, block, &best_ref);
+        if (cost != INT_MAX) cost += ((P.lambda_mf[2] * (P.num_refs <= 1 ? 0 : refbits(0))) >> 16) - 1;
+        tr8_cost += cost;
+        ref8ts[block] = best_ref; mv8ts[block][0] = L.all_mv[j0 * 4 + i0][best_ref][4][0]; mv8ts[block][1] = L.all_mv[j0 * 4 + i0][best_ref][4][1];
+        for (int j = j0; j < j0 + 2; j++) for (int i = i0; i < i0 + 2; i++) field_set(by0 + j, bx0 + i, best_ref, mv8ts[block][0], mv8ts[block][1]);
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) L.pass8ts = 0;
+      __syncthreads();
+    }
+    if (T8 != 2) {
     for (int block = 0; block < 4; block++) {
       int mc8 = INT_MAX;
       const int j0 = block & 2, i0 = (block & 1) * 2;
@@ -1323,16 +1476,53 @@ template <int SM> __device__ void macroblock_low(int mbx, int mby, jmhip_mb_inte
         field_set(by0 + j, bx0 + i, l0ref[4][block], L.all_mv[j * 4 + i][l0ref[4][block]][b8m[block]][0], L.all_mv[j * 4 + i][l0ref[4][block]][b8m[block]][1]);
       __syncthreads();
     }
-    if (cost8x8 < min_cost) { best_mode = 8; min_cost = cost8x8; }
+    tr4_cost = cost8x8;
+    }
+    if (tr4_cost < min_cost || tr8_cost < min_cost) {    // md_low.c:281-326
+      best_mode = 8;
+      if (T8 == 2) { min_cost = tr8_cost; t8_flag = 1; }
+      else if (T8) {
+        if (tr8_cost < tr4_cost) { min_cost = tr8_cost; t8_flag = 1; }
+        else if (tr4_cost < tr8_cost) { min_cost = tr4_cost; t8_flag = 0; }
+        else {                                           // GetBestTransformP8x8: the two passes' predictions against the source
+          int c4 = 0, c8 = 0;
+          if (P.md_metric == 2) {
+            for (int b = 0; b < 16; b++) {
+              const int k8 = 2 * (b >> 3) + ((b & 3) >> 1), r = l0ref[4][k8], m8 = b8m[k8];
+              c4 += pred_block_cost(mbx, mby, 4 * (b & 3), 4 * (b >> 2), 4, r, L.all_mv[b][r][m8][0], L.all_mv[b][r][m8][1], 0);
+            }
+            for (int k8 = 0; k8 < 4; k8++) c8 += pred_block_cost(mbx, mby, 8 * (k8 & 1), 8 * (k8 >> 1), 8, ref8ts[k8], mv8ts[k8][0], mv8ts[k8][1], 1);
+          } else {
+            for (int b = 0; b < 16; b++) {
+              const int k8 = 2 * (b >> 3) + ((b & 3) >> 1), r = l0ref[4][k8], m8 = b8m[k8];
+              c4 += pred_block_cost(mbx, mby, 4 * (b & 3), 4 * (b >> 2), 4, r, L.all_mv[b][r][m8][0], L.all_mv[b][r][m8][1], 0);
+              c8 += pred_block_cost(mbx, mby, 4 * (b & 3), 4 * (b >> 2), 4, ref8ts[k8], mv8ts[k8][0], mv8ts[k8][1], 0);
+            }
+          }
+          if (c8 < c4) { min_cost = tr8_cost; t8_flag = 1; } else { min_cost = tr4_cost; t8_flag = 0; }
+        }
+      } else { min_cost = tr4_cost; t8_flag = 0; }
+    }
   }
   find_skip_mv(mbx, mby);
+  if (best_mode != 8) t8_flag = best_tflag;
+  else if (t8_flag && T8 != 2) {                         // md_low.c:547-548: an 8x8-transform winner without a coded block gives way to the 4x4 pass
+    cbp8ts = t8_pass_cbp(mbx, mby, ref8ts, mv8ts);
+    if (cbp8ts == 0) t8_flag = 0;
+  }
+  if (best_mode == 8 && t8_flag) {                       // SetCoeffAndReconstruction8x8 (rdopt.c:1595): the 8x8-transform pass's partitioning
+    for (int k = 0; k < 4; k++) { b8m[k] = 4; l0ref[4][k] = ref8ts[k]; }
+    __syncthreads();
+    for (int b = 0; b < 16; b++) { const int k8 = 2 * (b >> 3) + ((b & 3) >> 1); L.all_mv[b][ref8ts[k8]][4][0] = mv8ts[k8][0]; L.all_mv[b][ref8ts[k8]][4][1] = mv8ts[k8][1]; }
+    __syncthreads();
+  }
   for (int b = 0; b < 16; b++) {
     const int k8 = 2 * (b >> 3) + ((b & 3) >> 1), m8 = best_mode == 8 ? b8m[k8] : best_mode, r = l0ref[best_mode == 8 ? 4 : best_mode][k8];
     field_set(by0 + (b >> 2), bx0 + (b & 3), r, L.all_mv[b][r][m8][0], L.all_mv[b][r][m8][1]);
     if (threadIdx.x == 0) { out->final_mv[b][0] = L.all_mv[b][r][m8][0]; out->final_mv[b][1] = L.all_mv[b][r][m8][1]; }
   }
   if (threadIdx.x == 0) {
-    out->best_mode = best_mode; out->min_cost = min_cost;
+    out->best_mode = best_mode; out->min_cost = min_cost; out->transform8x8_flag = t8_flag; out->cbp8ts = cbp8ts;
     for (int k = 0; k < 4; k++) { out->b8mode[k] = best_mode == 8 ? b8m[k] : best_mode; out->b8ref[k] = l0ref[best_mode == 8 ? 4 : best_mode][k]; }
     out->skip_mv[0] = L.all_mv[0][0][0][0]; out->skip_mv[1] = L.all_mv[0][0][0][1];
   }
@@ -1657,6 +1847,10 @@ extern "C" int jmhip_p_slice_search(jmhip_ctx *c, const jmhip_slice_params *prm,
   if ((prm->search_mode == JMHIP_SEARCH_FULL || prm->search_mode == JMHIP_SEARCH_FASTFULL) && prm->metric[0] != 0)
     return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_p_slice_search: the exhaustive searches take the SAD metric at full-pel positions");
   if (prm->md_metric != 0 && prm->md_metric != 2) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_p_slice_search: mode-decision metric SAD or SATD");
+  if (prm->transform8x8_mode < 0 || prm->transform8x8_mode > 2) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_p_slice_search: transform8x8_mode must be 0, 1 or 2");
+  if (prm->transform8x8_mode && !prm->valid[4]) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_p_slice_search: Transform8x8Mode needs the 8x8 sub-mode (valid[4])");
+  if (prm->transform8x8_mode == 1 && (prm->t8_qp < 0 || prm->t8_qp > 51 + 48 || prm->t8_disthres < 0 || prm->t8_disthres > 1))
+    return jm_fail(c, JMHIP_ERR_ARG, "jmhip_p_slice_search: the 8x8 quantiser of Transform8x8Mode 1 (t8_qp, t8_disthres)");
   if ((prm->wp_me || prm->wp_pred) && (prm->wp_denom < 0 || prm->wp_denom > 7)) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_p_slice_search: weighted-prediction denominator");
   for (int r = 0; r < prm->num_refs; r++) {
     const int sl = prm->ref_slot[r];

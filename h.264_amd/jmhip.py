@@ -100,13 +100,18 @@ class SliceParams(C.Structure):
                 ("epzs_nwin", C.c_int32), ("epzs_nwin_ext", C.c_int32), ("epzs_win", (C.c_int16 * 2) * 40), ("epzs_win_ext", (C.c_int16 * 2) * 100),
                 ("epzs_mv_scale", (C.c_int32 * SLICE_REFS) * SLICE_REFS),
                 ("umhex_dsr", C.c_int32), ("umhex_thres", (C.c_int32 * 8) * 4), ("umhex_bsize", C.c_float * 8), ("umhex_alpha1", C.c_float * 8),
-                ("umhex_alpha2", C.c_float * 8)]
+                ("umhex_alpha2", C.c_float * 8),
+                ("transform8x8_mode", C.c_int32), ("t8_qp", C.c_int32), ("t8_cavlc", C.c_int32), ("t8_disthres", C.c_int32),
+                ("t8_levelscale", C.c_int32 * 64), ("t8_leveloffset", C.c_int32 * 64)]
 
 
 MB_INTER_DTYPE = np.dtype([("best_mode", "<i4"), ("min_cost", "<i4"), ("b8mode", "<i4", (4,)), ("b8ref", "<i4", (4,)),
                            ("final_mv", "<i2", (16, 2)), ("skip_mv", "<i2", (2,)),
                            ("pred", "<i2", (SLICE_REFS, NPART, 2)), ("mv_int", "<i2", (SLICE_REFS, NPART, 2)), ("mv", "<i2", (SLICE_REFS, NPART, 2)),
-                           ("cost_int", "<i4", (SLICE_REFS, NPART)), ("cost", "<i4", (SLICE_REFS, NPART))], align=True)
+                           ("cost_int", "<i4", (SLICE_REFS, NPART)), ("cost", "<i4", (SLICE_REFS, NPART)),
+                           ("pred8ts", "<i2", (SLICE_REFS, 4, 2)), ("mv_int8ts", "<i2", (SLICE_REFS, 4, 2)), ("mv8ts", "<i2", (SLICE_REFS, 4, 2)),
+                           ("cost_int8ts", "<i4", (SLICE_REFS, 4)), ("cost8ts", "<i4", (SLICE_REFS, 4)),
+                           ("transform8x8_flag", "<i4"), ("cbp8ts", "<i4")], align=True)
 
 PREDCOST_JOB_DTYPE = np.dtype([("mb_x", "<i2"), ("mb_y", "<i2"), ("blocks", "<u2"), ("weighted", "<i2"), ("wp_round", "<i2"), ("wp_denom", "<i2"),
                                ("mv", "<i2", (16, 2)), ("mv1", "<i2", (16, 2)), ("ref", "i1", (16,)), ("ref1", "i1", (16,)), ("bi", "i1", (16,)),

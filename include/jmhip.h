@@ -313,6 +313,17 @@ typedef struct jmhip_slice_params {
   int32_t umhex_dsr;
   int32_t umhex_thres[4][8];               /* Median_Pred_Thd_MB, Big_Hexagon_Thd_MB, Multi_Ref_Thd_MB, Threshold_DSR_MB */
   float   umhex_bsize[8], umhex_alpha1[8], umhex_alpha2[8];
+  /* input->Transform8x8Mode (round 2): 0 = 4x4 transform only. 1 = both sizes compete: block types 1..4 are searched with the 8x8 Hadamard
+   * (src/mv-search.c:640), TransformDecision (src/macroblock.c:1458) follows each of modes 1..3 (src/md_low.c:183-188, incl. the references
+   * SetModesAndRefframeForBlocks writes into the picture array, src/rdopt.c:1470-1500), P8x8 runs an 8x8-transform pass (sub-mode 4 only)
+   * before the 4x4-transform pass (:203-262), the cheaper pass wins (:281-326, ties: GetBestTransformP8x8 src/rdopt.c:3262) -- and an
+   * 8x8-transform winner whose four blocks quantise to nothing falls back to the 4x4 pass's partitioning (:547-548): that needs the inter 8x8
+   * luma quantiser of the slice below (LumaResidualCoding8x8 src/macroblock.c:1009, dct_8x8 src/transform8x8.c:1452, flat or scaling-matrix
+   * tables as JM built them, AdaptiveRounding off, frame scan). 2 = 8x8 only (no 4x4 pass, no fallback, tables unused).
+   * valid[4] must be set with 1 or 2. The skip cost takes distortion8x8 (src/mv-search.c:1171). */
+  int32_t transform8x8_mode;
+  int32_t t8_qp, t8_cavlc, t8_disthres;                /* currMB->qp_scaled[0], input->symbol_mode == CAVLC, input->disthres */
+  int32_t t8_levelscale[64], t8_leveloffset[64];       /* LevelScale8x8Luma_Inter[qp % 6], LevelOffset8x8Luma_Inter[qp / 6], row-major [j][i] */
 } jmhip_slice_params;
 
 /* what JM knows of one macroblock after the decision + the outcome of each of its BlockMotionSearch calls */
@@ -324,6 +335,13 @@ typedef struct jmhip_mb_inter {
   int16_t skip_mv[2];                      /* all_mv[..][LIST_0][0][0] (FindSkipModeMotionVector) */
   int16_t pred[JMHIP_SLICE_REFS][JMHIP_NPART][2], mv_int[JMHIP_SLICE_REFS][JMHIP_NPART][2], mv[JMHIP_SLICE_REFS][JMHIP_NPART][2];
   int32_t cost_int[JMHIP_SLICE_REFS][JMHIP_NPART], cost[JMHIP_SLICE_REFS][JMHIP_NPART];
+  /* Transform8x8Mode: the BlockMotionSearch calls of the 8x8-transform P8x8 pass (block type 4, per 8x8 block; with mode 1 JM searches the
+   * same blocks again in the 4x4-transform pass: those calls are in the arrays above), the transform size of the chosen mode as the decision
+   * leaves it (before the residual coder's cbp == 0 reset), and the coded-block pattern of the 8x8-transform pass where the decision needed it
+   * (else -1) */
+  int16_t pred8ts[JMHIP_SLICE_REFS][4][2], mv_int8ts[JMHIP_SLICE_REFS][4][2], mv8ts[JMHIP_SLICE_REFS][4][2];
+  int32_t cost_int8ts[JMHIP_SLICE_REFS][4], cost8ts[JMHIP_SLICE_REFS][4];
+  int32_t transform8x8_flag, cbp8ts;
 } jmhip_mb_inter;
 
 /* Host helpers that fill the search-mode blocks of jmhip_slice_params exactly as JM's initialisation does. */

@@ -14,7 +14,8 @@ from tests.test_golden_field import CASES, GOLD, QP_N, part_index
 FIELDS = ("pred", "mv_int", "cost_int", "mv", "cost")
 
 
-def slice_params(pkg, mode, R, nref, lambda_mf, ref_cost1, W, mb_first=0, mb_count=None, H=None, metric=(0, 2, 2), qp_n=QP_N, full_search=2):
+def slice_params(pkg, mode, R, nref, lambda_mf, ref_cost1, W, mb_first=0, mb_count=None, H=None, metric=(0, 2, 2), qp_n=QP_N, full_search=2,
+                 t8=0, t8_qp=None, cavlc=1):
     lib = pkg.load_library()
     p = pkg.SliceParams()
     p.search_mode, p.search_range, p.full_search, p.num_refs = mode, R, full_search, nref
@@ -30,11 +31,20 @@ def slice_params(pkg, mode, R, nref, lambda_mf, ref_cost1, W, mb_first=0, mb_cou
     p.mb_count = mb_count if mb_count is not None else (W // 16) * (H // 16) - mb_first
     lib.jmhip_epzs_setup(p, R, 2, 3, 2, 1, 1, 1, 0, 1, 2, 2)
     lib.jmhip_umhex_setup(p, 1, 3, qp_n, W)
+    if t8:                                           # Transform8x8Mode: the inter 8x8 luma quantiser of the slice (flat matrices, default offsets)
+        ls, _, lo, _ = oracle.flat_tables(qp_n if t8_qp is None else t8_qp, 342, True)
+        p.transform8x8_mode, p.t8_qp, p.t8_cavlc, p.t8_disthres = t8, qp_n if t8_qp is None else t8_qp, cavlc, 0
+        for k in range(64):
+            p.t8_levelscale[k], p.t8_leveloffset[k] = int(ls[k]), int(lo[k])
     return p
 
 
 def compare(got, want, nref, what):
-    for f in ("best_mode", "min_cost", "b8mode", "b8ref", "final_mv", "skip_mv"):
+    for f in ("pred8ts", "mv_int8ts", "mv8ts", "cost_int8ts", "cost8ts"):
+        if not np.array_equal(got[f][:, :nref], want[f][:, :nref]):
+            i = int(np.argwhere(np.any((got[f][:, :nref] != want[f][:, :nref]).reshape(len(got), -1), axis=1))[0][0])
+            raise AssertionError("%s: %s differs at macroblock %d: device %s oracle %s" % (what, f, i, got[f][i, :nref].tolist(), want[f][i, :nref].tolist()))
+    for f in ("best_mode", "min_cost", "b8mode", "b8ref", "final_mv", "skip_mv", "transform8x8_flag", "cbp8ts"):
         if not np.array_equal(got[f], want[f]):
             i = int(np.argwhere(np.any((got[f] != want[f]).reshape(len(got), -1), axis=1))[0][0])
             raise AssertionError("%s: %s differs at macroblock %d: device %s oracle %s" % (what, f, i, got[f][i].tolist(), want[f][i].tolist()))
@@ -48,7 +58,7 @@ def compare(got, want, nref, what):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_fixture_pictures_match_the_real_jm(pkg, name):
-    mode = CASES[name]
+    mode, t8, cavlc = CASES[name] if isinstance(CASES[name], tuple) else (CASES[name], 0, 1)
     z = np.load(os.path.join(GOLD, name + ".npz"))
     n = int(z["n_frames"])
     W, H = int(z["f0_head"][0]), int(z["f0_head"][1])
@@ -65,7 +75,8 @@ def test_fixture_pictures_match_the_real_jm(pkg, name):
             ctx.ref_upload(r, z["f%d_refs" % k][r])
             ctx.interp_luma(r)
         ctx.cur_upload(z["f%d_cur" % k])
-        p = slice_params(pkg, mode, R, nref, [int(v) for v in head[6:9]], int(head[9]), W, H=H)
+        p = slice_params(pkg, mode, R, nref, [int(v) for v in head[6:9]], int(head[9]), W, H=H, t8=t8, cavlc=cavlc,
+                         **(dict(qp_n=int(head[2])) if t8 else {}))
         if mode == 3:
             ids = (refinfo[:, 1].astype(np.int64) & 0xffffffff) | (refinfo[:, 2].astype(np.int64) << 32)
             epzs.slice_init(int(head[10]), [int(v) for v in refinfo[:, 0]], ids, z["f%d_col_mv" % k], z["f%d_col_ref_id" % k], num_ref_idx_l0_active=int(head[11]))
@@ -74,10 +85,16 @@ def test_fixture_pictures_match_the_real_jm(pkg, name):
             lib.jmhip_epzs_scales(p, int(head[10]), (C.c_int * nref)(*pocs), nref)
         got = ctx.p_slice_search(p)
         bad = 0
+        seen = set()
         for (mb, ref, bt, bx, by, px, py, mx, my, cost, rng, lam) in z["f%d_calls" % k]:
             pi = part_index(int(bt), int(bx), int(by))
             g = got[int(mb)]
-            t = (int(g["pred"][ref, pi, 0]), int(g["pred"][ref, pi, 1]), int(g["mv"][ref, pi, 0]), int(g["mv"][ref, pi, 1]), int(g["cost"][ref, pi]))
+            first8 = t8 and int(bt) == 4 and (int(mb), int(ref), pi) not in seen          # the 8x8-transform P8x8 pass searches the 8x8 blocks first
+            seen.add((int(mb), int(ref), pi))
+            if first8:
+                t = (int(g["pred8ts"][ref, pi - 5, 0]), int(g["pred8ts"][ref, pi - 5, 1]), int(g["mv8ts"][ref, pi - 5, 0]), int(g["mv8ts"][ref, pi - 5, 1]), int(g["cost8ts"][ref, pi - 5]))
+            else:
+                t = (int(g["pred"][ref, pi, 0]), int(g["pred"][ref, pi, 1]), int(g["mv"][ref, pi, 0]), int(g["mv"][ref, pi, 1]), int(g["cost"][ref, pi]))
             if t != (px, py, mx, my, cost):
                 if not bad:
                     first = "picture %d mb %d ref %d blocktype %d block (%d,%d): JM pred (%d,%d) mv (%d,%d) cost %d, device %s" % (k, mb, ref, bt, bx, by, px, py, mx, my, cost, t)
@@ -103,7 +120,7 @@ def synth_clip(rng, W, H, nframes):
     return out
 
 
-def run_synthetic(pkg, mode, W, H, R, nref, slices=1, nframes=3, seed=5, metric=(0, 2, 2), qp=28, max_mbs=None):
+def run_synthetic(pkg, mode, W, H, R, nref, slices=1, nframes=3, seed=5, metric=(0, 2, 2), qp=28, max_mbs=None, t8=0, cavlc=1):
     """Frames 1.. are coded as P pictures against the previous `nref` SOURCE frames (the search does not care where a reference came from)."""
     rng = np.random.default_rng(seed)
     clip = synth_clip(rng, W, H, nframes + nref - 1)
@@ -136,12 +153,13 @@ def run_synthetic(pkg, mode, W, H, R, nref, slices=1, nframes=3, seed=5, metric=
         per = (nmb + slices - 1) // slices
         for s in range(slices):
             first, count = s * per, min(per, nmb - s * per)
-            q = oracle.lowcplx_params(mode, R, nref, lam3, ref_cost1, W, H, epzs=epzs, umhex=umhex, all_mv_state=all_mv_state, metric=metric)
+            q = oracle.lowcplx_params(mode, R, nref, lam3, ref_cost1, W, H, epzs=epzs, umhex=umhex, all_mv_state=all_mv_state, metric=metric,
+                                      transform8x8_mode=t8, qp=qp, cavlc=cavlc)
             sid = (np.arange(nmb) // per).astype(np.int32)
             q._sid = sid
             q.slice_id = sid.ctypes.data
             want, _, _ = oracle.lowcplx_p_slice(q, orefs, cur, ref_idx, mvf, mb_first=first, mb_count=count)
-            p = slice_params(pkg, mode, R, nref, lam3, ref_cost1, W, mb_first=first, mb_count=count, metric=metric, qp_n=qp)
+            p = slice_params(pkg, mode, R, nref, lam3, ref_cost1, W, mb_first=first, mb_count=count, metric=metric, qp_n=qp, t8=t8, cavlc=cavlc)
             if mode == 3:
                 lib.jmhip_epzs_scales(p, 2 * f, (C.c_int * nref)(*pocs), nref)
             got = ctx.p_slice_search(p)
@@ -281,3 +299,18 @@ def test_slice_search_feeds_the_frame_stage(pkg, mode, weighted, planes):
     for k in range(3):
         assert np.array_equal(recon[k], want["recon"][k]), "plane %d" % k
     assert (got["cbp"] != 0).any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,W,H,R,nref,slices,t8,qp,cavlc", [
+    (3, 176, 144, 16, 2, 1, 1, 36, 1),      # EPZS, both transform sizes, coarse quantiser: 8x8-transform P8x8 winners without a coded block fall back
+    (-1, 96, 64, 8, 2, 2, 1, 30, 0),        # FullSearch, CABAC cost counting, two slices
+    (0, 96, 64, 8, 2, 1, 2, 28, 1),         # FastFullSearch, 8x8 transform only
+    (1, 176, 144, 16, 2, 1, 1, 40, 1),      # UMHexagonS
+    (3, 320, 192, 32, 3, 3, 1, 34, 1),
+])
+def test_transform8x8_modes_match_the_oracle(pkg, mode, W, H, R, nref, slices, t8, qp, cavlc):
+    """Transform8x8Mode 1 / 2 in the slice search: the 8x8 Hadamard for block types 1..4, TransformDecision after modes 1..3 (with the references
+    it writes into the picture array), the 8x8-transform P8x8 pass, GetBestTransformP8x8 on ties, and the coded-block pattern of that pass
+    (prediction, dct_8x8, coefficient cost) deciding between the two passes' partitionings."""
+    run_synthetic(pkg, mode, W, H, R, nref, slices=slices, t8=t8, qp=qp, cavlc=cavlc)
