@@ -976,7 +976,10 @@ static int slice_mode_covered(void)
   if (!sl.decided) {
     sl.decided = 1;
     sl.on = (shim_mask & 0x1000) && input->rdopt == 0 && input->DisableIntraInInter && input->successive_Bframe == 0 && !input->PicInterlace &&
-            !input->MbInterlace && !input->ChromaMEEnable && input->Transform8x8Mode == 0 && !input->DisableSubpelME &&
+            !input->MbInterlace && !input->ChromaMEEnable && !input->DisableSubpelME &&
+            /* Transform8x8Mode 1: the device quantises the 8x8-transform P8x8 pass to decide the partitioning (md_low.c:547): the slice's inter 8x8 tables
+               as they stand when the slice begins, so no adaptive rounding */
+            (input->Transform8x8Mode != 1 || (!input->AdaptiveRounding && input->InterSearch[0][4])) && (input->Transform8x8Mode != 2 || input->InterSearch[0][4]) &&
             (input->SearchMode == -1 || input->SearchMode == 0 || input->SearchMode == 1 || input->SearchMode == 3) &&
             !(input->SearchMode <= 0 && input->MEErrorMetric[F_PEL] != ERROR_SAD) && !input->EPZSSubPelGrid &&
             input->search_range <= 33 && input->num_ref_frames <= JMHIP_SLICE_REFS && (input->slice_mode == 0 || input->slice_mode == 1) &&
@@ -1012,6 +1015,16 @@ static void slice_run(int *lambda_factor)
   p.wp_pred = active_pps->weighted_pred_flag != 0; p.wp_me = p.wp_pred && input->UseWeightedReferenceME;
   p.wp_round = wp_luma_round; p.wp_denom = luma_log_weight_denom;
   p.mb_first = first; p.mb_count = count;
+  p.transform8x8_mode = input->Transform8x8Mode;
+  if (input->Transform8x8Mode == 1) {                  /* the inter 8x8 luma quantiser (transform8x8.c:1487-1489) of the slice's macroblocks (no rate control: one qp) */
+    const Macroblock *mb = &img->mb_data[img->current_mb_nr];
+    const int qp = mb->qp_scaled[0], qp_rem = qp_rem_matrix[qp];
+    int i, j;
+    p.t8_qp = qp; p.t8_cavlc = (input->symbol_mode == CAVLC); p.t8_disthres = input->disthres;
+    for (j = 0; j < 8; j++) for (i = 0; i < 8; i++) {
+      p.t8_levelscale[j * 8 + i] = LevelScale8x8Comp[0][0][qp_rem][j][i]; p.t8_leveloffset[j * 8 + i] = LevelOffset8x8Comp[0][0][qp][j][i];
+    }
+  }
   if (!sl.started) { OK(jmhip_slice_state_reset(g)); sl.started = 1; }
   if (input->SearchMode == 3) {
     jmhip_epzs_setup(&p, input->search_range, input->EPZSPattern, input->EPZSDual, input->EPZSFixed, input->EPZSTemporal, input->EPZSSpatialMem,
@@ -1055,16 +1068,26 @@ int BlockMotionSearch(short ref, int list, int mb_x, int mb_y, int blocktype, in
     const int p = partition_of(blocktype, mb_x, mb_y), bx = mb_x >> 2, by = mb_y >> 2, bsx = input->blc_size[blocktype][0], bsy = input->blc_size[blocktype][1];
     short pmv[2], *pred_mv = img->pred_mv[by][bx][list][ref][blocktype];
     int i, j;
+    /* Transform8x8Mode: JM searches the 8x8 blocks in the 8x8-transform P8x8 pass first (md_low.c:203-228) and, mode 1, again in the 4x4-transform
+       pass: the first call per (macroblock, reference, block) is answered from the record of that pass */
+    static int t8_mb = -1; static unsigned long t8_serial; static unsigned char t8_seen[JMHIP_SLICE_REFS][4];
+    int first8 = 0;
+    const int16_t *rpred, *rmv; int rcost;
+    if (t8_mb != img->current_mb_nr || t8_serial != pic_serial) { t8_mb = img->current_mb_nr; t8_serial = pic_serial; memset(t8_seen, 0, sizeof(t8_seen)); }
+    if (input->Transform8x8Mode && blocktype == 4 && p >= 5 && !t8_seen[ref][p - 5]) { first8 = 1; t8_seen[ref][p - 5] = 1; }
+    rpred = (p < 0) ? NULL : first8 ? r->pred8ts[ref][p - 5] : r->pred[ref][p];
+    rmv = (p < 0) ? NULL : first8 ? r->mv8ts[ref][p - 5] : r->mv[ref][p];
+    rcost = (p < 0) ? 0 : first8 ? r->cost8ts[ref][p - 5] : r->cost[ref][p];
     /* the device predicted from ITS picture arrays; JM predicts from enc_picture: they must agree, or the slice has diverged */
     SetMotionVectorPredictor(pmv, enc_picture->ref_idx[list], enc_picture->mv[list], ref, list, bx, by, bsx, bsy);
-    if (p < 0 || pmv[0] != r->pred[ref][p][0] || pmv[1] != r->pred[ref][p][1]) {
-      fprintf(stderr, "jm_shim: slice binding diverged at mb %d ref %d blocktype %d block (%d,%d): JM predictor (%d,%d), device (%d,%d)\n",
-              img->current_mb_nr, ref, blocktype, bx, by, pmv[0], pmv[1], p < 0 ? 0 : r->pred[ref][p][0], p < 0 ? 0 : r->pred[ref][p][1]);
+    if (p < 0 || pmv[0] != rpred[0] || pmv[1] != rpred[1]) {
+      fprintf(stderr, "jm_shim: slice binding diverged at mb %d ref %d blocktype %d block (%d,%d)%s: JM predictor (%d,%d), device (%d,%d)\n",
+              img->current_mb_nr, ref, blocktype, bx, by, first8 ? " [8x8-transform pass]" : "", pmv[0], pmv[1], p < 0 ? 0 : rpred[0], p < 0 ? 0 : rpred[1]);
       exit(95);
     }
     pred_mv[0] = pmv[0]; pred_mv[1] = pmv[1];
     for (j = by; j < by + (bsy >> 2); j++) for (i = bx; i < bx + (bsx >> 2); i++) {
-      img->all_mv[j][i][list][ref][blocktype][0] = r->mv[ref][p][0]; img->all_mv[j][i][list][ref][blocktype][1] = r->mv[ref][p][1];
+      img->all_mv[j][i][list][ref][blocktype][0] = rmv[0]; img->all_mv[j][i][list][ref][blocktype][1] = rmv[1];
     }
     /* what BlockMotionSearch leaves behind besides its results (src/mv-search.c:612, :640, :779, :837) */
     ChromaMEEnable = 0;
@@ -1076,13 +1099,13 @@ int BlockMotionSearch(short ref, int list, int mb_x, int mb_y, int blocktype, in
       int c;
       if (!orig) orig = next_sym("BlockMotionSearch");
       c = orig(ref, list, mb_x, mb_y, blocktype, search_range, lambda_factor);
-      if (c != r->cost[ref][p] || img->all_mv[by][bx][list][ref][blocktype][0] != ax || img->all_mv[by][bx][list][ref][blocktype][1] != ay)
+      if (c != rcost || img->all_mv[by][bx][list][ref][blocktype][0] != ax || img->all_mv[by][bx][list][ref][blocktype][1] != ay)
         fprintf(stderr, "jm_shim VERIFY BlockMotionSearch mb %d ref %d bt %d (%d,%d): jm=(%d,%d,%d) dev=(%d,%d,%d)\n", img->current_mb_nr, ref, blocktype, bx, by,
-                img->all_mv[by][bx][list][ref][blocktype][0], img->all_mv[by][bx][list][ref][blocktype][1], c, ax, ay, r->cost[ref][p]);
+                img->all_mv[by][bx][list][ref][blocktype][0], img->all_mv[by][bx][list][ref][blocktype][1], c, ax, ay, rcost);
       return c;
     }
     n_dev[S_BMS]++;
-    return r->cost[ref][p];
+    return rcost;
   }
 }
 

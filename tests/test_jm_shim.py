@@ -214,6 +214,12 @@ SLICE_CASES = {
     "slice_epzs_satd_fpel": dict(search=3, profile=77, cabac=1, t8x8=0, bframes=0, refs=1, rdopt=0, adrnd=0, yuv=1, noi=1, fpel=2),
     "slice_umhex_2ref": dict(search=1, profile=66, cabac=0, t8x8=0, bframes=0, refs=2, rdopt=0, adrnd=1, yuv=1, noi=1),
     "slice_umhex_wp_422": dict(search=1, profile=122, cabac=1, t8x8=0, bframes=0, refs=2, rdopt=0, adrnd=0, yuv=2, wp=1, fade=1, noi=1),   # config 5 in small
+    # Transform8x8Mode in the slice binding (BASELINE config 3 says "8x8 transform enabled"): both transform sizes compete (1) -- the device also
+    # quantises the 8x8-transform P8x8 pass, whose coded-block pattern decides the partitioning -- and 8x8 only (2)
+    "slice_epzs_t8_high": dict(search=3, profile=100, cabac=1, t8x8=1, bframes=0, refs=2, rdopt=0, adrnd=0, yuv=1, noi=1, qp=36),
+    "slice_umhex_t8_cavlc": dict(search=1, profile=100, cabac=0, t8x8=1, bframes=0, refs=2, rdopt=0, adrnd=0, yuv=1, noi=1, qp=32),
+    "slice_fastfull_t8_q40": dict(search=0, profile=100, cabac=0, t8x8=1, bframes=0, refs=2, rdopt=0, adrnd=0, yuv=1, noi=1, qp=40),
+    "slice_full_t8only": dict(search=-1, profile=100, cabac=1, t8x8=2, bframes=0, refs=1, rdopt=0, adrnd=0, yuv=1, noi=1),
     "slice_epzs_four_slices_midrow": dict(search=3, profile=77, cabac=1, t8x8=0, bframes=0, refs=2, rdopt=0, adrnd=0, yuv=1, noi=1, slicemode=1, slicearg=27, lfflag=1, lfidc=2),
 }
 CASES.update(SLICE_CASES)
@@ -235,7 +241,8 @@ def test_jm_slice_level_binding_is_byte_identical(tmp_path, name):
     print(name, m.groups(), sl.groups(), info.groups())
     nslices = 4 if "slices_midrow" in name else 1          # 99 macroblocks in slices of 27
     assert int(sl.group(1)) == 3 * nslices, "one device call per P slice (3 P pictures)"
-    assert int(m.group(1)) >= 3 * 99 * 41 and int(m.group(2)) == 0, "every BlockMotionSearch call of the P pictures must be served from the slice records"
+    per_mb = {0: 41, 1: 45, 2: 9}[SLICE_CASES[name]["t8x8"]]      # Transform8x8Mode 1: four more calls (the 8x8-transform P8x8 pass); 2: modes 1..3 + that pass only
+    assert int(m.group(1)) >= 3 * 99 * per_mb and int(m.group(2)) == 0, "every BlockMotionSearch call of the P pictures must be served from the slice records"
     # JM's own search functions must not have run at all in the P pictures
     for sym in ("FullPelBlockMotionSearch", "FastFullPelBlockMotionSearch", "SubPelBlockMotionSearch", "EPZS_UMHex_integer_walks", "computeSAD", "computeSATD"):
         mm = re.search(r"^\s*%s\s+device\s+(\d+)\s+forwarded\s+(\d+)" % sym, stats, re.M)
