@@ -175,7 +175,7 @@ def cpu_baseline_reference(frames):
                       % (MBW * MBH, me_ms, tot_ms, MBW * MBH / (tot_ms * 1e-3), wall, os.cpu_count())}
 
 
-def jm_end_to_end(frames):
+def jm_end_to_end(frames, config3=False):
     """The reference encoder itself, same 1080p clip (frames 0-1: I + P), FullSearch +-32, low-complexity decision with intra off in the P
     picture (RDOptimization 0, DisableIntraInInter 1 -- the configuration whose whole P-slice search + inter decision is ONE device call):
     the unmodified JM (oracle/_ref/jm_plain) against JM bound to libjmhip.so at slice level (oracle/_ref/jm_hip, integration/jm_shim.c,
@@ -191,8 +191,14 @@ def jm_end_to_end(frames):
         with open(os.path.join(d, "synth1080.yuv"), "wb") as f:
             for (Y, U, V) in frames[:2]:
                 f.write(Y[:H_SRC].tobytes()); f.write(U[:H_SRC // 2].tobytes()); f.write(V[:H_SRC // 2].tobytes())
+        cfg = (JM_CFG % (QP, QP, R)).replace("RDOptimization = 1", "RDOptimization = 0") + "DisableIntraInInter = 1\n"
+        if config3:                                      # BASELINE config 3's tools: EPZS, Hadamard SAD at every level, 8x8 transform enabled, CABAC
+            for a, b in (("ProfileIDC = 66", "ProfileIDC = 100"), ("SymbolMode = 0", "SymbolMode = 1"), ("SearchMode = -1", "SearchMode = 3"),
+                         ("MEDistortionFPel = 0", "MEDistortionFPel = 2"), ("Transform8x8Mode = 0", "Transform8x8Mode = 1"), ("AdaptiveRounding = 1", "AdaptiveRounding = 0")):
+                assert a in cfg
+                cfg = cfg.replace(a, b)
         with open(os.path.join(d, "min.cfg"), "w") as f:
-            f.write((JM_CFG % (QP, QP, R)).replace("RDOptimization = 1", "RDOptimization = 0") + "DisableIntraInInter = 1\n")
+            f.write(cfg)
         digests = []
         for exe, key in zip(exes, ("jm_plain", "jm_hip")):
             env = dict(os.environ, JMHIP_SHIM="1801", JMHIP_SHIM_STATS="1")
@@ -214,7 +220,8 @@ def jm_end_to_end(frames):
                 out["block_motion_search_calls_served"] = int(mm.group(1)) if mm else None
                 out["block_motion_search_calls_forwarded"] = int(mm.group(2)) if mm else None
         out["bitstreams_identical"] = digests[0] == digests[1]
-        out["config"] = "1920x1080 I+P, FullSearch +-32, 1 reference, RDOptimization 0, DisableIntraInInter 1, CAVLC; jm_hip: JMHIP_SHIM=0x1801"
+        out["config"] = ("1920x1080 I+P, EPZS +-32, Hadamard SAD at every level, Transform8x8Mode 1, CABAC, 1 reference, RDOptimization 0, DisableIntraInInter 1; jm_hip: JMHIP_SHIM=0x1801"
+                         if config3 else "1920x1080 I+P, FullSearch +-32, 1 reference, RDOptimization 0, DisableIntraInInter 1, CAVLC; jm_hip: JMHIP_SHIM=0x1801")
     return out
 
 
@@ -277,10 +284,12 @@ def slice_search_times(pkg, ctx, lam, src, order):
     lib = pkg.load_library()
     out = {}
     ctx.interp_luma(0)                                  # the last step left a new integer picture in the slot
-    for name, mode in (("FullSearch", -1), ("FastFullSearch", 0), ("EPZS", 3), ("UMHexagonS", 1)):
+    # the last entry is BASELINE config 3's search: EPZS, Hadamard SAD at every level, both transform sizes competing (Transform8x8Mode 1)
+    for name, mode, metric, t8 in (("FullSearch", -1, (0, 2, 2), 0), ("FastFullSearch", 0, (0, 2, 2), 0), ("EPZS", 3, (0, 2, 2), 0), ("UMHexagonS", 1, (0, 2, 2), 0),
+                                   ("EPZS_satd_transform8x8", 3, (2, 2, 2), 1)):
         ctx.slice_state_reset()
         ctx.epzs_colocated_upload(np.zeros((H // 4, W // 4, 2), np.int16))
-        p = slice_params(pkg, mode, R, 1, [lam] * 3, 10, W, H=H)
+        p = slice_params(pkg, mode, R, 1, [lam] * 3, 10, W, H=H, metric=metric, t8=t8, qp_n=QP)
         lib.jmhip_epzs_scales(p, 2, (ctypes.c_int * 1)(0), 1)
         ts, sw = [], []
         for k in order[:2]:
@@ -605,6 +614,9 @@ def main():
             e2e = jm_end_to_end(frames)
             if e2e is not None:
                 out["jm_end_to_end"] = e2e
+            e2e = jm_end_to_end(frames, config3=True)
+            if e2e is not None:
+                out["jm_end_to_end_config3_tools"] = e2e
         if solo:
             out = {"DIAGNOSTIC_solo_rank": solo, "ms_per_step_of_this_rank": out["ms_per_step"], "stages_ms_per_launch": out.get("stages_ms_per_launch")}
         print(json.dumps(out))
