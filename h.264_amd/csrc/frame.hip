@@ -292,6 +292,10 @@ extern "C" int jmhip_residual_frame_q(jmhip_ctx *c, const jmhip_mb_mode *modes, 
       }
       if (!ok) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_residual_frame: bad macroblock mode");
     }
+  if (!modes && c->fr_from_slices && c->fr_slices_t8) {       // modes left on the device by a slice search with Transform8x8Mode
+    any_t8 = true;
+    if (nquants != 4) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_residual_frame: the searched slices use the 8x8 transform: quants[3] (the 8x8 luma quantiser) is needed");
+  }
   JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
   int rc = ensure_frame_buffers(c, n);
   if (rc) return rc;

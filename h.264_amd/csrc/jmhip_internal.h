@@ -55,6 +55,7 @@ struct jmhip_ctx {
   void *fr_rec = nullptr;                             // fused frame stage: one JmMbRes record per macroblock (frame_common.h)
   bool fr_fused = false;                              // the last jmhip_residual_frame took the fused kernel: results live in fr_rec
   void *fr_blk_ref = nullptr;                         // [n][4] reference slot per 8x8 block (frame stage fed from the slice search)
+  bool fr_slices_t8 = false;                          // ... and some of them may carry the 8x8-transform flag (Transform8x8Mode in the slice search)
   bool fr_from_slices = false;                        // modes + per-block references of the frame stage were left on the device by jmhip_slice_to_frame
   void *fr_bi = nullptr; int fr_bi_n = 0, fr_bi_capacity = 0; unsigned fr_bi_mask = 0;   // second list of B macroblocks (jmhip_frame_bipred_set), device array
   jmhip_frame_bw fr_bw{};

@@ -1771,6 +1771,7 @@ struct SliceState {
   int passes = 0;
   bool has_col = false;
   int searched_to = 0;                         // macroblocks [0, searched_to) of the current picture have been searched
+  bool t8_any = false;                         // a slice of the current picture was searched with Transform8x8Mode: macroblocks may carry the 8x8-transform flag
 };
 
 }  // namespace
@@ -1973,6 +1974,8 @@ extern "C" int jmhip_p_slice_search(jmhip_ctx *c, const jmhip_slice_params *prm,
   }
 #endif
   std::swap(s->carry_slice, s->carry_slice_next);
+  if (prm->mb_first == 0) s->t8_any = false;
+  s->t8_any = s->t8_any || prm->transform8x8_mode != 0;
   s->searched_to = (prm->mb_first == 0 || prm->mb_first == s->searched_to) ? prm->mb_first + prm->mb_count : 0;
   if (results) return jmhip_slice_results_download(c, results, prm->mb_first, prm->mb_count);
   return JMHIP_OK;
@@ -2024,6 +2027,13 @@ __global__ void slice_to_frame_kernel(const jmhip_mb_inter *__restrict__ rec, in
   for (int p = 0; p < JMHIP_NPART; p++) {
     const PartInfo q = c_part[p];
     const int ref = r.b8ref[2 * (q.y4 >> 1) + (q.x4 >> 1)];
+    if (r.best_mode == 8 && r.transform8x8_flag && p >= 5 && p < 9) {        // a P8x8 macroblock with the 8x8 transform keeps the vectors of its 8x8-transform pass
+      const int k = p - 5;
+      j.pred_mv[p][0] = r.pred8ts[ref][k][0]; j.pred_mv[p][1] = r.pred8ts[ref][k][1];
+      o.mv[p][0] = r.mv8ts[ref][k][0]; o.mv[p][1] = r.mv8ts[ref][k][1]; o.cost[p] = r.cost8ts[ref][k];
+      o.mv_int[p][0] = r.mv_int8ts[ref][k][0]; o.mv_int[p][1] = r.mv_int8ts[ref][k][1]; o.cost_int[p] = r.cost_int8ts[ref][k];
+      continue;
+    }
     j.pred_mv[p][0] = r.pred[ref][p][0]; j.pred_mv[p][1] = r.pred[ref][p][1];
     o.mv[p][0] = r.mv[ref][p][0]; o.mv[p][1] = r.mv[ref][p][1]; o.cost[p] = r.cost[ref][p];
     o.mv_int[p][0] = r.mv_int[ref][p][0]; o.mv_int[p][1] = r.mv_int[ref][p][1]; o.cost_int[p] = r.cost_int[ref][p];
@@ -2033,7 +2043,8 @@ __global__ void slice_to_frame_kernel(const jmhip_mb_inter *__restrict__ rec, in
   // (P skip is not a mode of the rdopt = 0 decision: md_low.c:655 turns a 16x16 macroblock into a skip AFTER residual coding, when cbp == 0,
   // ref_idx == 0 and the vector equals skip_mv -- the caller has all three)
   for (int k = 0; k < 4; k++) { m.b8mode[k] = (int8_t)(r.best_mode == 8 ? r.b8mode[k] : 4); blk_ref[(size_t)i * 4 + k] = (int8_t)slots[r.b8ref[k]]; }
-  m.pad[0] = m.pad[1] = m.pad[2] = 0;
+  m.pad[0] = (int8_t)(r.transform8x8_flag ? 1 : 0);      // luma_transform_size_8x8_flag as the decision left it (the residual coder's transform)
+  m.pad[1] = m.pad[2] = 0;
   modes[i] = m;
 }
 }  // namespace
@@ -2064,6 +2075,7 @@ extern "C" int jmhip_slice_to_frame(jmhip_ctx *c, const int32_t *ref_slot, int n
   // the search-stage arrays now hold this picture; a resident re-run of jmhip_me_frame on them is meaningless and is refused (geometry check)
   c->me_n = n; c->me_ref_mask = mask; c->me_last_mode = 0x7fffffff; c->me_fast_idx.clear(); c->me_gen_idx.clear();
   c->fr_from_slices = true;
+  c->fr_slices_t8 = s->t8_any;
   return JMHIP_OK;
 }
 

@@ -228,8 +228,9 @@ def upsampled_chroma(rng, Y):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode,weighted,planes", [(3, False, True), (3, True, False), (-1, True, True), (1, False, False)])
-def test_slice_search_feeds_the_frame_stage(pkg, mode, weighted, planes):
+@pytest.mark.parametrize("mode,weighted,planes,t8", [(3, False, True, 0), (3, True, False, 0), (-1, True, True, 0), (1, False, False, 0),
+                                                     (3, False, False, 1), (-1, True, True, 1), (0, False, True, 2)])
+def test_slice_search_feeds_the_frame_stage(pkg, mode, weighted, planes, t8):
     """The searched picture goes to jmhip_residual_frame without leaving the device (jmhip_slice_to_frame): every 8x8 block predicts from the
     reference ITS decision chose (LumaPrediction's l0_ref_idx), optionally with explicit weighted prediction; reconstruction, cbp and cbp_blk of
     every macroblock against the oracle's LumaResidualCoding / ChromaResidualCoding restatement fed with the same records."""
@@ -256,8 +257,11 @@ def test_slice_search_feeds_the_frame_stage(pkg, mode, weighted, planes):
     lib = pkg.load_library()
     recs = []
     for first, count in ((0, 40), (40, nmb - 40)):
-        p = slice_params(pkg, mode, R, nref, [lam] * 3, 8, W, mb_first=first, mb_count=count)
+        p = slice_params(pkg, mode, R, nref, [lam] * 3, 8, W, mb_first=first, mb_count=count, t8=t8, qp_n=28)
         p.ref_slot[0], p.ref_slot[1] = slot_of
+        if weighted and t8:                                # LumaPrediction's explicit weights take part in the transform decision's predictions
+            p.wp_pred, p.wp_round, p.wp_denom = 1, 16, 5
+            p.wp_weight[0], p.wp_offset[0], p.wp_weight[1], p.wp_offset[1] = 30, 2, 34, -3
         if mode == 3:
             lib.jmhip_epzs_scales(p, 4, (C.c_int * 2)(2, 0), 2)
         recs.append(ctx.p_slice_search(p))
@@ -270,7 +274,11 @@ def test_slice_search_feeds_the_frame_stage(pkg, mode, weighted, planes):
         wp["weight"][1], wp["offset"][1] = (34, 16, 14), (-3, 1, 2)
     ctx.frame_wp_set(wp)
     ctx.slice_to_frame(slot_of)
-    quants = np.array([pkg.flat_quant(28 + d, 342, adaptive_rounding=1, adapt_rnd_weight=4, cavlc=1) for d in (0, 0, 3)], dtype=pkg.QUANT_DTYPE)
+    ar = 0 if t8 else 1                                    # Transform8x8Mode 1 in the slice search: no adaptive rounding
+    quants = [pkg.flat_quant(28 + d, 342, adaptive_rounding=ar, adapt_rnd_weight=4, cavlc=1) for d in (0, 0, 3)]
+    if t8:
+        quants.append(pkg.flat_quant(28, 342, is8x8=True, adaptive_rounding=ar, adapt_rnd_weight=4, cavlc=1, transform8x8_flag=1))
+    quants = np.array(quants, dtype=pkg.QUANT_DTYPE)
     ctx.residual_frame(quants, None)
     got = ctx.residual_download(nmb)
     recon = ctx.recon_download()
@@ -286,11 +294,17 @@ def test_slice_search_feeds_the_frame_stage(pkg, mode, weighted, planes):
         mbs[i]["mb_x"], mbs[i]["mb_y"] = i % (W // 16), i // (W // 16)
         modes[i]["mode"] = rec[i]["best_mode"]
         modes[i]["b8mode"] = rec[i]["b8mode"] if rec[i]["best_mode"] == 8 else 4
+        modes[i]["pad"][0] = rec[i]["transform8x8_flag"]
         blk_ref[i] = [slot_of[int(r)] for r in rec[i]["b8ref"]]
         for pi in range(41):
             x4, y4 = parts[pi][1], parts[pi][2]
-            mv[i, pi] = rec[i]["mv"][int(rec[i]["b8ref"][2 * (y4 >> 1) + (x4 >> 1)]), pi]
+            rr = int(rec[i]["b8ref"][2 * (y4 >> 1) + (x4 >> 1)])
+            mv[i, pi] = rec[i]["mv"][rr, pi]
+            if rec[i]["best_mode"] == 8 and rec[i]["transform8x8_flag"] and 5 <= pi < 9:       # the 8x8-transform pass's vectors
+                mv[i, pi] = rec[i]["mv8ts"][rr, pi - 5]
     assert np.array_equal(got["modes"]["mode"], modes["mode"]) and np.array_equal(got["modes"]["b8mode"], modes["b8mode"])
+    if t8:
+        assert (rec["transform8x8_flag"] == 1).any() and (t8 == 2 or (rec["transform8x8_flag"] == 0).any())
     by_slot = [None, None]
     for r in range(nref):
         by_slot[slot_of[r]] = oracle.RefPic(refs[r], *refs_c[r], yuv_format=1)
