@@ -356,6 +356,10 @@ def main():
     ap.add_argument("--deblock-slices", type=int, default=0,
                     help="with --deblock on ONE GPU: filter as if the picture were cut into this many row slices with idc 2 "
                          "(what an N-GPU run does), to compare reference checksums")
+    ap.add_argument("--pred", choices=["one", "per-partition"], default="one",
+                    help="one = one predictor per macroblock (the metric's workload, SURVEY 8(d)); per-partition = JM's own predictors, one per partition, "
+                         "as SetMotionVectorPredictor yields them in raster order (from jmhip_p_slice_search of the first picture): FullSearch then "
+                         "walks one window per DISTINCT centre of a macroblock (N = 1 only; for information)")
     ap.add_argument("--size", choices=["1080p", "2160p"], default="1080p",
                     help="1080p = BASELINE config 2, the metric's workload (default); 2160p = config 4's picture size, for information only")
     args = ap.parse_args()
@@ -422,6 +426,18 @@ def main():
     prm.level_mv_min, prm.level_mv_max = -511, 511
     prm.lambda_[0] = prm.lambda_[1] = prm.lambda_[2] = lam
     prm.transform8x8_mode, prm.subpel, prm.partition_mask = 0, 1, (1 << 41) - 1
+    if args.pred == "per-partition":
+        if multi:
+            sys.exit("bench.py --pred per-partition runs on one GPU")
+        from tests.test_slice_gpu import slice_params
+        Y0, U0, V0 = src[1]
+        ctx.cur_bind(Y0.data_ptr(), U0.data_ptr(), V0.data_ptr())
+        ctx.interp_luma(0)
+        ctx.slice_state_reset()
+        rec = ctx.p_slice_search(slice_params(pkg, -1, R, 1, [lam] * 3, 10, W, H=H))
+        mbs = mbs.copy()
+        mbs["pred_mv"] = rec["pred"][:, 0]
+        args.cpu_mbs = 0                                  # the extras below are the default workload's
     quants = np.array([pkg.flat_quant(QP, 342, adaptive_rounding=1, adapt_rnd_weight=4, cavlc=1),
                        pkg.flat_quant(QP, 342, adaptive_rounding=1, adapt_rnd_weight=4, cavlc=1),
                        pkg.flat_quant(QP + 3, 342, adaptive_rounding=1, adapt_rnd_weight=4, cavlc=1)], dtype=pkg.QUANT_DTYPE)
@@ -547,7 +563,8 @@ def main():
         workload = ("1920x1080 (coded 1920x1088, 8160 MBs)" if args.size == "1080p" else "3840x2160 (32400 MBs)") + \
             " YUV420 P-frames, baseline tools, FullSearch +-32, 41 partitions, SAD full-pel + SATD sub-pel, dct_4x4 + dct_chroma, QP %d, 1 reference; " % QP + \
             "16 luma quarter-pel planes per reference, chroma eighth-pel samples " + ("from 2 x 64 planes; " if args.chroma_planes else "computed in MC; ") + \
-            "predictor field (16,-16)+U{-8..8} qpel per MB" + ("" if args.clip == "translation" else "; ADVERSARIAL i.i.d. noise clip") + \
+            ("predictor field (16,-16)+U{-8..8} qpel per MB" if args.pred == "one" else "JM's own predictor per PARTITION (jmhip_p_slice_search of the first picture)") + \
+            ("" if args.clip == "translation" else "; ADVERSARIAL i.i.d. noise clip") + \
             ("; + in-loop deblocking (NOT the metric's path)" if args.deblock else "")
         out = {
             "metric": "macroblocks/sec (full-search ME + DCT/quant), 1080p; bit-exact MV+coeff vs JM",
