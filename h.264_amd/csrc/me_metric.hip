@@ -3,7 +3,7 @@
 // The fast kernels (me_int.hip, me_sub.hip) cover JM's default metrics: SAD at integer positions, Hadamard SAD at sub-pel positions,
 // luma only. This file is the general form behind the same entry points (jmhip_me_params.metric_set = 1):
 //   computeUniPred[level + 3 * apply_weights]   lencod/src/mv-search.c:400-424  (level = F_PEL / H_PEL / Q_PEL, input->MEErrorMetric[])
-//   computeSAD :351 / computeSADWP :413 / computeSSE :1042 / computeSATD :657 / computeSATDWP :734   lencod/src/me_distortion.c
+//   computeSAD :351 / computeSADWP :413 / computeSSE :1042 / computeSSEWP :1107 / computeSATD :657 / computeSATDWP :734   lencod/src/me_distortion.c
 //   the chroma term of SAD / SADWP / SSE (input->ChromaMEEnable, :376-402, :443-470, :1072-1098): the Cb and Cr blocks that belong to
 //     the luma block, read from the eighth-pel chroma planes (UMVLine8X_chroma, refbuf.c:69), times input->ChromaMEWeight
 //   start_me_refinement_hp / _qp   mv-search.c:396-397: when two levels share a metric (and ChromaMEEnable != 1) the refinement skips
@@ -419,8 +419,6 @@ int jm_me_metric_check(jmhip_ctx *c, const jmhip_me_params *prm, unsigned ref_ma
     if (prm->metric[k] < 0 || prm->metric[k] > 2) { snprintf(msg, sizeof msg, "%s: metric[] must be 0 (SAD), 1 (SSE) or 2 (Hadamard SAD)", who); return jm_fail(c, JMHIP_ERR_ARG, msg); }
   if (prm->chroma_me < 0 || prm->chroma_me > 2) { snprintf(msg, sizeof msg, "%s: chroma_me must be 0, 1 or 2 (input->ChromaMEEnable)", who); return jm_fail(c, JMHIP_ERR_ARG, msg); }
   if (prm->wp_enable) {
-    for (int k = 0; k < 3; k++)
-      if (prm->metric[k] == 1) { snprintf(msg, sizeof msg, "%s: SSE with weighted reference ME (computeSSEWP) is not built", who); return jm_fail(c, JMHIP_ERR_UNSUPPORTED, msg); }
     if (prm->chroma_me && (prm->wp_chroma_denom < 0 || prm->wp_chroma_denom > 7 || prm->wp_chroma_round < 0 || prm->wp_chroma_round > 64)) {
       snprintf(msg, sizeof msg, "%s: chroma weighted-prediction denominator / rounding out of range", who); return jm_fail(c, JMHIP_ERR_ARG, msg);
     }

@@ -162,7 +162,7 @@ typedef struct {
    * src/me_fullfast.c:512); chroma_me = input->ChromaMEEnable (0; 1: Cb / Cr term at integer positions; 2: at sub-pel positions
    * too; src/me_distortion.c:376-402, :1072-1098), chroma_me_weight = input->ChromaMEWeight: needs the current picture's chroma
    * planes and jmhip_interp_chroma on every reference used. With wp_enable the chroma term is weighted per slot and component
-   * (wp_weight_cr[slot][uv], computeSADWP :443-470); SSE has no weighted form here. */
+   * (wp_weight_cr[slot][uv], computeSADWP :443-470, computeSSEWP :1107). */
   int32_t metric_set, metric[3], chroma_me, chroma_me_weight;
   int32_t wp_chroma_round, wp_chroma_denom;
   int16_t wp_weight_cr[16][2], wp_offset_cr[16][2];

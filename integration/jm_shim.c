@@ -254,7 +254,6 @@ static int me_ok_metric(short ref, int list, StorablePicture **rp, int *slot, in
   if (weighted) {
     me_wp.weight = wp_weight[list + list_offset][ref][0]; me_wp.offset = wp_offset[list + list_offset][ref][0];
     for (m = 0; m < 2; m++) { me_wp.weight_cr[m] = wp_weight[list + list_offset][ref][1 + m]; me_wp.offset_cr[m] = wp_offset[list + list_offset][ref][1 + m]; }
-    if (fixed_metrics) for (m = 0; m < 3; m++) if (input->MEErrorMetric[m] == ERROR_SSE) return 0;      /* computeSSEWP is not on the device */
   }
   if (!cur_ready()) return 0;
   *rp = listX[list][ref];

@@ -95,6 +95,7 @@ int jmo_sad_wp(const jmo_dist *d, const jmo_pel *src, int bsy, int bsx, int min_
 int jmo_satd   (const jmo_dist *d, const jmo_pel *src, int bsy, int bsx, int min_mcost, int cand_x, int cand_y);
 int jmo_satd_wp(const jmo_dist *d, const jmo_pel *src, int bsy, int bsx, int min_mcost, int cand_x, int cand_y);
 int jmo_sse    (const jmo_dist *d, const jmo_pel *src, int bsy, int bsx, int min_mcost, int cand_x, int cand_y);
+int jmo_sse_wp (const jmo_dist *d, const jmo_pel *src, int bsy, int bsx, int min_mcost, int cand_x, int cand_y);   /* computeSSEWP :1107 */
 int jmo_hadamard_sad4x4(const int *diff);   /* HadamardSAD4x4, me_distortion.c:182 */
 int jmo_hadamard_sad8x8(const int *diff);   /* HadamardSAD8x8, me_distortion.c:272 */
 

@@ -37,7 +37,7 @@ static const jmo_pel *chroma_line(const jmo_dist *d, int k, int y, int x)
 #define WP_LUMA(d, v)  clip1((d)->max_val, ((((d)->weight_luma * (v)) + (d)->wp_luma_round) >> (d)->luma_log_weight_denom) + (d)->offset_luma)
 #define WP_CR(d, k, v) clip1((d)->max_val_uv, ((((d)->weight_cr[k] * (v)) + (d)->wp_chroma_round) >> (d)->chroma_log_weight_denom) + (d)->offset_cr[k])
 
-/* computeSAD me_distortion.c:351 / computeSADWP :413 (wp != 0) / computeSSE :1042 (sse != 0) */
+/* computeSAD me_distortion.c:351 / computeSADWP :413 (wp != 0) / computeSSE :1042 (sse != 0) / computeSSEWP :1107 (both) */
 static int sad_core(const jmo_dist *d, const jmo_pel *src_pic, int bsy, int bsx, int min_mcost,
                     int cand_x, int cand_y, int wp, int sse)
 {
@@ -92,6 +92,9 @@ int jmo_sad_wp(const jmo_dist *d, const jmo_pel *src, int bsy, int bsx, int min_
 { return sad_core(d, src, bsy, bsx, min_mcost, cand_x, cand_y, 1, 0); }
 int jmo_sse(const jmo_dist *d, const jmo_pel *src, int bsy, int bsx, int min_mcost, int cand_x, int cand_y)
 { return sad_core(d, src, bsy, bsx, min_mcost, cand_x, cand_y, 0, 1); }
+/* computeSSEWP me_distortion.c:1107: the weighted samples of computeSADWP, squared differences */
+int jmo_sse_wp(const jmo_dist *d, const jmo_pel *src, int bsy, int bsx, int min_mcost, int cand_x, int cand_y)
+{ return sad_core(d, src, bsy, bsx, min_mcost, cand_x, cand_y, 1, 1); }
 
 /* HadamardSAD4x4, me_distortion.c:182-264: 2-D 4x4 Hadamard of the difference block, sum |.|, (s+1)>>1.
  * The butterfly below is the separable form of the reference's four-stage network; |.| sums are

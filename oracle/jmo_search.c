@@ -103,7 +103,8 @@ int jmo_uni_pred(const jmo_me_params *p, int level, const jmo_dist *d, const jmo
   switch (p->metric[level]) {
   case JMO_ERR_SAD: return p->apply_weights ? jmo_sad_wp(d, src, bsy, bsx, min_mcost, cx, cy)
                                             : jmo_sad(d, src, bsy, bsx, min_mcost, cx, cy);
-  case JMO_ERR_SSE: return jmo_sse(d, src, bsy, bsx, min_mcost, cx, cy);
+  case JMO_ERR_SSE: return p->apply_weights ? jmo_sse_wp(d, src, bsy, bsx, min_mcost, cx, cy)
+                                            : jmo_sse(d, src, bsy, bsx, min_mcost, cx, cy);
   default:          return p->apply_weights ? jmo_satd_wp(d, src, bsy, bsx, min_mcost, cx, cy)
                                             : jmo_satd(d, src, bsy, bsx, min_mcost, cx, cy);
   }

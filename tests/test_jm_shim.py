@@ -103,6 +103,7 @@ CASES = {
     "fastfull_chroma1": dict(search=0, profile=66, cabac=0, t8x8=0, bframes=0, refs=2, rdopt=0, adrnd=1, yuv=1, fpel=0, hpel=0, qpel=2, cme=1, cmw=1),
     "fastfull_satd_fpel_422": dict(search=0, profile=122, cabac=1, t8x8=1, bframes=0, refs=1, rdopt=1, adrnd=0, yuv=2, fpel=2, hpel=2, qpel=2, cme=2, cmw=1),
     "full_wp_chroma": dict(search=-1, profile=77, cabac=1, t8x8=0, bframes=0, refs=2, rdopt=1, adrnd=0, yuv=1, wp=1, fade=1, fpel=0, hpel=0, qpel=2, cme=2, cmw=1),
+    "full_wp_sse_chroma": dict(search=-1, profile=77, cabac=1, t8x8=0, bframes=0, refs=2, rdopt=1, adrnd=0, yuv=1, wp=1, fade=1, fpel=1, hpel=1, qpel=1, cme=2, cmw=1),
     "full_lowcplx_422": dict(search=-1, profile=122, cabac=0, t8x8=1, bframes=0, refs=1, rdopt=0, adrnd=1, yuv=2),  # rdopt off centre rule, 4:2:2 chroma DC
 }
 
