@@ -360,9 +360,13 @@ def main():
                     help="one = one predictor per macroblock (the metric's workload, SURVEY 8(d)); per-partition = JM's own predictors, one per partition, "
                          "as SetMotionVectorPredictor yields them in raster order (from jmhip_p_slice_search of the first picture): FullSearch then "
                          "walks one window per DISTINCT centre of a macroblock (N = 1 only; for information)")
-    ap.add_argument("--size", choices=["1080p", "2160p"], default="1080p",
-                    help="1080p = BASELINE config 2, the metric's workload (default); 2160p = config 4's picture size, for information only")
+    ap.add_argument("--size", choices=["1080p", "2160p"], default=None,
+                    help="1080p = BASELINE configs[1], the configuration the metric is quoted on: the default at --gpus 1; 2160p = BASELINE configs[3] "
+                         "(4K, FullSearch +-32, slices sharded across the GPUs with the reference picture gathered once per frame), the configuration "
+                         "BASELINE names for more than one GPU: the default at --gpus > 1 (north_star's scaling target is quoted on 4K)")
     args = ap.parse_args()
+    if args.size is None:
+        args.size = "1080p" if args.gpus == 1 else "2160p"
     if args.size == "2160p":
         W, H_SRC, H = 3840, 2160, 2160
         MBW, MBH = W // 16, H // 16

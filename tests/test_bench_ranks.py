@@ -26,7 +26,7 @@ def run(cmd, env=None):
 def test_ranks_rebuild_the_same_reference_as_one(ranks):
     one = run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--cpu-mbs", "0"])
     two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
-               "--master-port", str(29539 + ranks), "bench.py", "--gpus", str(ranks), "--steps", "3", "--warmup", "1", "--cpu-mbs", "0"],
+               "--master-port", str(29539 + ranks), "bench.py", "--gpus", str(ranks), "--size", "1080p", "--steps", "3", "--warmup", "1", "--cpu-mbs", "0"],
               {"JMHIP_BENCH_REHEARSAL": "1"})
     assert one["n_gpus"] == 1 and two["n_gpus"] == ranks and two["config"]["slices"] == ranks
     assert one["ref_checksum"] == two["ref_checksum"], "the sharded run did not reproduce the single-process reference picture"
@@ -40,7 +40,7 @@ def test_two_ranks_with_the_loop_filter_inside_their_slices():
     """--deblock: every rank filters its own slice (idc 2) before the exchange; one GPU filtering the same two slices must agree."""
     one = run([sys.executable, "bench.py", "--deblock", "--deblock-slices", "2", "--steps", "2", "--warmup", "1", "--cpu-mbs", "0"])
     two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-               "--master-port", "29547", "bench.py", "--gpus", "2", "--deblock", "--steps", "2", "--warmup", "1", "--cpu-mbs", "0"],
+               "--master-port", "29547", "bench.py", "--gpus", "2", "--size", "1080p", "--deblock", "--steps", "2", "--warmup", "1", "--cpu-mbs", "0"],
               {"JMHIP_BENCH_REHEARSAL": "1"})
     plain = run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--cpu-mbs", "0"])
     assert one["ref_checksum"] == two["ref_checksum"]
@@ -57,3 +57,13 @@ def test_rccl_transport_with_a_process_group_of_one():
              {"JMHIP_BENCH_RCCL1": "1", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29561"})
     assert one["ref_checksum"] == r1["ref_checksum"]
     assert r1["n_gpus"] == 1
+
+
+@pytest.mark.gpu
+def test_two_ranks_default_to_the_4k_configuration():
+    """--gpus > 1 without --size runs BASELINE configs[3] (3840x2160): same reference picture as one GPU coding that picture."""
+    one = run([sys.executable, "bench.py", "--size", "2160p", "--steps", "2", "--warmup", "1", "--cpu-mbs", "0"])
+    two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29551", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--cpu-mbs", "0"], {"JMHIP_BENCH_REHEARSAL": "1"})
+    assert "3840x2160" in two["config"]["workload"] and "3840x2160" in one["config"]["workload"]
+    assert one["ref_checksum"] == two["ref_checksum"]
