@@ -571,7 +571,8 @@ def main():
             ("" if args.clip == "translation" else "; ADVERSARIAL i.i.d. noise clip") + \
             ("; + in-loop deblocking (NOT the metric's path)" if args.deblock else "")
         out = {
-            "metric": "macroblocks/sec (full-search ME + DCT/quant), 1080p; bit-exact MV+coeff vs JM",
+            "metric": "macroblocks/sec (full-search ME + DCT/quant), %s; bit-exact MV+coeff vs JM" % (
+                "1080p" if args.size == "1080p" else "2160p (BASELINE configs[3]: the 4K picture sharded by slices; the metric's own 1080p is the --gpus 1 default)"),
             "metric_note": "predictors are an INPUT of this pipeline (one per macroblock, SURVEY 8(d)'s independent-MBs recipe); `parity_check` compares a sample of the "
                            "last step with the oracle; `slice_search` gives the JM-exact form (predictors + decision on the device, raster-order dependencies kept)",
             "value": round(total_mbs / elapsed, 1), "unit": "macroblocks/s",
