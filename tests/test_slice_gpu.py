@@ -220,6 +220,15 @@ def test_1080p_walkers_match_the_oracle(pkg, mode):
     print("passes per slice call:", passes)
 
 
+@pytest.mark.gpu
+def test_1080p_config3_tools_match_the_oracle(pkg):
+    """BASELINE config 3 as it is worded -- EPZS, Hadamard SAD cost at every level, 8x8 transform enabled (Transform8x8Mode 1) -- on one 1920x1088 P
+    picture, +-32, two references: every BlockMotionSearch call, the transform decisions, both P8x8 passes and the final field of every macroblock
+    against the oracle (coarse quantiser, so that the coded-block-pattern fallback of the 8x8-transform pass occurs)."""
+    passes = run_synthetic(pkg, 3, 1920, 1088, 32, 2, nframes=2, seed=13, metric=(2, 2, 2), t8=1, qp=34)
+    print("passes per slice call:", passes)
+
+
 def upsampled_chroma(rng, Y):
     H, W = Y.shape
     U = np.clip(Y[::2, ::2].astype(int) // 2 + 60 + rng.integers(-3, 4, (H // 2, W // 2)), 0, 255).astype(np.uint8)
