@@ -120,7 +120,7 @@ def synth_clip(rng, W, H, nframes):
     return out
 
 
-def run_synthetic(pkg, mode, W, H, R, nref, slices=1, nframes=3, seed=5, metric=(0, 2, 2), qp=28, max_mbs=None, t8=0, cavlc=1):
+def run_synthetic(pkg, mode, W, H, R, nref, slices=1, nframes=3, seed=5, metric=(0, 2, 2), qp=28, max_mbs=None, t8=0, cavlc=1, wp=None):
     """Frames 1.. are coded as P pictures against the previous `nref` SOURCE frames (the search does not care where a reference came from)."""
     rng = np.random.default_rng(seed)
     clip = synth_clip(rng, W, H, nframes + nref - 1)
@@ -155,6 +155,11 @@ def run_synthetic(pkg, mode, W, H, R, nref, slices=1, nframes=3, seed=5, metric=
             first, count = s * per, min(per, nmb - s * per)
             q = oracle.lowcplx_params(mode, R, nref, lam3, ref_cost1, W, H, epzs=epzs, umhex=umhex, all_mv_state=all_mv_state, metric=metric,
                                       transform8x8_mode=t8, qp=qp, cavlc=cavlc)
+            if wp:                                       # explicit weighted prediction, used in the search too (UseWeightedReferenceME): (denominator, [(weight, offset)] per reference)
+                q.wp_pred, q.me.apply_weights = 1, 1
+                q.me.luma_log_weight_denom, q.me.wp_luma_round = wp[0], (1 << (wp[0] - 1)) if wp[0] else 0
+                for r in range(nref):
+                    q.wp_weight[r], q.wp_offset[r] = wp[1][r]
             sid = (np.arange(nmb) // per).astype(np.int32)
             q._sid = sid
             q.slice_id = sid.ctypes.data
@@ -162,6 +167,10 @@ def run_synthetic(pkg, mode, W, H, R, nref, slices=1, nframes=3, seed=5, metric=
             p = slice_params(pkg, mode, R, nref, lam3, ref_cost1, W, mb_first=first, mb_count=count, metric=metric, qp_n=qp, t8=t8, cavlc=cavlc)
             if mode == 3:
                 lib.jmhip_epzs_scales(p, 2 * f, (C.c_int * nref)(*pocs), nref)
+            if wp:
+                p.wp_me, p.wp_pred, p.wp_denom, p.wp_round = 1, 1, wp[0], (1 << (wp[0] - 1)) if wp[0] else 0
+                for r in range(nref):
+                    p.wp_weight[r], p.wp_offset[r] = wp[1][r]
             got = ctx.p_slice_search(p)
             passes.append(ctx.slice_passes())
             compare(got, want, nref, "frame %d slice %d" % (f, s))
@@ -226,6 +235,22 @@ def test_1080p_config3_tools_match_the_oracle(pkg):
     picture, +-32, two references: every BlockMotionSearch call, the transform decisions, both P8x8 passes and the final field of every macroblock
     against the oracle (coarse quantiser, so that the coded-block-pattern fallback of the 8x8-transform pass occurs)."""
     passes = run_synthetic(pkg, 3, 1920, 1088, 32, 2, nframes=2, seed=13, metric=(2, 2, 2), t8=1, qp=34)
+    print("passes per slice call:", passes)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,t8", [(-1, 0), (0, 0), (3, 0), (1, 0), (3, 1), (1, 2)])
+def test_weighted_prediction_in_the_search(pkg, mode, t8):
+    """Explicit weights per reference in every evaluation of the search (computeSADWP / computeSATDWP), in the skip cost and -- with the 8x8
+    transform -- in the transform decision's predictions (LumaPrediction): all four search modes against the oracle."""
+    run_synthetic(pkg, mode, 176, 144, 16, 2, nframes=3, seed=17, wp=(5, [(30, 2), (35, -4)]), t8=t8, qp=32)
+
+
+@pytest.mark.gpu
+def test_2160p_config5_search_matches_the_oracle(pkg):
+    """BASELINE config 5's search at its picture size: UMHexagonS with explicit weighted prediction used in ME, 3840x2160, +-32, two references,
+    every macroblock of one P picture against the oracle (the 4:2:2 of that config concerns the frame stage, not the luma search)."""
+    passes = run_synthetic(pkg, 1, 3840, 2160, 32, 2, nframes=2, seed=19, wp=(6, [(60, 3), (70, -5)]))
     print("passes per slice call:", passes)
 
 
