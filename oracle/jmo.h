@@ -279,6 +279,16 @@ int jmo_umhex_bipred_search(jmo_umhex *u, jmo_bipred *b, const jmo_pel *cur_pic,
 int jmo_umhex_subpel_search(jmo_umhex *u, const jmo_me_params *p, const jmo_ref *ref_pic, const jmo_pel *orig_pic, int pic_pix_x, int pic_pix_y,
                             int blocktype, int pred_mv_x, int pred_mv_y, short *mv_x, short *mv_y, int min_mcost, int lambda_factor);               /* :562 */
 
+/* simplified UMHexagonS, me_umhexsmp.c (jmo_umhexsmp.c): integer search :152, sub-pel search of block types > 1 :616, of the 16x16 block :422;
+ * up_mv = smpUMHEX_pred_MV_uplayer (the vector of the block type one layer up, quarter-pel, smpUMHEX_setup :1194) */
+int jmo_umhexsmp_pel_search(const jmo_me_params *p, const jmo_ref *ref, const jmo_pel *orig_pic, int pic_pix_x, int pic_pix_y, int blocktype,
+                            int pred_mv_x, int pred_mv_y, short *mv_x, short *mv_y, int search_range, int min_mcost, int lambda_factor,
+                            int up_mv_x, int up_mv_y);
+int jmo_umhexsmp_full_subpel_search(const jmo_me_params *p, const jmo_ref *ref, const jmo_pel *orig_pic, int ref_is_0, int pic_pix_x, int pic_pix_y,
+                                    int blocktype, int pred_mv_x, int pred_mv_y, short *mv_x, short *mv_y, int min_mcost, int lambda_factor);
+int jmo_umhexsmp_subpel_search(const jmo_me_params *p, const jmo_ref *ref, const jmo_pel *orig_pic, int pic_pix_x, int pic_pix_y, int blocktype,
+                               int pred_mv_x, int pred_mv_y, short *mv_x, short *mv_y, int min_mcost, int lambda_factor, int up_mv_x, int up_mv_y);
+
 /* ------------------------------------------------------------------ low-complexity P-slice inter decision (jmo_lowcplx.c) */
 
 #define JMO_LC_REFS 4            /* references kept in the per-macroblock record (the driver itself takes up to JMO_MAX_REFS) */

@@ -13,7 +13,7 @@
  * is restated literally, INCLUDING what the picture-level vector / reference arrays hold between the steps (they feed the
  * predictors of the next partition: during a mode's reference loop they hold the reference being searched, after block 0 of modes
  * 2 / 3 and after every 8x8 block of P8x8 the winner, after block 1 of modes 2 / 3 the last reference searched).
- * Search modes: -1 FullSearch, 0 FastFullSearch, 1 UMHexagonS, 3 EPZS. Luma only (ChromaMEEnable 0), frame pictures.
+ * Search modes: -1 FullSearch, 0 FastFullSearch, 1 UMHexagonS, 2 simplified UMHexagonS, 3 EPZS. Luma only (ChromaMEEnable 0), frame pictures.
  */
 #include <stdlib.h>
 #include <string.h>
@@ -206,7 +206,7 @@ static int block_motion_search(lc_ctx *c, int ref, int mb_x, int mb_y, int block
   const int pic_pix_x = opix_x + mb_x, pic_pix_y = opix_y + mb_y;
   const int start_hp = (q->me.chroma_me == 1 || q->me.metric[JMO_F_PEL] != q->me.metric[JMO_H_PEL]) ? 0 : 1;
   int bsx, bsy, min_mcost = JMO_INT_MAX, i, j;
-  short mv[2], *pred_mv = c->pred_mv[block_y][block_x][ref][blocktype];
+  short mv[2], up_mv[2] = {0, 0}, *pred_mv = c->pred_mv[block_y][block_x][ref][blocktype];
   jmo_pel orig[256];
   jmo_me_params p;
   const jmo_ref *rp = &c->refs[ref];
@@ -243,6 +243,15 @@ static int block_motion_search(lc_ctx *c, int ref, int mb_x, int mb_y, int block
     mv[1] = (short)clip3(p.level_mv_min + search_range, p.level_mv_max - search_range, mv[1]);
     min_mcost = jmo_epzs_pel_search(q->epzs, &p, rp, orig, ref, 0, &nb, (const short (*)[8][2])allmv, 1, c->mb_nr, opix_x, opix_y, pic_pix_x, pic_pix_y,
                                     blocktype, pred_mv, mv, search_range, min_mcost, q->lambda_mf[JMO_F_PEL]);
+  } else if (q->search_mode == 2) {                         /* simplified UMHexagonS :674-706 (smpUMHEX_setup :634-637: the upper layer's vector) */
+    const int ub = blocktype > 6 ? 5 : blocktype > 4 ? 4 : blocktype == 4 ? 2 : 1;
+    up_mv[0] = c->all_mv[block_y][block_x][ref][ub][0]; up_mv[1] = c->all_mv[block_y][block_x][ref][ub][1];
+    mv[0] = pred_mv[0] / 4; mv[1] = pred_mv[1] / 4;
+    mv[0] = (short)clip3(-search_range, search_range, mv[0]); mv[1] = (short)clip3(-search_range, search_range, mv[1]);      /* rdopt 0 */
+    mv[0] = (short)clip3(-2047 + search_range, 2047 - search_range, mv[0]);
+    mv[1] = (short)clip3(p.level_mv_min + search_range, p.level_mv_max - search_range, mv[1]);
+    min_mcost = jmo_umhexsmp_pel_search(&p, rp, orig, pic_pix_x, pic_pix_y, blocktype, pred_mv[0], pred_mv[1], &mv[0], &mv[1], search_range, min_mcost,
+                                        q->lambda_mf[JMO_F_PEL], up_mv[0], up_mv[1]);
   } else if (q->search_mode == 0) {                         /* FastFull :741-748, SetupFastFullPelSearch on first use per reference */
     if (!c->ff_done[ref]) {
       const int R = (q->full_search == 2 || ref == 0) ? q->search_range : q->search_range / 2;
@@ -274,7 +283,11 @@ static int block_motion_search(lc_ctx *c, int ref, int mb_x, int mb_y, int block
   /* sub-pel :781-827 */
   if (q->search_mode != 3 || ref == 0 || (ref > 0 && min_mcost < 3.5 * jmo_epzs_distortion_row(q->epzs, 0, blocktype - 1)[pic_pix_x >> 2])) {
     if (!start_hp) min_mcost = JMO_INT_MAX;
-    if (q->search_mode == 1 && blocktype > 3)
+    if (q->search_mode == 2 && blocktype > 1)               /* :803-815 */
+      min_mcost = jmo_umhexsmp_subpel_search(&p, rp, orig, pic_pix_x, pic_pix_y, blocktype, pred_mv[0], pred_mv[1], &mv[0], &mv[1], min_mcost, q->lambda_mf[JMO_Q_PEL], up_mv[0], up_mv[1]);
+    else if (q->search_mode == 2)
+      min_mcost = jmo_umhexsmp_full_subpel_search(&p, rp, orig, ref == 0, pic_pix_x, pic_pix_y, blocktype, pred_mv[0], pred_mv[1], &mv[0], &mv[1], min_mcost, q->lambda_mf[JMO_Q_PEL]);
+    else if (q->search_mode == 1 && blocktype > 3)
       min_mcost = jmo_umhex_subpel_search(q->umhex, &p, rp, orig, pic_pix_x, pic_pix_y, blocktype, pred_mv[0], pred_mv[1], &mv[0], &mv[1], min_mcost, q->lambda_mf[JMO_Q_PEL]);
     else if (q->search_mode == 3 && q->epzs_subpel_me)
       min_mcost = jmo_epzs_subpel_search(q->epzs, &p, rp, orig, pic_pix_x, pic_pix_y, blocktype, pred_mv, mv, 9, 9, min_mcost, q->lambda_mf);

@@ -26,6 +26,9 @@ RUNS = {
     "field_fastfull_r16_2ref": COMMON + ["-p", "SearchMode=0", "-p", "NumberReferenceFrames=2"],
     "field_epzs_r16_2ref": COMMON + ["-p", "SearchMode=3", "-p", "NumberReferenceFrames=2"],
     "field_umhex_r16_2ref": COMMON + ["-p", "SearchMode=1", "-p", "NumberReferenceFrames=2"],
+    "field_umhexsmp_r16_2ref": COMMON + ["-p", "SearchMode=2", "-p", "NumberReferenceFrames=2"],      # the simplified UMHexagonS (me_umhexsmp.c)
+    "field_umhexsmp_t8_q34_r16_2ref": COMMON + ["-p", "SearchMode=2", "-p", "NumberReferenceFrames=2", "-p", "Transform8x8Mode=1", "-p", "ProfileIDC=100",
+                                                "-p", "AdaptiveRounding=0", "-p", "QPPSlice=34", "-p", "MEDistortionFPel=2"],
     # Transform8x8Mode (High profile, AdaptiveRounding off): 1 = both transform sizes compete in every mode and the P8x8 partitioning depends on the
     # coded-block pattern of the 8x8-transform pass (coarse quantiser: the pattern is often empty); 2 = 8x8 only
     "field_epzs_t8_r16_2ref": COMMON + ["-p", "SearchMode=3", "-p", "NumberReferenceFrames=2", "-p", "Transform8x8Mode=1", "-p", "ProfileIDC=100",
