@@ -1109,6 +1109,187 @@ __device__ int umhex_subpel(int *mvx, int *mvy, int min_mcost)
   return min_mcost;
 }
 
+
+// ---------------------------------------------------------------------------------------------- simplified UMHexagonS (me_umhexsmp.c, SearchMode 2)
+
+__constant__ int8_t c_smp_dia_x[4] = {-1, 1, 0, 0}, c_smp_dia_y[4] = {0, 0, -1, 1};
+__constant__ int8_t c_smp_hex_x[6] = {-2, 2, -1, 1, -1, 1}, c_smp_hex_y[6] = {0, 0, -2, 2, 2, -2};
+__constant__ int8_t c_smp_bhx[16] = {-4, 4, 0, 0, -4, 4, -4, 4, -4, 4, -4, 4, -2, 2, -2, 2}, c_smp_bhy[16] = {0, 0, -4, 4, -1, 1, 1, -1, -2, 2, 2, -2, -3, 3, 3, -3};
+__constant__ int8_t c_smp_shift[8] = {0, 0, 1, 1, 2, 3, 3, 1};                  // block_type_shift_factor :44
+
+// a group of candidates L.qx/qy[0..n) through SEARCH_ONE_PIXEL_HELPER (:56-69): in range -> evaluated, accepted on strict <. No visited map,
+// no mv-cost shortcut; the positions of a group never depend on the outcome inside the group.
+__device__ void smp_group(UmState &U, int n)
+{
+  int m = 0;
+  for (int k = 0; k < n; k++) {
+    const int vx = L.qx[k], vy = L.qy[k];
+    if (iabs(vx - U.cx) > U.R || iabs(vy - U.cy) > U.R) continue;
+    L.px[m] = vx; L.py[m] = vy;
+    L.cx[m] = padq(B.pic_x, vx << 2); L.cy[m] = padq(B.pic_y, vy << 2); m++;
+  }
+  if (m) eval_dist(B.planes, D.p.metric[0], B.t8, U.umv, B.wp, B.wpw, B.wpo, B.mb_x, B.mb_y, B.bsx, B.bsy, m);
+  for (int k = 0; k < m; k++) {
+    const int mcost = mvc(D.p.lambda_mf[0], L.px[k] << 2, L.py[k] << 2) + L.dist[k];
+    if (mcost < U.min_mcost) { U.best_x = L.px[k]; U.best_y = L.py[k]; U.min_mcost = mcost; }
+  }
+}
+__device__ __forceinline__ void smp_diamond(UmState &U, int ix, int iy)
+{
+  for (int m = 0; m < 4; m++) { L.qx[m] = ix + c_smp_dia_x[m]; L.qy[m] = iy + c_smp_dia_y[m]; }
+  smp_group(U, 4);
+}
+
+// smpUMHEXIntegerPelBlockMotionSearch :152. mvx/mvy: centre in, result out (pels); (upx, upy): smpUMHEX_pred_MV_uplayer (quarter-pel)
+__device__ int smp_pel(int R, int *mvx, int *mvy, int min_mcost, int upx, int upy)
+{
+  const jmhip_slice_params &P = D.p;
+  const int bt = B.bt, sf = c_smp_shift[bt];
+  UmState U{*mvx, *mvy, R, 0 - B.pic_x, 0 - B.pic_y, min_mcost, 0};
+  {
+    const int center_x = B.pic_x + U.cx, center_y = B.pic_y + U.cy;
+    U.umv = !((center_x > R) && (center_x < D.W - 1 - R - B.bsx) && (center_y > R) && (center_y < D.H - 1 - R - B.bsy));
+  }
+  {                                                                              // the centre :241-252 (no range test)
+    L.cx[0] = padq(B.pic_x, U.cx << 2); L.cy[0] = padq(B.pic_y, U.cy << 2);
+    eval_dist(B.planes, P.metric[0], B.t8, U.umv, B.wp, B.wpw, B.wpo, B.mb_x, B.mb_y, B.bsx, B.bsy, 1);
+    const int mcost = mvc(P.lambda_mf[0], U.cx << 2, U.cy << 2) + L.dist[0];
+    if (mcost < U.min_mcost) { U.min_mcost = mcost; U.best_x = U.cx; U.best_y = U.cy; }
+  }
+  int ix = U.best_x, iy = U.best_y;
+  if (B.pmx != 0 || B.pmy != 0) { L.qx[0] = 0; L.qy[0] = 0; smp_group(U, 1); }
+  if (U.min_mcost < (1000 >> sf)) {                                              // ConvergeThreshold :264-274
+    smp_diamond(U, ix, iy);
+    *mvx = U.best_x; *mvy = U.best_y;
+    return U.min_mcost;
+  }
+  smp_diamond(U, ix, iy);
+  if ((bt == 1 && U.min_mcost > (800 >> sf)) || U.min_mcost > (7000 >> sf)) {    // SymmetricalCrossSearchThreshold1 / 2 :287-330
+    ix = U.best_x; iy = U.best_y;
+    int n = 0;
+    for (int i = 1; i <= R / 2; i++) {
+      const int st = (i << 1) - 1;
+      L.qx[n] = ix + st; L.qy[n] = iy; n++; L.qx[n] = ix - st; L.qy[n] = iy; n++;
+      L.qx[n] = ix; L.qy[n] = iy + st; n++; L.qx[n] = ix; L.qy[n] = iy - st; n++;
+    }
+    smp_group(U, n);
+    ix = U.best_x; iy = U.best_y;
+    for (int m = 0; m < 6; m++) { L.qx[m] = ix + c_smp_hex_x[m]; L.qy[m] = iy + c_smp_hex_y[m]; }
+    smp_group(U, 6);
+    ix = U.best_x; iy = U.best_y;
+    n = 0;
+    for (int i = 1; i <= R / 4; i++) for (int m = 0; m < 16; m++) { L.qx[n] = ix + c_smp_bhx[m] * i; L.qy[n] = iy + c_smp_bhy[m] * i; n++; }
+    smp_group(U, n);
+  }
+  if (bt > 1) { L.qx[0] = upx / 4; L.qy[0] = upy / 4; smp_group(U, 1); }         // :333-338
+  if (U.cx != 0 || U.cy != 0) {
+    L.qx[0] = 0; L.qy[0] = 0; smp_group(U, 1);
+    smp_diamond(U, U.best_x, U.best_y);
+  }
+  if (U.min_mcost < (1000 >> sf)) {                                              // :364-376
+    smp_diamond(U, U.best_x, U.best_y);
+    *mvx = U.best_x; *mvy = U.best_y;
+    return U.min_mcost;
+  }
+  for (int i = 0; i < R; i++) {
+    ix = U.best_x; iy = U.best_y;
+    for (int m = 0; m < 6; m++) { L.qx[m] = ix + c_smp_hex_x[m]; L.qy[m] = iy + c_smp_hex_y[m]; }
+    smp_group(U, 6);
+    if (U.best_x == ix && U.best_y == iy) break;
+  }
+  for (int i = 0; i < R; i++) {
+    ix = U.best_x; iy = U.best_y;
+    smp_diamond(U, ix, iy);
+    if (U.best_x == ix && U.best_y == iy) break;
+  }
+  *mvx = U.best_x; *mvy = U.best_y;
+  return U.min_mcost;
+}
+
+// smpUMHEXFullSubPelBlockMotionSearch :422 (the 16x16 block): both refinements with the QUARTER-pel metric and lambda (:461), each leaves
+// its scan as soon as the minimum is below SubPelThreshold3 (:531, :586)
+__device__ int smp_full_subpel(int *mvx, int *mvy, int min_mcost)
+{
+  const jmhip_slice_params &P = D.p;
+  const int start_hp = P.metric[0] != P.metric[1] ? 0 : 1, start_qp = P.metric[1] != P.metric[2] ? 0 : 1, lam = P.lambda_mf[2], metric = P.metric[2];
+  const int sf = c_smp_shift[B.bt];
+  const int check0 = (B.ref == 0 && B.bt == 1 && *mvx == 0 && *mvy == 0);        // rdopt 0, P slice
+  const int max_x4 = (D.W - B.bsx + 2 * JMHIP_PAD) << 2, max_y4 = (D.H - B.bsy + 2 * JMHIP_PAD) << 2;
+  for (int phase = 0; phase < 2; phase++) {
+    const int start = phase ? start_qp : start_hp, step = phase ? 1 : 2, lo = phase ? 0 : 1;
+    const int p4x = padq(B.pic_x, *mvx), p4y = padq(B.pic_y, *mvy);
+    const int umv = !((p4x > lo) && (p4x < max_x4 - lo) && (p4y > lo) && (p4y < max_y4 - lo));
+    int n = 0;
+    for (int pos = start; pos < 9; pos++) { L.cx[n] = p4x + step * c_s9x[pos]; L.cy[n] = p4y + step * c_s9y[pos]; n++; }
+    eval_dist(B.planes, metric, B.t8, umv, B.wp, B.wpw, B.wpo, B.mb_x, B.mb_y, B.bsx, B.bsy, n);
+    int best = 0;
+    for (int pos = start, k = 0; pos < 9; pos++, k++) {
+      int mcost = mvc(lam, *mvx + step * c_s9x[pos], *mvy + step * c_s9y[pos]);
+      if (mcost >= min_mcost) continue;
+      mcost += L.dist[k];
+      if (phase == 0 && pos == 0 && check0) mcost -= (lam * 16) >> 16;
+      if (mcost < min_mcost) { min_mcost = mcost; best = pos; }
+      if (min_mcost < (400 >> sf)) break;
+    }
+    if (best) { *mvx += step * c_s9x[best]; *mvy += step * c_s9y[best]; }
+    if (phase == 0) {
+      if (*mvx == 0 && *mvy == 0 && B.pmx == 0 && B.pmy == 0 && min_mcost < (1000 >> sf)) return min_mcost;      // SubPelThreshold1 :547-552
+      if (!start_qp) min_mcost = INT_MAX;
+    }
+  }
+  return min_mcost;
+}
+
+// smpUMHEXSubPelBlockMotionSearch :616 (block types > 1): a diamond walk inside +-3 quarter-pels of the integer vector
+__device__ int smp_subpel(int *mvx, int *mvy, int min_mcost, int upx, int upy)
+{
+  const int start_hp = D.p.metric[0] != D.p.metric[1] ? 0 : 1, lam = D.p.lambda_mf[2], metric = D.p.metric[2], sf = c_smp_shift[B.bt];
+  const int p4x = padq(B.pic_x, 0), p4y = padq(B.pic_y, 0);
+  const short max_x4 = (short)((D.W - B.bsx + 2 * JMHIP_PAD) << 2), max_y4 = (short)((D.H - B.bsy + 2 * JMHIP_PAD) << 2);      // :645-646: short
+  const int umv = !((p4x + *mvx > 1) && (p4x + *mvx < max_x4 - 1) && (p4y + *mvy > 1) && (p4y + *mvy < max_y4 - 1));
+  const int cx0 = *mvx, cy0 = *mvy, pfx = (B.pmx - cx0) % 4, pfy = (B.pmy - cy0) % 4, pux = (upx - cx0) % 4, puy = (upy - cy0) % 4;
+  int cur_x = 0, cur_y = 0;
+  for (int i = 0; i < 49; i++) L.um_sstate[i] = 0;
+#define SS(x, y) L.um_sstate[((y) - cy0 + 3) * 7 + ((x) - cx0 + 3)]
+  SS(cx0, cy0) = 1;
+  if (!start_hp) {
+    L.cx[0] = p4x + cx0; L.cy[0] = p4y + cy0;
+    eval_dist(B.planes, metric, B.t8, umv, B.wp, B.wpw, B.wpo, B.mb_x, B.mb_y, B.bsx, B.bsy, 1);
+    const int mcost = mvc(lam, cx0, cy0) + L.dist[0];
+    if (mcost < min_mcost) { min_mcost = mcost; cur_x = cx0; cur_y = cy0; }
+  } else { cur_x = cx0; cur_y = cy0; }
+  if (cx0 == 0 && cy0 == 0 && pfx == 0 && pux == 0 && pfy == 0 && puy == 0 && min_mcost < (1000 >> sf)) { *mvx = cur_x; *mvy = cur_y; return min_mcost; }
+  if (pfx != 0 || pfy != 0) {
+    L.cx[0] = p4x + cx0 + pfx; L.cy[0] = p4y + cy0 + pfy;
+    eval_dist(B.planes, metric, B.t8, umv, B.wp, B.wpw, B.wpo, B.mb_x, B.mb_y, B.bsx, B.bsy, 1);
+    const int mcost = mvc(lam, cx0 + pfx, cy0 + pfy) + L.dist[0];
+    SS(cx0 + pfx, cy0 + pfy) = 1;
+    if (mcost < min_mcost) { min_mcost = mcost; cur_x = cx0 + pfx; cur_y = cy0 + pfy; }
+  }
+  for (int i = 0; i < 3; i++) {
+    const int ix = cur_x, iy = cur_y;
+    int n = 0, idx[4];
+    for (int m = 0; m < 4; m++) {
+      const int vx = ix + c_smp_dia_x[m], vy = iy + c_smp_dia_y[m];
+      idx[m] = -1;
+      if (iabs(vx - cx0) <= 3 && iabs(vy - cy0) <= 3 && !SS(vx, vy)) { L.cx[n] = p4x + vx; L.cy[n] = p4y + vy; idx[m] = n++; }
+    }
+    if (n) eval_dist(B.planes, metric, B.t8, umv, B.wp, B.wpw, B.wpo, B.mb_x, B.mb_y, B.bsx, B.bsy, n);
+    int abort_search = 1;
+    for (int m = 0; m < 4; m++) if (idx[m] >= 0) {
+      const int vx = ix + c_smp_dia_x[m], vy = iy + c_smp_dia_y[m];
+      const int mcost = mvc(lam, vx, vy) + L.dist[idx[m]];
+      SS(vx, vy) = 1;
+      if (mcost < min_mcost) { min_mcost = mcost; cur_x = vx; cur_y = vy; abort_search = 0; }
+      if (min_mcost < (400 >> sf)) { *mvx = cur_x; *mvy = cur_y; return min_mcost; }       // SubPelThreshold3 :794-799
+    }
+    if (abort_search) break;
+  }
+#undef SS
+  *mvx = cur_x; *mvy = cur_y;
+  return min_mcost;
+}
+
 // ---------------------------------------------------------------------------------------------- BlockMotionSearch and above
 
 __device__ __forceinline__ int part_index(int bt, int block_x, int block_y)
@@ -1150,7 +1331,7 @@ template <int SM> __device__ int block_motion_search(int mbx, int mby, int ref, 
   B.t8 = P.transform8x8_mode && bt <= 4;                                       // test8x8transform, mv-search.c:640
   const int block_x = mb_x >> 2, block_y = mb_y >> 2, pi = part_index(bt, block_x, block_y);
   const int start_hp = P.metric[0] != P.metric[1] ? 0 : 1;
-  int mvx, mvy, min_mcost = INT_MAX;
+  int mvx, mvy, min_mcost = INT_MAX, smp_upx = 0, smp_upy = 0;
   WPROF_T0;
   mv_predictor(mbx, mby, ref, mb_x, mb_y, B.bsx, B.bsy, &B.pmx, &B.pmy, SM == JMHIP_SEARCH_UMHEX && P.umhex_dsr, bt, &search_range, nullptr);
   WPROF(0);
@@ -1162,6 +1343,13 @@ template <int SM> __device__ int block_motion_search(int mbx, int mby, int ref, 
     mvx = clampi(mvx, -2047 + R, 2047 - R); mvy = clampi(mvy, P.level_mv_min + R, P.level_mv_max - R);
     min_mcost = umhex_pel(R, &mvx, &mvy, min_mcost);
     __syncthreads();                                                           // lane 0 wrote the cost map
+  } else if (SM == JMHIP_SEARCH_UMHEX_SIMPLE) {                                  // mv-search.c:674-706; smpUMHEX_setup :634: the upper layer's vector
+    const int ub = bt > 6 ? 5 : bt > 4 ? 4 : bt == 4 ? 2 : 1;
+    smp_upx = L.all_mv[block_y * 4 + block_x][ref][ub][0]; smp_upy = L.all_mv[block_y * 4 + block_x][ref][ub][1];
+    mvx = B.pmx / 4; mvy = B.pmy / 4;
+    mvx = clampi(mvx, -R, R); mvy = clampi(mvy, -R, R);
+    mvx = clampi(mvx, -2047 + R, 2047 - R); mvy = clampi(mvy, P.level_mv_min + R, P.level_mv_max - R);
+    min_mcost = smp_pel(R, &mvx, &mvy, min_mcost, smp_upx, smp_upy);
   } else if (SM == JMHIP_SEARCH_EPZS) {
     mvx = (B.pmx + 2) >> 2; mvy = (B.pmy + 2) >> 2;
     mvx = clampi(mvx, -R, R); mvy = clampi(mvy, -R, R);
@@ -1205,7 +1393,8 @@ template <int SM> __device__ int block_motion_search(int mbx, int mby, int ref, 
   if (SM == JMHIP_SEARCH_EPZS && ref > 0) do_sub = (2 * (long long)min_mcost < 7 * (long long)L.ep_sad[bt - 1][(B.pic_x >> 2) - (4 * mbx - 4)]);   // min_mcost < 3.5 * prevSad
   if (do_sub && !(D.debug & 1)) {
     if (!start_hp) min_mcost = INT_MAX;
-    if (SM == JMHIP_SEARCH_UMHEX && bt > 3) min_mcost = umhex_subpel(&mvx, &mvy, min_mcost);
+    if (SM == JMHIP_SEARCH_UMHEX_SIMPLE) min_mcost = bt > 1 ? smp_subpel(&mvx, &mvy, min_mcost, smp_upx, smp_upy) : smp_full_subpel(&mvx, &mvy, min_mcost);
+    else if (SM == JMHIP_SEARCH_UMHEX && bt > 3) min_mcost = umhex_subpel(&mvx, &mvy, min_mcost);
     else if (SM == JMHIP_SEARCH_EPZS && P.epzs_subpel_me) min_mcost = epzs_subpel(&mvx, &mvy, min_mcost);
     else min_mcost = subpel_full(&mvx, &mvy, min_mcost);
   }
@@ -1834,8 +2023,9 @@ extern "C" int jmhip_p_slice_search(jmhip_ctx *c, const jmhip_slice_params *prm,
 {
   if (!c || !prm) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_p_slice_search: NULL arguments") : JMHIP_ERR_ARG;
   const int nmb = c->mbw * c->mbh;
-  if (prm->search_mode != JMHIP_SEARCH_FULL && prm->search_mode != JMHIP_SEARCH_FASTFULL && prm->search_mode != JMHIP_SEARCH_UMHEX && prm->search_mode != JMHIP_SEARCH_EPZS)
-    return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_p_slice_search: search_mode must be -1, 0, 1 or 3 (simplified UMHexagonS, mode 2, is not built)");
+  if (prm->search_mode != JMHIP_SEARCH_FULL && prm->search_mode != JMHIP_SEARCH_FASTFULL && prm->search_mode != JMHIP_SEARCH_UMHEX &&
+      prm->search_mode != JMHIP_SEARCH_UMHEX_SIMPLE && prm->search_mode != JMHIP_SEARCH_EPZS)
+    return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_p_slice_search: search_mode must be -1, 0, 1, 2 or 3");
   if (prm->num_refs < 1 || prm->num_refs > JMHIP_SLICE_REFS) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_p_slice_search: 1..JMHIP_SLICE_REFS references");
   if (prm->search_range < 1 || prm->search_range > c->cfg.search_range || prm->search_range > 33) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_p_slice_search: search_range (at most 33 and the context's)");
   if (prm->mb_first < 0 || prm->mb_count < 1 || prm->mb_first + prm->mb_count > nmb) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_p_slice_search: slice outside the picture");
@@ -1914,6 +2104,7 @@ extern "C" int jmhip_p_slice_search(jmhip_ctx *c, const jmhip_slice_params *prm,
       switch (prm->search_mode) {
       case JMHIP_SEARCH_EPZS: p_slice_relax_kernel<JMHIP_SEARCH_EPZS><<<grid, 64, 0, c->stream>>>(s->carry_slice); break;
       case JMHIP_SEARCH_UMHEX: p_slice_relax_kernel<JMHIP_SEARCH_UMHEX><<<grid, 64, 0, c->stream>>>(s->carry_slice); break;
+      case JMHIP_SEARCH_UMHEX_SIMPLE: p_slice_relax_kernel<JMHIP_SEARCH_UMHEX_SIMPLE><<<grid, 64, 0, c->stream>>>(s->carry_slice); break;
       case JMHIP_SEARCH_FASTFULL: p_slice_relax_kernel<JMHIP_SEARCH_FASTFULL><<<grid, 64, 0, c->stream>>>(s->carry_slice); break;
       default: p_slice_relax_kernel<JMHIP_SEARCH_FULL><<<grid, 64, 0, c->stream>>>(s->carry_slice); break;
       }
@@ -1942,6 +2133,7 @@ extern "C" int jmhip_p_slice_search(jmhip_ctx *c, const jmhip_slice_params *prm,
     switch (prm->search_mode) {
     case JMHIP_SEARCH_EPZS: p_slice_kernel<JMHIP_SEARCH_EPZS><<<rows, 64, 0, c->stream>>>(s->carry_slice, s->carry_slice_next); break;
     case JMHIP_SEARCH_UMHEX: p_slice_kernel<JMHIP_SEARCH_UMHEX><<<rows, 64, 0, c->stream>>>(s->carry_slice, s->carry_slice_next); break;
+    case JMHIP_SEARCH_UMHEX_SIMPLE: p_slice_kernel<JMHIP_SEARCH_UMHEX_SIMPLE><<<rows, 64, 0, c->stream>>>(s->carry_slice, s->carry_slice_next); break;
     case JMHIP_SEARCH_FASTFULL: p_slice_kernel<JMHIP_SEARCH_FASTFULL><<<rows, 64, 0, c->stream>>>(s->carry_slice, s->carry_slice_next); break;
     default: p_slice_kernel<JMHIP_SEARCH_FULL><<<rows, 64, 0, c->stream>>>(s->carry_slice, s->carry_slice_next); break;
     }

@@ -271,8 +271,10 @@ int jmhip_me_subpel(jmhip_ctx *ctx, const jmhip_me_params *prm, const jmhip_me_m
  *   the integer search of the configured SearchMode:
  *     -1 FullPelBlockMotionSearch src/me_fullsearch.c:47      0 FastFullPelBlockMotionSearch src/me_fullfast.c:833 (+ Setup :491)
  *      1 UMHEXIntegerPelBlockMotionSearch src/me_umhex.c:229  3 EPZSPelBlockMotionSearch src/me_epzs.c:1500
+ *      2 smpUMHEXIntegerPelBlockMotionSearch src/me_umhexsmp.c:152 (the simplified UMHexagonS; stateless between calls)
  *   the sub-pel search: SubPelBlockMotionSearch src/me_fullsearch.c:341, UMHEXSubPelBlockMotionSearch src/me_umhex.c:562 (block
- *     types > 3), EPZSSubPelBlockMotionSearch src/me_epzs.c:2390
+ *     types > 3), EPZSSubPelBlockMotionSearch src/me_epzs.c:2390, smpUMHEXSubPelBlockMotionSearch src/me_umhexsmp.c:616 (block types > 1) /
+ *     smpUMHEXFullSubPelBlockMotionSearch :422 (the 16x16 block)
  *   the skip shortcut of the 16x16 block (FindSkipModeMotionVector src/mv-search.c:1189, GetSkipCostMB :1136, :829-849)
  *   list_prediction_cost src/mode_decision.c:255, submacroblock_mode_decision :530 (rdopt = 0 path), SetRefAndMotionVectors /
  *     SetModesAndRefframeForBlocks / SetMotionVectorsMB (src/rdopt.c:2777 / :1262 / :1845).
@@ -285,9 +287,9 @@ int jmhip_me_subpel(jmhip_ctx *ctx, const jmhip_me_params *prm, const jmhip_me_m
  * Not mirrored: the 16-bit wrap of EPZSBlkCount (a position visited exactly 65536 searches earlier reads as visited in JM).
  * Frame pictures, luma-only motion estimation (ChromaMEEnable 0), list 0 only, up to JMHIP_SLICE_REFS references. */
 #define JMHIP_SLICE_REFS 4
-enum { JMHIP_SEARCH_UMHEX = 1, JMHIP_SEARCH_EPZS = 3 };
+enum { JMHIP_SEARCH_UMHEX = 1, JMHIP_SEARCH_UMHEX_SIMPLE = 2, JMHIP_SEARCH_EPZS = 3 };
 typedef struct jmhip_slice_params {
-  int32_t search_mode;                     /* input->SearchMode: -1, 0, 1, 3 */
+  int32_t search_mode;                     /* input->SearchMode: -1, 0, 1, 2, 3 */
   int32_t search_range;                    /* input->search_range */
   int32_t full_search;                     /* input->full_search (RestrictSearchRange): range per reference / block type, mv-search.c:1411-1416 */
   int32_t num_refs;                        /* listXsize[LIST_0] */

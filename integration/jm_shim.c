@@ -979,7 +979,7 @@ static int slice_mode_covered(void)
             /* Transform8x8Mode 1: the device quantises the 8x8-transform P8x8 pass to decide the partitioning (md_low.c:547): the slice's inter 8x8 tables
                as they stand when the slice begins, so no adaptive rounding */
             (input->Transform8x8Mode != 1 || (!input->AdaptiveRounding && input->InterSearch[0][4])) && (input->Transform8x8Mode != 2 || input->InterSearch[0][4]) &&
-            (input->SearchMode == -1 || input->SearchMode == 0 || input->SearchMode == 1 || input->SearchMode == 3) &&
+            (input->SearchMode == -1 || input->SearchMode == 0 || input->SearchMode == 1 || input->SearchMode == 2 || input->SearchMode == 3) &&
             !(input->SearchMode <= 0 && input->MEErrorMetric[F_PEL] != ERROR_SAD) && !input->EPZSSubPelGrid &&
             input->search_range <= 33 && input->num_ref_frames <= JMHIP_SLICE_REFS && (input->slice_mode == 0 || input->slice_mode == 1) &&
             input->num_slice_groups_minus1 == 0 && !input->sp_periodicity && !input->BiPredMotionEstimation && input->InterSearch[0][1] &&

@@ -221,6 +221,8 @@ SLICE_CASES = {
     "slice_umhex_t8_cavlc": dict(search=1, profile=100, cabac=0, t8x8=1, bframes=0, refs=2, rdopt=0, adrnd=0, yuv=1, noi=1, qp=32),
     "slice_fastfull_t8_q40": dict(search=0, profile=100, cabac=0, t8x8=1, bframes=0, refs=2, rdopt=0, adrnd=0, yuv=1, noi=1, qp=40),
     "slice_full_t8only": dict(search=-1, profile=100, cabac=1, t8x8=2, bframes=0, refs=1, rdopt=0, adrnd=0, yuv=1, noi=1),
+    "slice_umhexsmp_2ref": dict(search=2, profile=66, cabac=0, t8x8=0, bframes=0, refs=2, rdopt=0, adrnd=1, yuv=1, noi=1),               # the simplified UMHexagonS
+    "slice_umhexsmp_t8_satd": dict(search=2, profile=100, cabac=1, t8x8=1, bframes=0, refs=2, rdopt=0, adrnd=0, yuv=1, noi=1, qp=34, fpel=2),
     "slice_epzs_four_slices_midrow": dict(search=3, profile=77, cabac=1, t8x8=0, bframes=0, refs=2, rdopt=0, adrnd=0, yuv=1, noi=1, slicemode=1, slicearg=27, lfflag=1, lfidc=2),
 }
 CASES.update(SLICE_CASES)

@@ -58,7 +58,9 @@ def compare(got, want, nref, what):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_fixture_pictures_match_the_real_jm(pkg, name):
-    mode, t8, cavlc = CASES[name] if isinstance(CASES[name], tuple) else (CASES[name], 0, 1)
+    case = CASES[name] if isinstance(CASES[name], tuple) else (CASES[name], 0, 1)
+    mode, t8, cavlc = case[:3]
+    metric = case[3] if len(case) > 3 else (0, 2, 2)
     z = np.load(os.path.join(GOLD, name + ".npz"))
     n = int(z["n_frames"])
     W, H = int(z["f0_head"][0]), int(z["f0_head"][1])
@@ -75,7 +77,7 @@ def test_fixture_pictures_match_the_real_jm(pkg, name):
             ctx.ref_upload(r, z["f%d_refs" % k][r])
             ctx.interp_luma(r)
         ctx.cur_upload(z["f%d_cur" % k])
-        p = slice_params(pkg, mode, R, nref, [int(v) for v in head[6:9]], int(head[9]), W, H=H, t8=t8, cavlc=cavlc,
+        p = slice_params(pkg, mode, R, nref, [int(v) for v in head[6:9]], int(head[9]), W, H=H, t8=t8, cavlc=cavlc, metric=metric,
                          **(dict(qp_n=int(head[2])) if t8 else {}))
         if mode == 3:
             ids = (refinfo[:, 1].astype(np.int64) & 0xffffffff) | (refinfo[:, 2].astype(np.int64) << 32)
@@ -196,6 +198,8 @@ def run_synthetic(pkg, mode, W, H, R, nref, slices=1, nframes=3, seed=5, metric=
     (3, 320, 192, 32, 3, 3),        # EPZS, +-32, three references, three slices (the last two begin mid-row)
     (1, 176, 144, 16, 2, 1),        # UMHexagonS with the dynamic search range
     (1, 320, 192, 32, 3, 3),
+    (2, 176, 144, 16, 2, 1),        # the simplified UMHexagonS (me_umhexsmp.c)
+    (2, 320, 192, 32, 3, 3),
 ])
 def test_synthetic_clip_matches_the_oracle(pkg, mode, W, H, R, nref, slices):
     run_synthetic(pkg, mode, W, H, R, nref, slices=slices)
@@ -215,7 +219,7 @@ def test_schedules_agree(pkg, mode, W, H, R, nref, slices, sched, sweeps, monkey
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", [3, 1])
+@pytest.mark.parametrize("mode", [3, 1, 2])
 def test_sad_everywhere_and_satd_everywhere(pkg, mode):
     run_synthetic(pkg, mode, 176, 144, 16, 2, metric=(0, 0, 0), nframes=2)
     run_synthetic(pkg, mode, 176, 144, 16, 2, metric=(2, 2, 2), nframes=2)     # SATD at full-pel positions too (BASELINE config 3: "EPZS + SATD cost")
@@ -239,7 +243,7 @@ def test_1080p_config3_tools_match_the_oracle(pkg):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode,t8", [(-1, 0), (0, 0), (3, 0), (1, 0), (3, 1), (1, 2)])
+@pytest.mark.parametrize("mode,t8", [(-1, 0), (0, 0), (3, 0), (1, 0), (2, 0), (3, 1), (1, 2)])
 def test_weighted_prediction_in_the_search(pkg, mode, t8):
     """Explicit weights per reference in every evaluation of the search (computeSADWP / computeSATDWP), in the skip cost and -- with the 8x8
     transform -- in the transform decision's predictions (LumaPrediction): all four search modes against the oracle."""
@@ -356,6 +360,7 @@ def test_slice_search_feeds_the_frame_stage(pkg, mode, weighted, planes, t8):
     (0, 96, 64, 8, 2, 1, 2, 28, 1),         # FastFullSearch, 8x8 transform only
     (1, 176, 144, 16, 2, 1, 1, 40, 1),      # UMHexagonS
     (3, 320, 192, 32, 3, 3, 1, 34, 1),
+    (2, 176, 144, 16, 2, 1, 1, 34, 1),      # simplified UMHexagonS
 ])
 def test_transform8x8_modes_match_the_oracle(pkg, mode, W, H, R, nref, slices, t8, qp, cavlc):
     """Transform8x8Mode 1 / 2 in the slice search: the 8x8 Hadamard for block types 1..4, TransformDecision after modes 1..3 (with the references
