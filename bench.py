@@ -285,7 +285,7 @@ def slice_search_times(pkg, ctx, lam, src, order):
     out = {}
     ctx.interp_luma(0)                                  # the last step left a new integer picture in the slot
     # the last entry is BASELINE config 3's search: EPZS, Hadamard SAD at every level, both transform sizes competing (Transform8x8Mode 1)
-    for name, mode, metric, t8 in (("FullSearch", -1, (0, 2, 2), 0), ("FastFullSearch", 0, (0, 2, 2), 0), ("EPZS", 3, (0, 2, 2), 0), ("UMHexagonS", 1, (0, 2, 2), 0),
+    for name, mode, metric, t8 in (("FullSearch", -1, (0, 2, 2), 0), ("FastFullSearch", 0, (0, 2, 2), 0), ("EPZS", 3, (0, 2, 2), 0), ("UMHexagonS", 1, (0, 2, 2), 0), ("UMHexagonS_simplified", 2, (0, 2, 2), 0),
                                    ("EPZS_satd_transform8x8", 3, (2, 2, 2), 1)):
         ctx.slice_state_reset()
         ctx.epzs_colocated_upload(np.zeros((H // 4, W // 4, 2), np.int16))
