@@ -1,6 +1,7 @@
 """Sweeps of the relaxation schedule with and without Transform8x8Mode (diagnostic): python tools/t8_passes.py"""
 import sys
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
 from tests.test_slice_gpu import run_synthetic
 pkg = ge._load_pkg()

@@ -1,7 +1,8 @@
 """How many macroblocks of the bench clip end the integer search with ONE vector for all 41 partitions (diagnostic for me_sub's uniform phase)."""
 import sys
 import numpy as np
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 import __graft_entry__ as ge
 pkg = ge._load_pkg()
