@@ -320,6 +320,10 @@ __device__ __forceinline__ int nbr_pos(int mbx, int mby, int xN, int yN, int *px
   if (nx < 0 || ny < 0 || nx >= D.mbw || ny >= D.mbh) return 0;
   const int a = ny * D.mbw + nx;
   if (a < D.p.mb_first || a >= D.p.mb_first + D.p.mb_count) return 0;
+  if (D.p.slice_mbs > 0) {                               // several slices in one call: the neighbour must lie in the current macroblock's slice
+    const int cur = mby * D.mbw + mbx, lo = D.p.mb_first + ((cur - D.p.mb_first) / D.p.slice_mbs) * D.p.slice_mbs;
+    if (a < lo) return 0;
+  }
   *px = (nx * 16 + ((xN + 16) & 15)) >> 2; *py = (ny * 16 + ((yN + 16) & 15)) >> 2;
   return 1;
 }
@@ -2038,6 +2042,9 @@ extern "C" int jmhip_p_slice_search(jmhip_ctx *c, const jmhip_slice_params *prm,
   if ((prm->search_mode == JMHIP_SEARCH_FULL || prm->search_mode == JMHIP_SEARCH_FASTFULL) && prm->metric[0] != 0)
     return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_p_slice_search: the exhaustive searches take the SAD metric at full-pel positions");
   if (prm->md_metric != 0 && prm->md_metric != 2) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_p_slice_search: mode-decision metric SAD or SATD");
+  if (prm->slice_mbs < 0) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_p_slice_search: slice_mbs");
+  if (prm->slice_mbs > 0 && (prm->search_mode == JMHIP_SEARCH_EPZS || prm->search_mode == JMHIP_SEARCH_UMHEX))
+    return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_p_slice_search: several slices in one call (slice_mbs) need a search without slice-carried memories: modes -1, 0, 2");
   if (prm->transform8x8_mode < 0 || prm->transform8x8_mode > 2) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_p_slice_search: transform8x8_mode must be 0, 1 or 2");
   if (prm->transform8x8_mode && !prm->valid[4]) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_p_slice_search: Transform8x8Mode needs the 8x8 sub-mode (valid[4])");
   if (prm->transform8x8_mode == 1 && (prm->t8_qp < 0 || prm->t8_qp > 51 + 48 || prm->t8_disthres < 0 || prm->t8_disthres > 1))

@@ -326,6 +326,12 @@ typedef struct jmhip_slice_params {
   int32_t transform8x8_mode;
   int32_t t8_qp, t8_cavlc, t8_disthres;                /* currMB->qp_scaled[0], input->symbol_mode == CAVLC, input->disthres */
   int32_t t8_levelscale[64], t8_leveloffset[64];       /* LevelScale8x8Luma_Inter[qp % 6], LevelOffset8x8Luma_Inter[qp / 6], row-major [j][i] */
+  /* Several slices in ONE call (input->slice_mode 1, fixed macroblock count: BASELINE config 4's eight slices): slice_mbs > 0 cuts
+   * [mb_first, mb_first + mb_count) into slices of slice_mbs macroblocks (the last one shorter). Neighbours across a slice boundary are
+   * unavailable (src/mb_access.c:30-36); img->all_mv runs on from one slice's last macroblock to the next slice's first as in JM. The slices
+   * relax together: the sweeps a picture needs are those of its slowest slice, not their sum. Search modes -1, 0 and 2 (the walkers of modes 1
+   * and 3 keep memories that JM carries from slice to slice in coding order: one call per slice for those). 0 = one slice. */
+  int32_t slice_mbs;
 } jmhip_slice_params;
 
 /* what JM knows of one macroblock after the decision + the outcome of each of its BlockMotionSearch calls */

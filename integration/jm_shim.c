@@ -965,6 +965,7 @@ static struct {
   int slice_nr, mb_first, mb_count;
   jmhip_mb_inter *rec; int cap;
   int decided, on;            /* once per run: is the configuration covered? */
+  int multi;                  /* the records cover every remaining slice of the picture (slice_mbs) */
   int started;                /* device state reset done */
   long passes, slices;
 } sl;
@@ -997,7 +998,10 @@ static void slice_run(int *lambda_factor)
   const int nmb = (int)img->PicSizeInMbs, first = img->current_mb_nr;
   int r, m, count = nmb - first, pocs[JMHIP_SLICE_REFS];
   memset(&p, 0, sizeof(p));
-  if (input->slice_mode == 1 && input->slice_argument < count) count = input->slice_argument;
+  /* fixed-size slices and a search without slice-carried memories: all remaining slices of the picture in this one call (slice_mbs) */
+  sl.multi = input->slice_mode == 1 && input->slice_argument < count && (input->SearchMode == -1 || input->SearchMode == 0 || input->SearchMode == 2);
+  if (sl.multi) p.slice_mbs = input->slice_argument;
+  else if (input->slice_mode == 1 && input->slice_argument < count) count = input->slice_argument;
   p.search_mode = input->SearchMode; p.search_range = input->search_range; p.full_search = input->full_search; p.num_refs = listXsize[LIST_0];
   for (r = 0; r < listXsize[LIST_0]; r++) {
     p.ref_slot[r] = slot_find(listX[LIST_0][r]);
@@ -1060,7 +1064,7 @@ int BlockMotionSearch(short ref, int list, int mb_x, int mb_y, int blocktype, in
     n_fwd[S_BMS]++;
     return orig(ref, list, mb_x, mb_y, blocktype, search_range, lambda_factor);
   }
-  if (!(sl.active && sl.serial == pic_serial && sl.slice_nr == img->current_slice_nr && img->current_mb_nr >= sl.mb_first && img->current_mb_nr < sl.mb_first + sl.mb_count))
+  if (!(sl.active && sl.serial == pic_serial && (sl.slice_nr == img->current_slice_nr || sl.multi) && img->current_mb_nr >= sl.mb_first && img->current_mb_nr < sl.mb_first + sl.mb_count))
     slice_run(lambda_factor);
   {
     const jmhip_mb_inter *r = &sl.rec[img->current_mb_nr - sl.mb_first];

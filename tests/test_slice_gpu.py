@@ -122,7 +122,7 @@ def synth_clip(rng, W, H, nframes):
     return out
 
 
-def run_synthetic(pkg, mode, W, H, R, nref, slices=1, nframes=3, seed=5, metric=(0, 2, 2), qp=28, max_mbs=None, t8=0, cavlc=1, wp=None):
+def run_synthetic(pkg, mode, W, H, R, nref, slices=1, nframes=3, seed=5, metric=(0, 2, 2), qp=28, max_mbs=None, t8=0, cavlc=1, wp=None, one_call=False):
     """Frames 1.. are coded as P pictures against the previous `nref` SOURCE frames (the search does not care where a reference came from)."""
     rng = np.random.default_rng(seed)
     clip = synth_clip(rng, W, H, nframes + nref - 1)
@@ -153,6 +153,7 @@ def run_synthetic(pkg, mode, W, H, R, nref, slices=1, nframes=3, seed=5, metric=
         ref_idx = np.full((H // 4, W // 4), -1, np.int8)
         mvf = np.zeros((H // 4, W // 4, 2), np.int16)
         per = (nmb + slices - 1) // slices
+        wants = []
         for s in range(slices):
             first, count = s * per, min(per, nmb - s * per)
             q = oracle.lowcplx_params(mode, R, nref, lam3, ref_cost1, W, H, epzs=epzs, umhex=umhex, all_mv_state=all_mv_state, metric=metric,
@@ -166,6 +167,9 @@ def run_synthetic(pkg, mode, W, H, R, nref, slices=1, nframes=3, seed=5, metric=
             q._sid = sid
             q.slice_id = sid.ctypes.data
             want, _, _ = oracle.lowcplx_p_slice(q, orefs, cur, ref_idx, mvf, mb_first=first, mb_count=count)
+            if one_call:                                 # the device searches all slices of the picture in ONE call (slice_mbs) below
+                wants.append(want)
+                continue
             p = slice_params(pkg, mode, R, nref, lam3, ref_cost1, W, mb_first=first, mb_count=count, metric=metric, qp_n=qp, t8=t8, cavlc=cavlc)
             if mode == 3:
                 lib.jmhip_epzs_scales(p, 2 * f, (C.c_int * nref)(*pocs), nref)
@@ -176,6 +180,12 @@ def run_synthetic(pkg, mode, W, H, R, nref, slices=1, nframes=3, seed=5, metric=
             got = ctx.p_slice_search(p)
             passes.append(ctx.slice_passes())
             compare(got, want, nref, "frame %d slice %d" % (f, s))
+        if one_call:
+            p = slice_params(pkg, mode, R, nref, lam3, ref_cost1, W, mb_first=0, mb_count=nmb, metric=metric, qp_n=qp, t8=t8, cavlc=cavlc)
+            p.slice_mbs = per
+            got = ctx.p_slice_search(p)
+            passes.append(ctx.slice_passes())
+            compare(got, np.concatenate(wants), nref, "frame %d, %d slices in one call" % (f, slices))
         gref, gmv = ctx.slice_field()
         assert np.array_equal(gref, ref_idx) and np.array_equal(gmv, mvf), "frame %d: final field" % f
         # what EPZS will read of this picture when it is the co-located one: its vectors and, as reference ids, the POCs of what they point to
@@ -367,3 +377,18 @@ def test_transform8x8_modes_match_the_oracle(pkg, mode, W, H, R, nref, slices, t
     it writes into the picture array), the 8x8-transform P8x8 pass, GetBestTransformP8x8 on ties, and the coded-block pattern of that pass
     (prediction, dct_8x8, coefficient cost) deciding between the two passes' partitionings."""
     run_synthetic(pkg, mode, W, H, R, nref, slices=slices, t8=t8, qp=qp, cavlc=cavlc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,W,H,slices,t8", [(-1, 176, 144, 3, 0), (0, 320, 192, 8, 0), (2, 320, 192, 5, 0), (-1, 320, 192, 4, 1)])
+def test_several_slices_in_one_call(pkg, mode, W, H, slices, t8):
+    """slice_mbs: the slices of a picture (input->slice_mode 1: fixed macroblock count, most of them beginning mid-row) searched in ONE call --
+    neighbours across slice boundaries unavailable, img->all_mv running on from slice to slice -- against the oracle run slice by slice."""
+    run_synthetic(pkg, mode, W, H, 16, 2, slices=slices, one_call=True, t8=t8, qp=32)
+
+
+@pytest.mark.gpu
+def test_2160p_config4_eight_slices_in_one_call(pkg):
+    """BASELINE config 4's picture and slice layout on ONE GPU: 3840x2160, FullSearch +-32, eight slices of 4050 macroblocks, one call."""
+    passes = run_synthetic(pkg, -1, 3840, 2160, 32, 1, slices=8, nframes=2, seed=23, one_call=True)
+    print("sweeps of the one call:", passes)
