@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--modes", default="3,1,0,-1")
     ap.add_argument("--range", type=int, default=32)
     ap.add_argument("--frames", type=int, default=4)
+    ap.add_argument("--slices", type=int, default=1, help="fixed-size slices per picture (search modes -1, 0, 2)")
+    ap.add_argument("--per-slice-calls", action="store_true", help="with --slices: one call per slice instead of slice_mbs")
     a = ap.parse_args()
     W, H = {"1080p": (1920, 1088), "720p": (1280, 720), "qcif": (176, 144), "2160p": (3840, 2160)}[a.size]
     pkg = ge._load_pkg()
@@ -44,8 +46,22 @@ def main():
             p = slice_params(pkg, mode, a.range, a.refs, [lam] * 3, 10, W, H=H)
             pocs = [2 * (f - 1 - r) for r in range(a.refs)]
             lib.jmhip_epzs_scales(p, 2 * f, (C.c_int * a.refs)(*pocs), a.refs)
+            nmb = (W // 16) * (H // 16)
+            per = (nmb + a.slices - 1) // a.slices
             ctx.sync()
             t0 = time.perf_counter()
+            if a.slices > 1 and a.per_slice_calls:
+                tot = 0
+                for k in range(a.slices):
+                    p.mb_first, p.mb_count = k * per, min(per, nmb - k * per)
+                    ctx.p_slice_search(p, download=False)
+                    tot += ctx.slice_passes()
+                ctx.sync()
+                ts.append(time.perf_counter() - t0)
+                sw.append(tot)
+                continue
+            if a.slices > 1:
+                p.slice_mbs = per
             ctx.p_slice_search(p, download=False)
             ctx.sync()
             ts.append(time.perf_counter() - t0)
