@@ -2043,8 +2043,6 @@ extern "C" int jmhip_p_slice_search(jmhip_ctx *c, const jmhip_slice_params *prm,
     return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_p_slice_search: the exhaustive searches take the SAD metric at full-pel positions");
   if (prm->md_metric != 0 && prm->md_metric != 2) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_p_slice_search: mode-decision metric SAD or SATD");
   if (prm->slice_mbs < 0) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_p_slice_search: slice_mbs");
-  if (prm->slice_mbs > 0 && (prm->search_mode == JMHIP_SEARCH_EPZS || prm->search_mode == JMHIP_SEARCH_UMHEX))
-    return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_p_slice_search: several slices in one call (slice_mbs) need a search without slice-carried memories: modes -1, 0, 2");
   if (prm->transform8x8_mode < 0 || prm->transform8x8_mode > 2) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_p_slice_search: transform8x8_mode must be 0, 1 or 2");
   if (prm->transform8x8_mode && !prm->valid[4]) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_p_slice_search: Transform8x8Mode needs the 8x8 sub-mode (valid[4])");
   if (prm->transform8x8_mode == 1 && (prm->t8_qp < 0 || prm->t8_qp > 51 + 48 || prm->t8_disthres < 0 || prm->t8_disthres > 1))

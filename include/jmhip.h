@@ -329,8 +329,9 @@ typedef struct jmhip_slice_params {
   /* Several slices in ONE call (input->slice_mode 1, fixed macroblock count: BASELINE config 4's eight slices): slice_mbs > 0 cuts
    * [mb_first, mb_first + mb_count) into slices of slice_mbs macroblocks (the last one shorter). Neighbours across a slice boundary are
    * unavailable (src/mb_access.c:30-36); img->all_mv runs on from one slice's last macroblock to the next slice's first as in JM. The slices
-   * relax together: the sweeps a picture needs are those of its slowest slice, not their sum. Search modes -1, 0 and 2 (the walkers of modes 1
-   * and 3 keep memories that JM carries from slice to slice in coding order: one call per slice for those). 0 = one slice. */
+   * relax together: the sweeps a picture needs are those of its slowest slice, not their sum. All search modes: the memories of the EPZS and
+   * UMHexagonS walkers are picture-level arrays that JM carries on from slice to slice in coding order, which is what the stored rows of the
+   * relaxation hold. 0 = one slice. */
   int32_t slice_mbs;
 } jmhip_slice_params;
 

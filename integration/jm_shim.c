@@ -998,8 +998,8 @@ static void slice_run(int *lambda_factor)
   const int nmb = (int)img->PicSizeInMbs, first = img->current_mb_nr;
   int r, m, count = nmb - first, pocs[JMHIP_SLICE_REFS];
   memset(&p, 0, sizeof(p));
-  /* fixed-size slices and a search without slice-carried memories: all remaining slices of the picture in this one call (slice_mbs) */
-  sl.multi = input->slice_mode == 1 && input->slice_argument < count && (input->SearchMode == -1 || input->SearchMode == 0 || input->SearchMode == 2);
+  /* fixed-size slices: all remaining slices of the picture in this one call (slice_mbs) */
+  sl.multi = input->slice_mode == 1 && input->slice_argument < count;
   if (sl.multi) p.slice_mbs = input->slice_argument;
   else if (input->slice_mode == 1 && input->slice_argument < count) count = input->slice_argument;
   p.search_mode = input->SearchMode; p.search_range = input->search_range; p.full_search = input->full_search; p.num_refs = listXsize[LIST_0];

@@ -245,7 +245,7 @@ def test_jm_slice_level_binding_is_byte_identical(tmp_path, name):
     sl = re.search(r"P slices \(one device call each\)\s+device\s+(\d+)", stats)
     info = re.search(r"slice binding: (\d+) slices, (\d+) kernel passes", stats)
     print(name, m.groups(), sl.groups(), info.groups())
-    nslices = 4 if "slices_midrow" in name else 1          # 99 macroblocks in slices of 27 (one call per picture with slice_mbs: "one_call" cases)
+    nslices = 1          # also with four slices of 27 macroblocks per picture: all slices of a picture go in ONE device call (slice_mbs)
     assert int(sl.group(1)) == 3 * nslices, "one device call per P slice (3 P pictures), or per picture where the slices go in one call"
     per_mb = {0: 41, 1: 45, 2: 9}[SLICE_CASES[name]["t8x8"]]      # Transform8x8Mode 1: four more calls (the 8x8-transform P8x8 pass); 2: modes 1..3 + that pass only
     assert int(m.group(1)) >= 3 * 99 * per_mb and int(m.group(2)) == 0, "every BlockMotionSearch call of the P pictures must be served from the slice records"

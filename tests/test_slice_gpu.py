@@ -183,6 +183,8 @@ def run_synthetic(pkg, mode, W, H, R, nref, slices=1, nframes=3, seed=5, metric=
         if one_call:
             p = slice_params(pkg, mode, R, nref, lam3, ref_cost1, W, mb_first=0, mb_count=nmb, metric=metric, qp_n=qp, t8=t8, cavlc=cavlc)
             p.slice_mbs = per
+            if mode == 3:
+                lib.jmhip_epzs_scales(p, 2 * f, (C.c_int * nref)(*pocs), nref)
             got = ctx.p_slice_search(p)
             passes.append(ctx.slice_passes())
             compare(got, np.concatenate(wants), nref, "frame %d, %d slices in one call" % (f, slices))
@@ -392,3 +394,11 @@ def test_2160p_config4_eight_slices_in_one_call(pkg):
     """BASELINE config 4's picture and slice layout on ONE GPU: 3840x2160, FullSearch +-32, eight slices of 4050 macroblocks, one call."""
     passes = run_synthetic(pkg, -1, 3840, 2160, 32, 1, slices=8, nframes=2, seed=23, one_call=True)
     print("sweeps of the one call:", passes)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,slices", [(3, 5), (1, 5), (3, 2), (1, 3)])
+def test_walkers_with_memories_several_slices_in_one_call(pkg, mode, slices):
+    """EPZS and UMHexagonS keep picture-level memories (EPZSDistortion / EPZSMotion row arrays, the UMHexagonS cost maps) that JM carries on from
+    slice to slice in coding order: the stored rows of the relaxation hold exactly that, so their slices go in one call too."""
+    run_synthetic(pkg, mode, 320, 192, 16, 2, slices=slices, one_call=True)
