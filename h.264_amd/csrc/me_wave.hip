@@ -438,7 +438,7 @@ __device__ int subpel_full(int *mvx, int *mvy, int min_mcost)
 {
   const int start_hp = D.p.metric[0] != D.p.metric[1] ? 0 : 1, start_qp = D.p.metric[1] != D.p.metric[2] ? 0 : 1;
   const int max_x4 = (D.W - B.bsx + 2 * JMHIP_PAD) << 2, max_y4 = (D.H - B.bsy + 2 * JMHIP_PAD) << 2;
-  const int check0 = (B.ref == 0 && B.bt == 1 && *mvx == 0 && *mvy == 0);       // check_position0 (!rdopt, P slice)
+  const int check0 = (!D.p.rdopt && B.ref == 0 && B.bt == 1 && *mvx == 0 && *mvy == 0);       // check_position0 (!rdopt, P slice)
   for (int phase = 0; phase < 2; phase++) {
     const int step = phase ? 1 : 2, first = phase ? start_qp : start_hp, lam = D.p.lambda_mf[phase ? 2 : 1], m = phase ? 0 : 1;
     const int p4x = padq(B.pic_x, *mvx), p4y = padq(B.pic_y, *mvy);
@@ -475,7 +475,7 @@ __device__ int full_window(int cx, int cy, int R, int ffs, int *mvx, int *mvy)
   const int rowdw = B.bsx >> 2, seg = rowdw * B.bsy, cpb = 64 / seg;
   const int d = lane % seg, row = d / rowdw, c4 = d - row * rowdw;
   const uint32_t curv = *reinterpret_cast<const uint32_t *>(&L.cur[B.mb_y + row][B.mb_x + 4 * c4]);
-  const int check00 = (!ffs && B.bt == 1 && B.ref == 0);
+  const int check00 = (!ffs && !D.p.rdopt && B.bt == 1 && B.ref == 0);
   const int w16 = (lam * 16) >> 16;
   unsigned best = 0xffffffffu;
   __syncthreads();
@@ -515,7 +515,7 @@ __device__ int full_window(int cx, int cy, int R, int ffs, int *mvx, int *mvy)
           mc -= w16;
           if (dx == 0 && dy == 0 && mc < 0) v = rowsum;                  // INT_MAX - (negative) wraps: computeSAD leaves after row 0
         }
-        if (ffs && cx + dx == 0 && cy + dy == 0) tie = 0;                // pos_00 pre-check
+        if (ffs && !D.p.rdopt && cx + dx == 0 && cy + dy == 0) tie = 0;                // pos_00 pre-check (!rdopt, me_fullfast.c:867)
         const int cost = mc + v;                                          // may be slightly negative through the bonus
         const unsigned key = ((unsigned)(cost + 4096) << TIE_BITS) | (unsigned)tie;
         best = min(best, key);
@@ -600,7 +600,7 @@ __device__ int surface_search(int cx, int cy, int R, int ffs, int *mvx, int *mvy
   int pl[4], npl = 0;
   if (w4 >= 2 && h4 >= 2) { for (int j = y4 >> 1; j < (y4 + h4) >> 1; j++) for (int i = x4 >> 1; i < (x4 + w4) >> 1; i++) pl[npl++] = 16 + j * 2 + i; }
   else { for (int j = y4; j < y4 + h4; j++) for (int i = x4; i < x4 + w4; i++) pl[npl++] = j * 4 + i; }
-  const int check00 = (!ffs && B.bt == 1 && B.ref == 0), w16 = (lam * 16) >> 16;
+  const int check00 = (!ffs && !D.p.rdopt && B.bt == 1 && B.ref == 0), w16 = (lam * 16) >> 16;
   unsigned best = 0xffffffffu;
   // the surface reads are L2 hits with a long latency: eight candidates per lane are in flight at a time
   constexpr int UN = 8;
@@ -627,7 +627,7 @@ __device__ int surface_search(int cx, int cy, int R, int ffs, int *mvx, int *mvy
         mc -= w16;
         skip = (dx == 0 && dy == 0 && mc < 0);                         // the wrapped first-row bound: settled below
       }
-      if (ffs && cx + dx == 0 && cy + dy == 0) tie = 0;
+      if (ffs && !D.p.rdopt && cx + dx == 0 && cy + dy == 0) tie = 0;
       const unsigned key = ((unsigned)(mc + v[u] + 4096) << TIE_BITS) | (unsigned)tie;
       best = min(best, skip ? 0xffffffffu : key);
     }
@@ -1217,7 +1217,7 @@ __device__ int smp_full_subpel(int *mvx, int *mvy, int min_mcost)
   const jmhip_slice_params &P = D.p;
   const int start_hp = P.metric[0] != P.metric[1] ? 0 : 1, start_qp = P.metric[1] != P.metric[2] ? 0 : 1, lam = P.lambda_mf[2], metric = P.metric[2];
   const int sf = c_smp_shift[B.bt];
-  const int check0 = (B.ref == 0 && B.bt == 1 && *mvx == 0 && *mvy == 0);        // rdopt 0, P slice
+  const int check0 = (!D.p.rdopt && B.ref == 0 && B.bt == 1 && *mvx == 0 && *mvy == 0);        // !rdopt, P slice
   const int max_x4 = (D.W - B.bsx + 2 * JMHIP_PAD) << 2, max_y4 = (D.H - B.bsy + 2 * JMHIP_PAD) << 2;
   for (int phase = 0; phase < 2; phase++) {
     const int start = phase ? start_qp : start_hp, step = phase ? 1 : 2, lo = phase ? 0 : 1;
@@ -1351,7 +1351,7 @@ template <int SM> __device__ int block_motion_search(int mbx, int mby, int ref, 
     const int ub = bt > 6 ? 5 : bt > 4 ? 4 : bt == 4 ? 2 : 1;
     smp_upx = L.all_mv[block_y * 4 + block_x][ref][ub][0]; smp_upy = L.all_mv[block_y * 4 + block_x][ref][ub][1];
     mvx = B.pmx / 4; mvy = B.pmy / 4;
-    mvx = clampi(mvx, -R, R); mvy = clampi(mvy, -R, R);
+    if (!P.rdopt) { mvx = clampi(mvx, -R, R); mvy = clampi(mvy, -R, R); }
     mvx = clampi(mvx, -2047 + R, 2047 - R); mvy = clampi(mvy, P.level_mv_min + R, P.level_mv_max - R);
     min_mcost = smp_pel(R, &mvx, &mvy, min_mcost, smp_upx, smp_upy);
   } else if (SM == JMHIP_SEARCH_EPZS) {
@@ -1366,7 +1366,7 @@ template <int SM> __device__ int block_motion_search(int mbx, int mby, int ref, 
     if (bt == 1) {
       int cx = B.pmx / 4, cy = B.pmy / 4;
       const int Rf = (P.full_search == 2 || ref == 0) ? P.search_range : P.search_range / 2;
-      cx = clampi(cx, -Rf, Rf); cy = clampi(cy, -Rf, Rf);
+      if (!P.rdopt) { cx = clampi(cx, -Rf, Rf); cy = clampi(cy, -Rf, Rf); }
       cx = clampi(cx, -2047 + Rf, 2047 - Rf); cy = clampi(cy, P.level_mv_min + Rf, P.level_mv_max - Rf);
       L.motion_cost[0][ref][0] = cx; L.motion_cost[0][ref][1] = cy; L.motion_cost[0][ref][2] = Rf;
       surface_build(cx, cy, Rf);
@@ -1375,7 +1375,7 @@ template <int SM> __device__ int block_motion_search(int mbx, int mby, int ref, 
     if (min_mcost == INT_MIN) min_mcost = full_window(L.motion_cost[0][ref][0], L.motion_cost[0][ref][1], L.motion_cost[0][ref][2], 1, &mvx, &mvy);
   } else {
     int cx = B.pmx / 4, cy = B.pmy / 4;
-    cx = clampi(cx, -R, R); cy = clampi(cy, -R, R);
+    if (!P.rdopt) { cx = clampi(cx, -R, R); cy = clampi(cy, -R, R); }
     cx = clampi(cx, -2047 + R, 2047 - R); cy = clampi(cy, P.level_mv_min + R, P.level_mv_max - R);
     if (bt == 1) surface_build(cx, cy, min(R + SURF_MARGIN, 33 + SURF_MARGIN));     // the other partitions' centres are usually within the margin
     min_mcost = surface_search(cx, cy, R, 0, &mvx, &mvy);
@@ -1403,7 +1403,7 @@ template <int SM> __device__ int block_motion_search(int mbx, int mby, int ref, 
     else min_mcost = subpel_full(&mvx, &mvy, min_mcost);
   }
   WPROF(2);
-  if (bt == 1 && !(D.debug & 4)) {                                             // skip shortcut :829-849, every reference
+  if (bt == 1 && !P.rdopt && !(D.debug & 4)) {                                 // skip shortcut :826-849 (!rdopt), every reference
     find_skip_mv(mbx, mby);
     const int smx = L.all_mv[0][0][0][0], smy = L.all_mv[0][0][0][1];
     int cost;
@@ -2043,6 +2043,8 @@ extern "C" int jmhip_p_slice_search(jmhip_ctx *c, const jmhip_slice_params *prm,
     return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_p_slice_search: the exhaustive searches take the SAD metric at full-pel positions");
   if (prm->md_metric != 0 && prm->md_metric != 2) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_p_slice_search: mode-decision metric SAD or SATD");
   if (prm->slice_mbs < 0) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_p_slice_search: slice_mbs");
+  if (prm->rdopt && (prm->search_mode == JMHIP_SEARCH_EPZS || prm->search_mode == JMHIP_SEARCH_UMHEX))
+    return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_p_slice_search: rdopt != 0 (call records for the high-complexity modes) with search modes -1, 0, 2");
   if (prm->transform8x8_mode < 0 || prm->transform8x8_mode > 2) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_p_slice_search: transform8x8_mode must be 0, 1 or 2");
   if (prm->transform8x8_mode && !prm->valid[4]) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_p_slice_search: Transform8x8Mode needs the 8x8 sub-mode (valid[4])");
   if (prm->transform8x8_mode == 1 && (prm->t8_qp < 0 || prm->t8_qp > 51 + 48 || prm->t8_disthres < 0 || prm->t8_disthres > 1))

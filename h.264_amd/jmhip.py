@@ -102,7 +102,7 @@ class SliceParams(C.Structure):
                 ("umhex_dsr", C.c_int32), ("umhex_thres", (C.c_int32 * 8) * 4), ("umhex_bsize", C.c_float * 8), ("umhex_alpha1", C.c_float * 8),
                 ("umhex_alpha2", C.c_float * 8),
                 ("transform8x8_mode", C.c_int32), ("t8_qp", C.c_int32), ("t8_cavlc", C.c_int32), ("t8_disthres", C.c_int32),
-                ("t8_levelscale", C.c_int32 * 64), ("t8_leveloffset", C.c_int32 * 64), ("slice_mbs", C.c_int32)]
+                ("t8_levelscale", C.c_int32 * 64), ("t8_leveloffset", C.c_int32 * 64), ("slice_mbs", C.c_int32), ("rdopt", C.c_int32)]
 
 
 MB_INTER_DTYPE = np.dtype([("best_mode", "<i4"), ("min_cost", "<i4"), ("b8mode", "<i4", (4,)), ("b8ref", "<i4", (4,)),

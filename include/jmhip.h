@@ -333,6 +333,14 @@ typedef struct jmhip_slice_params {
    * UMHexagonS walkers are picture-level arrays that JM carries on from slice to slice in coding order, which is what the stored rows of the
    * relaxation hold. 0 = one slice. */
   int32_t slice_mbs;
+  /* input->rdopt as BlockMotionSearch sees it: 0 (the configuration whose decision this call reproduces); != 0 drops what JM does only with
+   * RDOptimization off -- the clamp of the search centre to the range (src/mv-search.c:755), check_for_00 / check_position0
+   * (src/me_fullsearch.c:75, :361), the pos_00 pre-check of FastFullSearch (src/me_fullfast.c:867), the skip shortcut (src/mv-search.c:826-849) --
+   * so that every BlockMotionSearch record is what JM's call WITH THAT PREDICTOR returns in the high-complexity modes too. The decision between
+   * the calls stays the low-complexity one: with rdopt != 0 it is a GUESS of JM's rate-distortion decision, and a caller answers a call from a
+   * record only when its own predictor equals the recorded one (the JM binding's speculative mode). Search modes -1, 0, 2 (pure functions of
+   * the predictor). */
+  int32_t rdopt;
 } jmhip_slice_params;
 
 /* what JM knows of one macroblock after the decision + the outcome of each of its BlockMotionSearch calls */

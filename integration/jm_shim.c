@@ -966,6 +966,8 @@ static struct {
   jmhip_mb_inter *rec; int cap;
   int decided, on;            /* once per run: is the configuration covered? */
   int multi;                  /* the records cover every remaining slice of the picture (slice_mbs) */
+  int spec;                   /* speculative mode (mask 0x2000): JM decides with rate-distortion costs / intra candidates; a call is answered only when
+                                 its predictor equals the record's, otherwise JM's own BlockMotionSearch runs */
   int started;                /* device state reset done */
   long passes, slices;
 } sl;
@@ -975,11 +977,17 @@ static int slice_mode_covered(void)
   int m;
   if (!sl.decided) {
     sl.decided = 1;
-    sl.on = (shim_mask & 0x1000) && input->rdopt == 0 && input->DisableIntraInInter && input->successive_Bframe == 0 && !input->PicInterlace &&
+    /* exact mode: the low-complexity decision without intra candidates is reproduced on the device, every call is answered.
+       speculative mode (mask 0x2000, exhaustive searches and the simplified UMHexagonS -- pure functions of the predictor): whatever JM's decision
+       is (RDOptimization 1 / 2, intra candidates, adaptive rounding), the device's low-complexity decision is the guess that keeps the predictors of
+       the following macroblocks right most of the time */
+    const int exact = input->rdopt == 0 && input->DisableIntraInInter && input->successive_Bframe == 0 && (input->Transform8x8Mode != 1 || !input->AdaptiveRounding);
+    sl.spec = !exact && (shim_mask & 0x2000) && (input->SearchMode == -1 || input->SearchMode == 0 || input->SearchMode == 2);
+    sl.on = (shim_mask & 0x1000) && (exact || sl.spec) && !input->PicInterlace &&
             !input->MbInterlace && !input->ChromaMEEnable && !input->DisableSubpelME &&
             /* Transform8x8Mode 1: the device quantises the 8x8-transform P8x8 pass to decide the partitioning (md_low.c:547): the slice's inter 8x8 tables
-               as they stand when the slice begins, so no adaptive rounding */
-            (input->Transform8x8Mode != 1 || (!input->AdaptiveRounding && input->InterSearch[0][4])) && (input->Transform8x8Mode != 2 || input->InterSearch[0][4]) &&
+               as they stand when the slice begins (exact mode: no adaptive rounding) */
+            (input->Transform8x8Mode == 0 || input->InterSearch[0][4]) &&
             (input->SearchMode == -1 || input->SearchMode == 0 || input->SearchMode == 1 || input->SearchMode == 2 || input->SearchMode == 3) &&
             !(input->SearchMode <= 0 && input->MEErrorMetric[F_PEL] != ERROR_SAD) && !input->EPZSSubPelGrid &&
             input->search_range <= 33 && input->num_ref_frames <= JMHIP_SLICE_REFS && (input->slice_mode == 0 || input->slice_mode == 1) &&
@@ -1018,6 +1026,7 @@ static void slice_run(int *lambda_factor)
   p.wp_pred = active_pps->weighted_pred_flag != 0; p.wp_me = p.wp_pred && input->UseWeightedReferenceME;
   p.wp_round = wp_luma_round; p.wp_denom = luma_log_weight_denom;
   p.mb_first = first; p.mb_count = count;
+  p.rdopt = input->rdopt;
   p.transform8x8_mode = input->Transform8x8Mode;
   if (input->Transform8x8Mode == 1) {                  /* the inter 8x8 luma quantiser (transform8x8.c:1487-1489) of the slice's macroblocks (no rate control: one qp) */
     const Macroblock *mb = &img->mb_data[img->current_mb_nr];
@@ -1083,6 +1092,24 @@ int BlockMotionSearch(short ref, int list, int mb_x, int mb_y, int blocktype, in
     rcost = (p < 0) ? 0 : first8 ? r->cost8ts[ref][p - 5] : r->cost[ref][p];
     /* the device predicted from ITS picture arrays; JM predicts from enc_picture: they must agree, or the slice has diverged */
     SetMotionVectorPredictor(pmv, enc_picture->ref_idx[list], enc_picture->mv[list], ref, list, bx, by, bsx, bsy);
+    if (sl.spec) {
+      /* speculative mode: a record is JM's answer exactly when the call's predictor is the record's and nothing the search reads beside it differs:
+         FastFullSearch -- the window centre, i.e. the 16x16 call of this (macroblock, reference) matched too; simplified UMHexagonS -- the upper
+         layer's vector, i.e. no earlier call of this (macroblock, reference) went to JM */
+      static int sp_mb = -1; static unsigned long sp_serial; static unsigned char sp_ok16[JMHIP_SLICE_REFS], sp_dirty[JMHIP_SLICE_REFS];
+      int hit;
+      if (sp_mb != img->current_mb_nr || sp_serial != pic_serial) { sp_mb = img->current_mb_nr; sp_serial = pic_serial; memset(sp_ok16, 0, sizeof(sp_ok16)); memset(sp_dirty, 0, sizeof(sp_dirty)); }
+      hit = p >= 0 && pmv[0] == rpred[0] && pmv[1] == rpred[1];
+      if (hit && input->SearchMode == 0 && blocktype != 1 && !sp_ok16[ref]) hit = 0;
+      if (hit && input->SearchMode == 2 && sp_dirty[ref]) hit = 0;
+      if (blocktype == 1) sp_ok16[ref] = (unsigned char)hit;
+      if (!hit) {
+        sp_dirty[ref] = 1;
+        if (!orig) orig = next_sym("BlockMotionSearch");
+        n_fwd[S_BMS]++;
+        return orig(ref, list, mb_x, mb_y, blocktype, search_range, lambda_factor);
+      }
+    } else
     if (p < 0 || pmv[0] != rpred[0] || pmv[1] != rpred[1]) {
       fprintf(stderr, "jm_shim: slice binding diverged at mb %d ref %d blocktype %d block (%d,%d)%s: JM predictor (%d,%d), device (%d,%d)\n",
               img->current_mb_nr, ref, blocktype, bx, by, first8 ? " [8x8-transform pass]" : "", pmv[0], pmv[1], p < 0 ? 0 : rpred[0], p < 0 ? 0 : rpred[1]);

@@ -247,7 +247,7 @@ static int block_motion_search(lc_ctx *c, int ref, int mb_x, int mb_y, int block
     const int ub = blocktype > 6 ? 5 : blocktype > 4 ? 4 : blocktype == 4 ? 2 : 1;
     up_mv[0] = c->all_mv[block_y][block_x][ref][ub][0]; up_mv[1] = c->all_mv[block_y][block_x][ref][ub][1];
     mv[0] = pred_mv[0] / 4; mv[1] = pred_mv[1] / 4;
-    mv[0] = (short)clip3(-search_range, search_range, mv[0]); mv[1] = (short)clip3(-search_range, search_range, mv[1]);      /* rdopt 0 */
+    if (!q->me.rdopt) { mv[0] = (short)clip3(-search_range, search_range, mv[0]); mv[1] = (short)clip3(-search_range, search_range, mv[1]); }
     mv[0] = (short)clip3(-2047 + search_range, 2047 - search_range, mv[0]);
     mv[1] = (short)clip3(p.level_mv_min + search_range, p.level_mv_max - search_range, mv[1]);
     min_mcost = jmo_umhexsmp_pel_search(&p, rp, orig, pic_pix_x, pic_pix_y, blocktype, pred_mv[0], pred_mv[1], &mv[0], &mv[1], search_range, min_mcost,
@@ -295,7 +295,7 @@ static int block_motion_search(lc_ctx *c, int ref, int mb_x, int mb_y, int block
       min_mcost = jmo_subpel_search(&p, rp, orig, ref == 0, pic_pix_x, pic_pix_y, blocktype, pred_mv[0], pred_mv[1], &mv[0], &mv[1], 9, 9, min_mcost, q->lambda_mf);
   }
   /* skip-mode shortcut :829-849 (every reference of the 16x16 block) */
-  if (blocktype == 1) {
+  if (blocktype == 1 && !q->me.rdopt) {                      /* :826: if (!input->rdopt) */
     int cost;
     find_skip_mv(c);
     cost = skip_cost(c, orig) - ((q->lambda_mf[JMO_Q_PEL] + 4096) >> 13);

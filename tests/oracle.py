@@ -662,14 +662,14 @@ BLOCKTYPE_LUT = {(0, 0): 7, (0, 1): 6, (1, 0): 5, (1, 1): 4, (1, 3): 3, (3, 1): 
 
 def lowcplx_params(search_mode, search_range, num_refs, lambda_mf, ref_cost1, W, H, epzs=None, umhex=None, full_search=2, metric=(0, 2, 2),
                    md_metric=2, valid=(1, 1, 1, 1, 1, 1, 1), frame_ctr_b=0, img_number=1, level_mv=(-511, 511), all_mv_state=None,
-                   transform8x8_mode=0, qp=28, cavlc=1):
+                   transform8x8_mode=0, qp=28, cavlc=1, rdopt=0):
     q = LowcplxParams()
     q.search_mode, q.search_range, q.num_refs, q.full_search = search_mode, search_range, num_refs, full_search
     for m in range(1, 8):
         q.valid[m] = valid[m - 1]
     q.lambda_mf[0], q.lambda_mf[1], q.lambda_mf[2] = lambda_mf
     q.ref_cost1, q.md_metric = ref_cost1, md_metric
-    q.me = me_params(rdopt=0, metric=metric, level_mv=level_mv, transform8x8_mode=transform8x8_mode)
+    q.me = me_params(rdopt=rdopt, metric=metric, level_mv=level_mv, transform8x8_mode=transform8x8_mode)      # rdopt != 0: what BlockMotionSearch does in the high-complexity modes; the decision stays the low-complexity one
     q.transform8x8_mode = transform8x8_mode
     if transform8x8_mode:                    # the inter 8x8 luma quantiser of the slice: flat matrices, default offset (342 / 2048), no adaptive rounding
         ls, ils, lo, _ = flat_tables(qp, 342, True)

@@ -276,3 +276,34 @@ def test_jm_1080p_full_search_slice_binding_is_byte_identical_and_faster(tmp_pat
     print("1080p I+P, FullSearch +-32: jm_plain %.1f s, jm_hip %.1f s; %s of %s BlockMotionSearch calls answered from the slice record (hit rate 100%%)" % (
         t_plain, t_hip, m.group(1), m.group(1)))
     assert t_hip < t_plain
+
+
+# ------------------------------------------------------------------ speculative slice binding (mask 0x2000): JM's own decision is rate-distortion optimised
+SPEC_CASES = {
+    "spec_full_rdopt1_intra": dict(search=-1, profile=66, cabac=0, t8x8=0, bframes=0, refs=2, rdopt=1, adrnd=1, yuv=1, noi=0),       # JM's defaults: RD decision, intra candidates
+    "spec_fastfull_rdopt1_high_t8": dict(search=0, profile=100, cabac=1, t8x8=1, bframes=0, refs=2, rdopt=1, adrnd=1, yuv=1, noi=0),
+    "spec_umhexsmp_rdopt2": dict(search=2, profile=77, cabac=1, t8x8=0, bframes=0, refs=2, rdopt=2, adrnd=0, yuv=1, noi=0),
+    "spec_full_lowcplx_with_intra": dict(search=-1, profile=66, cabac=0, t8x8=0, bframes=0, refs=1, rdopt=0, adrnd=1, yuv=1, noi=0),   # rdopt 0 but intra candidates on
+    "spec_fastfull_rdopt1_bframes": dict(search=0, profile=77, cabac=1, t8x8=0, bframes=1, refs=2, rdopt=1, adrnd=0, yuv=1, noi=0),     # P pictures bound, B pictures JM's
+}
+CASES.update(SPEC_CASES)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not HAVE, reason="oracle/_ref/jm_hip did not travel")
+@pytest.mark.parametrize("name", list(SPEC_CASES))
+def test_jm_speculative_slice_binding_is_byte_identical(tmp_path, name):
+    """RDOptimization 1 / 2 and intra candidates in P slices -- JM's default kind of configuration: the device searches the slice with its
+    low-complexity decision as the guess, a BlockMotionSearch call is answered from the record when JM's predictor equals the recorded one and runs
+    in JM otherwise. Identical bitstreams whatever the hit rate; the hit rate is what makes it worth it."""
+    prepare(tmp_path, name, frames=4)
+    want = run("jm_plain", tmp_path)
+    got = run("jm_hip", tmp_path, {"JMHIP_SHIM_STATS": "1", "JMHIP_SHIM": "3801"})
+    stats = got[2]
+    assert got[0] == want[0], "bitstream differs\n" + stats
+    assert got[1] == want[1], "reconstruction differs\n" + stats
+    m = re.search(r"^\s*BlockMotionSearch\s+device\s+(\d+)\s+forwarded\s+(\d+)", stats, re.M)
+    served, fwd = int(m.group(1)), int(m.group(2))
+    print(name, "served", served, "forwarded", fwd, "hit rate %.1f %%" % (100.0 * served / max(1, served + fwd)))
+    # (with B pictures the forwarded count includes every call of the B slices, which are JM's own)
+    assert served > 2000 and (served > fwd or SPEC_CASES[name]["bframes"]), "the speculation should hit for most calls of P pictures"

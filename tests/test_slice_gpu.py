@@ -15,7 +15,7 @@ FIELDS = ("pred", "mv_int", "cost_int", "mv", "cost")
 
 
 def slice_params(pkg, mode, R, nref, lambda_mf, ref_cost1, W, mb_first=0, mb_count=None, H=None, metric=(0, 2, 2), qp_n=QP_N, full_search=2,
-                 t8=0, t8_qp=None, cavlc=1):
+                 t8=0, t8_qp=None, cavlc=1, rdopt=0):
     lib = pkg.load_library()
     p = pkg.SliceParams()
     p.search_mode, p.search_range, p.full_search, p.num_refs = mode, R, full_search, nref
@@ -27,6 +27,7 @@ def slice_params(pkg, mode, R, nref, lambda_mf, ref_cost1, W, mb_first=0, mb_cou
     p.ref_cost1, p.md_metric = ref_cost1, 2
     p.metric[0], p.metric[1], p.metric[2] = metric
     p.level_mv_min, p.level_mv_max = -511, 511
+    p.rdopt = rdopt
     p.mb_first = mb_first
     p.mb_count = mb_count if mb_count is not None else (W // 16) * (H // 16) - mb_first
     lib.jmhip_epzs_setup(p, R, 2, 3, 2, 1, 1, 1, 0, 1, 2, 2)
@@ -122,7 +123,7 @@ def synth_clip(rng, W, H, nframes):
     return out
 
 
-def run_synthetic(pkg, mode, W, H, R, nref, slices=1, nframes=3, seed=5, metric=(0, 2, 2), qp=28, max_mbs=None, t8=0, cavlc=1, wp=None, one_call=False):
+def run_synthetic(pkg, mode, W, H, R, nref, slices=1, nframes=3, seed=5, metric=(0, 2, 2), qp=28, max_mbs=None, t8=0, cavlc=1, wp=None, one_call=False, rdopt=0):
     """Frames 1.. are coded as P pictures against the previous `nref` SOURCE frames (the search does not care where a reference came from)."""
     rng = np.random.default_rng(seed)
     clip = synth_clip(rng, W, H, nframes + nref - 1)
@@ -157,7 +158,7 @@ def run_synthetic(pkg, mode, W, H, R, nref, slices=1, nframes=3, seed=5, metric=
         for s in range(slices):
             first, count = s * per, min(per, nmb - s * per)
             q = oracle.lowcplx_params(mode, R, nref, lam3, ref_cost1, W, H, epzs=epzs, umhex=umhex, all_mv_state=all_mv_state, metric=metric,
-                                      transform8x8_mode=t8, qp=qp, cavlc=cavlc)
+                                      transform8x8_mode=t8, qp=qp, cavlc=cavlc, rdopt=rdopt)
             if wp:                                       # explicit weighted prediction, used in the search too (UseWeightedReferenceME): (denominator, [(weight, offset)] per reference)
                 q.wp_pred, q.me.apply_weights = 1, 1
                 q.me.luma_log_weight_denom, q.me.wp_luma_round = wp[0], (1 << (wp[0] - 1)) if wp[0] else 0
@@ -170,7 +171,7 @@ def run_synthetic(pkg, mode, W, H, R, nref, slices=1, nframes=3, seed=5, metric=
             if one_call:                                 # the device searches all slices of the picture in ONE call (slice_mbs) below
                 wants.append(want)
                 continue
-            p = slice_params(pkg, mode, R, nref, lam3, ref_cost1, W, mb_first=first, mb_count=count, metric=metric, qp_n=qp, t8=t8, cavlc=cavlc)
+            p = slice_params(pkg, mode, R, nref, lam3, ref_cost1, W, mb_first=first, mb_count=count, metric=metric, qp_n=qp, t8=t8, cavlc=cavlc, rdopt=rdopt)
             if mode == 3:
                 lib.jmhip_epzs_scales(p, 2 * f, (C.c_int * nref)(*pocs), nref)
             if wp:
@@ -181,7 +182,7 @@ def run_synthetic(pkg, mode, W, H, R, nref, slices=1, nframes=3, seed=5, metric=
             passes.append(ctx.slice_passes())
             compare(got, want, nref, "frame %d slice %d" % (f, s))
         if one_call:
-            p = slice_params(pkg, mode, R, nref, lam3, ref_cost1, W, mb_first=0, mb_count=nmb, metric=metric, qp_n=qp, t8=t8, cavlc=cavlc)
+            p = slice_params(pkg, mode, R, nref, lam3, ref_cost1, W, mb_first=0, mb_count=nmb, metric=metric, qp_n=qp, t8=t8, cavlc=cavlc, rdopt=rdopt)
             p.slice_mbs = per
             if mode == 3:
                 lib.jmhip_epzs_scales(p, 2 * f, (C.c_int * nref)(*pocs), nref)
@@ -402,3 +403,11 @@ def test_walkers_with_memories_several_slices_in_one_call(pkg, mode, slices):
     """EPZS and UMHexagonS keep picture-level memories (EPZSDistortion / EPZSMotion row arrays, the UMHexagonS cost maps) that JM carries on from
     slice to slice in coding order: the stored rows of the relaxation hold exactly that, so their slices go in one call too."""
     run_synthetic(pkg, mode, 320, 192, 16, 2, slices=slices, one_call=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,slices,t8", [(-1, 1, 0), (0, 2, 0), (2, 1, 0), (-1, 3, 1), (0, 1, 2)])
+def test_call_records_for_the_high_complexity_modes(pkg, mode, slices, t8):
+    """rdopt != 0: BlockMotionSearch without what JM does only with RDOptimization off (centre clamp, zero-vector bonuses, pos_00 pre-check, skip
+    shortcut) -- the records the JM binding answers from, speculatively, when the encoder runs its rate-distortion decision."""
+    run_synthetic(pkg, mode, 176, 144, 16, 2, slices=slices, rdopt=1, t8=t8, qp=30, one_call=slices > 1)
