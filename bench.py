@@ -175,7 +175,7 @@ def cpu_baseline_reference(frames):
                       % (MBW * MBH, me_ms, tot_ms, MBW * MBH / (tot_ms * 1e-3), wall, os.cpu_count())}
 
 
-def jm_end_to_end(frames, config3=False):
+def jm_end_to_end(frames, config3=False, rdopt1=False):
     """The reference encoder itself, same 1080p clip (frames 0-1: I + P), FullSearch +-32, low-complexity decision with intra off in the P
     picture (RDOptimization 0, DisableIntraInInter 1 -- the configuration whose whole P-slice search + inter decision is ONE device call):
     the unmodified JM (oracle/_ref/jm_plain) against JM bound to libjmhip.so at slice level (oracle/_ref/jm_hip, integration/jm_shim.c,
@@ -192,6 +192,8 @@ def jm_end_to_end(frames, config3=False):
             for (Y, U, V) in frames[:2]:
                 f.write(Y[:H_SRC].tobytes()); f.write(U[:H_SRC // 2].tobytes()); f.write(V[:H_SRC // 2].tobytes())
         cfg = (JM_CFG % (QP, QP, R)).replace("RDOptimization = 1", "RDOptimization = 0") + "DisableIntraInInter = 1\n"
+        if rdopt1:                                       # JM's default kind of configuration: rate-distortion optimised decision, intra candidates in P pictures
+            cfg = JM_CFG % (QP, QP, R)
         if config3:                                      # BASELINE config 3's tools: EPZS, Hadamard SAD at every level, 8x8 transform enabled, CABAC
             for a, b in (("ProfileIDC = 66", "ProfileIDC = 100"), ("SymbolMode = 0", "SymbolMode = 1"), ("SearchMode = -1", "SearchMode = 3"),
                          ("MEDistortionFPel = 0", "MEDistortionFPel = 2"), ("Transform8x8Mode = 0", "Transform8x8Mode = 1"), ("AdaptiveRounding = 1", "AdaptiveRounding = 0")):
@@ -201,7 +203,7 @@ def jm_end_to_end(frames, config3=False):
             f.write(cfg)
         digests = []
         for exe, key in zip(exes, ("jm_plain", "jm_hip")):
-            env = dict(os.environ, JMHIP_SHIM="1801", JMHIP_SHIM_STATS="1")
+            env = dict(os.environ, JMHIP_SHIM="3801" if rdopt1 else "1801", JMHIP_SHIM_STATS="1")
             t0 = time.perf_counter()
             try:
                 r = subprocess.run([exe, "-d", "min.cfg"], cwd=d, env=env, capture_output=True, text=True, timeout=400)
@@ -220,6 +222,11 @@ def jm_end_to_end(frames, config3=False):
                 out["block_motion_search_calls_served"] = int(mm.group(1)) if mm else None
                 out["block_motion_search_calls_forwarded"] = int(mm.group(2)) if mm else None
         out["bitstreams_identical"] = digests[0] == digests[1]
+        if rdopt1:
+            out["config"] = ("1920x1080 I+P, FullSearch +-32, 1 reference, RDOptimization 1, intra candidates in the P picture, CAVLC; jm_hip: JMHIP_SHIM=0x3801 "
+                             "(speculative slice binding: a BlockMotionSearch call is answered from the device's record when JM's predictor equals the recorded one, "
+                             "else JM's own search runs)")
+            return out
         out["config"] = ("1920x1080 I+P, EPZS +-32, Hadamard SAD at every level, Transform8x8Mode 1, CABAC, 1 reference, RDOptimization 0, DisableIntraInInter 1; jm_hip: JMHIP_SHIM=0x1801"
                          if config3 else "1920x1080 I+P, FullSearch +-32, 1 reference, RDOptimization 0, DisableIntraInInter 1, CAVLC; jm_hip: JMHIP_SHIM=0x1801")
     return out
@@ -639,6 +646,9 @@ def main():
             e2e = jm_end_to_end(frames, config3=True)
             if e2e is not None:
                 out["jm_end_to_end_config3_tools"] = e2e
+            e2e = jm_end_to_end(frames, rdopt1=True)
+            if e2e is not None:
+                out["jm_end_to_end_rdopt1_speculative"] = e2e
         if solo:
             out = {"DIAGNOSTIC_solo_rank": solo, "ms_per_step_of_this_rank": out["ms_per_step"], "stages_ms_per_launch": out.get("stages_ms_per_launch")}
         print(json.dumps(out))
