@@ -12,11 +12,15 @@
  * 0x200 bi-predictive full-pel + sub-pel search,
  * 0x400 RD-off mode-decision costs (TransformDecision, GetSkipCostMB),
  * 0x800 in-loop deblocking filter (DeblockFrame),
- * 0x1000 SLICE-LEVEL binding: in low-complexity mode with intra off in P slices (RDOptimization 0, DisableIntraInInter 1, no B pictures,
- *        4x4 transform) the whole motion search + inter decision of a P slice is ONE device call (jmhip_p_slice_search) issued when JM
- *        asks for the slice's first block; every BlockMotionSearch call of the slice is then answered from its result record -- after
- *        checking that JM's own motion-vector predictor equals the one the device used (anything else is a fatal error, never a
- *        silent difference).
+ * 0x1000 SLICE-LEVEL binding: in low-complexity mode with intra off in P slices (RDOptimization 0, DisableIntraInInter 1, no B pictures;
+ *        4x4 transform or Transform8x8Mode 1 / 2; every search mode) the whole motion search + inter decision of a P slice -- or of all
+ *        fixed-size slices of a picture -- is ONE device call (jmhip_p_slice_search) issued when JM asks for the slice's first block;
+ *        every BlockMotionSearch call of the slice is then answered from its result record -- after checking that JM's own
+ *        motion-vector predictor equals the one the device used (anything else is a fatal error, never a silent difference).
+ * 0x2000 (with 0x1000) SPECULATIVE slice binding for the configurations the exact form does not cover (RDOptimization 1 / 2, intra
+ *        candidates in P pictures; search modes -1, 0, 2, whose result is a pure function of the predictor): the device's low-complexity
+ *        decision is only a guess of JM's; a call is answered from the record when JM's predictor equals the recorded one and runs JM's
+ *        own search otherwise (counted as forwarded), so the bitstream is JM's whatever the guess was worth.
  *
  * The proof of the drop-in claim is tests/test_jm_shim_gpu.py: the bitstream and the reconstruction this encoder
  * writes are byte-identical to the unmodified encoder's.
