@@ -212,6 +212,7 @@ def jm_end_to_end(frames, config3=False, rdopt1=False):
             out[key + "_s"] = round(time.perf_counter() - t0, 2)
             m = re.search(r"^0001\(P\)\s+\d+\s+\d+\s+[\d.]+\s+[\d.]+\s+[\d.]+\s+(\d+)\s+(\d+)", r.stdout, re.M)
             if not m:
+                sys.stderr.write("jm_end_to_end: %s did not report a P frame (exit %d): %s\n" % (key, r.returncode, (r.stderr or r.stdout)[-600:]))
                 return None
             out[key + "_p_frame_ms"] = int(m.group(1))
             out[key + "_p_frame_me_ms"] = int(m.group(2))
@@ -221,6 +222,12 @@ def jm_end_to_end(frames, config3=False, rdopt1=False):
                 mm = re.search(r"^\s*BlockMotionSearch\s+device\s+(\d+)\s+forwarded\s+(\d+)", r.stderr, re.M)
                 out["block_motion_search_calls_served"] = int(mm.group(1)) if mm else None
                 out["block_motion_search_calls_forwarded"] = int(mm.group(2)) if mm else None
+                # wall time the shim spent inside its coarse device-side hooks, whole encode (transfers and layout conversion included)
+                out["jm_hip_hooks"] = {k.strip(): {"calls": int(n), "ms": float(v), "last_call_ms": float(l)} for k, n, v, l in
+                                       re.findall(r"^\s*(\S[^\n]*?)\s+device\s+(\d+)\s+forwarded\s+\d+\s+([\d.]+) ms inside the hook \(last call ([\d.]+) ms\)", r.stderr, re.M)}
+                ms = re.search(r"slice binding: (\d+) slices, (\d+) kernel passes", r.stderr)
+                if ms:
+                    out["jm_hip_slice_sweeps"] = int(ms.group(2))
         out["bitstreams_identical"] = digests[0] == digests[1]
         if rdopt1:
             out["config"] = ("1920x1080 I+P, FullSearch +-32, 1 reference, RDOptimization 1, intra candidates in the P picture, CAVLC; jm_hip: JMHIP_SHIM=0x3801 "

@@ -1,5 +1,7 @@
 // jmhip_ctx.hip -- context, device pictures, upload/download, stage timing (C ABI entry points)
 #include "jmhip_internal.h"
+#include <atomic>
+#include <thread>
 
 static void chroma_geometry(int yuv, ChromaGeom *g)   // lencod/src/lencod.c:2851-2884, img_chroma.c:390-405
 {
@@ -116,6 +118,8 @@ extern "C" void jmhip_ctx_destroy(jmhip_ctx *c)
     (void)hipFree(r.cr_sub[0]); (void)hipFree(r.cr_sub[1]);
   }
   (void)hipFree(c->cur_own[0]); (void)hipFree(c->cur_own[1]); (void)hipFree(c->cur_own[2]);
+  if (c->pin_host) (void)hipHostFree(c->pin_host);
+  for (auto e : c->pin_evt) (void)hipEventDestroy(e);
   (void)hipFree(c->stage_dev); (void)hipFree(c->me_jobs_dev); (void)hipFree(c->me_res_dev); (void)hipFree(c->ref_ptrs_dev); (void)hipFree(c->me_idx_dev); (void)hipFree(c->surf_dev); (void)hipFree(c->surf_jobs_dev);
   (void)hipFree(c->tq_jobs_dev); (void)hipFree(c->tq_res_dev); (void)hipFree(c->tq_quant_dev);
   (void)hipFree(c->fr_bi); (void)hipFree(c->fr_rec); (void)hipFree(c->fr_blk_ref); (void)hipFree(c->fr_jobs_y); (void)hipFree(c->fr_jobs_c); (void)hipFree(c->fr_res_y); (void)hipFree(c->fr_res_c);
@@ -375,6 +379,73 @@ extern "C" int jmhip_ref_download_chroma(jmhip_ctx *c, int ref, int uv, void *ou
   if (!c->Wc) return jm_fail(c, JMHIP_ERR_ARG, "4:0:0 has no chroma");
   if (!c->refs[ref].has_cr_sub) return jm_fail(c, JMHIP_ERR_ARG, "chroma sub-pel planes not built (call jmhip_interp_chroma)");
   return jm_download_planes(c, c->refs[ref].cr_sub[uv], (size_t)c->cg.sub_x * c->cg.sub_y * c->Wcp * c->Hcp, out, pel_bytes);
+}
+
+// Planes to the caller's own row pointers (JM keeps every plane as an array of rows, imgpel **): each plane travels as packed bytes into a
+// page-locked staging buffer, and while the next planes are still on the link the host widens / copies the arrived one row by row.
+static int download_planes_rows(jmhip_ctx *c, const uint8_t *src, int planes, int rows, int width, void *const *out_rows, int pel_bytes)
+{
+  if (!out_rows) return jm_fail(c, JMHIP_ERR_ARG, "NULL row table");
+  if (pel_bytes != 1 && pel_bytes != 2) return jm_fail(c, JMHIP_ERR_ARG, "pel_bytes must be 1 or 2");
+  JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
+  const size_t plane = (size_t)rows * width, n = plane * planes;
+  if (c->pin_bytes < n) {
+    if (c->pin_host) JM_HIP_CHECK(c, hipHostFree(c->pin_host));
+    c->pin_host = nullptr; c->pin_bytes = 0;
+    if (hipHostMalloc((void **)&c->pin_host, n, hipHostMallocDefault) != hipSuccess) return jm_fail(c, JMHIP_ERR_NOMEM, "page-locked staging buffer");
+    c->pin_bytes = n;
+  }
+  while ((int)c->pin_evt.size() < planes) {
+    hipEvent_t e;
+    JM_HIP_CHECK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    c->pin_evt.push_back(e);
+  }
+  for (int p = 0; p < planes; p++) {
+    JM_HIP_CHECK(c, hipMemcpyAsync(c->pin_host + p * plane, src + p * plane, plane, hipMemcpyDeviceToHost, c->stream));
+    JM_HIP_CHECK(c, hipEventRecord(c->pin_evt[p], c->stream));
+  }
+  // the host side of the copy is memory-bound row work on up to a few hundred MB: a handful of threads, each taking every T-th plane as it arrives
+  int T = 4;
+  if (const char *e = getenv("JMHIP_HOST_THREADS")) T = atoi(e);
+  T = std::max(1, std::min(T, std::min(planes, 16)));
+  std::atomic<int> failed{0};
+  auto work = [&](int t) {
+    if (t && hipSetDevice(c->cfg.device) != hipSuccess) { failed = 1; return; }
+    for (int p = t; p < planes; p += T) {
+      if (hipEventSynchronize(c->pin_evt[p]) != hipSuccess) { failed = 1; return; }
+      for (int j = 0; j < rows; j++) {
+        const uint8_t *__restrict__ s = c->pin_host + p * plane + (size_t)j * width;
+        if (pel_bytes == 1) memcpy(out_rows[(size_t)p * rows + j], s, (size_t)width);
+        else {
+          uint16_t *__restrict__ d = static_cast<uint16_t *>(out_rows[(size_t)p * rows + j]);
+          for (int i = 0; i < width; i++) d[i] = s[i];
+        }
+      }
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < T; t++) pool.emplace_back(work, t);
+  work(0);
+  for (auto &th : pool) th.join();
+  if (failed) return jm_fail(c, JMHIP_ERR_DEVICE, "download of planes into rows");
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_ref_download_luma_rows(jmhip_ctx *c, int ref, void *const *rows, int pel_bytes)
+{
+  if (!c) return JMHIP_ERR_ARG;
+  if (ref < 0 || ref >= (int)c->refs.size()) return jm_fail(c, JMHIP_ERR_ARG, "ref slot out of range");
+  if (!c->refs[ref].has_luma_sub) return jm_fail(c, JMHIP_ERR_ARG, "luma sub-pel planes not built (call jmhip_interp_luma)");
+  return download_planes_rows(c, c->refs[ref].luma_sub, 16, c->Hp, c->Wp, rows, pel_bytes);
+}
+
+extern "C" int jmhip_ref_download_chroma_rows(jmhip_ctx *c, int ref, int uv, void *const *rows, int pel_bytes)
+{
+  if (!c) return JMHIP_ERR_ARG;
+  if (ref < 0 || ref >= (int)c->refs.size() || uv < 0 || uv > 1) return jm_fail(c, JMHIP_ERR_ARG, "ref/uv out of range");
+  if (!c->Wc) return jm_fail(c, JMHIP_ERR_ARG, "4:0:0 has no chroma");
+  if (!c->refs[ref].has_cr_sub) return jm_fail(c, JMHIP_ERR_ARG, "chroma sub-pel planes not built (call jmhip_interp_chroma)");
+  return download_planes_rows(c, c->refs[ref].cr_sub[uv], c->cg.sub_x * c->cg.sub_y, c->Hcp, c->Wcp, rows, pel_bytes);
 }
 
 extern "C" int jmhip_interp_luma(jmhip_ctx *c, int ref)

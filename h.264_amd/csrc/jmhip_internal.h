@@ -36,6 +36,9 @@ struct jmhip_ctx {
   bool has_cur = false;
   // staging for 16-bit sample conversion
   void *stage_dev = nullptr; size_t stage_bytes = 0;
+  // page-locked host staging of the row-pointer downloads (jmhip_ref_download_*_rows) and one event per plane in flight
+  uint8_t *pin_host = nullptr; size_t pin_bytes = 0;
+  std::vector<hipEvent_t> pin_evt;
   // ME job/result arrays
   void *me_jobs_dev = nullptr; void *me_res_dev = nullptr; int me_capacity = 0; int me_n = 0;
   int me_max_uw = 0, me_max_uh = 0, me_last_mode = 0, me_last_R = 0, me_last_rdopt = 0, me_last_lvl[2] = {0, 0};

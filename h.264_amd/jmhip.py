@@ -168,6 +168,8 @@ def load_library():
     lib.jmhip_interp_chroma.argtypes = [vp, ip]
     lib.jmhip_ref_download_luma.argtypes = [vp, ip, vp, ip]
     lib.jmhip_ref_download_chroma.argtypes = [vp, ip, ip, vp, ip]
+    lib.jmhip_ref_download_luma_rows.argtypes = [vp, ip, vp, ip]
+    lib.jmhip_ref_download_chroma_rows.argtypes = [vp, ip, ip, vp, ip]
     lib.jmhip_ref_device_planes.argtypes = [vp, ip, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(ip), C.POINTER(ip)]
     lib.jmhip_partition_info.argtypes = [ip] + [C.POINTER(ip)] * 5
     lib.jmhip_partition_info.restype = None
@@ -358,6 +360,24 @@ class Context:
     def download_chroma_planes(self, ref, uv, dtype=np.uint8):
         out = np.empty((self.sub[1], self.sub[0], self.Hcp, self.Wcp), dtype=dtype)
         self._chk(self.lib.jmhip_ref_download_chroma(self.h, ref, uv, _ptr(out), out.dtype.itemsize), "jmhip_ref_download_chroma")
+        return out
+
+    @staticmethod
+    def _row_table(out, gap):
+        """Row pointers into `out` [planes.., rows, width + gap] (JM's imgpel ** layout; `gap` unused samples after every row)."""
+        flat = out.reshape(-1, out.shape[-1])
+        base, pitch = flat.ctypes.data, flat.strides[0]
+        return (C.c_void_p * flat.shape[0])(*[base + j * pitch for j in range(flat.shape[0])])
+
+    def download_luma_rows(self, ref, dtype=np.uint16, gap=0):
+        """The 16 luma sub-pel planes through the row-pointer entry the JM binding uses (jmhip_ref_download_luma_rows)."""
+        out = np.zeros((4, 4, self.Hp, self.Wp + gap), dtype=dtype)
+        self._chk(self.lib.jmhip_ref_download_luma_rows(self.h, ref, self._row_table(out, gap), out.dtype.itemsize), "jmhip_ref_download_luma_rows")
+        return out
+
+    def download_chroma_rows(self, ref, uv, dtype=np.uint16, gap=0):
+        out = np.zeros((self.sub[1], self.sub[0], self.Hcp, self.Wcp + gap), dtype=dtype)
+        self._chk(self.lib.jmhip_ref_download_chroma_rows(self.h, ref, uv, self._row_table(out, gap), out.dtype.itemsize), "jmhip_ref_download_chroma_rows")
         return out
 
     # ---- motion estimation

@@ -107,6 +107,13 @@ int jmhip_interp_luma_rows(jmhip_ctx *ctx, int ref, int row0, int row1);
  * uv = 0/1) planes of padded size, contiguous, pel_bytes per sample. */
 int jmhip_ref_download_luma(jmhip_ctx *ctx, int ref, void *out, int pel_bytes);
 int jmhip_ref_download_chroma(jmhip_ctx *ctx, int ref, int uv, void *out, int pel_bytes);
+/* The same planes delivered the way JM stores them (imgY_sub[4][4][row], imgUV_sub[uv][sy][sx][row]: arrays of ROW pointers,
+ * inc/global.h StorablePicture): rows[plane * padded_height + row] points to padded_width samples of pel_bytes each. This is what the
+ * JM binding calls after jmhip_interp_luma / _chroma, because JM's own motion compensation (LumaPrediction, src/macroblock.c:836) reads
+ * the planes on the host: packed bytes cross the link into a page-locked staging buffer plane by plane, and the arrived planes are
+ * widened into the caller's rows while the rest are still in flight. */
+int jmhip_ref_download_luma_rows(jmhip_ctx *ctx, int ref, void *const *rows, int pel_bytes);
+int jmhip_ref_download_chroma_rows(jmhip_ctx *ctx, int ref, int uv, void *const *rows, int pel_bytes);
 
 /* Device addresses of a slot's integer-pel picture (for device-to-device exchange, e.g. the RCCL
  * all-gather of reconstructed slice bands): pitch in bytes. */

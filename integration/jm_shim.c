@@ -31,6 +31,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <limits.h>
+#include <time.h>
 
 #include "global.h"
 #include "mbuffer.h"
@@ -57,6 +58,9 @@ static const char *s_names[S_COUNT] = { "getSubImagesLuma", "getSubImagesChroma"
   "TransformDecision", "GetSkipCostMB", "BIDPartitionCost", "DeblockFrame",
   "P slices (one device call each)", "BlockMotionSearch" };
 static long n_dev[S_COUNT], n_fwd[S_COUNT];
+static double t_dev[S_COUNT], t_last[S_COUNT];             /* JMHIP_SHIM_STATS: wall seconds inside the coarse device-side hooks (planes, slice search, loop filter) */
+static int stats_on;
+static double now_s(void) { struct timespec ts; if (!stats_on) return 0.0; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
 static unsigned shim_mask = 0x1fff;
 static int verify;            /* JMHIP_SHIM_VERIFY=1: run JM's own search beside the device's and report differences */
 static jmhip_ctx *g;
@@ -82,7 +86,11 @@ static void print_stats(void)
   int i;
   if (!getenv("JMHIP_SHIM_STATS")) return;
   fprintf(stderr, "jm_shim: mask=0x%x\n", shim_mask);
-  for (i = 0; i < S_COUNT; i++) fprintf(stderr, "  %-30s device %8ld  forwarded %8ld\n", s_names[i], n_dev[i], n_fwd[i]);
+  for (i = 0; i < S_COUNT; i++) {
+    fprintf(stderr, "  %-30s device %8ld  forwarded %8ld", s_names[i], n_dev[i], n_fwd[i]);
+    if (t_dev[i] > 0.0) fprintf(stderr, "  %8.1f ms inside the hook (last call %.1f ms)", t_dev[i] * 1e3, t_last[i] * 1e3);
+    fprintf(stderr, "\n");
+  }
   if (sl_slices()) fprintf(stderr, "  slice binding: %ld slices, %ld kernel passes\n", sl_slices(), sl_passes());
 }
 
@@ -91,6 +99,7 @@ int main(int argc, char **argv)
   const char *m = getenv("JMHIP_SHIM");
   if (m) shim_mask = (unsigned)strtoul(m, NULL, 16);
   verify = getenv("JMHIP_SHIM_VERIFY") != NULL;
+  stats_on = getenv("JMHIP_SHIM_STATS") != NULL;
   atexit(print_stats);
   return jm_main(argc, argv);
 }
@@ -173,7 +182,7 @@ static void jm_side_effects(StorablePicture *rp)
 void getSubImagesLuma(StorablePicture *s)
 {
   static void (*orig)(StorablePicture *);
-  static imgpel *tmp; static size_t tmp_n;
+  static void **rows; static size_t rows_n;
   if (!(shim_mask & 0x01) || !frame_ok(s) || s->p_curr_img != s->imgY) {
     /* (4:4:4 independent planes interpolate U/V through this function too: left to JM) */
     int i = slot_find(s);
@@ -182,26 +191,26 @@ void getSubImagesLuma(StorablePicture *s)
     n_fwd[S_LUMA]++; orig(s); return;
   }
   {
-    const int Wp = s->size_x_padded, Hp = s->size_y_padded;
-    const size_t need = (size_t)16 * Wp * Hp;
+    const int Hp = s->size_y_padded;
+    const size_t need = (size_t)16 * Hp;
     int slot = slot_assign(s), p, j;
-    if (tmp_n < need) { free(tmp); tmp = malloc(need * sizeof(imgpel)); tmp_n = need; }
+    const double t0 = now_s();
+    if (rows_n < need) { free(rows); rows = malloc(need * sizeof(*rows)); rows_n = need; }
     /* UnifiedOneForthPix calls this on the finished picture, chroma included (image.c:1642-1659) */
     OK(jmhip_ref_upload(g, slot, s->imgY[0], img->yuv_format != YUV400 ? s->imgUV[0][0] : NULL,
                         img->yuv_format != YUV400 ? s->imgUV[1][0] : NULL, (int)sizeof(imgpel), s->size_x, s->size_x_cr, 0));
     OK(jmhip_interp_luma(g, slot));
-    OK(jmhip_ref_download_luma(g, slot, tmp, (int)sizeof(imgpel)));      /* JM's own MC reads imgY_sub */
-    for (p = 0; p < 16; p++)
-      for (j = 0; j < Hp; j++)
-        memcpy(s->p_curr_img_sub[p >> 2][p & 3][j], tmp + ((size_t)p * Hp + j) * Wp, sizeof(imgpel) * Wp);
-    n_dev[S_LUMA]++;
+    /* JM's own MC reads imgY_sub on the host: every plane straight into JM's rows */
+    for (p = 0; p < 16; p++) for (j = 0; j < Hp; j++) rows[(size_t)p * Hp + j] = s->p_curr_img_sub[p >> 2][p & 3][j];
+    OK(jmhip_ref_download_luma_rows(g, slot, rows, (int)sizeof(imgpel)));
+    n_dev[S_LUMA]++; t_last[S_LUMA] = now_s() - t0; t_dev[S_LUMA] += t_last[S_LUMA];
   }
 }
 
 void getSubImagesChroma(StorablePicture *s)
 {
   static void (*orig)(StorablePicture *);
-  static imgpel *tmp; static size_t tmp_n;
+  static void **rows; static size_t rows_n;
   int slot = g ? slot_find(s) : -1;
   if (!(shim_mask & 0x01) || slot < 0 || img->yuv_format == YUV400) {
     if (!orig) orig = next_sym("getSubImagesChroma");
@@ -209,19 +218,18 @@ void getSubImagesChroma(StorablePicture *s)
   }
   {
     const int sub_x = img->yuv_format == YUV444 ? 4 : 8, sub_y = img->yuv_format == YUV420 ? 8 : 4;
-    const int Wcp = s->size_x_cr + 2 * img_pad_size_uv_x, Hcp = s->size_y_cr + 2 * img_pad_size_uv_y;
-    const size_t need = (size_t)sub_x * sub_y * Wcp * Hcp;
+    const int Hcp = s->size_y_cr + 2 * img_pad_size_uv_y;
+    const size_t need = (size_t)sub_x * sub_y * Hcp;
     int uv, p, j;
-    if (tmp_n < need) { free(tmp); tmp = malloc(need * sizeof(imgpel)); tmp_n = need; }
+    const double t0 = now_s();
+    if (rows_n < need) { free(rows); rows = malloc(need * sizeof(*rows)); rows_n = need; }
     OK(jmhip_interp_chroma(g, slot));
     for (uv = 0; uv < 2; uv++) {
-      OK(jmhip_ref_download_chroma(g, slot, uv, tmp, (int)sizeof(imgpel)));
-      for (p = 0; p < sub_x * sub_y; p++)
-        for (j = 0; j < Hcp; j++)
-          memcpy(s->imgUV_sub[uv][p / sub_x][p % sub_x][j], tmp + ((size_t)p * Hcp + j) * Wcp, sizeof(imgpel) * Wcp);
+      for (p = 0; p < sub_x * sub_y; p++) for (j = 0; j < Hcp; j++) rows[(size_t)p * Hcp + j] = s->imgUV_sub[uv][p / sub_x][p % sub_x][j];
+      OK(jmhip_ref_download_chroma_rows(g, slot, uv, rows, (int)sizeof(imgpel)));
     }
     slots[slot].has_chroma = 1;
-    n_dev[S_CHROMA]++;
+    n_dev[S_CHROMA]++; t_last[S_CHROMA] = now_s() - t0; t_dev[S_CHROMA] += t_last[S_CHROMA];
   }
 }
 
@@ -1009,6 +1017,7 @@ static void slice_run(int *lambda_factor)
   jmhip_slice_params p;
   const int nmb = (int)img->PicSizeInMbs, first = img->current_mb_nr;
   int r, m, count = nmb - first, pocs[JMHIP_SLICE_REFS];
+  const double t0 = now_s();
   memset(&p, 0, sizeof(p));
   /* fixed-size slices: all remaining slices of the picture in this one call (slice_mbs) */
   sl.multi = input->slice_mode == 1 && input->slice_argument < count;
@@ -1061,7 +1070,7 @@ static void slice_run(int *lambda_factor)
   { int n = 0; jmhip_slice_result_info(g, &n); sl.passes += n; }
   sl.slices++;
   sl.active = 1; sl.serial = pic_serial; sl.slice_nr = img->current_slice_nr; sl.mb_first = first; sl.mb_count = count;
-  n_dev[S_SLICE]++;
+  n_dev[S_SLICE]++; t_last[S_SLICE] = now_s() - t0; t_dev[S_SLICE] += t_last[S_SLICE];
 }
 
 static long sl_slices(void) { return sl.slices; }
@@ -1153,6 +1162,7 @@ void DeblockFrame(ImageParameters *im, imgpel **imgY, imgpel ***imgUV)
   const int W = im->width, H = im->height, nmb = (int)im->PicSizeInMbs, w4 = W / 4, h4 = H / 4;
   const int chroma = imgUV && im->yuv_format != YUV400;
   int i, l, x, y;
+  double t0;
   int ok = (shim_mask & 0x800) && !im->MbaffFrameFlag && im->structure == FRAME && im->type != SP_SLICE && im->type != SI_SLICE &&
            imgUV && !(im->yuv_format == YUV444 && IS_INDEPENDENT(input)) && ctx_ready() && W == g_w && H == g_h &&
            imgY[1] == imgY[0] + W && (!chroma || imgUV[0][1] == imgUV[0][0] + im->width_cr);
@@ -1163,6 +1173,7 @@ void DeblockFrame(ImageParameters *im, imgpel **imgY, imgpel ***imgUV)
     return;
   }
   n_dev[S_DEBLOCK]++;
+  t0 = now_s();
   if (!mbs) {
     mbs = malloc(sizeof(*mbs) * (size_t)nmb);
     blks = malloc(sizeof(*blks) * (size_t)w4 * h4);
@@ -1190,4 +1201,5 @@ void DeblockFrame(ImageParameters *im, imgpel **imgY, imgpel ***imgUV)
   OK(jmhip_deblock_frame(g, mbs, blks, 4, 0, 0));
   OK(jmhip_recon_download(g, imgY[0], chroma ? imgUV[0][0] : NULL, chroma ? imgUV[1][0] : NULL, 2));
   im->current_mb_nr = nmb - 1;                                                     /* where DeblockMb :178 leaves it */
+  t_last[S_DEBLOCK] = now_s() - t0; t_dev[S_DEBLOCK] += t_last[S_DEBLOCK];
 }

@@ -64,3 +64,27 @@ def test_uint16_imgpel_boundary(pkg):
     got = ctx.download_luma_planes(0, dtype=np.uint16)
     assert np.array_equal(got, oracle.interp_luma(Y))
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt,w,h,dtype,gap", [(1, 176, 144, np.uint16, 0), (2, 64, 48, np.uint16, 5), (1, 1920, 1088, np.uint16, 0), (3, 64, 48, np.uint8, 3)])
+def test_planes_into_row_pointers(pkg, fmt, w, h, dtype, gap):
+    """The JM binding's download (jmhip_ref_download_luma_rows / _chroma_rows): the planes land in the caller's own rows -- JM's imgpel **
+    layout, here with `gap` unused samples after every row -- equal to the contiguous download, nothing written past a row's end; called twice
+    (the page-locked staging buffer and its events are reused)."""
+    rng = np.random.default_rng(fmt * 31 + w)
+    wc, hc = (w // 2, h // 2) if fmt == 1 else ((w // 2, h) if fmt == 2 else (w, h))
+    ctx = pkg.Context(w, h, yuv_format=fmt, max_refs=2)
+    for slot in (0, 1):
+        Y = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        U = rng.integers(0, 256, (hc, wc), dtype=np.uint8)
+        V = rng.integers(0, 256, (hc, wc), dtype=np.uint8)
+        ctx.ref_upload(slot, Y, U, V)
+        ctx.interp_luma(slot)
+        ctx.interp_chroma(slot)
+        got = ctx.download_luma_rows(slot, dtype=dtype, gap=gap)
+        assert np.array_equal(got[..., :ctx.Wp], ctx.download_luma_planes(slot)) and not got[..., ctx.Wp:].any()
+        for uv in (0, 1):
+            got = ctx.download_chroma_rows(slot, uv, dtype=dtype, gap=gap)
+            assert np.array_equal(got[..., :ctx.Wcp], ctx.download_chroma_planes(slot, uv)) and not got[..., ctx.Wcp:].any()
+    ctx.close()

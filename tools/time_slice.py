@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--range", type=int, default=32)
     ap.add_argument("--frames", type=int, default=4)
     ap.add_argument("--slices", type=int, default=1, help="fixed-size slices per picture (search modes -1, 0, 2)")
+    ap.add_argument("--rdopt", type=int, default=0, help="the call records of RDOptimization 1 / 2 (search modes -1, 0, 2; the speculative binding's call)")
+    ap.add_argument("--download", action="store_true", help="include the download of the result records in the timed region")
     ap.add_argument("--per-slice-calls", action="store_true", help="with --slices: one call per slice instead of slice_mbs")
     a = ap.parse_args()
     W, H = {"1080p": (1920, 1088), "720p": (1280, 720), "qcif": (176, 144), "2160p": (3840, 2160)}[a.size]
@@ -62,7 +64,8 @@ def main():
                 continue
             if a.slices > 1:
                 p.slice_mbs = per
-            ctx.p_slice_search(p, download=False)
+            p.rdopt = a.rdopt
+            ctx.p_slice_search(p, download=a.download)
             ctx.sync()
             ts.append(time.perf_counter() - t0)
             sw.append(ctx.slice_passes())
