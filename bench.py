@@ -210,6 +210,9 @@ def jm_end_to_end(frames, config3=False, rdopt1=False):
             except Exception:
                 return None
             out[key + "_s"] = round(time.perf_counter() - t0, 2)
+            if os.environ.get("JMHIP_E2E_STDERR"):           # diagnostics (e.g. with JMHIP_SLICE_TRACE=1): keep what the encoders wrote to stderr
+                with open(os.environ["JMHIP_E2E_STDERR"], "a") as f:
+                    f.write("==== %s\n%s\n" % (key, r.stderr))
             m = re.search(r"^0001\(P\)\s+\d+\s+\d+\s+[\d.]+\s+[\d.]+\s+[\d.]+\s+(\d+)\s+(\d+)", r.stdout, re.M)
             if not m:
                 sys.stderr.write("jm_end_to_end: %s did not report a P frame (exit %d): %s\n" % (key, r.returncode, (r.stderr or r.stdout)[-600:]))
