@@ -111,7 +111,8 @@ int jmhip_ref_download_chroma(jmhip_ctx *ctx, int ref, int uv, void *out, int pe
  * inc/global.h StorablePicture): rows[plane * padded_height + row] points to padded_width samples of pel_bytes each. This is what the
  * JM binding calls after jmhip_interp_luma / _chroma, because JM's own motion compensation (LumaPrediction, src/macroblock.c:836) reads
  * the planes on the host: packed bytes cross the link into a page-locked staging buffer plane by plane, and the arrived planes are
- * widened into the caller's rows while the rest are still in flight. */
+ * widened into the caller's rows while the rest are still in flight (by four host threads; JMHIP_HOST_THREADS=n sets another count, 1 = the
+ * calling thread alone). */
 int jmhip_ref_download_luma_rows(jmhip_ctx *ctx, int ref, void *const *rows, int pel_bytes);
 int jmhip_ref_download_chroma_rows(jmhip_ctx *ctx, int ref, int uv, void *const *rows, int pel_bytes);
 
