@@ -45,6 +45,10 @@ struct WaveDev {
   short *carry_mb;                             // [nmb][WR][CARRY][2]: img->all_mv entries every macroblock leaves for the next one in coding order
   // relaxation schedule (p_slice_relax_kernel): which macroblocks changed what they hand on, last sweep / this sweep
   const uint8_t *chg_prev; uint8_t *chg_next; int *n_changed; int first_sweep;
+  // ... and, exhaustive searches: which (reference, partition) call records a macroblock's last evaluation in THIS call wrote. A call whose
+  // predictor equals the recorded one is a pure function of it (FastFull: and of the reference's 16x16 predictor, the window centre), so a
+  // re-evaluation takes the record instead of searching again -- what is recomputed in later sweeps is only what actually changed
+  unsigned long long *memo; int memo_on;
   uint16_t *surf;                              // exhaustive searches: per row, per reference, SAD surfaces [SURF_PLANES][surf_n]
   int surf_n;                                  // candidates per plane (capacity)
   int debug;                                   // JMHIP_WAVE_DEBUG (timing experiments only; results are wrong): 1 no sub-pel, 2 no integer search, 4 no skip cost
@@ -72,6 +76,8 @@ struct Lds {
   // Grid [y + 1][x + 1] of the 4x4 blocks x = -1..4, y = -1..3: the macroblock's own sixteen and the ring its predictors read (A, B, C, D)
   int mbx, mby;
   int pass8ts;                                 // inside the 8x8-transform P8x8 pass (Transform8x8Mode): the call records go to the *8ts arrays
+  int memo_live, ff_same[WR];                  // this evaluation may reuse call records (WaveDev.memo); FastFull: the reference's window centre is the recorded one
+  unsigned long long memo_old[WR], memo_new[WR];
   int8_t f_ref[5][6];                          // enc_picture->ref_idx[LIST_0]
   short f_mv[5][6][2];                         // enc_picture->mv[LIST_0]
   int um_loc[8][5][6];                         // fastme_l0_cost per block type
@@ -1340,6 +1346,16 @@ template <int SM> __device__ int block_motion_search(int mbx, int mby, int ref, 
   mv_predictor(mbx, mby, ref, mb_x, mb_y, B.bsx, B.bsy, &B.pmx, &B.pmy, SM == JMHIP_SEARCH_UMHEX && P.umhex_dsr, bt, &search_range, nullptr);
   WPROF(0);
   const int R = search_range;
+  if ((SM == JMHIP_SEARCH_FULL || SM == JMHIP_SEARCH_FASTFULL) && L.memo_live) {
+    const bool same = ((L.memo_old[ref] >> pi) & 1) && out->pred[ref][pi][0] == B.pmx && out->pred[ref][pi][1] == B.pmy;
+    if (bt == 1) L.ff_same[ref] = same;                                       // (one wave: every lane stores the same value)
+    else if (same && (SM == JMHIP_SEARCH_FULL || L.ff_same[ref])) {
+      mvx = out->mv[ref][pi][0]; mvy = out->mv[ref][pi][1]; min_mcost = out->cost[ref][pi];
+      for (int j = block_y; j < block_y + (B.bsy >> 2); j++) for (int i = block_x; i < block_x + (B.bsx >> 2); i++) { L.all_mv[j * 4 + i][ref][bt][0] = (short)mvx; L.all_mv[j * 4 + i][ref][bt][1] = (short)mvy; }
+      if (threadIdx.x == 0) L.memo_new[ref] |= 1ull << pi;
+      return min_mcost;
+    }
+  }
   if (D.debug & 2) { mvx = clampi((B.pmx + 2) >> 2, -R, R); mvy = clampi((B.pmy + 2) >> 2, -R, R); min_mcost = 1000; }
   else if (SM == JMHIP_SEARCH_UMHEX) {
     mvx = B.pmx / 4; mvy = B.pmy / 4;
@@ -1432,6 +1448,7 @@ template <int SM> __device__ int block_motion_search(int mbx, int mby, int ref, 
     } else {
       out->pred[ref][pi][0] = (int16_t)B.pmx; out->pred[ref][pi][1] = (int16_t)B.pmy;
       out->mv[ref][pi][0] = (int16_t)mvx; out->mv[ref][pi][1] = (int16_t)mvy; out->cost[ref][pi] = min_mcost;
+      L.memo_new[ref] |= 1ull << pi;
     }
   }
   return min_mcost;
@@ -1861,6 +1878,8 @@ template <int SM> __global__ __launch_bounds__(64, 2) void p_slice_kernel(const 
       }
     }
     mb_stage(mbx, mby);
+    if (threadIdx.x == 0) L.memo_live = 0;                                    // the coding-order walk evaluates every macroblock once: nothing to reuse
+    __syncthreads();
 #ifdef JMHIP_WAVE_PROF
     const unsigned long long mb_t0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1908,11 +1927,18 @@ template <int SM> __global__ __launch_bounds__(64, 2) void p_slice_relax_kernel(
     const unsigned long long mb_t0 = __builtin_amdgcn_s_memtime();
 #endif
     mb_stage(mbx, mby);
+    if (lane < WR) {
+      const int live = D.memo_on && !D.first_sweep;
+      L.memo_old[lane] = live ? D.memo[(size_t)addr * WR + lane] : 0ull; L.memo_new[lane] = 0ull; L.ff_same[lane] = 0;
+      if (lane == 0) L.memo_live = live;
+    }
+    __syncthreads();
     macroblock_low<SM>(mbx, mby, D.out + addr);
     const int changed = mb_commit(mbx, mby);
 #ifdef JMHIP_WAVE_PROF
     if (lane == 0) { atomicAdd(&g_wave_prof[8], __builtin_amdgcn_s_memtime() - mb_t0); atomicAdd(&g_wave_prof[9], 1ull); }
 #endif
+    if (D.memo_on && lane < WR) D.memo[(size_t)addr * WR + lane] = L.memo_new[lane];
     if (lane == 0) { D.chg_next[addr - first] = (uint8_t)changed; if (changed) atomicAdd(D.n_changed, 1); }
     __syncthreads();
   }
@@ -1958,6 +1984,7 @@ struct SliceState {
   jmhip_mb_inter *out = nullptr;
   int *ep_dist = nullptr; short *ep_motion = nullptr; short *ep_col = nullptr;        // row memories: [mbh + 1] stored rows (WaveDev)
   short *carry_mb = nullptr; uint8_t *chg[2] = {nullptr, nullptr};
+  unsigned long long *memo = nullptr;
   short *carry_in = nullptr, *carry_out = nullptr, *carry_slice = nullptr, *carry_slice_next = nullptr;
   int *um_cost = nullptr, *um_cost_snap = nullptr;
   uint16_t *surf = nullptr; size_t surf_rows = 0; int surf_n = 0, surf_refs = 0;
@@ -1982,6 +2009,7 @@ static SliceState *slice_state(jmhip_ctx *c)
             hipMalloc((void **)&s->ep_motion, sizeof(short) * (c->mbh + 1) * WR * 7 * 4 * w4 * 2) == hipSuccess &&
             hipMalloc((void **)&s->carry_mb, sizeof(short) * nmb * WR * CARRY * 2) == hipSuccess &&
             hipMalloc((void **)&s->chg[0], nmb) == hipSuccess && hipMalloc((void **)&s->chg[1], nmb) == hipSuccess &&
+            hipMalloc((void **)&s->memo, sizeof(unsigned long long) * nmb * WR) == hipSuccess &&
             hipMalloc((void **)&s->ep_col, sizeof(short) * h4 * w4 * 2) == hipSuccess &&
             hipMalloc((void **)&s->carry_in, sizeof(short) * c->mbh * WR * CARRY * 2) == hipSuccess && hipMalloc((void **)&s->carry_out, sizeof(short) * c->mbh * WR * CARRY * 2) == hipSuccess &&
             hipMalloc((void **)&s->carry_slice, sizeof(short) * WR * CARRY * 2) == hipSuccess && hipMalloc((void **)&s->carry_slice_next, sizeof(short) * WR * CARRY * 2) == hipSuccess &&
@@ -2094,6 +2122,8 @@ extern "C" int jmhip_p_slice_search(jmhip_ctx *c, const jmhip_slice_params *prm,
   D.ep_dist = s->ep_dist; D.ep_motion = s->ep_motion; D.ep_col = s->ep_col; D.row0 = row_first;
   D.carry_in = s->carry_in; D.carry_out = s->carry_out; D.um_cost = s->um_cost; D.um_in = s->um_cost_snap; D.carry_mb = s->carry_mb;
   D.n_changed = s->flags + 2;
+  D.memo = s->memo;
+  D.memo_on = exhaustive && relax_grid && !prm->transform8x8_mode && !(getenv("JMHIP_SLICE_MEMO") && !atoi(getenv("JMHIP_SLICE_MEMO")));
   const bool epzs = prm->search_mode == JMHIP_SEARCH_EPZS;
   // a macroblock's own cost-map entries start from what the slice found (mb_stage)
   if (prm->search_mode == JMHIP_SEARCH_UMHEX) JM_HIP_CHECK(c, hipMemcpyAsync(s->um_cost_snap, s->um_cost, sizeof(int) * 8 * h4 * w4, hipMemcpyDeviceToDevice, c->stream));
@@ -2282,7 +2312,7 @@ void jm_slice_state_free(jmhip_ctx *c)
 {
   SliceState *s = static_cast<SliceState *>(c->slice_state);
   if (!s) return;
-  void *bufs[] = {s->ref_idx, s->mv, s->prog, s->flags, s->out, s->ep_dist, s->ep_motion, s->carry_mb, s->chg[0], s->chg[1], s->ep_col, s->carry_in, s->carry_out,
+  void *bufs[] = {s->ref_idx, s->mv, s->prog, s->flags, s->out, s->ep_dist, s->ep_motion, s->carry_mb, s->chg[0], s->chg[1], s->memo, s->ep_col, s->carry_in, s->carry_out,
                   s->carry_slice, s->carry_slice_next, s->um_cost, s->um_cost_snap, s->surf};
   for (void *b : bufs) if (b) (void)hipFree(b);
   delete s;
