@@ -232,6 +232,23 @@ def jm_end_to_end(frames, config3=False, rdopt1=False):
                 if ms:
                     out["jm_hip_slice_sweeps"] = int(ms.group(2))
         out["bitstreams_identical"] = digests[0] == digests[1]
+        if not rdopt1 and not config3 and len(frames) >= 4:
+            # the bound encoder alone over four frames (I P P P): what a P frame costs once the one-time work of the first one -- device
+            # allocations of the slice search (1 GB of SAD surfaces), first-touch pages of the record buffer -- is behind it
+            with open(os.path.join(d, "synth1080.yuv"), "wb") as f:
+                for (Y, U, V) in frames[:4]:
+                    f.write(Y[:H_SRC].tobytes()); f.write(U[:H_SRC // 2].tobytes()); f.write(V[:H_SRC // 2].tobytes())
+            with open(os.path.join(d, "min4.cfg"), "w") as f:
+                f.write(cfg.replace("FramesToBeEncoded = 2", "FramesToBeEncoded = 4"))
+            try:
+                r = subprocess.run([exes[1], "-d", "min4.cfg"], cwd=d, env=dict(os.environ, JMHIP_SHIM="1801", JMHIP_SHIM_STATS="1"),
+                                   capture_output=True, text=True, timeout=200)
+                pf = re.findall(r"^000\d\(P\)\s+\d+\s+\d+\s+[\d.]+\s+[\d.]+\s+[\d.]+\s+(\d+)\s+(\d+)", r.stdout, re.M)
+                mh = re.search(r"P slices \(one device call each\)\s+device\s+\d+\s+forwarded\s+\d+\s+[\d.]+ ms inside the hook \(last call ([\d.]+) ms\)", r.stderr)
+                if len(pf) == 3:
+                    out["jm_hip_four_frames"] = {"p_frame_ms": [int(a) for a, _ in pf], "slice_hook_last_call_ms": float(mh.group(1)) if mh else None}
+            except Exception:
+                pass
         if rdopt1:
             out["config"] = ("1920x1080 I+P, FullSearch +-32, 1 reference, RDOptimization 1, intra candidates in the P picture, CAVLC; jm_hip: JMHIP_SHIM=0x3801 "
                              "(speculative slice binding: a BlockMotionSearch call is answered from the device's record when JM's predictor equals the recorded one, "
