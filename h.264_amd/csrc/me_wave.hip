@@ -960,6 +960,39 @@ __device__ void um_group(UmState &U, int n)
     }
   }
 }
+// The multi-hexagon grid (me_umhex.c:474-494): nr rings of 16 points round (ix, iy), an early-termination test after every ring. The positions do
+// not depend on any outcome and are pairwise distinct, so all rings are evaluated in ONE batch and replayed ring by ring; a ring past the
+// terminating one is never replayed, i.e. never marked visited or accepted -- its distortions were computed for nothing, as JM's partial sums are.
+// Returns true when the termination threshold stopped the search.
+__device__ bool um_rings(UmState &U, int ix, int iy, int nr, int et)
+{
+  int m = 0;
+  for (int k = 0; k < 16 * nr; k++) {
+    const int i = (k >> 4) + 1, vx = ix + c_bhx[k & 15] * i, vy = iy + c_bhy[k & 15] * i;
+    if (iabs(vx - U.cx) > U.R || iabs(vy - U.cy) > U.R) continue;
+    if (map_test(U.R, vx - U.cx, vy - U.cy)) continue;
+    L.px[m] = vx; L.py[m] = vy; m++;
+  }
+  for (int k = 0; k < m; k++) { L.cx[k] = padq(B.pic_x, L.px[k] << 2); L.cy[k] = padq(B.pic_y, L.py[k] << 2); }
+  if (m) eval_dist(B.planes, D.p.metric[0], B.t8, U.umv, B.wp, B.wpw, B.wpo, B.mb_x, B.mb_y, B.bsx, B.bsy, m);
+  int j = 0;
+  for (int i = 1; i <= nr; i++) {
+    for (int q = 0; q < 16; q++) {
+      const int vx = ix + c_bhx[q] * i, vy = iy + c_bhy[q] * i;
+      if (iabs(vx - U.cx) > U.R || iabs(vy - U.cy) > U.R) continue;
+      if (map_test(U.R, vx - U.cx, vy - U.cy)) continue;                       // (distinct positions: nothing replayed here has set this bit)
+      const int jj = j++;
+      int mcost = mvc(D.p.lambda_mf[0], vx << 2, vy << 2);
+      if (mcost < U.min_mcost) {
+        mcost += L.dist[jj];
+        map_set(U.R, vx - U.cx, vy - U.cy);
+        if (mcost < U.min_mcost) { U.best_x = vx; U.best_y = vy; U.min_mcost = mcost; }
+      }
+    }
+    if (U.min_mcost < et) return true;
+  }
+  return false;
+}
 __device__ __forceinline__ void um_diamond(UmState &U)
 {
   for (int m = 0; m < 4; m++) { L.qx[m] = U.best_x + c_dia_x[m]; L.qy[m] = U.best_y + c_dia_y[m]; }
@@ -1035,11 +1068,7 @@ __device__ int umhex_pel(int R, int *mvx, int *mvy, int min_mcost)
       for (int pos = 1; pos < 25; pos++) { int dx, dy; spiral_offset(pos, &dx, &dy); L.qx[pos - 1] = ix + dx; L.qy[pos - 1] = iy + dy; }
       um_group(U, 24);
       EARLY(fourth_2, fourth_1)
-      for (int i = 1; i <= (R / 4); i++) {                                       // multi-hexagon grid :475-494
-        for (int m = 0; m < 16; m++) { L.qx[m] = ix + c_bhx[m] * i; L.qy[m] = iy + c_bhy[m] * i; }
-        um_group(U, 16);
-        if (U.min_mcost < et) goto terminate;
-      }
+      if (um_rings(U, ix, iy, R / 4, et)) goto terminate;                        // multi-hexagon grid :475-494
     }
   fourth_1:
     for (int i = 0; i < R; i++) {

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--range", type=int, default=32)
     ap.add_argument("--frames", type=int, default=4)
     ap.add_argument("--slices", type=int, default=1, help="fixed-size slices per picture (search modes -1, 0, 2)")
+    ap.add_argument("--clip", choices=["smooth", "bench"], default="smooth", help="bench: bench.py's 1080p translation + noise clip (slower to settle)")
     ap.add_argument("--rdopt", type=int, default=0, help="the call records of RDOptimization 1 / 2 (search modes -1, 0, 2; the speculative binding's call)")
     ap.add_argument("--download", action="store_true", help="include the download of the result records in the timed region")
     ap.add_argument("--per-slice-calls", action="store_true", help="with --slices: one call per slice instead of slice_mbs")
@@ -34,6 +35,11 @@ def main():
     rng = np.random.default_rng(3)
     nfr = a.frames
     clip = synth_clip(rng, W, H, a.refs + nfr)
+    if a.clip == "bench":
+        import bench
+        assert (W, H) == (bench.W, bench.H), "--clip bench is the 1080p clip"
+        fr = bench.synth_frames(4, False)
+        clip = [fr[i % 4][0] for i in range(a.refs + nfr)]
     ctx = pkg.Context(W, H, yuv_format=0, max_refs=a.refs, search_range=a.range)
     lam = int(65536 * np.sqrt(0.85 * 2 ** ((28 - 12) / 3.0)) + 0.5)
     for mode in [int(m) for m in a.modes.split(",")]:
