@@ -931,29 +931,35 @@ struct UmState { int cx, cy, R, best_x, best_y, min_mcost, umv; };     // centre
 
 // a group of candidates L.qx/qy[0..n) through SEARCH_ONE_PIXEL (me_umhex.h:32-51): in range, not visited, mv cost below the minimum -> evaluated,
 // marked visited, accepted on strict <. The positions of a group never depend on the outcome inside the group.
-__device__ void um_group(UmState &U, int n)
+__device__ void um_group(UmState &U, int n, bool distinct = false)
 {
   int m = 0;
   for (int k = 0; k < n; k++) {
     const int vx = L.qx[k], vy = L.qy[k];
     if (iabs(vx - U.cx) > U.R || iabs(vy - U.cy) > U.R) continue;
     if (map_test(U.R, vx - U.cx, vy - U.cy)) continue;
-    bool dup = false;                                      // the same position twice in one group: the second sees what the first left
-    for (int j = 0; j < m; j++) dup |= (L.px[j] == vx && L.py[j] == vy);
-    if (dup) continue;
+    if (!distinct) {
+      bool dup = false;                                    // the same position twice in one group: the second sees what the first left
+      for (int j = 0; j < m; j++) dup |= (L.px[j] == vx && L.py[j] == vy);
+      if (dup) continue;
+    }
     L.px[m] = vx; L.py[m] = vy; m++;
   }
   for (int k = 0; k < m; k++) { L.cx[k] = padq(B.pic_x, L.px[k] << 2); L.cy[k] = padq(B.pic_y, L.py[k] << 2); }
   if (m) eval_dist(B.planes, D.p.metric[0], B.t8, U.umv, B.wp, B.wpw, B.wpo, B.mb_x, B.mb_y, B.bsx, B.bsy, m);
-  // replay in the group's own order (duplicates re-tested against the map as it evolves)
+  // replay in the group's own order (duplicates re-tested against the map as it evolves). A group of pairwise distinct positions (the fixed
+  // patterns) passes the two filters in the replay exactly where it passed them above -- nothing replayed here sets another position's bit --,
+  // so its distortions are taken in order instead of being looked up
+  int next = 0;
   for (int k = 0; k < n; k++) {
     const int vx = L.qx[k], vy = L.qy[k];
     if (iabs(vx - U.cx) > U.R || iabs(vy - U.cy) > U.R) continue;
     if (map_test(U.R, vx - U.cx, vy - U.cy)) continue;
+    const int jd = next++;
     int mcost = mvc(D.p.lambda_mf[0], vx << 2, vy << 2);
     if (mcost < U.min_mcost) {
-      int j = 0;
-      while (!(L.px[j] == vx && L.py[j] == vy)) j++;
+      int j = jd;
+      if (!distinct) { j = 0; while (!(L.px[j] == vx && L.py[j] == vy)) j++; }
       mcost += L.dist[j];
       map_set(U.R, vx - U.cx, vy - U.cy);
       if (mcost < U.min_mcost) { U.best_x = vx; U.best_y = vy; U.min_mcost = mcost; }
@@ -996,7 +1002,7 @@ __device__ bool um_rings(UmState &U, int ix, int iy, int nr, int et)
 __device__ __forceinline__ void um_diamond(UmState &U)
 {
   for (int m = 0; m < 4; m++) { L.qx[m] = U.best_x + c_dia_x[m]; L.qy[m] = U.best_y + c_dia_y[m]; }
-  um_group(U, 4);
+  um_group(U, 4, true);
 }
 
 // UMHEXIntegerPelBlockMotionSearch, me_umhex.c:229. mvx/mvy: centre in, result out (pels). R: the (dynamic) search range of this block.
@@ -1060,13 +1066,13 @@ __device__ int umhex_pel(int R, int *mvx, int *mvy, int min_mcost)
       int n = 0;
       for (int i = 1; i < R; i += 2) { L.qx[n] = ix + i; L.qy[n] = iy; n++; L.qx[n] = ix - i; L.qy[n] = iy; n++; }
       for (int i = 1; i < (R / 2); i += 2) { L.qx[n] = ix; L.qy[n] = iy + i; n++; L.qx[n] = ix; L.qy[n] = iy - i; n++; }
-      um_group(U, n);
+      um_group(U, n, true);
     }
     EARLY(fourth_2, fourth_1)
     {
       const int ix = U.best_x, iy = U.best_y;
       for (int pos = 1; pos < 25; pos++) { int dx, dy; spiral_offset(pos, &dx, &dy); L.qx[pos - 1] = ix + dx; L.qy[pos - 1] = iy + dy; }
-      um_group(U, 24);
+      um_group(U, 24, true);
       EARLY(fourth_2, fourth_1)
       if (um_rings(U, ix, iy, R / 4, et)) goto terminate;                        // multi-hexagon grid :475-494
     }
@@ -1074,7 +1080,7 @@ __device__ int umhex_pel(int R, int *mvx, int *mvy, int min_mcost)
     for (int i = 0; i < R; i++) {
       const int ix = U.best_x, iy = U.best_y;
       for (int m = 0; m < 6; m++) { L.qx[m] = ix + c_hex_x[m]; L.qy[m] = iy + c_hex_y[m]; }
-      um_group(U, 6);
+      um_group(U, 6, true);
       if (U.best_x == ix && U.best_y == iy) break;
     }
   fourth_2:
