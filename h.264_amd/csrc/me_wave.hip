@@ -548,8 +548,9 @@ __device__ void surface_build(int scx, int scy, int Rs, int slot = 0, int y4lo =
   const int lane = threadIdx.x, side = 2 * Rs + 1, wside = side + 15, n = side * side;
   const int ox = B.mbx * 16 + scx - Rs + JMHIP_PAD, oy = B.mby * 16 + scy - Rs + JMHIP_PAD;     // window origin in the padded integer plane
   __syncthreads();
+  const float rwside = 1.0f / (float)wside, rsd = 1.0f / (float)side;             // quotients below: (i + 0.5) * reciprocal, exact for these ranges (surface_search)
   for (int i = lane + 4 * y4lo * wside; i < (4 * y4hi + side - 1) * wside; i += 64) {     // the window rows these block rows read
-    const int wy = i / wside, wx = i - wy * wside;
+    const int wy = (int)(((float)i + 0.5f) * rwside), wx = i - wy * wside;
     const int py = clampi(oy + wy, 0, D.Hp - 1), px = clampi(ox + wx, 0, D.Wp - 1);                // the ring replicates the edge: per-sample clamp == origin clamp
     int v = B.planes[(size_t)py * D.Wp + px];
     if (B.wp) v = min(max(((B.wpw * v + D.p.wp_round) >> D.p.wp_denom) + B.wpo, 0), 255);
@@ -558,7 +559,7 @@ __device__ void surface_build(int scx, int scy, int Rs, int slot = 0, int y4lo =
   __syncthreads();
   uint16_t *sf = D.surf + (((size_t)blockIdx.x * 2 + slot) * D.p.num_refs + B.ref) * SURF_PLANES * D.surf_n;
   for (int k = lane; k < n; k += 64) {
-    const int dy = k / side, dx = k - dy * side;
+    const int dy = (int)(((float)k + 0.5f) * rsd), dx = k - dy * side;
     unsigned s4[16];
 #pragma unroll
     for (int by = 0; by < 4; by++) {
@@ -610,6 +611,7 @@ __device__ int surface_search(int cx, int cy, int R, int ffs, int *mvx, int *mvy
   unsigned best = 0xffffffffu;
   // the surface reads are L2 hits with a long latency: eight candidates per lane are in flight at a time
   constexpr int UN = 8;
+  const float rside = 1.0f / (float)side;
   const uint16_t *p0 = sf + (size_t)pl[0] * D.surf_n, *p1 = sf + (size_t)pl[npl > 1 ? 1 : 0] * D.surf_n;
   const uint16_t *p2 = sf + (size_t)pl[npl > 2 ? 2 : 0] * D.surf_n, *p3 = sf + (size_t)pl[npl > 3 ? 3 : 0] * D.surf_n;
   const int m1 = npl > 1 ? 0xffff : 0, m2 = npl > 2 ? 0xffff : 0, m3 = npl > 3 ? 0xffff : 0;
@@ -618,7 +620,10 @@ __device__ int surface_search(int cx, int cy, int R, int ffs, int *mvx, int *mvy
 #pragma unroll
     for (int u = 0; u < UN; u++) {
       const int k = min(k0 + 64 * u, npos - 1);                       // past the end: the last candidate again (harmless for a minimum)
-      const int dy = k / side - R, dx = k - (dy + R) * side - R;
+      // k / side without the integer-division sequence: k + 0.5 is never closer than 0.5 / side (> 0.007) to a multiple of side, the float
+      // product's error stays below 1e-3 for k < 2^13
+      const int row = (int)(((float)k + 0.5f) * rside);
+      const int dy = row - R, dx = k - row * side - R;
       const int si = (cy + dy - scy + Rs) * sside + (cx + dx - scx + Rs);
       ddx[u] = dx; ddy[u] = dy;
       v[u] = (int)p0[si] + ((int)p1[si] & m1) + ((int)p2[si] & m2) + ((int)p3[si] & m3);
