@@ -82,6 +82,7 @@ struct Lds {
   short f_mv[5][6][2];                         // enc_picture->mv[LIST_0]
   int um_loc[8][5][6];                         // fastme_l0_cost per block type
   int ep_sad[7][12];                           // EPZSDistortion, 4x4 columns 4 * mbx - 4 .. 4 * mbx + 7
+  short ep_colb[6][6][2];                      // EPZSCo_located->mv of the 4x4 blocks [4 mby - 1 .. 4 mby + 4][4 mbx - 1 .. 4 mbx + 4] (temporal predictors)
   union {
     __attribute__((aligned(16))) uint8_t win[WIN_MAX * WIN_MAX];   // exhaustive modes: reference window of the surface pass
     short ep_mot[WR][7][4][12][2];                                   // EPZS: EPZSMotion, same columns as ep_sad
@@ -758,7 +759,7 @@ __device__ int epzs_pel(int mb_nr, int R, int *mvx, int *mvy)
     }
     if (P.epzs_temporal) {
       const int sc = P.epzs_mv_scale[ref][0];
-#define COLP(y, x) ADDP(rshift_rnd_sf(sc * (int)D.ep_col[((size_t)(y) * D.w4 + (x)) * 2], sh), rshift_rnd_sf(sc * (int)D.ep_col[((size_t)(y) * D.w4 + (x)) * 2 + 1], sh))
+#define COLP(y, x) ADDP(rshift_rnd_sf(sc * (int)L.ep_colb[(y) - (4 * B.mby - 1)][(x) - (4 * B.mbx - 1)][0], sh), rshift_rnd_sf(sc * (int)L.ep_colb[(y) - (4 * B.mby - 1)][(x) - (4 * B.mbx - 1)][1], sh))
       COLP(py2, px2);
       if (S.min_mcost > stop && ref < 2) {
         if (nb.avail[0]) {
@@ -1826,6 +1827,10 @@ __device__ void mb_stage(int mbx, int mby)
     for (int e = lane; e < 7 * 12; e += 64) {
       const int t = e / 12, j = e - t * 12, col = clampi(col0 + j, 0, D.w4 - 1);
       L.ep_sad[t][j] = D.ep_dist[((size_t)state_row(col, mbx, mby) * 7 + t) * D.w4 + col];
+    }
+    if (P.epzs_temporal && lane < 36) {            // the co-located vectors the temporal predictors of this macroblock's blocks can ask for
+      const int gy = lane / 6, gx = lane - gy * 6, px = clampi(4 * mbx - 1 + gx, 0, D.w4 - 1), py = clampi(4 * mby - 1 + gy, 0, D.h4 - 1);
+      *reinterpret_cast<uint32_t *>(L.ep_colb[gy][gx]) = *reinterpret_cast<const uint32_t *>(D.ep_col + ((size_t)py * D.w4 + px) * 2);
     }
     if (P.epzs_spatial_mem)
       for (int e = lane; e < P.num_refs * 7 * 4 * 12; e += 64) {
