@@ -49,6 +49,7 @@ struct WaveDev {
   // predictor equals the recorded one is a pure function of it (FastFull: and of the reference's 16x16 predictor, the window centre), so a
   // re-evaluation takes the record instead of searching again -- what is recomputed in later sweeps is only what actually changed
   unsigned long long *memo; int memo_on;
+  const uint16_t *tie_tab; int tie_R;           // exhaustive searches: spiral index + 1 of every offset of a (2 tie_R + 1)^2 window, row-major (built per call)
   uint16_t *surf;                              // exhaustive searches: per row, per reference, SAD surfaces [SURF_PLANES][surf_n]
   int surf_n;                                  // candidates per plane (capacity)
   int debug;                                   // JMHIP_WAVE_DEBUG (timing experiments only; results are wrong): 1 no sub-pel, 2 no integer search, 4 no skip cost
@@ -613,14 +614,16 @@ __device__ int surface_search(int cx, int cy, int R, int ffs, int *mvx, int *mvy
   // the surface reads are L2 hits with a long latency: eight candidates per lane are in flight at a time
   constexpr int UN = 8;
   const float rside = 1.0f / (float)side;
+  const bool tabbed = D.tie_tab && R == D.tie_R;                       // the tie-break index from the per-call table instead of ~15 instructions per candidate
   const uint16_t *p0 = sf + (size_t)pl[0] * D.surf_n, *p1 = sf + (size_t)pl[npl > 1 ? 1 : 0] * D.surf_n;
   const uint16_t *p2 = sf + (size_t)pl[npl > 2 ? 2 : 0] * D.surf_n, *p3 = sf + (size_t)pl[npl > 3 ? 3 : 0] * D.surf_n;
   const int m1 = npl > 1 ? 0xffff : 0, m2 = npl > 2 ? 0xffff : 0, m3 = npl > 3 ? 0xffff : 0;
   for (int k0 = lane; k0 < npos; k0 += 64 * UN) {
-    int v[UN], ddx[UN], ddy[UN];
+    int v[UN], ddx[UN], ddy[UN], tt[UN];
 #pragma unroll
     for (int u = 0; u < UN; u++) {
       const int k = min(k0 + 64 * u, npos - 1);                       // past the end: the last candidate again (harmless for a minimum)
+      tt[u] = tabbed ? (int)D.tie_tab[k] : 0;
       // k / side without the integer-division sequence: k + 0.5 is never closer than 0.5 / side (> 0.007) to a multiple of side, the float
       // product's error stays below 1e-3 for k < 2^13
       const int row = (int)(((float)k + 0.5f) * rside);
@@ -633,7 +636,7 @@ __device__ int surface_search(int cx, int cy, int R, int ffs, int *mvx, int *mvy
     for (int u = 0; u < UN; u++) {
       const int dx = ddx[u], dy = ddy[u];
       int mc = mv_cost(lam, ((cx + dx) << 2) - B.pmx, ((cy + dy) << 2) - B.pmy);
-      int tie = spiral_pos(dx, dy) + 1;
+      int tie = tabbed ? tt[u] : spiral_pos(dx, dy) + 1;
       bool skip = false;
       if (check00 && ((B.pic_x + cx + dx) << 2) == B.pic_x && ((B.pic_y + cy + dy) << 2) == B.pic_y) {
         mc -= w16;
@@ -2030,6 +2033,7 @@ struct SliceState {
   int *ep_dist = nullptr; short *ep_motion = nullptr; short *ep_col = nullptr;        // row memories: [mbh + 1] stored rows (WaveDev)
   short *carry_mb = nullptr; uint8_t *chg[2] = {nullptr, nullptr};
   unsigned long long *memo = nullptr;
+  uint16_t *tie_tab = nullptr; int tie_R = 0;
   short *carry_in = nullptr, *carry_out = nullptr, *carry_slice = nullptr, *carry_slice_next = nullptr;
   int *um_cost = nullptr, *um_cost_snap = nullptr;
   uint16_t *surf = nullptr; size_t surf_rows = 0; int surf_n = 0, surf_refs = 0;
@@ -2168,6 +2172,28 @@ extern "C" int jmhip_p_slice_search(jmhip_ctx *c, const jmhip_slice_params *prm,
   D.carry_in = s->carry_in; D.carry_out = s->carry_out; D.um_cost = s->um_cost; D.um_in = s->um_cost_snap; D.carry_mb = s->carry_mb;
   D.n_changed = s->flags + 2;
   D.memo = s->memo;
+  if (exhaustive) {
+    if (s->tie_R != prm->search_range) {
+      const int R = prm->search_range, side = 2 * R + 1;
+      std::vector<uint16_t> t((size_t)side * side);
+      for (int dy = -R; dy <= R; dy++) for (int dx = -R; dx <= R; dx++) {        // spiral_search_x / _y order, mv-search.c:366-393 (me_common.h spiral_pos)
+        const int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy, l = std::max(adx, ady);
+        int pos = 0;
+        if (l) {
+          const int k0 = (2 * l - 1) * (2 * l - 1);
+          pos = (ady == l && adx < l) ? k0 + 2 * (dx + l - 1) + (dy > 0 ? 1 : 0) : k0 + 2 * (2 * l - 1) + 2 * (dy + l) + (dx > 0 ? 1 : 0);
+        }
+        t[(size_t)(dy + R) * side + (dx + R)] = (uint16_t)(pos + 1);
+      }
+      if (s->tie_tab) JM_HIP_CHECK(c, hipFree(s->tie_tab));
+      s->tie_tab = nullptr; s->tie_R = 0;
+      if (hipMalloc((void **)&s->tie_tab, t.size() * sizeof(uint16_t)) != hipSuccess) return jm_fail(c, JMHIP_ERR_NOMEM, "spiral table of the slice search");
+      JM_HIP_CHECK(c, hipMemcpyAsync(s->tie_tab, t.data(), t.size() * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+      JM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+      s->tie_R = R;
+    }
+    D.tie_tab = s->tie_tab; D.tie_R = s->tie_R;
+  }
   D.memo_on = exhaustive && relax_grid && !prm->transform8x8_mode && !(getenv("JMHIP_SLICE_MEMO") && !atoi(getenv("JMHIP_SLICE_MEMO")));
   const bool epzs = prm->search_mode == JMHIP_SEARCH_EPZS;
   // a macroblock's own cost-map entries start from what the slice found (mb_stage)
@@ -2357,7 +2383,7 @@ void jm_slice_state_free(jmhip_ctx *c)
 {
   SliceState *s = static_cast<SliceState *>(c->slice_state);
   if (!s) return;
-  void *bufs[] = {s->ref_idx, s->mv, s->prog, s->flags, s->out, s->ep_dist, s->ep_motion, s->carry_mb, s->chg[0], s->chg[1], s->memo, s->ep_col, s->carry_in, s->carry_out,
+  void *bufs[] = {s->ref_idx, s->mv, s->prog, s->flags, s->out, s->ep_dist, s->ep_motion, s->carry_mb, s->chg[0], s->chg[1], s->memo, s->tie_tab, s->ep_col, s->carry_in, s->carry_out,
                   s->carry_slice, s->carry_slice_next, s->um_cost, s->um_cost_snap, s->surf};
   for (void *b : bufs) if (b) (void)hipFree(b);
   delete s;
