@@ -940,8 +940,44 @@ struct UmState { int cx, cy, R, best_x, best_y, min_mcost, umv; };     // centre
 
 // a group of candidates L.qx/qy[0..n) through SEARCH_ONE_PIXEL (me_umhex.h:32-51): in range, not visited, mv cost below the minimum -> evaluated,
 // marked visited, accepted on strict <. The positions of a group never depend on the outcome inside the group.
+// The wave-wide form of a group of pairwise distinct positions (n <= 64): lane <-> candidate. JM's scan -- skip when the mv cost alone reaches the
+// minimum, else add the distortion, accept on strict < -- ends on the FIRST candidate in order that attains the smallest total below the incoming
+// minimum, because a skipped candidate's total could not have been smaller; that is a wave minimum plus a ballot. Every evaluated candidate is
+// marked visited: JM leaves the skipped ones unmarked, but the running minimum only falls, so they would be skipped again wherever they recur.
+__device__ void um_group_wave(UmState &U, int n)
+{
+  const int lane = threadIdx.x;
+  int vx = 0, vy = 0;
+  bool ok = false;
+  if (lane < n) {
+    vx = L.qx[lane]; vy = L.qy[lane];
+    ok = iabs(vx - U.cx) <= U.R && iabs(vy - U.cy) <= U.R && !map_test(U.R, vx - U.cx, vy - U.cy);
+  }
+  const unsigned long long bal = __ballot(ok);
+  const int m = __popcll(bal);
+  if (!m) return;
+  const int idx = __popcll(bal & ((1ull << lane) - 1ull));
+  if (ok) { L.cx[idx] = padq(B.pic_x, vx << 2); L.cy[idx] = padq(B.pic_y, vy << 2); }
+  __syncthreads();
+  eval_dist(B.planes, D.p.metric[0], B.t8, U.umv, B.wp, B.wpw, B.wpo, B.mb_x, B.mb_y, B.bsx, B.bsy, m);
+  int cost = INT_MAX;
+  if (ok) {
+    cost = mvc(D.p.lambda_mf[0], vx << 2, vy << 2) + L.dist[idx];
+    const int i = (vy - U.cy + U.R) * (2 * U.R + 1) + (vx - U.cx + U.R);
+    atomicOr(&L.map[i >> 5], 1u << (i & 31));
+  }
+  int mn = cost;
+  for (int o = 1; o < 64; o <<= 1) mn = min(mn, __shfl_xor(mn, o));
+  if (mn < U.min_mcost) {
+    const int src = __ffsll((long long)__ballot(ok && cost == mn)) - 1;
+    U.best_x = __shfl(vx, src); U.best_y = __shfl(vy, src); U.min_mcost = mn;
+  }
+  __syncthreads();
+}
+
 __device__ void um_group(UmState &U, int n, bool distinct = false)
 {
+  if (distinct && n <= 64) { um_group_wave(U, n); return; }
   int m = 0;
   for (int k = 0; k < n; k++) {
     const int vx = L.qx[k], vy = L.qy[k];
@@ -981,32 +1017,47 @@ __device__ void um_group(UmState &U, int n, bool distinct = false)
 // Returns true when the termination threshold stopped the search.
 __device__ bool um_rings(UmState &U, int ix, int iy, int nr, int et)
 {
-  int m = 0;
-  for (int k = 0; k < 16 * nr; k++) {
-    const int i = (k >> 4) + 1, vx = ix + c_bhx[k & 15] * i, vy = iy + c_bhy[k & 15] * i;
-    if (iabs(vx - U.cx) > U.R || iabs(vy - U.cy) > U.R) continue;
-    if (map_test(U.R, vx - U.cx, vy - U.cy)) continue;
-    L.px[m] = vx; L.py[m] = vy; m++;
+  // lane <-> candidates lane and lane + 64 (ring-major order); see um_group_wave for the equivalence with JM's scan
+  const int lane = threadIdx.x, n = 16 * nr;
+  int vx[2], vy[2], idx[2], cost[2] = {INT_MAX, INT_MAX};
+  bool ok[2];
+  int base = 0;
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const int k = lane + 64 * h, i = (k >> 4) + 1;
+    vx[h] = ix + c_bhx[k & 15] * i; vy[h] = iy + c_bhy[k & 15] * i;
+    ok[h] = k < n && iabs(vx[h] - U.cx) <= U.R && iabs(vy[h] - U.cy) <= U.R && !map_test(U.R, vx[h] - U.cx, vy[h] - U.cy);
+    const unsigned long long bal = __ballot(ok[h]);
+    idx[h] = base + __popcll(bal & ((1ull << lane) - 1ull));
+    base += __popcll(bal);
+    if (ok[h]) { L.cx[idx[h]] = padq(B.pic_x, vx[h] << 2); L.cy[idx[h]] = padq(B.pic_y, vy[h] << 2); }
   }
-  for (int k = 0; k < m; k++) { L.cx[k] = padq(B.pic_x, L.px[k] << 2); L.cy[k] = padq(B.pic_y, L.py[k] << 2); }
-  if (m) eval_dist(B.planes, D.p.metric[0], B.t8, U.umv, B.wp, B.wpw, B.wpo, B.mb_x, B.mb_y, B.bsx, B.bsy, m);
-  int j = 0;
-  for (int i = 1; i <= nr; i++) {
-    for (int q = 0; q < 16; q++) {
-      const int vx = ix + c_bhx[q] * i, vy = iy + c_bhy[q] * i;
-      if (iabs(vx - U.cx) > U.R || iabs(vy - U.cy) > U.R) continue;
-      if (map_test(U.R, vx - U.cx, vy - U.cy)) continue;                       // (distinct positions: nothing replayed here has set this bit)
-      const int jj = j++;
-      int mcost = mvc(D.p.lambda_mf[0], vx << 2, vy << 2);
-      if (mcost < U.min_mcost) {
-        mcost += L.dist[jj];
-        map_set(U.R, vx - U.cx, vy - U.cy);
-        if (mcost < U.min_mcost) { U.best_x = vx; U.best_y = vy; U.min_mcost = mcost; }
+  if (base) {
+    __syncthreads();
+    eval_dist(B.planes, D.p.metric[0], B.t8, U.umv, B.wp, B.wpw, B.wpo, B.mb_x, B.mb_y, B.bsx, B.bsy, base);
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+      if (ok[h]) {
+        cost[h] = mvc(D.p.lambda_mf[0], vx[h] << 2, vy[h] << 2) + L.dist[idx[h]];
+        const int i = (vy[h] - U.cy + U.R) * (2 * U.R + 1) + (vx[h] - U.cx + U.R);
+        atomicOr(&L.map[i >> 5], 1u << (i & 31));
       }
-    }
-    if (U.min_mcost < et) return true;
   }
-  return false;
+  bool stop = false;
+  for (int r = 0; r < nr && !stop; r++) {                  // ring r + 1: candidates 16 r .. 16 r + 15 = lanes (16 r) & 63 .. of half (16 r) >> 6
+    const int h = (16 * r) >> 6, l0 = (16 * r) & 63;
+    const bool mine = lane >= l0 && lane < l0 + 16;
+    const int c = mine ? (h ? cost[1] : cost[0]) : INT_MAX;
+    int mn = c;
+    for (int o = 1; o < 64; o <<= 1) mn = min(mn, __shfl_xor(mn, o));
+    if (mn < U.min_mcost) {
+      const int src = __ffsll((long long)__ballot(mine && c == mn)) - 1;
+      U.best_x = __shfl(h ? vx[1] : vx[0], src); U.best_y = __shfl(h ? vy[1] : vy[0], src); U.min_mcost = mn;
+    }
+    stop = U.min_mcost < et;
+  }
+  __syncthreads();
+  return stop;
 }
 __device__ __forceinline__ void um_diamond(UmState &U)
 {
