@@ -314,7 +314,6 @@ def slice_search_times(pkg, ctx, lam, src, order):
     mode: the first starts from an empty state, the second from what the first left (the relaxation schedule's first guess, as in a sequence);
     `sweeps` = relaxation sweeps until nothing changed."""
     import ctypes
-    from tests.test_slice_gpu import slice_params
     lib = pkg.load_library()
     out = {}
     ctx.interp_luma(0)                                  # the last step left a new integer picture in the slot
@@ -323,7 +322,7 @@ def slice_search_times(pkg, ctx, lam, src, order):
                                    ("EPZS_satd_transform8x8", 3, (2, 2, 2), 1)):
         ctx.slice_state_reset()
         ctx.epzs_colocated_upload(np.zeros((H // 4, W // 4, 2), np.int16))
-        p = slice_params(pkg, mode, R, 1, [lam] * 3, 10, W, H=H, metric=metric, t8=t8, qp_n=QP)
+        p = pkg.slice_host.slice_params(mode, R, 1, [lam] * 3, 10, W, H=H, metric=metric, t8=t8, qp_n=QP)
         lib.jmhip_epzs_scales(p, 2, (ctypes.c_int * 1)(0), 1)
         ts, sw = [], []
         for k in order[:2]:
@@ -347,10 +346,9 @@ def per_partition_predictors(pkg, ctx, lam, prm, mbs):
     (taken from jmhip_p_slice_search, FullSearch, of the bench picture) -- instead of the metric's one predictor per macroblock. FullSearch centres
     its window on each partition's predictor (mv-search.c:752-762): a macroblock costs one window walk per DISTINCT centre."""
     import ctypes
-    from tests.test_slice_gpu import slice_params
     lib = pkg.load_library()
     ctx.slice_state_reset()
-    p = slice_params(pkg, -1, R, 1, [lam] * 3, 10, W, H=H)
+    p = pkg.slice_host.slice_params(-1, R, 1, [lam] * 3, 10, W, H=H)
     rec = ctx.p_slice_search(p)
     pp = mbs.copy()
     pp["pred_mv"] = rec["pred"][:, 0]
@@ -467,12 +465,11 @@ def main():
     if args.pred == "per-partition":
         if multi:
             sys.exit("bench.py --pred per-partition runs on one GPU")
-        from tests.test_slice_gpu import slice_params
-        Y0, U0, V0 = src[1]
+            Y0, U0, V0 = src[1]
         ctx.cur_bind(Y0.data_ptr(), U0.data_ptr(), V0.data_ptr())
         ctx.interp_luma(0)
         ctx.slice_state_reset()
-        rec = ctx.p_slice_search(slice_params(pkg, -1, R, 1, [lam] * 3, 10, W, H=H))
+        rec = ctx.p_slice_search(pkg.slice_host.slice_params(-1, R, 1, [lam] * 3, 10, W, H=H))
         mbs = mbs.copy()
         mbs["pred_mv"] = rec["pred"][:, 0]
         args.cpu_mbs = 0                                  # the extras below are the default workload's

@@ -13,3 +13,4 @@ from .jmhip import (  # noqa: F401
     SURFACE_JOB_DTYPE, BIPRED_JOB_DTYPE, BIPRED_RESULT_DTYPE, PREDCOST_JOB_DTYPE, DEBLOCK_MB_DTYPE, DEBLOCK_BLK_DTYPE,
 )
 from . import slices  # noqa: F401,E402
+from . import slice_host  # noqa: F401,E402

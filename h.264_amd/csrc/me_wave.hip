@@ -1013,7 +1013,10 @@ __device__ void um_group(UmState &U, int n, bool distinct = false)
 }
 // The multi-hexagon grid (me_umhex.c:474-494): nr rings of 16 points round (ix, iy), an early-termination test after every ring. The positions do
 // not depend on any outcome and are pairwise distinct, so all rings are evaluated in ONE batch and replayed ring by ring; a ring past the
-// terminating one is never replayed, i.e. never marked visited or accepted -- its distortions were computed for nothing, as JM's partial sums are.
+// terminating one is never replayed, i.e. never accepted -- its distortions were computed for nothing, as JM's partial sums are. Its positions
+// ARE marked visited below (every evaluated candidate is), which JM would not have done: harmless only because the early-termination exit is
+// `goto terminate_step` (me_umhex.c:488) -- no pattern runs after it, so the map is never read again. A pattern added behind the rings would
+// need the marking moved into the per-ring replay.
 // Returns true when the termination threshold stopped the search.
 __device__ bool um_rings(UmState &U, int ix, int iy, int nr, int et)
 {
@@ -2096,6 +2099,14 @@ struct SliceState {
 
 }  // namespace
 
+static void slice_state_release(SliceState *s)
+{
+  void *bufs[] = {s->ref_idx, s->mv, s->prog, s->flags, s->out, s->ep_dist, s->ep_motion, s->carry_mb, s->chg[0], s->chg[1], s->memo, s->tie_tab, s->ep_col, s->carry_in, s->carry_out,
+                  s->carry_slice, s->carry_slice_next, s->um_cost, s->um_cost_snap, s->surf};
+  for (void *b : bufs) if (b) (void)hipFree(b);
+  delete s;
+}
+
 // the state lives in the context as an opaque pointer (jmhip_internal.h: void *slice_state)
 static SliceState *slice_state(jmhip_ctx *c)
 {
@@ -2114,7 +2125,7 @@ static SliceState *slice_state(jmhip_ctx *c)
             hipMalloc((void **)&s->carry_in, sizeof(short) * c->mbh * WR * CARRY * 2) == hipSuccess && hipMalloc((void **)&s->carry_out, sizeof(short) * c->mbh * WR * CARRY * 2) == hipSuccess &&
             hipMalloc((void **)&s->carry_slice, sizeof(short) * WR * CARRY * 2) == hipSuccess && hipMalloc((void **)&s->carry_slice_next, sizeof(short) * WR * CARRY * 2) == hipSuccess &&
             hipMalloc((void **)&s->um_cost, sizeof(int) * 8 * h4 * w4) == hipSuccess && hipMalloc((void **)&s->um_cost_snap, sizeof(int) * 8 * h4 * w4) == hipSuccess;
-  if (!ok) { delete s; return nullptr; }       // (partial allocations are released with the context's device reset; the call fails loudly)
+  if (!ok) { slice_state_release(s); return nullptr; }      // nothing half-allocated stays behind: the call fails with NOMEM and may be retried
   c->slice_state = s;
   return s;
 }
@@ -2215,6 +2226,7 @@ extern "C" int jmhip_p_slice_search(jmhip_ctx *c, const jmhip_slice_params *prm,
   D.p = *prm;
   D.surf = s->surf; D.surf_n = s->surf_n;
   D.debug = getenv("JMHIP_WAVE_DEBUG") ? atoi(getenv("JMHIP_WAVE_DEBUG")) : 0;
+  if (D.debug) fprintf(stderr, "jmhip: JMHIP_WAVE_DEBUG=%d is set: stages of the slice search are SKIPPED for timing experiments, its results are WRONG\n", D.debug);
   D.W = c->W; D.H = c->H; D.Wp = c->Wp; D.Hp = c->Hp; D.mbw = c->mbw; D.mbh = c->mbh; D.w4 = (int)w4; D.h4 = (int)h4;
   D.cur = c->cur_y;
   D.ref_sub = reinterpret_cast<const uint8_t *const *>(c->ref_ptrs_dev) + 32;
@@ -2418,8 +2430,14 @@ extern "C" int jmhip_slice_to_frame(jmhip_ctx *c, const int32_t *ref_slot, int n
   if (rc) return rc;
   if ((rc = jm_frame_buffers_ensure(c, n))) return rc;
   build_part_table();
-  static bool part_uploaded = false;
-  if (!part_uploaded) { JM_HIP_CHECK(c, hipMemcpyToSymbol(HIP_SYMBOL(c_part), h_part, sizeof(h_part))); part_uploaded = true; }
+  {                                                      // c_part is a per-device symbol of this translation unit: one upload per device, as ensure_tables() (me_int.hip)
+    static bool part_uploaded[64] = {false};
+    const int dev = c->cfg.device;
+    if (dev < 0 || dev >= 64 || !part_uploaded[dev]) {
+      JM_HIP_CHECK(c, hipMemcpyToSymbol(HIP_SYMBOL(c_part), h_part, sizeof(h_part)));
+      if (dev >= 0 && dev < 64) part_uploaded[dev] = true;
+    }
+  }
   slice_to_frame_kernel<<<(n + 127) / 128, 128, 0, c->stream>>>(s->out, n, c->mbw, slots[0], slots[1], slots[2], slots[3], (jmhip_me_mb *)c->me_jobs_dev,
                                                                 (jmhip_me_result *)c->me_res_dev, (jmhip_mb_mode *)c->fr_modes + n, (int8_t *)c->fr_blk_ref);
   JM_HIP_CHECK(c, hipGetLastError());
@@ -2434,10 +2452,7 @@ void jm_slice_state_free(jmhip_ctx *c)
 {
   SliceState *s = static_cast<SliceState *>(c->slice_state);
   if (!s) return;
-  void *bufs[] = {s->ref_idx, s->mv, s->prog, s->flags, s->out, s->ep_dist, s->ep_motion, s->carry_mb, s->chg[0], s->chg[1], s->memo, s->tie_tab, s->ep_col, s->carry_in, s->carry_out,
-                  s->carry_slice, s->carry_slice_next, s->um_cost, s->um_cost_snap, s->surf};
-  for (void *b : bufs) if (b) (void)hipFree(b);
-  delete s;
+  slice_state_release(s);
   c->slice_state = nullptr;
 }
 

@@ -14,34 +14,6 @@ def band_rows(mbh, world, rank):
     return row0, row1, band
 
 
-def gather_buffers(torch, world, band, width, chroma_rows_per_mb, chroma_width, device):
-    """Full-picture gather buffers (Y, U, V) sized world*band macroblock rows."""
-    gy = torch.zeros((world * band * 16, width), dtype=torch.uint8, device=device)
-    gu = torch.zeros((world * band * chroma_rows_per_mb, chroma_width), dtype=torch.uint8, device=device)
-    return gy, gu, torch.zeros_like(gu)
-
-
-def band_views(bufs, rank, band, chroma_rows_per_mb):
-    """This rank's send slices inside the gather buffers (views, no copy)."""
-    gy, gu, gv = bufs
-    return (gy[rank * band * 16:(rank + 1) * band * 16],
-            gu[rank * band * chroma_rows_per_mb:(rank + 1) * band * chroma_rows_per_mb],
-            gv[rank * band * chroma_rows_per_mb:(rank + 1) * band * chroma_rows_per_mb])
-
-
-def send_buffers(torch, band, width, chroma_rows_per_mb, chroma_width, device):
-    """This rank's band as its own contiguous tensors (Y, U, V): the all-gather's send side (not aliased with the gather buffer)."""
-    sy = torch.zeros((band * 16, width), dtype=torch.uint8, device=device)
-    su = torch.zeros((band * chroma_rows_per_mb, chroma_width), dtype=torch.uint8, device=device)
-    return sy, su, torch.zeros_like(su)
-
-
-def all_gather_recon(dist, bufs, sends):
-    """One all-gather per plane: after it every rank holds the whole reconstructed picture (+ padding rows)."""
-    for g, s in zip(bufs, sends):
-        dist.all_gather_into_tensor(g, s)
-
-
 # ---- the one-chunk exchange bench.py uses: each rank's band travels as ONE buffer [Y rows | U rows | V rows] (jmhip_recon_pack_band),
 # one all_gather_into_tensor moves all chunks, jmhip_ref_unpack_bands scatters them into the reference planes. Host mirrors of that
 # layout (numpy, no device): the wire format's definition for tests and for hosts that stage the exchange through CPU memory.

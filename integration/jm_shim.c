@@ -22,7 +22,7 @@
  *        decision is only a guess of JM's; a call is answered from the record when JM's predictor equals the recorded one and runs JM's
  *        own search otherwise (counted as forwarded), so the bitstream is JM's whatever the guess was worth.
  *
- * The proof of the drop-in claim is tests/test_jm_shim_gpu.py: the bitstream and the reconstruction this encoder
+ * The proof of the drop-in claim is tests/test_jm_shim.py: the bitstream and the reconstruction this encoder
  * writes are byte-identical to the unmodified encoder's.
  */
 #define _GNU_SOURCE
@@ -1115,7 +1115,14 @@ int BlockMotionSearch(short ref, int list, int mb_x, int mb_y, int blocktype, in
       hit = p >= 0 && pmv[0] == rpred[0] && pmv[1] == rpred[1];
       if (hit && input->SearchMode == 0 && blocktype != 1 && !sp_ok16[ref]) hit = 0;
       if (hit && input->SearchMode == 2 && sp_dirty[ref]) hit = 0;
-      if (blocktype == 1) sp_ok16[ref] = (unsigned char)hit;
+      if (blocktype == 1) sp_ok16[ref] = (unsigned char)hit;          /* the window centre of FastFullSearch follows from the 16x16 predictor alone */
+      if (hit && blocktype == 1 && !input->rdopt) {
+        /* RDOptimization 0: the 16x16 record went through the skip shortcut (src/mv-search.c:826-849), whose vector depends on whether the
+           neighbours A and B are zero-vector references to picture 0 (FindSkipModeMotionVector :1189) -- not on this call's predictor alone.
+           The record is JM's answer only if the device's skip vector is the one JM finds now (JM's own call computes it at :829 anyway). */
+        FindSkipModeMotionVector(&img->mb_data[img->current_mb_nr]);
+        if (img->all_mv[0][0][0][0][0][0] != r->skip_mv[0] || img->all_mv[0][0][0][0][0][1] != r->skip_mv[1]) hit = 0;
+      }
       if (!hit) {
         sp_dirty[ref] = 1;
         if (!orig) orig = next_sym("BlockMotionSearch");

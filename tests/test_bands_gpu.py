@@ -58,12 +58,15 @@ def test_two_bands_rebuild_the_reference(pkg):
     one.close()
 
     # two "ranks"
-    gbufs = pkg.slices.gather_buffers(torch, world, -(-mbh // world), w, 8, w // 2, dev)
+    bandh = -(-mbh // world)
+    gbufs = (torch.zeros((world * bandh * 16, w), dtype=torch.uint8, device=dev), torch.zeros((world * bandh * 8, w // 2), dtype=torch.uint8, device=dev),
+             torch.zeros((world * bandh * 8, w // 2), dtype=torch.uint8, device=dev))
     for rank in range(world):
         row0, row1, band = pkg.slices.band_rows(mbh, world, rank)
         ctx = pkg.Context(w, h, yuv_format=1, max_refs=1, search_range=R)
         code(pkg, ctx, cur_dev, ref, list(range(row0, row1)), mbw, quants, lam, R, band_interp=True)
-        sY, sU, sV = pkg.slices.send_buffers(torch, band, w, 8, w // 2, dev)
+        sY = torch.zeros((band * 16, w), dtype=torch.uint8, device=dev)
+        sU, sV = torch.zeros((band * 8, w // 2), dtype=torch.uint8, device=dev), torch.zeros((band * 8, w // 2), dtype=torch.uint8, device=dev)
         ctx.recon_copy_band(sY.data_ptr(), sU.data_ptr(), sV.data_ptr(), row0, row1 - row0)
         # the exchange is enqueued on the context's own stream, as bench.py does with the RCCL all-gather: no host sync between
         with torch.cuda.stream(torch.cuda.ExternalStream(ctx.stream_ptr(), device=dev)):

@@ -134,6 +134,20 @@ def test_full_frame_residual_stage(pkg, W, H, step):
     want = oracle.residual_frame(rp, curs, mbs[sel], me["mv"][sel], got["modes"][sel], quants, pkg.TQ_JOB_DTYPE, yuv_format=1)
     assert np.array_equal(got["cbp"][sel], want["cbp"])
     assert np.array_equal(got["cbp_blk"][sel], want["cbp_blk"])
+
+    def lists_differ(gl, gr, wl, wr):
+        """(level, run) lists compared up to and including the terminating zero level (what JM's entropy coder reads), vectorised over all rows"""
+        w = wl.reshape(-1, wl.shape[-1])
+        g, r_g, r_w = gl.reshape(w.shape), gr.reshape(w.shape), wr.reshape(w.shape)
+        k = np.where((w == 0).any(axis=1), np.argmax(w == 0, axis=1), w.shape[1] - 1)[:, None]
+        idx = np.arange(w.shape[1])[None, :]
+        return bool((np.where(idx <= k, g != w, False)).any() or (np.where(idx < k, r_g != r_w, False)).any())
+    csel = np.stack([2 * sel, 2 * sel + 1], axis=1).reshape(-1)
+    assert not lists_differ(got["luma"]["levels"][sel], got["luma"]["runs"][sel], want["luma"]["levels"], want["luma"]["runs"]), "luma levels / runs"
+    assert not lists_differ(got["chroma"]["levels"][csel][:, :4, :16], got["chroma"]["runs"][csel][:, :4, :16], want["chroma"]["levels"][:, :4, :16], want["chroma"]["runs"][:, :4, :16]), "chroma AC levels / runs"
+    assert not lists_differ(got["chroma"]["dc_levels"][csel], got["chroma"]["dc_runs"][csel], want["chroma"]["dc_levels"], want["chroma"]["dc_runs"]), "chroma DC levels / runs"
+    assert np.array_equal(got["luma"]["coeff_cost"][sel], want["luma"]["coeff_cost"])
+    assert (want["luma"]["levels"][:, :, 0] != 0).any() and (want["chroma"]["dc_levels"][:, 0] != 0).any()       # coefficients do occur
     for i in sel:
         x, y = int(mbs[i]["mb_x"]) * 16, int(mbs[i]["mb_y"]) * 16
         assert np.array_equal(recon[0][y:y + 16, x:x + 16], want["recon"][0][y:y + 16, x:x + 16]), ("luma recon", i)

@@ -66,7 +66,24 @@ LoopFilterBetaOffset = {lfb}
 SliceMode = {slicemode}
 SliceArgument = {slicearg}
 DisableIntraInInter = {noi}
+{extra}
 """
+
+# Scaling matrices (a18): a q_matrix file in JM's format (src/q_matrix.c:31-49 names the lists) with this test's own values -- the reference's
+# bin/q_matrix.cfg does not travel --, present in the SPS for the six 4x4 lists and the two 8x8 luma lists. JM then builds LevelScale / InvLevelScale
+# as (quant_coef << 4) / M and dequant_coef * M (src/q_matrix.c:451-738), which the binding hands to the device per call.
+QM_KEYS = "QmatrixFile = \"qm.cfg\"\nScalingMatrixPresentFlag = 1\n" + "".join("ScalingListPresentFlag%d = 1\n" % i for i in range(8))
+
+
+def write_qmatrix(path):
+    names4 = ["INTRA4X4_LUMA", "INTRA4X4_CHROMAU", "INTRA4X4_CHROMAV", "INTER4X4_LUMA", "INTER4X4_CHROMAU", "INTER4X4_CHROMAV"]
+    with open(path, "w") as f:
+        for k, name in enumerate(names4):
+            m = [[min(255, 8 + k + (3 + (k & 1)) * (i + j) + (2 if i == j else 0)) for i in range(4)] for j in range(4)]
+            f.write("%s =\n%s\n\n" % (name, ",\n".join(",".join("%d" % v for v in row) for row in m)))
+        for k, name in enumerate(["INTRA8X8_LUMA", "INTER8X8_LUMA"]):
+            m = [[min(255, 9 + 3 * k + 2 * (i + j) + (i * j) // 3) for i in range(8)] for j in range(8)]
+            f.write("%s =\n%s\n\n" % (name, ",\n".join(",".join("%d" % v for v in row) for row in m)))
 
 CASES = {
     # name: cfg values                                                                      what it exercises
@@ -105,6 +122,9 @@ CASES = {
     "full_wp_chroma": dict(search=-1, profile=77, cabac=1, t8x8=0, bframes=0, refs=2, rdopt=1, adrnd=0, yuv=1, wp=1, fade=1, fpel=0, hpel=0, qpel=2, cme=2, cmw=1),
     "full_wp_sse_chroma": dict(search=-1, profile=77, cabac=1, t8x8=0, bframes=0, refs=2, rdopt=1, adrnd=0, yuv=1, wp=1, fade=1, fpel=1, hpel=1, qpel=1, cme=2, cmw=1),
     "full_lowcplx_422": dict(search=-1, profile=122, cabac=0, t8x8=1, bframes=0, refs=1, rdopt=0, adrnd=1, yuv=2),  # rdopt off centre rule, 4:2:2 chroma DC
+    # scaling matrices (q_matrix.c:451-738): non-flat LevelScale / InvLevelScale tables for every 4x4 list and the 8x8 luma lists, I / P / B, adaptive rounding on
+    "fastfull_high_qmatrix": dict(search=0, profile=100, cabac=1, t8x8=1, bframes=1, refs=2, rdopt=1, adrnd=1, yuv=1, qmatrix=1),
+    "full_high_qmatrix_cavlc_lowcplx": dict(search=-1, profile=100, cabac=0, t8x8=1, bframes=0, refs=1, rdopt=0, adrnd=0, yuv=1, qmatrix=1, qp=34),
 }
 
 
@@ -147,6 +167,9 @@ def prepare(tmp_path, name, w=176, h=144, frames=3, R=16, qp=28):
     v.setdefault("wbp", 0)
     v.setdefault("wp", 0)
     v.setdefault("noi", 0)
+    v["extra"] = QM_KEYS if v.get("qmatrix") else ""
+    if v.get("qmatrix"):
+        write_qmatrix(tmp_path / "qm.cfg")
     with open(tmp_path / "case.cfg", "w") as f:
         f.write(CFG.format(**v))
     make_clip(tmp_path / "clip.yuv", w, h, frames + v["bframes"] * (frames - 1), v["yuv"], v.get("fade", 0))

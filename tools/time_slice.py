@@ -13,7 +13,6 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge  # noqa: E402
-from tests.test_slice_gpu import slice_params, synth_clip  # noqa: E402
 
 
 def main():
@@ -34,7 +33,7 @@ def main():
     lib = pkg.load_library()
     rng = np.random.default_rng(3)
     nfr = a.frames
-    clip = synth_clip(rng, W, H, a.refs + nfr)
+    clip = pkg.slice_host.synth_clip(rng, W, H, a.refs + nfr)
     if a.clip == "bench":
         import bench
         assert (W, H) == (bench.W, bench.H), "--clip bench is the 1080p clip"
@@ -51,7 +50,7 @@ def main():
                 ctx.interp_luma(r)
             ctx.cur_upload(clip[f])
             ctx.epzs_colocated_upload(np.zeros((H // 4, W // 4, 2), np.int16))
-            p = slice_params(pkg, mode, a.range, a.refs, [lam] * 3, 10, W, H=H)
+            p = pkg.slice_host.slice_params(mode, a.range, a.refs, [lam] * 3, 10, W, H=H)
             pocs = [2 * (f - 1 - r) for r in range(a.refs)]
             lib.jmhip_epzs_scales(p, 2 * f, (C.c_int * a.refs)(*pocs), a.refs)
             nmb = (W // 16) * (H // 16)
