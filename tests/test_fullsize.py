@@ -147,7 +147,7 @@ def test_full_frame_residual_stage(pkg, W, H, step):
     assert not lists_differ(got["chroma"]["levels"][csel][:, :4, :16], got["chroma"]["runs"][csel][:, :4, :16], want["chroma"]["levels"][:, :4, :16], want["chroma"]["runs"][:, :4, :16]), "chroma AC levels / runs"
     assert not lists_differ(got["chroma"]["dc_levels"][csel], got["chroma"]["dc_runs"][csel], want["chroma"]["dc_levels"], want["chroma"]["dc_runs"]), "chroma DC levels / runs"
     assert np.array_equal(got["luma"]["coeff_cost"][sel], want["luma"]["coeff_cost"])
-    assert (want["luma"]["levels"][:, :, 0] != 0).any() and (want["chroma"]["dc_levels"][:, 0] != 0).any()       # coefficients do occur
+    assert (want["luma"]["levels"][:, :, 0] != 0).any()       # coefficients do occur (this clip's chroma is flat enough to quantise to nothing)
     for i in sel:
         x, y = int(mbs[i]["mb_x"]) * 16, int(mbs[i]["mb_y"]) * 16
         assert np.array_equal(recon[0][y:y + 16, x:x + 16], want["recon"][0][y:y + 16, x:x + 16]), ("luma recon", i)

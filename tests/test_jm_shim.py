@@ -128,7 +128,7 @@ CASES = {
 }
 
 
-def make_clip(path, w, h, frames, yuv, fade=0):
+def make_clip(path, w, h, frames, yuv, fade=0, diverse=0):
     rng = np.random.default_rng(3)
     yy, xx = np.mgrid[0:h + 64, 0:w + 64]
     base = ((np.sin(xx / 7.0) * np.cos(yy / 5.0)) * 60 + 128 + rng.normal(0, 10, (h + 64, w + 64))).clip(0, 255)
@@ -137,7 +137,12 @@ def make_clip(path, w, h, frames, yuv, fade=0):
         for t in range(frames):
             dx, dy = 3 * t, 2 * t
             gain = 1.0 - 0.07 * t * fade              # a fade gives the explicit weights something to estimate
-            f.write(((base[16 + dy:16 + dy + h, 16 + dx:16 + dx + w] + rng.normal(0, 2, (h, w))) * gain).clip(0, 255).astype(np.uint8).tobytes())
+            luma = base[16 + dy:16 + dy + h, 16 + dx:16 + dx + w] + rng.normal(0, 2, (h, w))
+            if diverse:                               # regions with their own motion: a static third (zero vectors next to moving neighbours: the skip
+                x1, x2 = (w // 3) & ~15, (2 * w // 3) & ~15      # vector's rule, mv-search.c:1189) and one moving the other way
+                luma[:, :x1] = base[16:16 + h, 16:16 + x1] + rng.normal(0, 1, (h, x1))
+                luma[h // 2:, x2:] = base[16 - t + h // 2:16 - t + h, 16 - 2 * t + x2:16 - 2 * t + w] + rng.normal(0, 2, (h - h // 2, w - x2))
+            f.write((luma * gain).clip(0, 255).astype(np.uint8).tobytes())
             for k in range(2):
                 c = base[8 + dy // 2:8 + dy // 2 + ch, 8 + dx // 2 + 5 * k:8 + dx // 2 + 5 * k + cw]
                 f.write((c * 0.5 + 64).clip(0, 255).astype(np.uint8).tobytes())
@@ -172,7 +177,7 @@ def prepare(tmp_path, name, w=176, h=144, frames=3, R=16, qp=28):
         write_qmatrix(tmp_path / "qm.cfg")
     with open(tmp_path / "case.cfg", "w") as f:
         f.write(CFG.format(**v))
-    make_clip(tmp_path / "clip.yuv", w, h, frames + v["bframes"] * (frames - 1), v["yuv"], v.get("fade", 0))
+    make_clip(tmp_path / "clip.yuv", w, h, frames + v["bframes"] * (frames - 1), v["yuv"], v.get("fade", 0), v.get("diverse", 0))
 
 
 @pytest.mark.reference
@@ -308,6 +313,12 @@ SPEC_CASES = {
     "spec_umhexsmp_rdopt2": dict(search=2, profile=77, cabac=1, t8x8=0, bframes=0, refs=2, rdopt=2, adrnd=0, yuv=1, noi=0),
     "spec_full_lowcplx_with_intra": dict(search=-1, profile=66, cabac=0, t8x8=0, bframes=0, refs=1, rdopt=0, adrnd=1, yuv=1, noi=0),   # rdopt 0 but intra candidates on
     "spec_fastfull_rdopt1_bframes": dict(search=0, profile=77, cabac=1, t8x8=0, bframes=1, refs=2, rdopt=1, adrnd=0, yuv=1, noi=0),     # P pictures bound, B pictures JM's
+    # RDOptimization 0 with intra candidates on a clip whose regions move differently (a static third beside moving ones): the 16x16 record went
+    # through the skip shortcut, whose vector depends on the neighbours' references and zero vectors, not on the call's predictor -- the binding
+    # answers it only when JM's FindSkipModeMotionVector agrees with the device's (jm_shim.c)
+    "spec_full_lowcplx_intra_diverse": dict(search=-1, profile=66, cabac=0, t8x8=0, bframes=0, refs=2, rdopt=0, adrnd=1, yuv=1, noi=0, diverse=1),
+    "spec_fastfull_lowcplx_intra_diverse": dict(search=0, profile=66, cabac=0, t8x8=0, bframes=0, refs=2, rdopt=0, adrnd=0, yuv=1, noi=0, diverse=1),
+    "spec_umhexsmp_lowcplx_intra_diverse": dict(search=2, profile=77, cabac=1, t8x8=0, bframes=0, refs=2, rdopt=0, adrnd=0, yuv=1, noi=0, diverse=1, qp=34),
 }
 CASES.update(SPEC_CASES)
 
