@@ -124,6 +124,7 @@ extern "C" void jmhip_ctx_destroy(jmhip_ctx *c)
   (void)hipFree(c->tq_jobs_dev); (void)hipFree(c->tq_res_dev); (void)hipFree(c->tq_quant_dev);
   (void)hipFree(c->fr_bi); (void)hipFree(c->fr_rec); (void)hipFree(c->fr_blk_ref); (void)hipFree(c->fr_jobs_y); (void)hipFree(c->fr_jobs_c); (void)hipFree(c->fr_res_y); (void)hipFree(c->fr_res_c);
   jm_slice_state_free(c);
+  jm_xslice_free(c);
   (void)hipFree(c->dbk_dev); (void)hipFree(c->dbr_dev); (void)hipFree(c->fr_quant); (void)hipFree(c->fr_modes); (void)hipFree(c->rec_y); (void)hipFree(c->rec_u); (void)hipFree(c->rec_v);
   for (auto &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto e : c->evt_pool) (void)hipEventDestroy(e);

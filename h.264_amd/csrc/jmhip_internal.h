@@ -72,6 +72,7 @@ struct jmhip_ctx {
   // TQ arrays
   void *tq_jobs_dev = nullptr, *tq_res_dev = nullptr, *tq_quant_dev = nullptr; int tq_capacity = 0, tq_qcap = 0;
   void *slice_state = nullptr;                         // me_wave.hip: the P-slice search state (field arrays, EPZS / UMHexagonS memories)
+  void *xslice_state = nullptr;                        // me_xslice.hip: call records and work lists of the exhaustive searches' sweeps
   // timing
   bool timing = false;
   unsigned timing_mask = ~0u;                        // stages that record events while timing is on (jmhip_timing_select)
@@ -114,11 +115,18 @@ int jm_ensure_ref_table(jmhip_ctx *ctx);
 int jm_ensure_recon(jmhip_ctx *ctx);                                                       // jmhip_ctx.hip: all three recon planes or none
 int jm_flush_table_fix(jmhip_ctx *ctx);
 void jm_slice_state_free(jmhip_ctx *ctx);
+void jm_xslice_free(jmhip_ctx *ctx);                                                       // me_xslice.hip
+bool jm_xslice_covers(const jmhip_slice_params *prm);
+int jm_xslice_run(jmhip_ctx *ctx, const jmhip_slice_params *prm, int8_t *ref_idx, short *mv, jmhip_mb_inter *out, int *passes, int *settled);
 int jm_me_arrays_ensure(jmhip_ctx *ctx, int n);                                            // me_int.hip
 int jm_frame_buffers_ensure(jmhip_ctx *ctx, int n);                                        // frame.hip                                                   // me_wave.hip                                                    // frame.hip
 struct MeDev;
 int jm_me_sub_tables(jmhip_ctx *ctx);                                                   // me_sub.hip
 void jm_launch_me_sub(jmhip_ctx *ctx, const MeDev &P, const jmhip_me_mb *jobs_dev, jmhip_me_result *res_dev, int n);
+// device-resident work lists (me_xslice.hip): the pair-lane integer search over items, the refinement over (job index, partition mask) pairs
+int jm_me_pair_geometry(jmhip_ctx *ctx, int R, MeDev *P, size_t *lds);                     // me_int.hip
+void jm_launch_me_pair_list(jmhip_ctx *ctx, const MeDev &P, size_t lds, const jmhip_me_mb *jobs_dev, const int *idx_dev, jmhip_me_result *res_dev, const int *n_items_dev, int grid);
+void jm_launch_me_sub_list(jmhip_ctx *ctx, const MeDev &P, const jmhip_me_mb *jobs_dev, jmhip_me_result *res_dev, const int *list_dev, const unsigned long long *masks_dev, const int *n_dev, int grid);
 // me_metric.hip: the search chain for every error metric / the chroma term (jmhip_me_params.metric_set)
 static inline bool jm_me_metric_path(const jmhip_me_params *prm)
 { return prm->metric_set && (prm->metric[0] != 0 || prm->metric[1] != 2 || prm->metric[2] != 2 || prm->chroma_me != 0); }
@@ -129,10 +137,11 @@ int jm_launch_me_metric(jmhip_ctx *ctx, const jmhip_me_params *prm, const MeDev 
 // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8) and every XCD has its own L2. Kernels whose neighbouring
 // work items share data (adjacent macroblocks: overlapping reference windows) take their item through this mapping, which
 // hands each XCD one contiguous run of items. Launch jm_xcd_grid(n) workgroups; blocks past the end get -1 and leave.
-static inline int jm_xcd_grid(int n) { return ((n + 7) / 8) * 8; }
-__device__ __forceinline__ int jm_xcd_item(int n)
+__host__ __device__ static inline int jm_xcd_grid(int n) { return ((n + 7) / 8) * 8; }
+__device__ __forceinline__ int jm_xcd_item_of(int block, int n)
 {
   const int per = (n + 7) >> 3;
-  const int i = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  const int i = (block & 7) * per + (block >> 3);
   return i < n ? i : -1;
 }
+__device__ __forceinline__ int jm_xcd_item(int n) { return jm_xcd_item_of((int)blockIdx.x, n); }

@@ -44,7 +44,11 @@ __device__ __forceinline__ void wrapped_bound_00v(const MeDev &P, int mb_x, int 
   if (c0 >= 0) return;
   const uint8_t *ref_y = P.ref_y[ref];
   int row = 0;
-  for (int x = 0; x < 16; x++) row += iabs((int)P.cur[x] - (int)ref_y[x]);
+  for (int x = 0; x < 16; x++) {
+    int v = ref_y[x];
+    if (P.wp_on) v = min(max(((P.wp_w[ref] * v + P.wp_round) >> P.wp_denom) + P.wp_o[ref], 0), 255);     // computeSADWP's row (me_distortion.c:431)
+    row += iabs((int)P.cur[x] - v);
+  }
   if (c0 + row <= *cost) { *mvx = 0; *mvy = 0; *cost = c0 + row; }
 }
 __device__ __forceinline__ void wrapped_bound_00(const MeDev &P, const jmhip_me_mb &job, int cx, int cy, int *mvx, int *mvy, int *cost)
@@ -701,15 +705,21 @@ __device__ __forceinline__ unsigned quad_swap_add(unsigned v)
   return v + (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);      // quad_perm [1,0,3,2]: the partner lane
 }
 
+// LIST: the work items are a device-resident list whose LENGTH is device-resident too (*n_items_dev; the slice search's relaxation sweeps,
+// me_xslice.hip, build it on the device and must not wait for the host): a fixed grid strides over it, one item per trip.
+template <bool LIST>
 __global__ __launch_bounds__(256, 3) void me_int_pair_kernel(MeDev P, const jmhip_me_mb *__restrict__ jobs, const int *__restrict__ job_index,
-                                                            jmhip_me_result *__restrict__ res, int n_items)
+                                                            jmhip_me_result *__restrict__ res, int n_items, const int *__restrict__ n_items_dev)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t swin[];      // 4 shifted window copies
   __shared__ PairShared S;
-  const int item = jm_xcd_item(n_items);
-  if (item < 0) return;
-
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (LIST) n_items = __builtin_amdgcn_readfirstlane(*n_items_dev);
+  for (int vblock = blockIdx.x; vblock < jm_xcd_grid(n_items); vblock += gridDim.x) {
+  if (LIST && vblock != (int)blockIdx.x) __syncthreads();              // the previous trip's last readers of S / swin
+  const int item = jm_xcd_item_of(vblock, n_items);
+  if (item < 0) { if (LIST) continue; return; }
+
   STAMP(0);
   const int mbi = job_index[item] & 0xffffff, rep = (job_index[item] >> 24) & 63;
   const int uni = __builtin_amdgcn_readfirstlane((job_index[item] >> 30) & 1);      // one predictor for all 41 partitions
@@ -1007,6 +1017,8 @@ __global__ __launch_bounds__(256, 3) void me_int_pair_kernel(MeDev P, const jmhi
     }
   }
   STAMP(6);
+  if (!LIST) break;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ persistent pair-lane search
@@ -1394,6 +1406,25 @@ extern "C" void jmhip_partition_info(int p, int *blocktype, int *x4, int *y4, in
   if (h4) *h4 = h_part[p].h4;
 }
 
+// The pair-lane search over a device-resident item list (me_xslice.hip): window geometry of the fast kernels for range R, and the launch.
+// Items: job index | representative partition << 24 | (all 41 predictors equal) << 30, as jmhip_me_frame builds them on the host.
+int jm_me_pair_geometry(jmhip_ctx *c, int R, MeDev *P, size_t *lds)
+{
+  if (2 * R + 1 < 32 || 2 * R + 1 > 81 || (2 * R + 1) * (2 * R + 1) + 1 >= (1 << TIE_BITS)) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "pair-lane search: 16 <= search_range <= 40");
+  const int fpitch_dw = ((2 * R + 1 + 15 + 3) >> 2) + 2, frows = 2 * R + 1 + 15;
+  int fcs = fpitch_dw * frows;
+  while ((fcs & 31) != 8) fcs++;
+  size_t plds = ((size_t)3 * fcs + (size_t)fpitch_dw * frows) * 4;
+  if (plds < (size_t)44 * 128 * 4) plds = (size_t)44 * 128 * 4;
+  P->win_pitch = fpitch_dw * 4; P->win_rows = frows; P->win_copy_stride = fcs;
+  *lds = plds;
+  return ensure_tables(c);
+}
+void jm_launch_me_pair_list(jmhip_ctx *c, const MeDev &P, size_t lds, const jmhip_me_mb *jobs_dev, const int *idx_dev, jmhip_me_result *res_dev, const int *n_items_dev, int grid)
+{
+  me_int_pair_kernel<true><<<grid, 256, lds, c->stream>>>(P, jobs_dev, idx_dev, res_dev, 0, n_items_dev);
+}
+
 // host mirror of search_center (mv-search.c:752-762) to size the LDS window
 constexpr int FAST_MAX_CENTRES = JMHIP_NPART;  // one walk per distinct centre always: a single macroblock in the union-window kernel is a 0.5 ms serial chain
 
@@ -1607,7 +1638,7 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
       PF.win_pitch = ppitch; PF.win_copy_stride = nwp;
       me_int_pers_kernel<<<grid, 256, wlds, c->stream>>>(PF, (const jmhip_me_mb *)c->me_jobs_dev, (const int *)c->me_idx_dev, (jmhip_me_result *)c->me_res_dev, nfast);
     }
-    else if (use_pair) me_int_pair_kernel<<<jm_xcd_grid(nfast), 256, plds, c->stream>>>(PF, (const jmhip_me_mb *)c->me_jobs_dev, (const int *)c->me_idx_dev, (jmhip_me_result *)c->me_res_dev, nfast);
+    else if (use_pair) me_int_pair_kernel<false><<<jm_xcd_grid(nfast), 256, plds, c->stream>>>(PF, (const jmhip_me_mb *)c->me_jobs_dev, (const int *)c->me_idx_dev, (jmhip_me_result *)c->me_res_dev, nfast, nullptr);
     else me_int_fast_kernel<<<jm_xcd_grid(nfast), 256, flds, c->stream>>>(PF, (const jmhip_me_mb *)c->me_jobs_dev, (const int *)c->me_idx_dev, (jmhip_me_result *)c->me_res_dev, nfast);
   }
   if (ngen)

@@ -62,11 +62,12 @@ void build_sub_tables()
 // all partitions are then costed in parallel and JM's sequential strict-< scan becomes an atomic min on (cost, position).
 // The kernel is latency-bound (dependent LDS/global reads between barriers), hence the small register footprint
 // (T8 = false drops the 8x8 Hadamard path) for many resident workgroups.
-template <bool T8, int NT, bool WP>
-__global__ __launch_bounds__(NT) void me_sub_kernel(MeDev P, const jmhip_me_mb *__restrict__ jobs, jmhip_me_result *__restrict__ res, int n_items)
+// LIST: the macroblocks are a device-resident list of job indices with a partition mask each, its length device-resident too (the slice
+// search's relaxation sweeps, me_xslice.hip): a fixed grid strides over it; only the masked partitions are refined and written.
+template <bool T8, int NT, bool WP, bool LIST>
+__global__ __launch_bounds__(NT) void me_sub_kernel(MeDev P, const jmhip_me_mb *__restrict__ jobs, jmhip_me_result *__restrict__ res, int n_items,
+                                                    const int *__restrict__ list, const unsigned long long *__restrict__ masks, const int *__restrict__ n_dev)
 {
-  const int item = jm_xcd_item(n_items);
-  if (item < 0) return;
   constexpr int NSUB = T8 ? 64 : 112;
   __shared__ __attribute__((aligned(16))) uint8_t s_cur[16][16];
   __shared__ __attribute__((aligned(16))) uint32_t s_c16[16][8];           // (x, x+1) sample pairs, biased (see satd4x4_packed)
@@ -78,11 +79,17 @@ __global__ __launch_bounds__(NT) void me_sub_kernel(MeDev P, const jmhip_me_mb *
   __shared__ int s_nlead;
 
   const int tid = threadIdx.x;
+  if (LIST) n_items = __builtin_amdgcn_readfirstlane(*n_dev);
+  for (int vblock = blockIdx.x; vblock < jm_xcd_grid(n_items); vblock += gridDim.x) {
+  if (LIST && vblock != (int)blockIdx.x) __syncthreads();              // the previous trip's last readers of the shared arrays
+  const int item0 = jm_xcd_item_of(vblock, n_items);
+  if (item0 < 0) { if (LIST) continue; return; }
+  const int item = LIST ? list[item0] : item0;
   SSTAMP(0);
   const jmhip_me_mb &job = jobs[item];
   jmhip_me_result &o = res[item];
   const int mbx = job.mb_x, mby = job.mb_y;
-  const unsigned long long mask = P.mask;
+  const unsigned long long mask = LIST ? masks[item] : P.mask;
   const uint8_t *sub = P.ref_sub[job.ref];
   const int wpw = WP ? P.wp_w[job.ref] : 0, wpo = WP ? P.wp_o[job.ref] : 0;       // WP: weighted reference ME, a separate instantiation
   const size_t plane = (size_t)P.Wp * P.Hp;
@@ -240,6 +247,8 @@ __global__ __launch_bounds__(NT) void me_sub_kernel(MeDev P, const jmhip_me_mb *
     o.mv[tid][0] = (int16_t)s_mvx[tid]; o.mv[tid][1] = (int16_t)s_mvy[tid]; o.cost[tid] = (int)(carried >> 4) - w16h;
   }
   SSTAMP(11);
+  if (!LIST) break;
+  }
 }
 
 }  // namespace
@@ -261,10 +270,17 @@ int jm_me_sub_tables(jmhip_ctx *c)
 void jm_launch_me_sub(jmhip_ctx *c, const MeDev &P, const jmhip_me_mb *jobs_dev, jmhip_me_result *res_dev, int n)
 {
   if (P.wp_on) {
-    if (P.t8x8) me_sub_kernel<true, 128, true><<<jm_xcd_grid(n), 128, 0, c->stream>>>(P, jobs_dev, res_dev, n);
-    else me_sub_kernel<false, SUB_NT, true><<<jm_xcd_grid(n), SUB_NT, 0, c->stream>>>(P, jobs_dev, res_dev, n);
-  } else if (P.t8x8) me_sub_kernel<true, 128, false><<<jm_xcd_grid(n), 128, 0, c->stream>>>(P, jobs_dev, res_dev, n);
-  else me_sub_kernel<false, SUB_NT, false><<<jm_xcd_grid(n), SUB_NT, 0, c->stream>>>(P, jobs_dev, res_dev, n);
+    if (P.t8x8) me_sub_kernel<true, 128, true, false><<<jm_xcd_grid(n), 128, 0, c->stream>>>(P, jobs_dev, res_dev, n, nullptr, nullptr, nullptr);
+    else me_sub_kernel<false, SUB_NT, true, false><<<jm_xcd_grid(n), SUB_NT, 0, c->stream>>>(P, jobs_dev, res_dev, n, nullptr, nullptr, nullptr);
+  } else if (P.t8x8) me_sub_kernel<true, 128, false, false><<<jm_xcd_grid(n), 128, 0, c->stream>>>(P, jobs_dev, res_dev, n, nullptr, nullptr, nullptr);
+  else me_sub_kernel<false, SUB_NT, false, false><<<jm_xcd_grid(n), SUB_NT, 0, c->stream>>>(P, jobs_dev, res_dev, n, nullptr, nullptr, nullptr);
+}
+
+// the list form (4x4 Hadamard only: the slice search's exhaustive path runs without the 8x8 transform): list[i] = job index, masks[job index] = partitions
+void jm_launch_me_sub_list(jmhip_ctx *c, const MeDev &P, const jmhip_me_mb *jobs_dev, jmhip_me_result *res_dev, const int *list_dev, const unsigned long long *masks_dev, const int *n_dev, int grid)
+{
+  if (P.wp_on) me_sub_kernel<false, SUB_NT, true, true><<<grid, SUB_NT, 0, c->stream>>>(P, jobs_dev, res_dev, 0, list_dev, masks_dev, n_dev);
+  else me_sub_kernel<false, SUB_NT, false, true><<<grid, SUB_NT, 0, c->stream>>>(P, jobs_dev, res_dev, 0, list_dev, masks_dev, n_dev);
 }
 
 extern "C" int jmhip_me_subpel(jmhip_ctx *c, const jmhip_me_params *prm, const jmhip_me_mb *mbs, int n, jmhip_me_result *results)

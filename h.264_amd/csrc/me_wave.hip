@@ -2170,7 +2170,9 @@ extern "C" int jmhip_p_slice_search(jmhip_ctx *c, const jmhip_slice_params *prm,
       prm->search_mode != JMHIP_SEARCH_UMHEX_SIMPLE && prm->search_mode != JMHIP_SEARCH_EPZS)
     return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_p_slice_search: search_mode must be -1, 0, 1, 2 or 3");
   if (prm->num_refs < 1 || prm->num_refs > JMHIP_SLICE_REFS) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_p_slice_search: 1..JMHIP_SLICE_REFS references");
-  if (prm->search_range < 1 || prm->search_range > c->cfg.search_range || prm->search_range > 33) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_p_slice_search: search_range (at most 33 and the context's)");
+  // ranges up to 33 fit this file's LDS windows; the exhaustive searches' sweeps over the frame kernels (me_xslice.hip) take up to 40
+  if (prm->search_range < 1 || prm->search_range > c->cfg.search_range || (prm->search_range > 33 && !jm_xslice_covers(prm)))
+    return jm_fail(c, JMHIP_ERR_ARG, "jmhip_p_slice_search: search_range (at most the context's; at most 33, or 40 for search modes -1 / 0 with JM's default metrics and the 4x4 transform)");
   if (prm->mb_first < 0 || prm->mb_count < 1 || prm->mb_first + prm->mb_count > nmb) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_p_slice_search: slice outside the picture");
   if (!prm->valid[1]) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_p_slice_search: the 16x16 mode must be enabled");
   if (!c->has_cur) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_p_slice_search: current picture not uploaded");
@@ -2212,7 +2214,22 @@ extern "C" int jmhip_p_slice_search(jmhip_ctx *c, const jmhip_slice_params *prm,
     if (!(e && !strcmp(e, "wave"))) relax_grid = 2048;                                      // two waves per SIMD (256 VGPRs): all that can be resident
     if (const char *g = getenv("JMHIP_SLICE_GRID")) if (relax_grid) relax_grid = std::max(1, atoi(g));
   }
-  if (exhaustive) {
+  // the exhaustive searches go through the frame kernels' sweeps (me_xslice.hip) where those cover the configuration; what they do not cover,
+  // or do not settle within their cap, runs on this file's one-wave-per-macroblock kernels
+  const bool x_path = exhaustive && relax_grid && jm_xslice_covers(prm);
+  bool x_settled = false;
+  if (x_path) {
+    int xs = 0, xp = 0;
+    s->passes = 0;
+    jm_stage_begin(c, JMHIP_STAGE_ME_INT);
+    rc = jm_xslice_run(c, prm, s->ref_idx, s->mv, s->out, &xp, &xs);
+    jm_stage_end(c, JMHIP_STAGE_ME_INT);
+    if (rc) return rc;
+    s->passes = xp;
+    x_settled = xs != 0;
+    if (!x_settled && prm->search_range > 33) return jm_fail(c, JMHIP_ERR_DEVICE, "jmhip_p_slice_search: the sweeps did not settle within their cap and the range exceeds what the macroblock kernels take over (33)");
+  }
+  if (exhaustive && !x_settled) {
     const int rs = prm->search_range + SURF_MARGIN, n = ((2 * rs + 1) * (2 * rs + 1) + 63) & ~63;
     const size_t slots = (size_t)std::max(rows, relax_grid);      // one surface set per resident workgroup (blockIdx.x)
     if (s->surf_rows < slots || s->surf_n < n || s->surf_refs < prm->num_refs) {
@@ -2261,10 +2278,10 @@ extern "C" int jmhip_p_slice_search(jmhip_ctx *c, const jmhip_slice_params *prm,
   const bool epzs = prm->search_mode == JMHIP_SEARCH_EPZS;
   // a macroblock's own cost-map entries start from what the slice found (mb_stage)
   if (prm->search_mode == JMHIP_SEARCH_UMHEX) JM_HIP_CHECK(c, hipMemcpyAsync(s->um_cost_snap, s->um_cost, sizeof(int) * 8 * h4 * w4, hipMemcpyDeviceToDevice, c->stream));
-  s->passes = 0;
+  if (!x_path) s->passes = 0;
   jm_stage_begin(c, JMHIP_STAGE_ME_INT);
-  bool settled = false;
-  if (relax_grid) {
+  bool settled = x_settled;
+  if (relax_grid && !settled) {
     // relaxation sweeps (p_slice_relax_kernel); the coding-order walk below remains the fallback if they do not settle within the cap
     const int cap = getenv("JMHIP_SLICE_SWEEPS") ? atoi(getenv("JMHIP_SLICE_SWEEPS")) : 160;      // a sweep costs >= one macroblock (1.2 ms), the walk 250+
     const int grid = std::min(relax_grid, prm->mb_count);
@@ -2293,7 +2310,7 @@ extern "C" int jmhip_p_slice_search(jmhip_ctx *c, const jmhip_slice_params *prm,
         t_last = t_now;
       }
     }
-    if (settled)
+    if (settled && !x_settled)
       JM_HIP_CHECK(c, hipMemcpyAsync(s->carry_slice_next, s->carry_mb + (size_t)(prm->mb_first + prm->mb_count - 1) * WR * CARRY * 2, sizeof(short) * WR * CARRY * 2, hipMemcpyDeviceToDevice, c->stream));
   }
   for (; !settled;) {
@@ -2336,7 +2353,7 @@ extern "C" int jmhip_p_slice_search(jmhip_ctx *c, const jmhip_slice_params *prm,
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wave_prof), z, sizeof(z));
   }
 #endif
-  std::swap(s->carry_slice, s->carry_slice_next);
+  if (!x_settled) std::swap(s->carry_slice, s->carry_slice_next);      // (the exhaustive searches neither read nor write img->all_mv's carry)
   if (prm->mb_first == 0) s->t8_any = false;
   s->t8_any = s->t8_any || prm->transform8x8_mode != 0;
   s->searched_to = (prm->mb_first == 0 || prm->mb_first == s->searched_to) ? prm->mb_first + prm->mb_count : 0;

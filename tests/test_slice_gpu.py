@@ -191,6 +191,36 @@ def test_synthetic_clip_matches_the_oracle(pkg, mode, W, H, R, nref, slices):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode,W,H,R,nref,slices", [
+    (-1, 176, 144, 16, 1, 1),       # FullSearch: one work item per distinct window centre of a macroblock
+    (-1, 176, 144, 16, 2, 2),
+    (0, 176, 144, 16, 2, 1),        # FastFullSearch: one window per macroblock and reference, centred on the 16x16 predictor
+    (0, 320, 192, 32, 3, 3),        # +-32, three references, three slices (the last two begin mid-row)
+    (-1, 320, 192, 32, 4, 3),
+    (0, 176, 144, 20, 4, 1),        # a range between the kernel's column groupings (2R+1 = 41)
+    (-1, 176, 144, 40, 1, 1),       # the largest range of the pair-lane kernel
+])
+def test_exhaustive_searches_as_sweeps_over_the_frame_kernels(pkg, mode, W, H, R, nref, slices):
+    """16 <= search_range <= 40, JM's default metrics, the 4x4 transform: FullSearch / FastFullSearch slices run as relaxation sweeps whose
+    searches are the frame kernels over device-built work lists (me_xslice.hip): replay of the decision on call records -> integer search of the
+    records whose predictor changed -> their refinement -> skip costs, until a sweep asks for nothing and changes nothing."""
+    passes = run_synthetic(pkg, mode, W, H, R, nref, slices=slices)
+    print("sweeps per slice call:", passes)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,nref,sweeps", [(-1, 2, "1"), (0, 2, "2"), (-1, 1, "3")])
+def test_exhaustive_sweeps_hand_over_to_the_macroblock_kernels(pkg, mode, nref, sweeps, monkeypatch):
+    """The sweeps are capped; when they have not settled, the one-wave-per-macroblock schedules of me_wave.hip finish from the field they left
+    (any state is a legal first guess). JMHIP_SLICE_SWEEPS caps both; JMHIP_SLICE_X=0 switches the frame-kernel sweeps off altogether."""
+    monkeypatch.setenv("JMHIP_SLICE_SWEEPS", sweeps)
+    run_synthetic(pkg, mode, 176, 144, 16, nref, nframes=2)
+    monkeypatch.delenv("JMHIP_SLICE_SWEEPS")
+    monkeypatch.setenv("JMHIP_SLICE_X", "0")
+    run_synthetic(pkg, mode, 176, 144, 16, nref, nframes=2)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("sched,sweeps", [("wave", None), ("relax", "1"), ("relax", "3")])
 @pytest.mark.parametrize("mode,W,H,R,nref,slices", [(3, 320, 192, 32, 3, 3), (1, 176, 144, 16, 2, 1), (0, 96, 64, 8, 2, 1), (-1, 96, 64, 8, 2, 2)])
 def test_schedules_agree(pkg, mode, W, H, R, nref, slices, sched, sweeps, monkeypatch):
