@@ -125,8 +125,8 @@ int jm_me_sub_tables(jmhip_ctx *ctx);                                           
 void jm_launch_me_sub(jmhip_ctx *ctx, const MeDev &P, const jmhip_me_mb *jobs_dev, jmhip_me_result *res_dev, int n);
 // device-resident work lists (me_xslice.hip): the pair-lane integer search over items, the refinement over (job index, partition mask) pairs
 int jm_me_pair_geometry(jmhip_ctx *ctx, int R, MeDev *P, size_t *lds);                     // me_int.hip
-void jm_launch_me_pair_list(jmhip_ctx *ctx, const MeDev &P, size_t lds, const jmhip_me_mb *jobs_dev, const int *idx_dev, jmhip_me_result *res_dev, const int *n_items_dev, int grid);
-void jm_launch_me_sub_list(jmhip_ctx *ctx, const MeDev &P, const jmhip_me_mb *jobs_dev, jmhip_me_result *res_dev, const int *list_dev, const unsigned long long *masks_dev, const int *n_dev, int grid);
+void jm_launch_me_pair_list(jmhip_ctx *ctx, const MeDev &P, const MeDev *P_dev, size_t lds, const jmhip_me_mb *jobs_dev, const int *idx_dev, jmhip_me_result *res_dev, const int *cnt_dev, int cap, int grid);
+void jm_launch_me_sub_list(jmhip_ctx *ctx, const MeDev &P, const jmhip_me_mb *jobs_dev, jmhip_me_result *res_dev, const int *list_dev, const unsigned long long *masks_dev, const int *cnt_dev, int cap, int grid);
 // me_metric.hip: the search chain for every error metric / the chroma term (jmhip_me_params.metric_set)
 static inline bool jm_me_metric_path(const jmhip_me_params *prm)
 { return prm->metric_set && (prm->metric[0] != 0 || prm->metric[1] != 2 || prm->metric[2] != 2 || prm->chroma_me != 0); }
@@ -145,3 +145,22 @@ __device__ __forceinline__ int jm_xcd_item_of(int block, int n)
   return i < n ? i : -1;
 }
 __device__ __forceinline__ int jm_xcd_item(int n) { return jm_xcd_item_of((int)blockIdx.x, n); }
+
+// Device-built work lists in JM_SHARDS shards (me_xslice.hip): producers append to the shard of their macroblock address, so that thousands of
+// workgroups do not queue on one counter (one word takes ~88 atomics per microsecond: 8160 producers x 6 counters cost 0.5 ms). Shard s keeps
+// its count at cnt[s * JM_SHARD_STRIDE] (a cache line of its own) and its entries at list[s * cap + 0 ..]. A consumer walks VIRTUAL slots
+// v = offset * JM_SHARDS + shard, 0 <= v < JM_SHARDS * max count; jm_shard_slots() is that bound (every lane of the calling wave gets it).
+constexpr int JM_SHARDS = 64, JM_SHARD_STRIDE = 16;
+__device__ __forceinline__ int jm_shard_slots(const int *cnt)
+{
+  int m = cnt[(threadIdx.x & 63) * JM_SHARD_STRIDE];
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) m = max(m, __shfl_xor(m, o));
+  return __builtin_amdgcn_readfirstlane(m) * JM_SHARDS;
+}
+// the list entry of virtual slot v, or -1 when the shard has no such entry
+__device__ __forceinline__ int jm_shard_entry(const int *cnt, const int *list, int cap, int v)
+{
+  const int s = v & (JM_SHARDS - 1), o = v / JM_SHARDS;
+  return o < cnt[s * JM_SHARD_STRIDE] ? list[(size_t)s * cap + o] : -1;
+}

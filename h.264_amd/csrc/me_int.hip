@@ -707,22 +707,37 @@ __device__ __forceinline__ unsigned quad_swap_add(unsigned v)
 
 // LIST: the work items are a device-resident list whose LENGTH is device-resident too (*n_items_dev; the slice search's relaxation sweeps,
 // me_xslice.hip, build it on the device and must not wait for the host): a fixed grid strides over it, one item per trip.
+#ifndef JMHIP_PAIR_LIST_WAVES
+#define JMHIP_PAIR_LIST_WAVES 2        /* list form: two waves per SIMD without spills measured 5 % faster than three with 55 spilled dwords */
+#endif
 template <bool LIST>
-__global__ __launch_bounds__(256, 3) void me_int_pair_kernel(MeDev P, const jmhip_me_mb *__restrict__ jobs, const int *__restrict__ job_index,
-                                                            jmhip_me_result *__restrict__ res, int n_items, const int *__restrict__ n_items_dev)
+__global__ __launch_bounds__(256, LIST ? JMHIP_PAIR_LIST_WAVES : 3) void me_int_pair_kernel(MeDev P0, const jmhip_me_mb *__restrict__ jobs, const int *__restrict__ job_index,
+                                                            jmhip_me_result *__restrict__ res, int n_items, const int *__restrict__ n_items_dev, int list_cap,
+                                                            const MeDev *__restrict__ P_dev)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t swin[];      // 4 shifted window copies
   __shared__ PairShared S;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (LIST) n_items = __builtin_amdgcn_readfirstlane(*n_items_dev);
+  if (LIST) n_items = jm_shard_slots(n_items_dev);                     // sharded list (jmhip_internal.h): virtual slots
   for (int vblock = blockIdx.x; vblock < jm_xcd_grid(n_items); vblock += gridDim.x) {
   if (LIST && vblock != (int)blockIdx.x) __syncthreads();              // the previous trip's last readers of S / swin
+  // the thread index is re-read (opaquely) in every trip: otherwise everything derived from it is hoisted out of the loop and kept alive across
+  // the whole body, which is already at the register budget of three waves per SIMD (93 dwords per lane went to scratch)
+  int tid = threadIdx.x;
+  if (LIST) asm volatile("" : "+v"(tid));
+  const int lane = tid & 63, wave = tid >> 6;
+  // ... and the parameter block is re-read from memory in every trip (LIST): as a by-value argument its forty-odd scalars stay live across the loop
+  // and the scalar file overflows into vector registers
+  const MeDev *pp = P_dev;
+  if (LIST) asm volatile("" : "+s"(pp));
+  const MeDev &P = LIST ? *pp : P0;
   const int item = jm_xcd_item_of(vblock, n_items);
   if (item < 0) { if (LIST) continue; return; }
+  const int word = LIST ? jm_shard_entry(n_items_dev, job_index, list_cap, item) : job_index[item];
+  if (LIST && word < 0) continue;
 
   STAMP(0);
-  const int mbi = job_index[item] & 0xffffff, rep = (job_index[item] >> 24) & 63;
-  const int uni = __builtin_amdgcn_readfirstlane((job_index[item] >> 30) & 1);      // one predictor for all 41 partitions
+  const int mbi = word & 0xffffff, rep = (word >> 24) & 63;
+  const int uni = __builtin_amdgcn_readfirstlane((word >> 30) & 1);      // one predictor for all 41 partitions
   const jmhip_me_mb &job = jobs[mbi];
   const int mbx = job.mb_x, mby = job.mb_y;
   const int R = P.R, UW = 2 * R + 1, UH = UW;
@@ -1420,9 +1435,9 @@ int jm_me_pair_geometry(jmhip_ctx *c, int R, MeDev *P, size_t *lds)
   *lds = plds;
   return ensure_tables(c);
 }
-void jm_launch_me_pair_list(jmhip_ctx *c, const MeDev &P, size_t lds, const jmhip_me_mb *jobs_dev, const int *idx_dev, jmhip_me_result *res_dev, const int *n_items_dev, int grid)
+void jm_launch_me_pair_list(jmhip_ctx *c, const MeDev &P, const MeDev *P_dev, size_t lds, const jmhip_me_mb *jobs_dev, const int *idx_dev, jmhip_me_result *res_dev, const int *cnt_dev, int cap, int grid)
 {
-  me_int_pair_kernel<true><<<grid, 256, lds, c->stream>>>(P, jobs_dev, idx_dev, res_dev, 0, n_items_dev);
+  me_int_pair_kernel<true><<<grid, 256, lds, c->stream>>>(P, jobs_dev, idx_dev, res_dev, 0, cnt_dev, cap, P_dev);
 }
 
 // host mirror of search_center (mv-search.c:752-762) to size the LDS window
@@ -1638,7 +1653,7 @@ extern "C" int jmhip_me_frame_async(jmhip_ctx *c, const jmhip_me_params *prm, co
       PF.win_pitch = ppitch; PF.win_copy_stride = nwp;
       me_int_pers_kernel<<<grid, 256, wlds, c->stream>>>(PF, (const jmhip_me_mb *)c->me_jobs_dev, (const int *)c->me_idx_dev, (jmhip_me_result *)c->me_res_dev, nfast);
     }
-    else if (use_pair) me_int_pair_kernel<false><<<jm_xcd_grid(nfast), 256, plds, c->stream>>>(PF, (const jmhip_me_mb *)c->me_jobs_dev, (const int *)c->me_idx_dev, (jmhip_me_result *)c->me_res_dev, nfast, nullptr);
+    else if (use_pair) me_int_pair_kernel<false><<<jm_xcd_grid(nfast), 256, plds, c->stream>>>(PF, (const jmhip_me_mb *)c->me_jobs_dev, (const int *)c->me_idx_dev, (jmhip_me_result *)c->me_res_dev, nfast, nullptr, 0, nullptr);
     else me_int_fast_kernel<<<jm_xcd_grid(nfast), 256, flds, c->stream>>>(PF, (const jmhip_me_mb *)c->me_jobs_dev, (const int *)c->me_idx_dev, (jmhip_me_result *)c->me_res_dev, nfast);
   }
   if (ngen)

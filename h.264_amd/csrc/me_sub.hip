@@ -66,7 +66,7 @@ void build_sub_tables()
 // search's relaxation sweeps, me_xslice.hip): a fixed grid strides over it; only the masked partitions are refined and written.
 template <bool T8, int NT, bool WP, bool LIST>
 __global__ __launch_bounds__(NT) void me_sub_kernel(MeDev P, const jmhip_me_mb *__restrict__ jobs, jmhip_me_result *__restrict__ res, int n_items,
-                                                    const int *__restrict__ list, const unsigned long long *__restrict__ masks, const int *__restrict__ n_dev)
+                                                    const int *__restrict__ list, const unsigned long long *__restrict__ masks, const int *__restrict__ n_dev, int list_cap)
 {
   constexpr int NSUB = T8 ? 64 : 112;
   __shared__ __attribute__((aligned(16))) uint8_t s_cur[16][16];
@@ -79,12 +79,13 @@ __global__ __launch_bounds__(NT) void me_sub_kernel(MeDev P, const jmhip_me_mb *
   __shared__ int s_nlead;
 
   const int tid = threadIdx.x;
-  if (LIST) n_items = __builtin_amdgcn_readfirstlane(*n_dev);
+  if (LIST) n_items = jm_shard_slots(n_dev);                          // sharded list (jmhip_internal.h): virtual slots
   for (int vblock = blockIdx.x; vblock < jm_xcd_grid(n_items); vblock += gridDim.x) {
   if (LIST && vblock != (int)blockIdx.x) __syncthreads();              // the previous trip's last readers of the shared arrays
   const int item0 = jm_xcd_item_of(vblock, n_items);
   if (item0 < 0) { if (LIST) continue; return; }
-  const int item = LIST ? list[item0] : item0;
+  const int item = LIST ? jm_shard_entry(n_dev, list, list_cap, item0) : item0;
+  if (LIST && item < 0) continue;
   SSTAMP(0);
   const jmhip_me_mb &job = jobs[item];
   jmhip_me_result &o = res[item];
@@ -270,17 +271,17 @@ int jm_me_sub_tables(jmhip_ctx *c)
 void jm_launch_me_sub(jmhip_ctx *c, const MeDev &P, const jmhip_me_mb *jobs_dev, jmhip_me_result *res_dev, int n)
 {
   if (P.wp_on) {
-    if (P.t8x8) me_sub_kernel<true, 128, true, false><<<jm_xcd_grid(n), 128, 0, c->stream>>>(P, jobs_dev, res_dev, n, nullptr, nullptr, nullptr);
-    else me_sub_kernel<false, SUB_NT, true, false><<<jm_xcd_grid(n), SUB_NT, 0, c->stream>>>(P, jobs_dev, res_dev, n, nullptr, nullptr, nullptr);
-  } else if (P.t8x8) me_sub_kernel<true, 128, false, false><<<jm_xcd_grid(n), 128, 0, c->stream>>>(P, jobs_dev, res_dev, n, nullptr, nullptr, nullptr);
-  else me_sub_kernel<false, SUB_NT, false, false><<<jm_xcd_grid(n), SUB_NT, 0, c->stream>>>(P, jobs_dev, res_dev, n, nullptr, nullptr, nullptr);
+    if (P.t8x8) me_sub_kernel<true, 128, true, false><<<jm_xcd_grid(n), 128, 0, c->stream>>>(P, jobs_dev, res_dev, n, nullptr, nullptr, nullptr, 0);
+    else me_sub_kernel<false, SUB_NT, true, false><<<jm_xcd_grid(n), SUB_NT, 0, c->stream>>>(P, jobs_dev, res_dev, n, nullptr, nullptr, nullptr, 0);
+  } else if (P.t8x8) me_sub_kernel<true, 128, false, false><<<jm_xcd_grid(n), 128, 0, c->stream>>>(P, jobs_dev, res_dev, n, nullptr, nullptr, nullptr, 0);
+  else me_sub_kernel<false, SUB_NT, false, false><<<jm_xcd_grid(n), SUB_NT, 0, c->stream>>>(P, jobs_dev, res_dev, n, nullptr, nullptr, nullptr, 0);
 }
 
 // the list form (4x4 Hadamard only: the slice search's exhaustive path runs without the 8x8 transform): list[i] = job index, masks[job index] = partitions
-void jm_launch_me_sub_list(jmhip_ctx *c, const MeDev &P, const jmhip_me_mb *jobs_dev, jmhip_me_result *res_dev, const int *list_dev, const unsigned long long *masks_dev, const int *n_dev, int grid)
+void jm_launch_me_sub_list(jmhip_ctx *c, const MeDev &P, const jmhip_me_mb *jobs_dev, jmhip_me_result *res_dev, const int *list_dev, const unsigned long long *masks_dev, const int *cnt_dev, int cap, int grid)
 {
-  if (P.wp_on) me_sub_kernel<false, SUB_NT, true, true><<<grid, SUB_NT, 0, c->stream>>>(P, jobs_dev, res_dev, 0, list_dev, masks_dev, n_dev);
-  else me_sub_kernel<false, SUB_NT, false, true><<<grid, SUB_NT, 0, c->stream>>>(P, jobs_dev, res_dev, 0, list_dev, masks_dev, n_dev);
+  if (P.wp_on) me_sub_kernel<false, SUB_NT, true, true><<<grid, SUB_NT, 0, c->stream>>>(P, jobs_dev, res_dev, 0, list_dev, masks_dev, cnt_dev, cap);
+  else me_sub_kernel<false, SUB_NT, false, true><<<grid, SUB_NT, 0, c->stream>>>(P, jobs_dev, res_dev, 0, list_dev, masks_dev, cnt_dev, cap);
 }
 
 extern "C" int jmhip_me_subpel(jmhip_ctx *c, const jmhip_me_params *prm, const jmhip_me_mb *mbs, int n, jmhip_me_result *results)
