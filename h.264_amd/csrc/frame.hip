@@ -301,14 +301,14 @@ extern "C" int jmhip_residual_frame_q(jmhip_ctx *c, const jmhip_mb_mode *modes, 
   if (rc) return rc;
   if ((rc = jm_ensure_ref_table(c))) return rc;
   // chroma prediction reads the eighth-pel planes when every used reference has them (JM's ChromaMCBuffer = 1 layout); otherwise the
-  // same sample values are computed in mc_kernel from the integer chroma pictures (reference slots 0..3)
+  // same sample values are computed in mc_kernel from the integer chroma pictures (reference slots 0..7)
   bool chroma_fly = false;
   const unsigned used_refs = c->me_ref_mask | (c->fr_bi_n ? c->fr_bi_mask : 0u);      // list 0 of the search stage, list 1 of jmhip_frame_bipred_set
   for (size_t k = 0; k < c->refs.size(); k++)
     if ((used_refs >> k) & 1) {
       if (!c->refs[k].has_luma_sub) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_residual_frame: quarter-pel planes of a used reference not built (jmhip_interp_luma)");
       if (c->Wc && !c->refs[k].has_cr_sub) {
-        if (k >= 4 || !c->refs[k].has_pic) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_residual_frame: chroma planes of a used reference not built (jmhip_interp_chroma)");
+        if (k >= 8 || !c->refs[k].has_pic) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_residual_frame: chroma planes of a used reference not built (jmhip_interp_chroma)");
         chroma_fly = true;
       }
     }
@@ -334,7 +334,7 @@ extern "C" int jmhip_residual_frame_q(jmhip_ctx *c, const jmhip_mb_mode *modes, 
   F.ref_sub = tab + 32; F.ref_cb = tab + 64; F.ref_cr = tab + 96;
   F.rec_y = c->rec_y; F.rec_u = c->rec_u; F.rec_v = c->rec_v;
   F.fly = chroma_fly ? 1 : 0; F.mul_x = c->cg.mul_x; F.mul_y = c->cg.mul_y; F.pad_cx = c->cg.pad_x; F.pad_cy = c->cg.pad_y;
-  for (int k = 0; k < 4; k++) { F.ref_u[k] = k < (int)c->refs.size() ? c->refs[k].u : nullptr; F.ref_v[k] = k < (int)c->refs.size() ? c->refs[k].v : nullptr; }
+  for (int k = 0; k < 8; k++) { F.ref_u[k] = k < (int)c->refs.size() ? c->refs[k].u : nullptr; F.ref_v[k] = k < (int)c->refs.size() ? c->refs[k].v : nullptr; }
   F.blk_ref = c->fr_from_slices ? (const int8_t *)c->fr_blk_ref : nullptr;
   F.bi = nullptr;
   if (c->fr_bi_n) {

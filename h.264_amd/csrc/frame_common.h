@@ -11,9 +11,9 @@ struct FrameDev {
   const uint8_t *const *ref_sub, *const *ref_cb, *const *ref_cr;
   uint8_t *rec_y, *rec_u, *rec_v;
   // chroma prediction without the eighth-pel planes: the sample a plane WOULD hold, computed from the integer chroma picture
-  // (reference slots 0..3; see mc_kernel)
+  // (reference slots 0..7; see mc_kernel)
   int fly, mul_x, mul_y, pad_cx, pad_cy;
-  const uint8_t *ref_u[4], *ref_v[4];
+  const uint8_t *ref_u[8], *ref_v[8];
   // explicit weighted prediction of P slices (LumaPrediction macroblock.c:880-914, ChromaPrediction4x4 :1895-1903), per reference SLOT
   int wp_on, wp_lround, wp_ldenom, wp_cround, wp_cdenom;
   short wp_w[16][3], wp_o[16][3];

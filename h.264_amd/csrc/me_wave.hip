@@ -1681,7 +1681,7 @@ __device__ __forceinline__ int list0_cost(int mode, int block, int *best_ref)
   }
   return best;
 }
-__device__ __forceinline__ int refbits(int r) { return r == 0 ? 1 : (r < 3 ? 3 : 5); }       // mv-search.c:344-352, r <= 3
+__device__ __forceinline__ int refbits(int r) { return r == 0 ? 1 : (r < 3 ? 3 : 5); }       // mv-search.c:344-352, r <= 6
 
 // encode_one_macroblock_low (md_low.c:46), inter part, for one macroblock
 template <int SM> __device__ void macroblock_low(int mbx, int mby, jmhip_mb_inter *out)
@@ -2394,13 +2394,14 @@ extern "C" int jmhip_slice_result_info(jmhip_ctx *c, int *passes)
 namespace {
 // one thread per macroblock: the slice search's record -> the search-stage result layout the frame stage reads (vector per partition: the
 // one of the reference its 8x8 block settled on), the decided mode, the reference slot per 8x8 block
-__global__ void slice_to_frame_kernel(const jmhip_mb_inter *__restrict__ rec, int n, int mbw, int slot0, int slot1, int slot2, int slot3,
+struct SlotMap { int s[WR]; };
+__global__ void slice_to_frame_kernel(const jmhip_mb_inter *__restrict__ rec, int n, int mbw, SlotMap sm,
                                       jmhip_me_mb *__restrict__ jobs, jmhip_me_result *__restrict__ res, jmhip_mb_mode *__restrict__ modes, int8_t *__restrict__ blk_ref)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const jmhip_mb_inter &r = rec[i];
-  const int slots[4] = {slot0, slot1, slot2, slot3};
+  const int *slots = sm.s;
   jmhip_me_mb &j = jobs[i];
   j.mb_x = (int16_t)(i % mbw); j.mb_y = (int16_t)(i / mbw); j.ref = (int16_t)slots[r.b8ref[0]]; j.ref_is_0 = (int16_t)(r.b8ref[0] == 0);
   jmhip_me_result &o = res[i];
@@ -2437,10 +2438,10 @@ extern "C" int jmhip_slice_to_frame(jmhip_ctx *c, const int32_t *ref_slot, int n
   const int n = c->mbw * c->mbh;
   if (s->searched_to != n) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_slice_to_frame: not every macroblock of the picture has been searched (slices must cover it in order)");
   unsigned mask = 0;
-  int slots[4] = {0, 0, 0, 0};
+  SlotMap sm{};
   for (int r = 0; r < num_refs; r++) {
-    if (ref_slot[r] < 0 || ref_slot[r] >= (int)c->refs.size() || ref_slot[r] >= 4) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_slice_to_frame: reference slots 0..3");
-    slots[r] = ref_slot[r]; mask |= 1u << ref_slot[r];
+    if (ref_slot[r] < 0 || ref_slot[r] >= (int)c->refs.size() || ref_slot[r] >= 8) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_slice_to_frame: reference slots 0..7");
+    sm.s[r] = ref_slot[r]; mask |= 1u << ref_slot[r];
   }
   JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
   int rc = jm_me_arrays_ensure(c, n);
@@ -2455,7 +2456,7 @@ extern "C" int jmhip_slice_to_frame(jmhip_ctx *c, const int32_t *ref_slot, int n
       if (dev >= 0 && dev < 64) part_uploaded[dev] = true;
     }
   }
-  slice_to_frame_kernel<<<(n + 127) / 128, 128, 0, c->stream>>>(s->out, n, c->mbw, slots[0], slots[1], slots[2], slots[3], (jmhip_me_mb *)c->me_jobs_dev,
+  slice_to_frame_kernel<<<(n + 127) / 128, 128, 0, c->stream>>>(s->out, n, c->mbw, sm, (jmhip_me_mb *)c->me_jobs_dev,
                                                                 (jmhip_me_result *)c->me_res_dev, (jmhip_mb_mode *)c->fr_modes + n, (int8_t *)c->fr_blk_ref);
   JM_HIP_CHECK(c, hipGetLastError());
   // the search-stage arrays now hold this picture; a resident re-run of jmhip_me_frame on them is meaningless and is refused (geometry check)

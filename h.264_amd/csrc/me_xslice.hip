@@ -779,13 +779,14 @@ __global__ void x_jobs_init_kernel(XDev D)
 
 template <bool FFS, bool CHAIN> void launch_sim_refs(int nr, int grid, size_t lds, hipStream_t st, const XDev &D)
 {
-  static_assert(XR == 4, "one instantiation per reference count");
+  static_assert(XR == 5, "one instantiation per reference count");
   constexpr int NT = CHAIN ? 256 : 64;
   switch (nr) {
   case 1: x_sim_kernel<FFS, 1, CHAIN><<<grid, NT, lds, st>>>(D); break;
   case 2: x_sim_kernel<FFS, 2, CHAIN><<<grid, NT, lds, st>>>(D); break;
   case 3: x_sim_kernel<FFS, 3, CHAIN><<<grid, NT, lds, st>>>(D); break;
-  default: x_sim_kernel<FFS, 4, CHAIN><<<grid, NT, lds, st>>>(D); break;
+  case 4: x_sim_kernel<FFS, 4, CHAIN><<<grid, NT, lds, st>>>(D); break;
+  default: x_sim_kernel<FFS, 5, CHAIN><<<grid, NT, lds, st>>>(D); break;
   }
 }
 void launch_sim(bool ffs, bool chain, int nr, int grid, hipStream_t st, const XDev &D)

@@ -73,7 +73,7 @@ class BipredParams(C.Structure):
                 ("offset_bi", C.c_int), ("wp_luma_round", C.c_int), ("luma_log_weight_denom", C.c_int)]
 
 
-SLICE_REFS = 4
+SLICE_REFS = 5
 
 
 class FrameWp(C.Structure):

@@ -294,7 +294,7 @@ int jmhip_me_subpel(jmhip_ctx *ctx, const jmhip_me_params *prm, const jmhip_me_m
  * every row started from what the row above really left (at most rows + 1 passes; jmhip_slice_result_info reports the count).
  * Not mirrored: the 16-bit wrap of EPZSBlkCount (a position visited exactly 65536 searches earlier reads as visited in JM).
  * Frame pictures, luma-only motion estimation (ChromaMEEnable 0), list 0 only, up to JMHIP_SLICE_REFS references. */
-#define JMHIP_SLICE_REFS 4
+#define JMHIP_SLICE_REFS 5                /* every cfg the reference ships has NumberReferenceFrames = 5 (bin/encoder_baseline.cfg:53) */
 enum { JMHIP_SEARCH_UMHEX = 1, JMHIP_SEARCH_UMHEX_SIMPLE = 2, JMHIP_SEARCH_EPZS = 3 };
 typedef struct jmhip_slice_params {
   int32_t search_mode;                     /* input->SearchMode: -1, 0, 1, 2, 3 */
@@ -400,7 +400,7 @@ int jmhip_slice_result_info(jmhip_ctx *ctx, int *passes);
  * reference slot of every 8x8 block become the inputs of jmhip_residual_frame(modes = NULL), which then runs LumaResidualCoding /
  * ChromaResidualCoding on them (per-8x8 reference pictures: macroblock.c:1009-1110 with SetModesAndRefframe), and of jmhip_deblock_recon.
  * ref_slot: list-0 index -> reference slot, as in the slice calls. */
-int jmhip_slice_to_frame(jmhip_ctx *ctx, const int32_t *ref_slot, int num_refs);
+int jmhip_slice_to_frame(jmhip_ctx *ctx, const int32_t *ref_slot, int num_refs);     /* reference slots 0..7 */
 
 /* ------------------------------------------------------------------ low-complexity (rdopt off) mode-decision costs */
 

@@ -291,7 +291,7 @@ int jmo_umhexsmp_subpel_search(const jmo_me_params *p, const jmo_ref *ref, const
 
 /* ------------------------------------------------------------------ low-complexity P-slice inter decision (jmo_lowcplx.c) */
 
-#define JMO_LC_REFS 4            /* references kept in the per-macroblock record (the driver itself takes up to JMO_MAX_REFS) */
+#define JMO_LC_REFS 5            /* references kept in the per-macroblock record (the driver itself takes up to JMO_MAX_REFS) */
 typedef struct {
   int search_mode;               /* -1 FullSearch, 0 FastFullSearch, 1 UMHexagonS, 3 EPZS */
   int search_range, num_refs, full_search;     /* input->search_range, listXsize[LIST_0], input->full_search (RestrictSearchRange) */

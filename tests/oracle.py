@@ -552,7 +552,7 @@ def deblock_frame(Y, U, V, yuv_format, mbs, blks, mvlimit=4):
 
 # ------------------------------------------------------------------ EPZS / UMHexagonS state + the low-complexity P-slice driver
 
-MAX_LIST, MAX_REFS, LC_REFS = 33, 32, 4
+MAX_LIST, MAX_REFS, LC_REFS = 33, 32, 5
 
 
 class EpzsConfig(C.Structure):

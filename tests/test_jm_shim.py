@@ -255,6 +255,10 @@ SLICE_CASES = {
     "slice_full_four_slices_one_call": dict(search=-1, profile=66, cabac=0, t8x8=0, bframes=0, refs=2, rdopt=0, adrnd=1, yuv=1, noi=1, slicemode=1, slicearg=27, lfflag=1, lfidc=2),
     "slice_umhexsmp_slices_one_call_t8": dict(search=2, profile=100, cabac=1, t8x8=1, bframes=0, refs=2, rdopt=0, adrnd=0, yuv=1, noi=1, slicemode=1, slicearg=40, qp=34),
     "slice_epzs_four_slices_midrow": dict(search=3, profile=77, cabac=1, t8x8=0, bframes=0, refs=2, rdopt=0, adrnd=0, yuv=1, noi=1, slicemode=1, slicearg=27, lfflag=1, lfidc=2),
+    # NumberReferenceFrames = 5, as in every cfg the reference ships (bin/encoder_baseline.cfg:53): seven pictures, so that list 0 grows to five entries
+    "slice_fastfull_5ref": dict(search=0, profile=66, cabac=0, t8x8=0, bframes=0, refs=5, rdopt=0, adrnd=1, yuv=1, noi=1, frames=7),
+    "slice_epzs_5ref": dict(search=3, profile=77, cabac=1, t8x8=0, bframes=0, refs=5, rdopt=0, adrnd=0, yuv=1, noi=1, frames=7),
+    "slice_umhex_5ref_t8": dict(search=1, profile=100, cabac=1, t8x8=1, bframes=0, refs=5, rdopt=0, adrnd=0, yuv=1, noi=1, frames=7, qp=32),
 }
 CASES.update(SLICE_CASES)
 
@@ -263,7 +267,8 @@ CASES.update(SLICE_CASES)
 @pytest.mark.skipif(not HAVE, reason="oracle/_ref/jm_hip did not travel")
 @pytest.mark.parametrize("name", list(SLICE_CASES))
 def test_jm_slice_level_binding_is_byte_identical(tmp_path, name):
-    prepare(tmp_path, name, frames=4)
+    nframes = SLICE_CASES[name].get("frames", 4)
+    prepare(tmp_path, name, frames=nframes)
     want = run("jm_plain", tmp_path)
     got = run("jm_hip", tmp_path, {"JMHIP_SHIM_STATS": "1"})
     stats = got[2]
@@ -274,9 +279,9 @@ def test_jm_slice_level_binding_is_byte_identical(tmp_path, name):
     info = re.search(r"slice binding: (\d+) slices, (\d+) kernel passes", stats)
     print(name, m.groups(), sl.groups(), info.groups())
     nslices = 1          # also with four slices of 27 macroblocks per picture: all slices of a picture go in ONE device call (slice_mbs)
-    assert int(sl.group(1)) == 3 * nslices, "one device call per P slice (3 P pictures), or per picture where the slices go in one call"
+    assert int(sl.group(1)) == (nframes - 1) * nslices, "one device call per P slice, or per picture where the slices go in one call"
     per_mb = {0: 41, 1: 45, 2: 9}[SLICE_CASES[name]["t8x8"]]      # Transform8x8Mode 1: four more calls (the 8x8-transform P8x8 pass); 2: modes 1..3 + that pass only
-    assert int(m.group(1)) >= 3 * 99 * per_mb and int(m.group(2)) == 0, "every BlockMotionSearch call of the P pictures must be served from the slice records"
+    assert int(m.group(1)) >= (nframes - 1) * 99 * per_mb and int(m.group(2)) == 0, "every BlockMotionSearch call of the P pictures must be served from the slice records"
     # JM's own search functions must not have run at all in the P pictures
     for sym in ("FullPelBlockMotionSearch", "FastFullPelBlockMotionSearch", "SubPelBlockMotionSearch", "EPZS_UMHex_integer_walks", "computeSAD", "computeSATD"):
         mm = re.search(r"^\s*%s\s+device\s+(\d+)\s+forwarded\s+(\d+)" % sym, stats, re.M)

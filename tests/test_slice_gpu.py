@@ -185,6 +185,9 @@ def run_synthetic(pkg, mode, W, H, R, nref, slices=1, nframes=3, seed=5, metric=
     (1, 320, 192, 32, 3, 3),
     (2, 176, 144, 16, 2, 1),        # the simplified UMHexagonS (me_umhexsmp.c)
     (2, 320, 192, 32, 3, 3),
+    (3, 176, 144, 16, 5, 1),        # five references (JMHIP_SLICE_REFS): EPZS, UMHexagonS, simplified UMHexagonS
+    (1, 176, 144, 16, 5, 2),
+    (2, 176, 144, 16, 5, 1),
 ])
 def test_synthetic_clip_matches_the_oracle(pkg, mode, W, H, R, nref, slices):
     run_synthetic(pkg, mode, W, H, R, nref, slices=slices)
@@ -199,6 +202,8 @@ def test_synthetic_clip_matches_the_oracle(pkg, mode, W, H, R, nref, slices):
     (-1, 320, 192, 32, 4, 3),
     (0, 176, 144, 20, 4, 1),        # a range between the kernel's column groupings (2R+1 = 41)
     (-1, 176, 144, 40, 1, 1),       # the largest range of the pair-lane kernel
+    (0, 176, 144, 16, 5, 2),        # five references: what every cfg the reference ships asks for (NumberReferenceFrames = 5)
+    (-1, 176, 144, 16, 5, 1),
 ])
 def test_exhaustive_searches_as_sweeps_over_the_frame_kernels(pkg, mode, W, H, R, nref, slices):
     """16 <= search_range <= 40, JM's default metrics, the 4x4 transform: FullSearch / FastFullSearch slices run as relaxation sweeps whose
