@@ -392,6 +392,14 @@ def main():
                     help="one = one predictor per macroblock (the metric's workload, SURVEY 8(d)); per-partition = JM's own predictors, one per partition, "
                          "as SetMotionVectorPredictor yields them in raster order (from jmhip_p_slice_search of the first picture): FullSearch then "
                          "walks one window per DISTINCT centre of a macroblock (N = 1 only; for information)")
+    ap.add_argument("--exact", action="store_true",
+                    help="the JM-EXACT form of the step: instead of the independent-macroblocks search with given predictors, every rank runs "
+                         "jmhip_p_slice_search on ITS slice (predictors, FullSearch +-32, sub-pel, skip shortcut and the low-complexity decision on the "
+                         "device, raster-order dependencies kept: JM's vectors), hands the slice to the frame stage (jmhip_slice_to_frame_band -> "
+                         "jmhip_residual_frame) and the bands are exchanged as in the default step. For information next to the metric's workload")
+    ap.add_argument("--exact-slices", type=int, default=0,
+                    help="with --exact on ONE GPU: cut the picture into this many slices of whole macroblock rows, all searched in one call (slice_mbs) -- "
+                         "what N ranks compute between them; the reference checksum must equal the N-rank run's")
     ap.add_argument("--size", choices=["1080p", "2160p"], default=None,
                     help="1080p = BASELINE configs[1], the configuration the metric is quoted on: the default at --gpus 1; 2160p = BASELINE configs[3] "
                          "(4K, FullSearch +-32, slices sharded across the GPUs with the reference picture gathered once per frame), the configuration "
@@ -462,6 +470,13 @@ def main():
     prm.level_mv_min, prm.level_mv_max = -511, 511
     prm.lambda_[0] = prm.lambda_[1] = prm.lambda_[2] = lam
     prm.transform8x8_mode, prm.subpel, prm.partition_mask = 0, 1, (1 << 41) - 1
+    if args.exact:
+        args.cpu_mbs = 0
+        ctx.slice_state_reset()
+        first_mb, count_mb = row0 * MBW, (row1 - row0) * MBW
+        sp = pkg.slice_host.slice_params(-1, R, 1, [lam] * 3, 10, W, H=H, mb_first=first_mb, mb_count=max(count_mb, 1))
+        if not multi and args.exact_slices > 1:
+            sp.slice_mbs = -(-MBH // args.exact_slices) * MBW
     if args.pred == "per-partition":
         if multi:
             sys.exit("bench.py --pred per-partition runs on one GPU")
@@ -489,6 +504,7 @@ def main():
     ext = torch.cuda.ExternalStream(ctx.stream_ptr(), device=dev) if multi else None
 
     done = [0]                                          # steps run so far (the clip position of the resident reference)
+    sweeps = []                                         # --exact: sweeps of each slice search
 
     def step(k):
         done[0] = k + 1
@@ -502,9 +518,16 @@ def main():
             if args.chroma_planes:
                 ctx.interp_chroma(0)
         elif n:
-            # a rank only needs the sub-pel planes its band can reach: own rows +- (range + predictor reach 6 + slack)
-            ctx.interp_rows(0, row0 * 16 - (R + 16), row1 * 16 + (R + 16), chroma=args.chroma_planes)
-        if n:
+            # a rank only needs the sub-pel planes its band can reach: own rows +- (range + predictor reach 6 + slack); the exact form centres its
+            # windows on JM's predictors, themselves clamped to the range: twice the range
+            reach = 2 * R + 24 if args.exact else R + 16
+            ctx.interp_rows(0, row0 * 16 - reach, row1 * 16 + reach, chroma=args.chroma_planes)
+        if n and args.exact:
+            ctx.p_slice_search(sp, download=False)
+            sweeps.append(ctx.slice_passes())
+            ctx.slice_to_frame_band([0], first_mb, count_mb)
+            ctx.residual_frame(quants)
+        elif n:
             if first[0]:
                 ctx.me_frame_async(prm, mbs)
                 first[0] = False
@@ -673,6 +696,20 @@ def main():
             e2e = jm_end_to_end(frames, rdopt1=True)
             if e2e is not None:
                 out["jm_end_to_end_rdopt1_speculative"] = e2e
+        if args.exact:
+            out["metric_note"] = ("--exact: the JM-EXACT form of the step -- jmhip_p_slice_search per slice (predictors, FullSearch +-32 per partition round its own "
+                                  "predictor, sub-pel, skip shortcut, low-complexity decision; relaxation sweeps to JM's fixpoint), jmhip_slice_to_frame_band, "
+                                  "jmhip_residual_frame, band exchange. The metric's own workload is the default run (independent macroblocks)")
+            out["config"]["workload"] = workload.replace("predictor field (16,-16)+U{-8..8} qpel per MB", "JM's own predictors (SetMotionVectorPredictor in raster order, on the device)")
+            out["config"]["slices"] = max(world, args.exact_slices or 1)
+            me_ms, me_launches = stage["me_int"]
+            out["roofline"] = {"kernel": "jmhip_p_slice_search (x_sim_kernel + me_int_pair_kernel<list> + me_sub_kernel<list>, sweeps to the fixpoint)", "bound": "valu",
+                               "achieved": round((2 * R + 1) ** 2 * 256 * n / (me_ms / max(1, me_launches) * 1e-3) / 1e12, 3) if me_launches else None,
+                               "peak": round((2 * R + 1) ** 2 * 256 * n / (valu_floor_ms * 1e-3) / 1e12, 3), "unit": "T abs-diff/s",
+                               "frac": round(valu_floor_ms / (me_ms / max(1, me_launches)), 4) if me_launches else None, "traffic": None,
+                               "note": "achieved = ONE exhaustive search per macroblock's worth of abs-diffs over the whole slice search's time (its sweeps search "
+                                       "several times that: every record whose predictor changed); peak = the same VALU model as the default line",
+                               "slice_search_ms": round(me_ms / max(1, me_launches), 3), "sweeps_last_steps": sweeps[-4:]}
         if solo:
             out = {"DIAGNOSTIC_solo_rank": solo, "ms_per_step_of_this_rank": out["ms_per_step"], "stages_ms_per_launch": out.get("stages_ms_per_launch")}
         print(json.dumps(out))

@@ -2093,7 +2093,7 @@ struct SliceState {
   uint16_t *surf = nullptr; size_t surf_rows = 0; int surf_n = 0, surf_refs = 0;
   int passes = 0;
   bool has_col = false;
-  int searched_to = 0;                         // macroblocks [0, searched_to) of the current picture have been searched
+  int searched_from = 0, searched_to = 0;      // macroblocks [searched_from, searched_to) of the current picture have been searched (by slice calls in order)
   bool t8_any = false;                         // a slice of the current picture was searched with Transform8x8Mode: macroblocks may carry the 8x8-transform flag
 };
 
@@ -2356,7 +2356,9 @@ extern "C" int jmhip_p_slice_search(jmhip_ctx *c, const jmhip_slice_params *prm,
   if (!x_settled) std::swap(s->carry_slice, s->carry_slice_next);      // (the exhaustive searches neither read nor write img->all_mv's carry)
   if (prm->mb_first == 0) s->t8_any = false;
   s->t8_any = s->t8_any || prm->transform8x8_mode != 0;
-  s->searched_to = (prm->mb_first == 0 || prm->mb_first == s->searched_to) ? prm->mb_first + prm->mb_count : 0;
+  // slices in coding order extend the searched range; anything else starts a new one (a rank of the slice-parallel layout searches only its band)
+  if (prm->mb_first != 0 && prm->mb_first == s->searched_to) s->searched_to = prm->mb_first + prm->mb_count;
+  else { s->searched_from = prm->mb_first; s->searched_to = prm->mb_first + prm->mb_count; }
   if (results) return jmhip_slice_results_download(c, results, prm->mb_first, prm->mb_count);
   return JMHIP_OK;
 }
@@ -2395,15 +2397,15 @@ namespace {
 // one thread per macroblock: the slice search's record -> the search-stage result layout the frame stage reads (vector per partition: the
 // one of the reference its 8x8 block settled on), the decided mode, the reference slot per 8x8 block
 struct SlotMap { int s[WR]; };
-__global__ void slice_to_frame_kernel(const jmhip_mb_inter *__restrict__ rec, int n, int mbw, SlotMap sm,
+__global__ void slice_to_frame_kernel(const jmhip_mb_inter *__restrict__ rec, int first, int n, int mbw, SlotMap sm,
                                       jmhip_me_mb *__restrict__ jobs, jmhip_me_result *__restrict__ res, jmhip_mb_mode *__restrict__ modes, int8_t *__restrict__ blk_ref)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const jmhip_mb_inter &r = rec[i];
+  const jmhip_mb_inter &r = rec[first + i];              // job i of the frame stage = macroblock first + i of the picture
   const int *slots = sm.s;
   jmhip_me_mb &j = jobs[i];
-  j.mb_x = (int16_t)(i % mbw); j.mb_y = (int16_t)(i / mbw); j.ref = (int16_t)slots[r.b8ref[0]]; j.ref_is_0 = (int16_t)(r.b8ref[0] == 0);
+  j.mb_x = (int16_t)((first + i) % mbw); j.mb_y = (int16_t)((first + i) / mbw); j.ref = (int16_t)slots[r.b8ref[0]]; j.ref_is_0 = (int16_t)(r.b8ref[0] == 0);
   jmhip_me_result &o = res[i];
   for (int p = 0; p < JMHIP_NPART; p++) {
     const PartInfo q = c_part[p];
@@ -2432,11 +2434,18 @@ __global__ void slice_to_frame_kernel(const jmhip_mb_inter *__restrict__ rec, in
 
 extern "C" int jmhip_slice_to_frame(jmhip_ctx *c, const int32_t *ref_slot, int num_refs)
 {
+  if (!c) return JMHIP_ERR_ARG;
+  return jmhip_slice_to_frame_band(c, ref_slot, num_refs, 0, c->mbw * c->mbh);
+}
+
+extern "C" int jmhip_slice_to_frame_band(jmhip_ctx *c, const int32_t *ref_slot, int num_refs, int mb_first, int mb_count)
+{
   if (!c || !ref_slot || num_refs < 1 || num_refs > JMHIP_SLICE_REFS) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_slice_to_frame: arguments") : JMHIP_ERR_ARG;
   if (!c->slice_state) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_slice_to_frame: no slice has been searched");
   SliceState *s = static_cast<SliceState *>(c->slice_state);
-  const int n = c->mbw * c->mbh;
-  if (s->searched_to != n) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_slice_to_frame: not every macroblock of the picture has been searched (slices must cover it in order)");
+  const int n = mb_count;
+  if (mb_first < 0 || mb_count < 1 || mb_first + mb_count > c->mbw * c->mbh) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_slice_to_frame: macroblock range outside the picture");
+  if (mb_first < s->searched_from || mb_first + mb_count > s->searched_to) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_slice_to_frame: not every macroblock of the range has been searched in the current picture (slices must cover it in order)");
   unsigned mask = 0;
   SlotMap sm{};
   for (int r = 0; r < num_refs; r++) {
@@ -2456,7 +2465,7 @@ extern "C" int jmhip_slice_to_frame(jmhip_ctx *c, const int32_t *ref_slot, int n
       if (dev >= 0 && dev < 64) part_uploaded[dev] = true;
     }
   }
-  slice_to_frame_kernel<<<(n + 127) / 128, 128, 0, c->stream>>>(s->out, n, c->mbw, sm, (jmhip_me_mb *)c->me_jobs_dev,
+  slice_to_frame_kernel<<<(n + 127) / 128, 128, 0, c->stream>>>(s->out, mb_first, n, c->mbw, sm, (jmhip_me_mb *)c->me_jobs_dev,
                                                                 (jmhip_me_result *)c->me_res_dev, (jmhip_mb_mode *)c->fr_modes + n, (int8_t *)c->fr_blk_ref);
   JM_HIP_CHECK(c, hipGetLastError());
   // the search-stage arrays now hold this picture; a resident re-run of jmhip_me_frame on them is meaningless and is refused (geometry check)

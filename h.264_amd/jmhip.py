@@ -216,6 +216,7 @@ def load_library():
     lib.jmhip_slice_field_download.argtypes = [vp, vp, vp]
     lib.jmhip_slice_result_info.argtypes = [vp, C.POINTER(ip)]
     lib.jmhip_slice_to_frame.argtypes = [vp, vp, ip]
+    lib.jmhip_slice_to_frame_band.argtypes = [vp, vp, ip, ip, ip]
     lib.jmhip_frame_wp_set.argtypes = [vp, vp]
     lib.jmhip_frame_bipred_set.argtypes = [vp, vp, ip, vp]
     for which, dt in ((0, ME_MB_DTYPE), (1, ME_RESULT_DTYPE), (2, QUANT_DTYPE), (3, TQ_JOB_DTYPE), (4, TQ_RESULT_DTYPE),
@@ -420,6 +421,11 @@ class Context:
         """Hand the searched picture (slices covering it in order) to residual_frame: per-8x8 reference slots, decided modes, vectors."""
         a = np.ascontiguousarray(ref_slot, dtype=np.int32)
         self._chk(self.lib.jmhip_slice_to_frame(self.h, _ptr(a), len(a)), "jmhip_slice_to_frame")
+
+    def slice_to_frame_band(self, ref_slot, mb_first, mb_count):
+        """The same for macroblocks [mb_first, mb_first + mb_count) alone (a rank's slice): job i of residual_frame is macroblock mb_first + i."""
+        a = np.ascontiguousarray(ref_slot, dtype=np.int32)
+        self._chk(self.lib.jmhip_slice_to_frame_band(self.h, _ptr(a), len(a), mb_first, mb_count), "jmhip_slice_to_frame_band")
 
     def frame_wp_set(self, wp=None):
         """wp: None (off) or dict(luma_round, luma_denom, chroma_round, chroma_denom, weight[(slot, comp)], offset[(slot, comp)] as (16,3) arrays)."""

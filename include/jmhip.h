@@ -401,6 +401,10 @@ int jmhip_slice_result_info(jmhip_ctx *ctx, int *passes);
  * ChromaResidualCoding on them (per-8x8 reference pictures: macroblock.c:1009-1110 with SetModesAndRefframe), and of jmhip_deblock_recon.
  * ref_slot: list-0 index -> reference slot, as in the slice calls. */
 int jmhip_slice_to_frame(jmhip_ctx *ctx, const int32_t *ref_slot, int num_refs);     /* reference slots 0..7 */
+/* The same for the macroblocks [mb_first, mb_first + mb_count) alone -- a rank of the slice-parallel layout (one slice per GPU,
+ * src/slice.c:214 with SliceMode 1) hands ITS slice to the frame stage: job i of jmhip_residual_frame is macroblock mb_first + i, the
+ * reconstruction covers those macroblocks' rows (jmhip_recon_pack_band). The range must have been searched in the current picture. */
+int jmhip_slice_to_frame_band(jmhip_ctx *ctx, const int32_t *ref_slot, int num_refs, int mb_first, int mb_count);
 
 /* ------------------------------------------------------------------ low-complexity (rdopt off) mode-decision costs */
 

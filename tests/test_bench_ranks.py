@@ -67,3 +67,21 @@ def test_two_ranks_default_to_the_4k_configuration():
                "--master-port", "29551", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--cpu-mbs", "0"], {"JMHIP_BENCH_REHEARSAL": "1"})
     assert "3840x2160" in two["config"]["workload"] and "3840x2160" in one["config"]["workload"]
     assert one["ref_checksum"] == two["ref_checksum"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_ranks_of_the_jm_exact_path_rebuild_the_reference_of_one_gpu_coding_the_same_slices(ranks):
+    """bench.py --exact: every rank searches ITS slice with jmhip_p_slice_search (JM's predictors never cross a slice, src/mb_access.c:30-36),
+    hands it to the frame stage (jmhip_slice_to_frame_band) and the reconstructed bands are gathered. One GPU coding the same picture cut into
+    the same slices (--exact-slices, all slices in one call) must produce the same reference pictures; and cutting the picture differently must
+    not (the slices' predictors differ), which shows the slicing is really in the result."""
+    one = run([sys.executable, "bench.py", "--exact", "--exact-slices", str(ranks), "--steps", "2", "--warmup", "1"])
+    many = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+                "--master-port", str(29570 + ranks), "bench.py", "--gpus", str(ranks), "--size", "1080p", "--exact", "--steps", "2", "--warmup", "1"],
+               {"JMHIP_BENCH_REHEARSAL": "1"})
+    whole = run([sys.executable, "bench.py", "--exact", "--steps", "2", "--warmup", "1"])
+    assert many["n_gpus"] == ranks and many["config"]["slices"] == ranks and one["config"]["slices"] == ranks
+    assert one["ref_checksum"] == many["ref_checksum"], "the ranks' slices did not reproduce the one-GPU coding of the same slices"
+    assert whole["ref_checksum"] != one["ref_checksum"], "one slice and %d slices gave the same picture: the slicing is not in the result" % ranks
+    assert "jmhip_p_slice_search" in many["roofline"]["kernel"]
