@@ -18,6 +18,7 @@ namespace {
 constexpr int WR = JMHIP_SLICE_REFS;
 constexpr int MAXC = 128;                      // candidates per batch
 constexpr int CARRY = 5;
+constexpr uint8_t EP_STAMPED = 255;             // WaveDev.ep_first: the macroblock's first touch of the cell was a search stamping its centre (:1598), not a test
 constexpr int SURF_PLANES = 20;                // the sixteen 4x4 blocks + the four 8x8 blocks of a macroblock
 constexpr int SURF_MARGIN = 6;                 // FullSearch: the surface is built round the 16x16 centre, this much wider than the range
 constexpr int WIN_MAX = 96;                    // LDS reference window side: 2 * (33 + SURF_MARGIN) + 1 + 15 = 94                       // vectors of the previous macroblock EPZS may read per reference: 16x16 + four 8x8
@@ -38,6 +39,16 @@ struct WaveDev {
   short *ep_motion;                            // EPZSMotion[LIST_0] [rows + 1][WR][7][4][w4][2]
   int row0;                                    // first macroblock row of the slice
   const short *ep_col;                         // EPZSCo_located->mv[LIST_0] [h4][w4][2]
+  // EPZSMap / EPZSBlkCount (me_epzs.c:49,92,1550,1598,1757,1840): JM never clears the map, a cell counts as visited when it holds the 16-bit
+  // stamp of the running search -- also when a search 65536 k calls earlier left that stamp, or the counter passes the zero the map was
+  // allocated with. A macroblock keeps a fresh bitmap per search and records, per map cell, the first and the last of ITS searches that
+  // tested the cell; a scan over the macroblocks in coding order (ep_alias_* kernels below) finds the tests JM would have answered from an old
+  // stamp, and the macroblocks they fall in are searched again with those cells pre-marked (ep_alias)
+  uint8_t *ep_first, *ep_last;                 // [nmb][ep_cells]: search of the macroblock (1-based, 0 = none) that tested the cell first (EP_STAMPED: it was stamped before any test) / touched it last
+  uint16_t *ep_nsearch;                        // [nmb]: integer searches of the macroblock
+  int ep_cells;                                // (2 search_range + 1)^2, padded to a multiple of 4
+  const unsigned long long *ep_alias; int ep_alias_n;      // macroblock << 32 | search << 16 | cell: tests answered "visited" from an old stamp
+  uint8_t *ep_alias_flag;                      // [nmb]: bit 0 the macroblock has entries in ep_alias, bit 1 search it again in the next sweep
   const short *carry_in;                       // [mbh][WR][CARRY][2]: img->all_mv the first macroblock of a row finds (speculated)
   short *carry_out;                            // [mbh][WR][CARRY][2]: what the last macroblock of a row leaves
   int *um_cost;                                // fastme_l0_cost [8][h4][w4]
@@ -52,7 +63,7 @@ struct WaveDev {
   const uint16_t *tie_tab; int tie_R;           // exhaustive searches: spiral index + 1 of every offset of a (2 tie_R + 1)^2 window, row-major (built per call)
   uint16_t *surf;                              // exhaustive searches: per row, per reference, SAD surfaces [SURF_PLANES][surf_n]
   int surf_n;                                  // candidates per plane (capacity)
-  int debug;                                   // JMHIP_WAVE_DEBUG (timing experiments only; results are wrong): 1 no sub-pel, 2 no integer search, 4 no skip cost
+  int debug;                                   // JMHIP_WAVE_DEBUG (timing experiments only; results are wrong): 1 no sub-pel, 2 no integer search, 4 no skip cost, 16 no EPZS map records
 };
 
 // The slice's parameter block lives in constant memory and the block being searched in LDS, both named directly by every device function:
@@ -69,9 +80,6 @@ struct Lds {
   uint32_t map[160];                           // visited map of one search, (2R+1)^2 bits
   short all_mv[16][WR][8][2];                  // img->all_mv[by][bx][LIST_0][ref][blocktype]
   int motion_cost[8][WR][4];
-  int um_ref_cost[WR][8][16];                  // fastme_ref_cost[ref][blocktype][by][bx]
-  int um_best_cost[8][4];                      // fastme_best_cost[blocktype - 1][pic_pix_x >> 2] (only ever read after being written by the same block)
-  uint8_t um_sstate[52];                       // SearchState 7x7
   int surf_c[2 * WR][5];                       // per surface slot (0: the macroblock's, 1: a partition's own) and reference: centre (pels), half side, valid, block rows
   // the macroblock's view of the picture-level state: staged once by mb_stage, used and updated in LDS, handed on by mb_commit.
   // Grid [y + 1][x + 1] of the 4x4 blocks x = -1..4, y = -1..3: the macroblock's own sixteen and the ring its predictors read (A, B, C, D)
@@ -81,12 +89,23 @@ struct Lds {
   unsigned long long memo_old[WR], memo_new[WR];
   int8_t f_ref[5][6];                          // enc_picture->ref_idx[LIST_0]
   short f_mv[5][6][2];                         // enc_picture->mv[LIST_0]
-  int um_loc[8][5][6];                         // fastme_l0_cost per block type
-  int ep_sad[7][12];                           // EPZSDistortion, 4x4 columns 4 * mbx - 4 .. 4 * mbx + 7
-  short ep_colb[6][6][2];                      // EPZSCo_located->mv of the 4x4 blocks [4 mby - 1 .. 4 mby + 4][4 mbx - 1 .. 4 mbx + 4] (temporal predictors)
+  // what only one family of search modes uses shares its space: with all of it side by side the block was 22 KB and the eighth workgroup of
+  // a CU (2 waves per SIMD) no longer fitted -- 2048 resident workgroups became 1792 and a full sweep two rounds of workgroups instead of one
   union {
     __attribute__((aligned(16))) uint8_t win[WIN_MAX * WIN_MAX];   // exhaustive modes: reference window of the surface pass
-    short ep_mot[WR][7][4][12][2];                                   // EPZS: EPZSMotion, same columns as ep_sad
+    struct {                                                        // EPZS
+      short ep_mot[WR][7][4][12][2];             // EPZSMotion, same columns as ep_sad
+      int ep_sad[7][12];                         // EPZSDistortion, 4x4 columns 4 * mbx - 4 .. 4 * mbx + 7
+      short ep_colb[6][6][2];                    // EPZSCo_located->mv of the 4x4 blocks [4 mby - 1 .. 4 mby + 4][4 mbx - 1 .. 4 mbx + 4] (temporal predictors)
+      uint32_t ep_seen[160];                     // cells of JM's map (side 2 search_range + 1) some search of this macroblock has tested
+      int ep_i, ep_alias_on;                     // integer searches of this macroblock so far; the macroblock has pre-marked cells
+    };
+    struct {                                                        // UMHexagonS and its simplified form
+      int um_ref_cost[WR][8][16];                // fastme_ref_cost[ref][blocktype][by][bx]
+      int um_best_cost[8][4];                    // fastme_best_cost[blocktype - 1][pic_pix_x >> 2] (only ever read after being written by the same block)
+      int um_loc[8][5][6];                       // fastme_l0_cost per block type
+      uint8_t um_sstate[52];                     // SearchState 7x7
+    };
   };
 };
 
@@ -439,6 +458,45 @@ __device__ __forceinline__ int map_test_set(int R, int dx, int dy)
 }
 __device__ __forceinline__ int map_test(int R, int dx, int dy) { const int i = (dy + R) * (2 * R + 1) + (dx + R); return (L.map[i >> 5] >> (i & 31)) & 1u; }
 __device__ __forceinline__ void map_set(int R, int dx, int dy) { const int i = (dy + R) * (2 * R + 1) + (dx + R); L.map[i >> 5] |= 1u << (i & 31); }
+// EPZS: search `si` of this macroblock tests (or, the centre, stamps) the cell JM addresses as EPZSMap[R + dy][R + dx] (mapCenter, me_epzs.c:1537).
+// Recorded per test only in a macroblock that has pre-marked cells (a set bit of its bitmaps need not be a tested cell); every other macroblock
+// records a whole search at once from the search's bitmap (ep_record) -- a store per test would be waited for at every evaluation call.
+__device__ __forceinline__ void ep_touch(int R, int dx, int dy, int si, bool stamped = false)
+{
+  const int cell = (R + dy) * (2 * D.p.search_range + 1) + (R + dx);
+  const uint32_t w = L.ep_seen[cell >> 5], b = 1u << (cell & 31);
+  if (threadIdx.x == 0) {
+    const size_t at = (size_t)(L.mby * D.mbw + L.mbx) * D.ep_cells + cell;
+    if (!(w & b)) D.ep_first[at] = stamped ? EP_STAMPED : (uint8_t)si;
+    D.ep_last[at] = (uint8_t)si;
+  }
+  L.ep_seen[cell >> 5] = w | b;
+}
+
+// EPZS, after search `si` of a macroblock without pre-marked cells: every set bit of the search's bitmap is a cell the search tested or stamped
+__device__ void ep_record(int R, int si)
+{
+  const int side = 2 * R + 1, nw = (side * side + 31) >> 5, jside = 2 * D.p.search_range + 1;
+  const size_t at = (size_t)(L.mby * D.mbw + L.mbx) * D.ep_cells;
+  const float inv = 1.0f / (float)side;
+  const int centre = R * side + R;
+  __syncthreads();
+  for (int w = threadIdx.x; w < nw; w += 64) {
+    uint32_t bits = L.map[w];
+    while (bits) {
+      const int i = (w << 5) + __builtin_ctz(bits);
+      bits &= bits - 1;
+      int row = (int)((float)i * inv);
+      if (row * side > i) row--;
+      if ((row + 1) * side <= i) row++;
+      const int cell = row * jside + (i - row * side);
+      const uint32_t b = 1u << (cell & 31);
+      if (!(atomicOr(&L.ep_seen[cell >> 5], b) & b)) D.ep_first[at + cell] = i == centre ? EP_STAMPED : (uint8_t)si;
+      D.ep_last[at + cell] = (uint8_t)si;
+    }
+  }
+  __syncthreads();
+}
 
 // ---------------------------------------------------------------------------------------------- SubPelBlockMotionSearch (me_fullsearch.c:341)
 
@@ -698,7 +756,7 @@ __device__ void ep_eval(int n)
 }
 
 // EPZSPelBlockMotionSearch, me_epzs.c:1500. mvx/mvy: search centre in, result out (pels). all_mv: this block's img->all_mv row [ref][blocktype].
-__device__ int epzs_pel(int mb_nr, int R, int *mvx, int *mvy)
+__device__ __forceinline__ int epzs_pel_search(int mb_nr, int R, int *mvx, int *mvy)
 {
   const jmhip_slice_params &P = D.p;
   const int lam = P.lambda_mf[0], bt = B.bt, ref = B.ref;
@@ -710,8 +768,24 @@ __device__ int epzs_pel(int mb_nr, int R, int *mvx, int *mvy)
   const int medthres = P.epzs_thres[1][bt];
   int stop = medthres;
   EpState S{cx0, cy0, 0, 0, 0, INT_MAX};
+  const int si = L.ep_i + 1;                                    // EPZSBlkCount++ (:1550), counted per macroblock
   map_clear(R);
+  L.ep_i = si;
+  if (L.ep_alias_on) {                                          // cells whose old stamp equals this search's (ep_alias_detect_kernel)
+    const int side = 2 * P.search_range + 1, addr = L.mby * D.mbw + L.mbx;
+    for (int k = threadIdx.x; k < D.ep_alias_n; k += 64) {
+      const unsigned long long e = D.ep_alias[k];
+      if ((int)(e >> 32) != addr || (int)((e >> 16) & 0xffff) != si) continue;
+      const int cell = (int)(e & 0xffff), row = cell / side, col = cell - row * side;
+      if (row > 2 * R || col > 2 * R) continue;
+      const int i = row * (2 * R + 1) + col;
+      atomicOr(&L.map[i >> 5], 1u << (i & 31));
+    }
+    __syncthreads();
+  }
   map_set(R, 0, 0);
+  const int per_test = L.ep_alias_on;
+  if (per_test) ep_touch(R, 0, 0, si, true);
   L.qx[0] = cx0; L.qy[0] = cy0;
   ep_eval(1);
   S.min_mcost = mvc(lam, cx0 << 2, cy0 << 2) + L.dist[0];
@@ -805,6 +879,7 @@ __device__ int epzs_pel(int mb_nr, int R, int *mvx, int *mvy)
     for (int k = 0; k < np; k++) {
       const int tx = L.px[k], ty = L.py[k];
       if (iabs(tx - cx0) > R || iabs(ty - cy0) > R) continue;
+      if (per_test) ep_touch(R, tx - cx0, ty - cy0, si);
       if (map_test_set(R, tx - cx0, ty - cy0)) continue;
       L.qx[n] = tx; L.qy[n] = ty; n++;
     }
@@ -838,7 +913,10 @@ __device__ int epzs_pel(int mb_nr, int R, int *mvx, int *mvy)
           int pidx[12];
           for (int c = 0, pt = point; c < total; c++) {
             const int tx = center_x + c_pat[pf].mvx[pt], ty = center_y + c_pat[pf].mvy[pt];
-            if (iabs(tx - cx0) <= R && iabs(ty - cy0) <= R && !map_test_set(R, tx - cx0, ty - cy0)) { L.qx[cnt] = tx; L.qy[cnt] = ty; pidx[cnt] = pt; cnt++; }
+            if (iabs(tx - cx0) <= R && iabs(ty - cy0) <= R) {
+              if (per_test) ep_touch(R, tx - cx0, ty - cy0, si);
+              if (!map_test_set(R, tx - cx0, ty - cy0)) { L.qx[cnt] = tx; L.qy[cnt] = ty; pidx[cnt] = pt; cnt++; }
+            }
             if (++pt >= c_pat[pf].n) pt -= c_pat[pf].n;
           }
           ep_eval(cnt);
@@ -879,6 +957,13 @@ __device__ int epzs_pel(int mb_nr, int R, int *mvx, int *mvy)
 }
 
 // one level of EPZSSubPelBlockMotionSearch (me_epzs.c:2472-2579 / :2605-2715). Returns 1 on the sub-threshold early return.
+__device__ int epzs_pel(int mb_nr, int R, int *mvx, int *mvy)
+{
+  const int cost = epzs_pel_search(mb_nr, R, mvx, mvy);
+  if (!L.ep_alias_on && !(D.debug & 16)) ep_record(R, L.ep_i);
+  return cost;
+}
+
 __device__ int epzs_sub_level(int half, int start, int lam, int metric, int umv, int *mvx, int *mvy, int *min_mcost, int subthres)
 {
   const int8_t (*pts)[2] = half ? c_sp_hp : c_sp_qp;
@@ -1880,6 +1965,14 @@ __device__ void mb_stage(int mbx, int mby)
       L.um_loc[bt][gy][gx] = v;
     }
   if (P.search_mode == JMHIP_SEARCH_EPZS) {
+    // nothing of this macroblock has tested a map cell yet
+    for (int e = lane; e < 160; e += 64) L.ep_seen[e] = 0u;
+    {
+      const size_t at = (size_t)(mby * D.mbw + mbx) * D.ep_cells;
+      uint32_t *f = reinterpret_cast<uint32_t *>(D.ep_first + at), *z = reinterpret_cast<uint32_t *>(D.ep_last + at);
+      if (!(D.debug & 16)) for (int e = lane; e < D.ep_cells / 4; e += 64) { f[e] = 0u; z[e] = 0u; }
+    }
+    if (lane == 0) { L.ep_i = 0; L.ep_alias_on = D.ep_alias_flag[mby * D.mbw + mbx] & 1; }
     const int col0 = 4 * mbx - 4;
     for (int e = lane; e < 7 * 12; e += 64) {
       const int t = e / 12, j = e - t * 12, col = clampi(col0 + j, 0, D.w4 - 1);
@@ -1926,6 +2019,7 @@ __device__ int mb_commit(int mbx, int mby)
     }
   if (P.search_mode == JMHIP_SEARCH_EPZS) {
     const size_t row = (size_t)(mby - D.row0 + 1);
+    if (lane == 0) D.ep_nsearch[mby * D.mbw + mbx] = (uint16_t)L.ep_i;
     if (lane < 28) {
       const int t = lane >> 2, j = lane & 3;
       const size_t at = (row * 7 + t) * D.w4 + 4 * mbx + j;
@@ -2022,7 +2116,9 @@ template <int SM> __global__ __launch_bounds__(64, 2) void p_slice_relax_kernel(
         return a >= first && a <= last && D.chg_prev[a - first] != 0;
       };
       active = chg(mbx - 1, mby) || chg(mbx, mby - 1) || chg(mbx + 1, mby - 1) || chg(mbx - 1, mby - 1) || (addr > first && D.chg_prev[addr - 1 - first] != 0);
+      if (SM == JMHIP_SEARCH_EPZS && (D.ep_alias_flag[addr] & 2)) active = true;      // its pre-marked cells changed
     }
+    if (SM == JMHIP_SEARCH_EPZS && active && lane == 0) D.ep_alias_flag[addr] &= 1;
     if (!active) { if (lane == 0) D.chg_next[addr - first] = 0; continue; }
     all_mv_from_carry(addr == first ? carry_slice_in : D.carry_mb + (size_t)(addr - 1) * WR * CARRY * 2);
 #ifdef JMHIP_WAVE_PROF
@@ -2070,6 +2166,91 @@ __global__ void epzs_rows_fold_kernel(int *ep_dist, short *ep_motion, int w4, in
 #undef FMV
 #undef UMLOC
 
+
+// ---------------------------------------------------------------------------------------------- EPZSMap across searches (me_epzs.c:49,92,1550,1598,1757,1840)
+// JM's visited map holds, per cell, the 16-bit EPZSBlkCount of the search that stamped it last, and is never cleared: a test "stamp == the
+// running search's" also succeeds for a stamp left 65536 k searches ago, or for the initial zero of a cell no search has touched when the counter
+// passes zero. The slice's macroblocks each searched with fresh per-search bitmaps and recorded, per cell, their first and last search that
+// tested it (WaveDev.ep_first / ep_last) and how many searches they ran (ep_nsearch). These kernels walk the macroblocks in coding order per cell
+// with JM's stamps and list the tests JM would have answered from an old stamp: cell c of macroblock m's search i, where nothing of m touched c
+// before i (first[m][c] == i) and the stamp c carries into m equals the stamp of i. Only such tests can differ: inside a macroblock two searches
+// are fewer than 65536 apart.
+constexpr int EP_SEG = 32;                     // macroblocks per segment of the walk
+constexpr int EP_ALIAS_CAP = 8192;
+constexpr uint32_t EP_NONE = 0x10000u;
+
+// base[k] = searches before macroblock mb_first + k (k <= mb_count), starting from the counter the slice found; one workgroup
+__global__ void ep_alias_base_kernel(const uint16_t *__restrict__ nsearch, int mb_first, int mb_count, const uint32_t *count_in, uint32_t *base, uint32_t *count_out)
+{
+  __shared__ uint32_t part[1024];
+  __shared__ uint32_t carry;
+  if (threadIdx.x == 0) carry = *count_in;
+  __syncthreads();
+  for (int k0 = 0; k0 < mb_count; k0 += 1024) {
+    const int k = k0 + threadIdx.x;
+    const uint32_t v = k < mb_count ? nsearch[mb_first + k] : 0u;
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+      const uint32_t a = threadIdx.x >= (unsigned)d ? part[threadIdx.x - d] : 0u;
+      __syncthreads();
+      part[threadIdx.x] += a;
+      __syncthreads();
+    }
+    if (k < mb_count) base[k] = carry + part[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += part[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { base[mb_count] = carry; *count_out = carry; }
+}
+
+// seg_last[s][c]: the stamp cell c carries out of segment s if a macroblock of the segment touched it, else EP_NONE
+__global__ void ep_alias_seglast_kernel(const uint8_t *__restrict__ last, const uint32_t *__restrict__ base, int mb_first, int mb_count, int cells, uint32_t *seg_last)
+{
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
+  if (c >= cells) return;
+  const int k0 = s * EP_SEG, k1 = min(mb_count, k0 + EP_SEG);
+  uint32_t r = EP_NONE;
+  for (int k = k1 - 1; k >= k0; k--) {
+    const uint32_t z = last[(size_t)(mb_first + k) * cells + c];
+    if (z) { r = (base[k] + z) & 0xffffu; break; }
+  }
+  seg_last[(size_t)s * cells + c] = r;
+}
+
+// seg_in[s][c]: the stamp cell c carries into segment s; map_out: JM's map after the slice
+__global__ void ep_alias_segin_kernel(const uint32_t *__restrict__ seg_last, int nseg, int cells, const uint16_t *__restrict__ map_in, uint32_t *seg_in, uint16_t *map_out)
+{
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cells) return;
+  uint32_t l = map_in[c];
+  for (int s = 0; s < nseg; s++) {
+    seg_in[(size_t)s * cells + c] = l;
+    const uint32_t v = seg_last[(size_t)s * cells + c];
+    if (v != EP_NONE) l = v;
+  }
+  map_out[c] = (uint16_t)l;
+}
+
+__global__ void ep_alias_detect_kernel(const uint8_t *__restrict__ first_, const uint8_t *__restrict__ last, const uint16_t *__restrict__ nsearch, const uint32_t *__restrict__ base,
+                                       const uint32_t *__restrict__ seg_in, int mb_first, int mb_count, int cells, unsigned long long *list, int *n_list)
+{
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
+  if (c >= cells) return;
+  const int k0 = s * EP_SEG, k1 = min(mb_count, k0 + EP_SEG);
+  uint32_t l = seg_in[(size_t)s * cells + c];
+  for (int k = k0; k < k1; k++) {
+    const size_t at = (size_t)(mb_first + k) * cells + c;
+    const uint32_t b = base[k], i = (l - b) & 0xffffu, f = first_[at], z = last[at];
+    if (i >= 1u && i <= nsearch[mb_first + k] && f == i) {
+      const int slot = atomicAdd(n_list, 1);
+      if (slot < EP_ALIAS_CAP) list[slot] = ((unsigned long long)(mb_first + k) << 32) | ((unsigned long long)i << 16) | (unsigned)c;
+    }
+    if (z) l = (b + z) & 0xffffu;
+  }
+}
+
 // rows whose speculated start differs from what the row above left: flag[1] = first such row (min), else untouched
 __global__ void carry_check_kernel(const short *carry_in, const short *carry_out, int row_first, int rows, int *flags)
 {
@@ -2085,6 +2266,12 @@ struct SliceState {
   int *prog = nullptr, *flags = nullptr;
   jmhip_mb_inter *out = nullptr;
   int *ep_dist = nullptr; short *ep_motion = nullptr; short *ep_col = nullptr;        // row memories: [mbh + 1] stored rows (WaveDev)
+  // EPZSMap / EPZSBlkCount: the map (16-bit stamps) and the search counter as the last slice left them (and where the running call writes the
+  // next ones), the per-macroblock touch records and the scan's scratch
+  uint16_t *ep_map = nullptr, *ep_map_next = nullptr; uint32_t *ep_count = nullptr, *ep_count_next = nullptr; int ep_cells = 0;
+  uint8_t *ep_first = nullptr, *ep_last = nullptr, *ep_alias_flag = nullptr; uint16_t *ep_nsearch = nullptr;
+  uint32_t *ep_base = nullptr, *ep_seg_last = nullptr, *ep_seg_in = nullptr; unsigned long long *ep_alias = nullptr, *ep_alias_new = nullptr; int *ep_alias_n = nullptr;
+  int ep_aliases = 0;                          // map tests of the last call answered from an old stamp
   short *carry_mb = nullptr; uint8_t *chg[2] = {nullptr, nullptr};
   unsigned long long *memo = nullptr;
   uint16_t *tie_tab = nullptr; int tie_R = 0;
@@ -2102,7 +2289,8 @@ struct SliceState {
 static void slice_state_release(SliceState *s)
 {
   void *bufs[] = {s->ref_idx, s->mv, s->prog, s->flags, s->out, s->ep_dist, s->ep_motion, s->carry_mb, s->chg[0], s->chg[1], s->memo, s->tie_tab, s->ep_col, s->carry_in, s->carry_out,
-                  s->carry_slice, s->carry_slice_next, s->um_cost, s->um_cost_snap, s->surf};
+                  s->carry_slice, s->carry_slice_next, s->um_cost, s->um_cost_snap, s->surf, s->ep_map, s->ep_map_next, s->ep_count, s->ep_count_next, s->ep_first, s->ep_last,
+                  s->ep_alias_flag, s->ep_nsearch, s->ep_base, s->ep_seg_last, s->ep_seg_in, s->ep_alias, s->ep_alias_new, s->ep_alias_n};
   for (void *b : bufs) if (b) (void)hipFree(b);
   delete s;
 }
@@ -2130,6 +2318,35 @@ static SliceState *slice_state(jmhip_ctx *c)
   return s;
 }
 
+// the EPZS map state and scan scratch, sized for the context's picture and this search range (a different range starts from a fresh map, as a
+// JM encoder configured with it would)
+static int ep_state_ensure(jmhip_ctx *c, SliceState *s, int search_range)
+{
+  const int side = 2 * search_range + 1, cells = (side * side + 3) & ~3;
+  if (s->ep_cells == cells) return JMHIP_OK;
+  void *old[] = {s->ep_map, s->ep_map_next, s->ep_count, s->ep_count_next, s->ep_first, s->ep_last, s->ep_alias_flag, s->ep_nsearch, s->ep_base, s->ep_seg_last, s->ep_seg_in, s->ep_alias,
+                 s->ep_alias_new, s->ep_alias_n};
+  for (void *b : old) if (b) (void)hipFree(b);
+  s->ep_map = s->ep_map_next = nullptr; s->ep_count = s->ep_count_next = nullptr; s->ep_first = s->ep_last = s->ep_alias_flag = nullptr; s->ep_nsearch = nullptr;
+  s->ep_base = s->ep_seg_last = s->ep_seg_in = nullptr; s->ep_alias = s->ep_alias_new = nullptr; s->ep_alias_n = nullptr; s->ep_cells = 0;
+  const size_t nmb = (size_t)c->mbw * c->mbh, nseg = (nmb + EP_SEG - 1) / EP_SEG;
+  const bool ok = hipMalloc((void **)&s->ep_map, sizeof(uint16_t) * cells) == hipSuccess && hipMalloc((void **)&s->ep_map_next, sizeof(uint16_t) * cells) == hipSuccess &&
+                  hipMalloc((void **)&s->ep_count, sizeof(uint32_t)) == hipSuccess && hipMalloc((void **)&s->ep_count_next, sizeof(uint32_t)) == hipSuccess &&
+                  hipMalloc((void **)&s->ep_first, nmb * cells) == hipSuccess && hipMalloc((void **)&s->ep_last, nmb * cells) == hipSuccess &&
+                  hipMalloc((void **)&s->ep_alias_flag, nmb) == hipSuccess && hipMalloc((void **)&s->ep_nsearch, sizeof(uint16_t) * nmb) == hipSuccess &&
+                  hipMalloc((void **)&s->ep_base, sizeof(uint32_t) * (nmb + 1)) == hipSuccess && hipMalloc((void **)&s->ep_seg_last, sizeof(uint32_t) * nseg * cells) == hipSuccess &&
+                  hipMalloc((void **)&s->ep_seg_in, sizeof(uint32_t) * nseg * cells) == hipSuccess && hipMalloc((void **)&s->ep_alias, sizeof(unsigned long long) * EP_ALIAS_CAP) == hipSuccess &&
+                  hipMalloc((void **)&s->ep_alias_new, sizeof(unsigned long long) * EP_ALIAS_CAP) == hipSuccess && hipMalloc((void **)&s->ep_alias_n, sizeof(int)) == hipSuccess;
+  if (!ok) return jm_fail(c, JMHIP_ERR_NOMEM, "EPZS map state of the slice search");
+  s->ep_cells = cells;
+  JM_HIP_CHECK(c, hipMemsetAsync(s->ep_map, 0, sizeof(uint16_t) * cells, c->stream));
+  JM_HIP_CHECK(c, hipMemsetAsync(s->ep_count, 0, sizeof(uint32_t), c->stream));
+  JM_HIP_CHECK(c, hipMemsetAsync(s->ep_first, 0, nmb * cells, c->stream));
+  JM_HIP_CHECK(c, hipMemsetAsync(s->ep_last, 0, nmb * cells, c->stream));
+  JM_HIP_CHECK(c, hipMemsetAsync(s->ep_nsearch, 0, sizeof(uint16_t) * nmb, c->stream));
+  return JMHIP_OK;
+}
+
 extern "C" int jmhip_slice_state_reset(jmhip_ctx *c)
 {
   if (!c) return JMHIP_ERR_ARG;
@@ -2146,6 +2363,10 @@ extern "C" int jmhip_slice_state_reset(jmhip_ctx *c)
   JM_HIP_CHECK(c, hipMemsetAsync(s->um_cost, 0, sizeof(int) * 8 * h4 * w4, c->stream));
   JM_HIP_CHECK(c, hipMemsetAsync(s->ref_idx, 0xff, w4 * h4, c->stream));
   JM_HIP_CHECK(c, hipMemsetAsync(s->mv, 0, w4 * h4 * 4, c->stream));
+  // EPZSMap is calloc'ed and EPZSBlkCount starts at zero (me_epzs.c:49,396)
+  if (s->ep_map) JM_HIP_CHECK(c, hipMemsetAsync(s->ep_map, 0, sizeof(uint16_t) * s->ep_cells, c->stream));
+  if (s->ep_count) JM_HIP_CHECK(c, hipMemsetAsync(s->ep_count, 0, sizeof(uint32_t), c->stream));
+  s->ep_aliases = 0;
   s->has_col = false;
   return JMHIP_OK;
 }
@@ -2276,18 +2497,31 @@ extern "C" int jmhip_p_slice_search(jmhip_ctx *c, const jmhip_slice_params *prm,
   }
   D.memo_on = exhaustive && relax_grid && !prm->transform8x8_mode && !(getenv("JMHIP_SLICE_MEMO") && !atoi(getenv("JMHIP_SLICE_MEMO")));
   const bool epzs = prm->search_mode == JMHIP_SEARCH_EPZS;
+  std::vector<unsigned long long> ep_used;       // EPZS: the map tests this call's searches took as answered from an old stamp (sorted)
   // a macroblock's own cost-map entries start from what the slice found (mb_stage)
   if (prm->search_mode == JMHIP_SEARCH_UMHEX) JM_HIP_CHECK(c, hipMemcpyAsync(s->um_cost_snap, s->um_cost, sizeof(int) * 8 * h4 * w4, hipMemcpyDeviceToDevice, c->stream));
   if (!x_path) s->passes = 0;
+  if (epzs) {
+    rc = ep_state_ensure(c, s, prm->search_range);
+    if (rc) return rc;
+    if (45 * prm->num_refs >= EP_STAMPED) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_p_slice_search: EPZS search counts per macroblock are kept in 8 bits");
+    JM_HIP_CHECK(c, hipMemsetAsync(s->ep_alias_flag, 0, (size_t)nmb, c->stream));
+    D.ep_first = s->ep_first; D.ep_last = s->ep_last; D.ep_nsearch = s->ep_nsearch; D.ep_cells = s->ep_cells;
+    D.ep_alias = s->ep_alias; D.ep_alias_n = 0; D.ep_alias_flag = s->ep_alias_flag;
+    s->ep_aliases = 0;
+  }
   jm_stage_begin(c, JMHIP_STAGE_ME_INT);
   bool settled = x_settled;
+  int sweep_no = 0;                              // sweeps of this call so far (the changed-flag arrays alternate with it)
+  // the slice under the current set of pre-marked map cells: relaxation sweeps to the fixpoint, else the coding-order walk
+  auto settle = [&]() -> int {
   if (relax_grid && !settled) {
     // relaxation sweeps (p_slice_relax_kernel); the coding-order walk below remains the fallback if they do not settle within the cap
     const int cap = getenv("JMHIP_SLICE_SWEEPS") ? atoi(getenv("JMHIP_SLICE_SWEEPS")) : 160;      // a sweep costs >= one macroblock (1.2 ms), the walk 250+
     const int grid = std::min(relax_grid, prm->mb_count);
-    for (int sweep = 0; sweep < cap && !settled; sweep++) {
+    for (int sweep = 0; sweep < cap && !settled; sweep++, sweep_no++) {
       JM_HIP_CHECK(c, hipMemsetAsync(s->flags, 0, sizeof(int) * 4, c->stream));
-      D.first_sweep = sweep == 0; D.chg_prev = s->chg[sweep & 1]; D.chg_next = s->chg[(sweep + 1) & 1];
+      D.first_sweep = sweep_no == 0; D.chg_prev = s->chg[sweep_no & 1]; D.chg_next = s->chg[(sweep_no + 1) & 1];
       JM_HIP_CHECK(c, hipMemcpyToSymbolAsync(HIP_SYMBOL(c_wave), &D, sizeof(D), 0, hipMemcpyHostToDevice, c->stream));
       switch (prm->search_mode) {
       case JMHIP_SEARCH_EPZS: p_slice_relax_kernel<JMHIP_SEARCH_EPZS><<<grid, 64, 0, c->stream>>>(s->carry_slice); break;
@@ -2306,7 +2540,7 @@ extern "C" int jmhip_p_slice_search(jmhip_ctx *c, const jmhip_slice_params *prm,
         static double t_last = 0.0;
         struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
         const double t_now = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
-        fprintf(stderr, "sweep %d: %d macroblocks changed what they hand on (%.2f ms since the previous line)\n", sweep, flags[2], t_now - t_last);
+        fprintf(stderr, "sweep %d: %d macroblocks changed what they hand on (%.2f ms since the previous line)\n", sweep_no, flags[2], t_now - t_last);
         t_last = t_now;
       }
     }
@@ -2331,14 +2565,54 @@ extern "C" int jmhip_p_slice_search(jmhip_ctx *c, const jmhip_slice_params *prm,
     if (epzs && rows > 1) carry_check_kernel<<<(rows + 63) / 64, 64, 0, c->stream>>>(s->carry_in, s->carry_out, row_first, rows, s->flags);
     JM_HIP_CHECK(c, hipMemcpyAsync(flags, s->flags, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
     JM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-    if (flags[0]) { jm_stage_end(c, JMHIP_STAGE_ME_INT); return jm_fail(c, JMHIP_ERR_DEVICE, "p_slice_kernel: a row waited too long for the row above (internal error)"); }
+    if (flags[0]) { return jm_fail(c, JMHIP_ERR_DEVICE, "p_slice_kernel: a row waited too long for the row above (internal error)"); }
     if (!epzs || rows == 1 || flags[1] == (1 << 30)) break;
-    if (s->passes > rows + 80) { jm_stage_end(c, JMHIP_STAGE_ME_INT); return jm_fail(c, JMHIP_ERR_DEVICE, "p_slice_kernel: row-start speculation did not settle (internal error)"); }
+    if (s->passes > rows + 80) { return jm_fail(c, JMHIP_ERR_DEVICE, "p_slice_kernel: row-start speculation did not settle (internal error)"); }
     // next pass: every row starts from what the row above left in this pass; rows up to the first wrong one were exact already. (The stored
     // rows of the row memories are rewritten in coding order by every pass; row 0, what the slice found, is never written.)
     JM_HIP_CHECK(c, hipMemcpyAsync(s->carry_in + (size_t)(row_first + 1) * WR * CARRY * 2, s->carry_out + (size_t)row_first * WR * CARRY * 2,
                                    sizeof(short) * (size_t)(rows - 1) * WR * CARRY * 2, hipMemcpyDeviceToDevice, c->stream));
   }
+  return JMHIP_OK;
+  };
+  for (int round = 0;; round++) {
+    rc = settle();
+    if (rc) { jm_stage_end(c, JMHIP_STAGE_ME_INT); return rc; }
+    if (!epzs) break;
+    // JM's map across the slice's searches: which tests would an old stamp have answered? (ep_alias_* kernels)
+    const int cells = s->ep_cells, nseg = (prm->mb_count + EP_SEG - 1) / EP_SEG;
+    JM_HIP_CHECK(c, hipMemsetAsync(s->ep_alias_n, 0, sizeof(int), c->stream));
+    ep_alias_base_kernel<<<1, 1024, 0, c->stream>>>(s->ep_nsearch, prm->mb_first, prm->mb_count, s->ep_count, s->ep_base, s->ep_count_next);
+    ep_alias_seglast_kernel<<<dim3((cells + 255) / 256, nseg), 256, 0, c->stream>>>(s->ep_last, s->ep_base, prm->mb_first, prm->mb_count, cells, s->ep_seg_last);
+    ep_alias_segin_kernel<<<(cells + 255) / 256, 256, 0, c->stream>>>(s->ep_seg_last, nseg, cells, s->ep_map, s->ep_seg_in, s->ep_map_next);
+    ep_alias_detect_kernel<<<dim3((cells + 255) / 256, nseg), 256, 0, c->stream>>>(s->ep_first, s->ep_last, s->ep_nsearch, s->ep_base, s->ep_seg_in, prm->mb_first, prm->mb_count, cells,
+                                                                                 s->ep_alias_new, s->ep_alias_n);
+    JM_HIP_CHECK(c, hipGetLastError());
+    int n_new = 0;
+    JM_HIP_CHECK(c, hipMemcpyAsync(&n_new, s->ep_alias_n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    JM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    if (n_new > EP_ALIAS_CAP) { jm_stage_end(c, JMHIP_STAGE_ME_INT); return jm_fail(c, JMHIP_ERR_DEVICE, "jmhip_p_slice_search: more aliased EPZS map tests in one slice than the list holds"); }
+    std::vector<unsigned long long> fresh((size_t)n_new);
+    if (n_new) {
+      JM_HIP_CHECK(c, hipMemcpyAsync(fresh.data(), s->ep_alias_new, sizeof(unsigned long long) * n_new, hipMemcpyDeviceToHost, c->stream));
+      JM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+      std::sort(fresh.begin(), fresh.end());
+    }
+    if (getenv("JMHIP_SLICE_TRACE")) fprintf(stderr, "EPZS map round %d: %d tests answered from an old stamp (%zu pre-marked in this round's searches)\n", round, n_new, ep_used.size());
+    if (fresh == ep_used) break;                  // the searches ran with exactly the cells JM's map would have shown them
+    if (round >= 64) { jm_stage_end(c, JMHIP_STAGE_ME_INT); return jm_fail(c, JMHIP_ERR_DEVICE, "jmhip_p_slice_search: the aliased EPZS map tests did not settle (internal error)"); }
+    // search the macroblocks whose pre-marked cells changed again (they, and whatever their results change downstream, through the sweeps)
+    std::vector<uint8_t> fl((size_t)nmb, 0);
+    for (unsigned long long e : ep_used) fl[(size_t)(e >> 32)] |= 2;
+    for (unsigned long long e : fresh) fl[(size_t)(e >> 32)] |= 3;
+    ep_used.swap(fresh);
+    JM_HIP_CHECK(c, hipMemcpyAsync(s->ep_alias_flag, fl.data(), (size_t)nmb, hipMemcpyHostToDevice, c->stream));
+    if (!ep_used.empty()) JM_HIP_CHECK(c, hipMemcpyAsync(s->ep_alias, ep_used.data(), sizeof(unsigned long long) * ep_used.size(), hipMemcpyHostToDevice, c->stream));
+    JM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    D.ep_alias_n = (int)ep_used.size();
+    settled = false;
+  }
+  if (epzs) { std::swap(s->ep_map, s->ep_map_next); std::swap(s->ep_count, s->ep_count_next); s->ep_aliases = (int)ep_used.size(); }
   if (epzs) epzs_rows_fold_kernel<<<((int)w4 + 63) / 64, 64, 0, c->stream>>>(s->ep_dist, s->ep_motion, (int)w4, c->mbw, prm->mb_first, prm->mb_count, row_first, prm->epzs_spatial_mem);
   jm_stage_end(c, JMHIP_STAGE_ME_INT);
 #ifdef JMHIP_WAVE_PROF
@@ -2390,6 +2664,38 @@ extern "C" int jmhip_slice_result_info(jmhip_ctx *c, int *passes)
   return JMHIP_OK;
 }
 
+extern "C" int jmhip_epzs_map_upload(jmhip_ctx *c, const int16_t *map, int search_range, int blk_count)
+{
+  if (!c || search_range < 1 || search_range > 33) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_epzs_map_upload: arguments") : JMHIP_ERR_ARG;
+  JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
+  SliceState *s = slice_state(c);
+  if (!s) return jm_fail(c, JMHIP_ERR_NOMEM, "slice search state");
+  const int rc = ep_state_ensure(c, s, search_range);
+  if (rc) return rc;
+  const int side = 2 * search_range + 1;
+  const uint32_t count = (uint16_t)blk_count;
+  JM_HIP_CHECK(c, hipMemsetAsync(s->ep_map, 0, sizeof(uint16_t) * s->ep_cells, c->stream));
+  if (map) JM_HIP_CHECK(c, hipMemcpyAsync(s->ep_map, map, sizeof(int16_t) * side * side, hipMemcpyHostToDevice, c->stream));
+  JM_HIP_CHECK(c, hipMemcpyAsync(s->ep_count, &count, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  JM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_epzs_map_info(jmhip_ctx *c, int *aliased_tests, uint32_t *searches)
+{
+  if (!c || !c->slice_state) return JMHIP_ERR_ARG;
+  SliceState *s = static_cast<SliceState *>(c->slice_state);
+  if (aliased_tests) *aliased_tests = s->ep_aliases;
+  if (searches) {
+    *searches = 0;
+    if (s->ep_count) {
+      JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
+      JM_HIP_CHECK(c, hipMemcpyAsync(searches, s->ep_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+      JM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    }
+  }
+  return JMHIP_OK;
+}
 
 // ---------------------------------------------------------------------------------------------- hand-over to the frame stage
 

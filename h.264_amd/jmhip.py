@@ -215,6 +215,8 @@ def load_library():
     lib.jmhip_slice_results_download.argtypes = [vp, vp, ip, ip]
     lib.jmhip_slice_field_download.argtypes = [vp, vp, vp]
     lib.jmhip_slice_result_info.argtypes = [vp, C.POINTER(ip)]
+    lib.jmhip_epzs_map_info.argtypes = [vp, C.POINTER(ip), C.POINTER(C.c_uint32)]
+    lib.jmhip_epzs_map_upload.argtypes = [vp, vp, ip, ip]
     lib.jmhip_slice_to_frame.argtypes = [vp, vp, ip]
     lib.jmhip_slice_to_frame_band.argtypes = [vp, vp, ip, ip, ip]
     lib.jmhip_frame_wp_set.argtypes = [vp, vp]
@@ -462,6 +464,18 @@ class Context:
         n = C.c_int()
         self._chk(self.lib.jmhip_slice_result_info(self.h, C.byref(n)), "jmhip_slice_result_info")
         return n.value
+
+    def epzs_map_upload(self, stamps, search_range, blk_count):
+        """EPZSMap ((2R+1, 2R+1) int16, or None = zeros) and EPZSBlkCount of an encoder that is already running"""
+        m = None if stamps is None else np.ascontiguousarray(stamps, dtype=np.int16)
+        assert m is None or m.shape == (2 * search_range + 1, 2 * search_range + 1)
+        self._chk(self.lib.jmhip_epzs_map_upload(self.h, _ptr(m) if m is not None else None, search_range, int(blk_count)), "jmhip_epzs_map_upload")
+
+    def epzs_map_info(self):
+        """(map tests of the last slice search answered from an old EPZSMap stamp, EPZS integer searches since the state reset)"""
+        n, k = C.c_int(), C.c_uint32()
+        self._chk(self.lib.jmhip_epzs_map_info(self.h, C.byref(n), C.byref(k)), "jmhip_epzs_map_info")
+        return n.value, k.value
 
     def me_results(self, n):
         res = np.zeros(n, dtype=ME_RESULT_DTYPE)

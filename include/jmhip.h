@@ -292,7 +292,11 @@ int jmhip_me_subpel(jmhip_ctx *ctx, const jmhip_me_params *prm, const jmhip_me_m
  * the PREVIOUS macroblock in coding order (src/me_epzs.c:1433-1471 on vectors the current macroblock has not searched yet), i.e. the
  * last macroblock of the row above for the first of a row -- is speculated per row and verified: the call re-runs the slice until
  * every row started from what the row above really left (at most rows + 1 passes; jmhip_slice_result_info reports the count).
- * Not mirrored: the 16-bit wrap of EPZSBlkCount (a position visited exactly 65536 searches earlier reads as visited in JM).
+ * EPZS's visited map is JM's: never cleared, a cell counts as visited when it holds the 16-bit EPZSBlkCount of the running search
+ * (src/me_epzs.c:49,1550,1598,1757,1840) -- so also when the search 65536 k calls earlier stamped it last, or when the counter passes
+ * the zero the map was allocated with. The map and the counter live in the context across slices and pictures (jmhip_slice_state_reset
+ * = a freshly started encoder); a call finds the tests an old stamp answers by a scan over its macroblocks' touch records and searches
+ * those macroblocks again with the cells pre-marked, until the set is stable (jmhip_epzs_map_info reports how many there were).
  * Frame pictures, luma-only motion estimation (ChromaMEEnable 0), list 0 only, up to JMHIP_SLICE_REFS references. */
 #define JMHIP_SLICE_REFS 5                /* every cfg the reference ships has NumberReferenceFrames = 5 (bin/encoder_baseline.cfg:53) */
 enum { JMHIP_SEARCH_UMHEX = 1, JMHIP_SEARCH_UMHEX_SIMPLE = 2, JMHIP_SEARCH_EPZS = 3 };
@@ -396,6 +400,12 @@ int jmhip_slice_results_download(jmhip_ctx *ctx, jmhip_mb_inter *results, int mb
 int jmhip_slice_field_download(jmhip_ctx *ctx, int8_t *ref_idx, int16_t *mv);
 /* sweeps (relaxation) plus passes (wavefront) the last jmhip_p_slice_search needed */
 int jmhip_slice_result_info(jmhip_ctx *ctx, int *passes);
+/* EPZS: map tests of the last jmhip_p_slice_search that JM answers "visited" from a stamp this search did not write (see above), and the
+ * integer searches since jmhip_slice_state_reset (its low 16 bits are EPZSBlkCount, src/me_epzs.c:49). Either pointer may be NULL. */
+int jmhip_epzs_map_info(jmhip_ctx *ctx, int *aliased_tests, uint32_t *searches);
+/* EPZSMap ([2 search_range + 1]^2 stamps, row-major as JM indexes it; NULL = all zero) and EPZSBlkCount of an encoder that is already
+ * running (src/me_epzs.c:49,92): what a binding hands over when it attaches mid-stream, or after JM ran EPZS searches of its own. */
+int jmhip_epzs_map_upload(jmhip_ctx *ctx, const int16_t *map, int search_range, int blk_count);
 /* Hand the searched picture (every macroblock: all its slices searched) to the frame stage: the decided modes, the vector and the
  * reference slot of every 8x8 block become the inputs of jmhip_residual_frame(modes = NULL), which then runs LumaResidualCoding /
  * ChromaResidualCoding on them (per-8x8 reference pictures: macroblock.c:1009-1110 with SetModesAndRefframe), and of jmhip_deblock_recon.

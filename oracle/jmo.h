@@ -215,6 +215,11 @@ int *jmo_epzs_distortion_row(jmo_epzs *e, int list, int blocktype_m1);   /* EPZS
 int jmo_epzs_threshold(const jmo_epzs *e, int which /*0 min 1 med 2 max 3 sub*/, int blocktype);
 int jmo_epzs_mv_scale(const jmo_epzs *e, int list, int i, int k);
 const short *jmo_epzs_colocated(const jmo_epzs *e);               /* [2][H/4][W/4][2] */
+unsigned jmo_epzs_search_count(const jmo_epzs *e);                /* EPZSBlkCount without its 16-bit wrap: integer searches since EPZSInit */
+void jmo_epzs_ideal_map(jmo_epzs *e, int on);                    /* NOT JM: answer those tests as a per-search map would (a what-if for tools/find_epzs_alias.py) */
+void jmo_epzs_map_set(jmo_epzs *e, const short *map, int blk_count);  /* EPZSMap [2 search_range + 1]^2 and EPZSBlkCount of a running encoder */
+void jmo_epzs_first_touch(const jmo_epzs *e, unsigned *out);      /* [2 search_range + 1]^2: first search (ordinal) that touched each map cell, 0 = none */
+long jmo_epzs_alias_events(const jmo_epzs *e);                    /* map tests answered "visited" by a stamp 65536 k searches old (or by the initial zero) */
 
 /* EPZSSliceInit :501 for a frame picture of a frame_mbs_only sequence */
 typedef struct {

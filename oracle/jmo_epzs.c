@@ -40,6 +40,12 @@ struct jmo_epzs {
   int searcharray;
   short *map;                        /* EPZSMap [searcharray][searcharray] */
   short blk_count;                   /* EPZSBlkCount */
+  /* NOT part of JM: a shadow of the map with the FULL ordinal of the search that last stamped each cell, kept beside the 16-bit stamps only to
+   * COUNT how often the 16-bit comparison answers "visited" for a cell this search never stamped (a stamp 65536 k searches old, or the zero
+   * of a cell never stamped when the counter passes zero). The results never read it. */
+  unsigned *map_ord; unsigned ord; long alias_events;
+  unsigned *first_ord;               /* ... and the ordinal of the FIRST search that tested or stamped each cell since jmo_epzs_map_set (0: none yet) */
+  int ideal_map;                     /* what-if (tools/find_epzs_alias.py only): answer such tests as a map cleared per search would */
   int w4, h4;
   int *distortion;                   /* EPZSDistortion [6][7][w4] */
   short *motion;                     /* EPZSMotion [6][max_refs][7][4][w4][2] */
@@ -134,6 +140,8 @@ jmo_epzs *jmo_epzs_create(const jmo_epzs_config *c)                   /* EPZSIni
   e->w4 = c->width / 4; e->h4 = c->height / 4;
   e->distortion = (int *)calloc((size_t)6 * 7 * e->w4, sizeof(int));
   e->map = (short *)calloc((size_t)e->searcharray * e->searcharray, sizeof(short));
+  e->map_ord = (unsigned *)calloc((size_t)e->searcharray * e->searcharray, sizeof(unsigned));
+  e->first_ord = (unsigned *)calloc((size_t)e->searcharray * e->searcharray, sizeof(unsigned));
   if (c->spatial_mem) e->motion = (short *)calloc((size_t)6 * c->max_refs * 7 * 4 * e->w4 * 2, sizeof(short));
   if (c->temporal) e->col_mv = (short *)calloc((size_t)2 * e->h4 * e->w4 * 2, sizeof(short));
   e->search_pattern = pat_of[(c->pattern >= 1 && c->pattern <= 5) ? c->pattern : 0];        /* :410-431 */
@@ -144,7 +152,7 @@ jmo_epzs *jmo_epzs_create(const jmo_epzs_config *c)                   /* EPZSIni
 void jmo_epzs_destroy(jmo_epzs *e)
 {
   if (!e) return;
-  free(e->distortion); free(e->map); free(e->motion); free(e->col_mv); free(e);
+  free(e->distortion); free(e->map); free(e->map_ord); free(e->first_ord); free(e->motion); free(e->col_mv); free(e);
 }
 
 int *jmo_epzs_distortion_row(jmo_epzs *e, int list, int blocktype_m1) { return e->distortion + ((size_t)list * 7 + blocktype_m1) * e->w4; }
@@ -232,6 +240,18 @@ static int cost_dist(walk_ctx *w, int bound, int cand_x, int cand_y)
 }
 
 #define MAP(e, y, x) ((e)->map[(size_t)(y) * (e)->searcharray + (x)])
+#define MAP_ORD(e, y, x) ((e)->map_ord[(size_t)(y) * (e)->searcharray + (x)])
+#define FIRST_ORD(e, y, x) ((e)->first_ord[(size_t)(y) * (e)->searcharray + (x)])
+/* the shadow's bookkeeping for one test of cell (y, x): an alias is a cell the 16-bit stamp calls visited that this search did not stamp */
+static inline void map_shadow(jmo_epzs *e, int y, int x)
+{
+  if (MAP(e, y, x) == e->blk_count && MAP_ORD(e, y, x) != e->ord) {
+    e->alias_events++;
+    if (e->ideal_map) MAP(e, y, x) = (short)(e->blk_count - 1);
+  }
+  MAP_ORD(e, y, x) = e->ord;
+  if (!FIRST_ORD(e, y, x)) FIRST_ORD(e, y, x) = e->ord;
+}
 
 /* the refinement loop, me_epzs.c:1801-1942 (uni) / :2215-2341 (bi). Returns 1 when the uni form's ref > 0 early return fires. */
 static int refine(walk_ctx *w, int pat0, int pic_pix_x, int pic_pix_y, const short mv[2], int search_range, int blocktype, int ref,
@@ -250,6 +270,7 @@ static int refine(walk_ctx *w, int pat0, int pic_pix_x, int pic_pix_y, const sho
         cand_x = (pic_pix_x + tmv[0]) << MV_RESCALE;
         cand_y = (pic_pix_y + tmv[1]) << MV_RESCALE;
         if (iabs_(tmv[0] - mv[0]) <= search_range && iabs_(tmv[1] - mv[1]) <= search_range) {
+          map_shadow(e, map_cy + tmv[1], map_cx + tmv[0]);
           if (MAP(e, map_cy + tmv[1], map_cx + tmv[0]) != e->blk_count) MAP(e, map_cy + tmv[1], map_cx + tmv[0]) = e->blk_count;
           else {
             if (++point >= e->pat[pf].n) point -= e->pat[pf].n;
@@ -309,6 +330,7 @@ static int scan_predictors(walk_ctx *w, int (*pred)[2], int prednum, int pic_pix
     int cand_x, cand_y, mcost;
     if (outside && (!w->b || tx || ty)) continue;        /* the bi form still tests an out-of-range ZERO vector (:2166) */
     if (!outside) {
+      map_shadow(e, map_cy + ty, map_cx + tx);
       if (MAP(e, map_cy + ty, map_cx + tx) == e->blk_count) continue;
       MAP(e, map_cy + ty, map_cx + tx) = e->blk_count;
     }
@@ -395,8 +417,11 @@ int jmo_epzs_pel_search(jmo_epzs *e, const jmo_me_params *p, const jmo_ref *ref_
     w.d.test8x8 = p->transform8x8_mode && blocktype <= 4;  /* mv-search.c:640 */
     stop = e->medthres[blocktype];
     e->blk_count = (short)(e->blk_count + 1);              /* :1550 */
+    e->ord++;
     if (e->cfg.spatial_mem) motion = e->motion + (((((size_t)list * e->cfg.max_refs + ref) * 7 + (blocktype - 1)) * 4 + block_y) * e->w4 + px2) * 2;
     MAP(e, search_range, search_range) = e->blk_count;     /* :1598 */
+    MAP_ORD(e, search_range, search_range) = e->ord;
+    if (!FIRST_ORD(e, search_range, search_range)) FIRST_ORD(e, search_range, search_range) = e->ord;
     min_mcost = cost_mv(&w, cand_x, cand_y);
     min_mcost += cost_dist(&w, JMO_INT_MAX, cand_x, cand_y);
 
@@ -515,9 +540,12 @@ int jmo_epzs_bipred_search(jmo_epzs *e, jmo_bipred *b, const jmo_pel *cur_pic, i
     w.fixed_cost = jmo_mv_cost(lambda_factor, w.c1x, w.c1y, (pic_pix_x << 2) + pred_mv1[0], (pic_pix_y << 2) + pred_mv1[1]);
     stop = e->medthres[blocktype];
     e->blk_count = (short)(e->blk_count + 1);
+    e->ord++;
     b->umv2 = !((center2_x > search_range) && (center2_x < (W - bsx) - search_range) && (center2_y > search_range) && (center2_y < (H - bsy) - search_range));   /* :2083 */
     b->umv1 = !((center1_x > search_range) && (center1_x < (W - bsx) - search_range) && (center1_y > search_range) && (center1_y < (H - bsy) - search_range));   /* :2094 */
     MAP(e, search_range, search_range) = e->blk_count;
+    MAP_ORD(e, search_range, search_range) = e->ord;
+    if (!FIRST_ORD(e, search_range, search_range)) FIRST_ORD(e, search_range, search_range) = e->ord;
     min_mcost = cost_mv(&w, center2_x << MV_RESCALE, center2_y << MV_RESCALE);
     min_mcost += cost_dist(&w, JMO_INT_MAX, center2_x << MV_RESCALE, center2_y << MV_RESCALE);
     if (min_mcost > stop) {
@@ -659,4 +687,21 @@ int jmo_epzs_subpel_bipred(jmo_bipred *b, const jmo_pel *orig_pic, int pic_pix_x
   s.fixed_cost = jmo_mv_cost(lambda[JMO_Q_PEL], s_mv[0], s_mv[1], pred_mv2[0], pred_mv2[1]);
   (void)sub_level(&s, search_point_qp, 0, b->start_qp, search_pos4, lambda[JMO_Q_PEL], pred_mv1, mv, pic4_x, pic4_y, &min_mcost, 0, 0);
   return min_mcost;
+}
+
+/* the alias bookkeeping (not JM's): searches so far, and how many map tests read "visited" from a stamp this search did not write */
+unsigned jmo_epzs_search_count(const jmo_epzs *e) { return e->ord; }
+long jmo_epzs_alias_events(const jmo_epzs *e) { return e->alias_events; }
+/* per cell, the ordinal (jmo_epzs_search_count) of the first search that tested or stamped it since jmo_epzs_map_set / create; 0 = none */
+void jmo_epzs_first_touch(const jmo_epzs *e, unsigned *out) { memcpy(out, e->first_ord, sizeof(unsigned) * (size_t)e->searcharray * e->searcharray); }
+void jmo_epzs_ideal_map(jmo_epzs *e, int on) { e->ideal_map = on; }
+/* EPZSMap / EPZSBlkCount as a running encoder holds them (map: [searcharray][searcharray] stamps, NULL = all zero). The shadow takes every
+ * stamp as written in the previous 65536-search epoch, so a test it answers counts as an alias event. */
+void jmo_epzs_map_set(jmo_epzs *e, const short *map, int blk_count)
+{
+  const size_t n = (size_t)e->searcharray * e->searcharray;
+  size_t i;
+  for (i = 0; i < n; i++) { e->map[i] = map ? map[i] : 0; e->map_ord[i] = (unsigned short)e->map[i]; e->first_ord[i] = 0; }
+  e->blk_count = (short)blk_count;
+  e->ord = 65536u + (unsigned short)blk_count;
 }

@@ -601,6 +601,13 @@ def _walker_protos():
     L.jmo_epzs_create.argtypes = [C.POINTER(EpzsConfig)]
     L.jmo_epzs_destroy.argtypes = [vp]
     L.jmo_epzs_slice_init.argtypes = [vp, C.POINTER(EpzsSlice)]
+    L.jmo_epzs_search_count.restype = C.c_uint
+    L.jmo_epzs_search_count.argtypes = [vp]
+    L.jmo_epzs_alias_events.restype = C.c_long
+    L.jmo_epzs_alias_events.argtypes = [vp]
+    L.jmo_epzs_map_set.argtypes = [vp, vp, C.c_int]
+    L.jmo_epzs_ideal_map.argtypes = [vp, C.c_int]
+    L.jmo_epzs_first_touch.argtypes = [vp, vp]
     L.jmo_umhex_create.restype = vp
     L.jmo_umhex_create.argtypes = [C.POINTER(UmhexConfig)]
     L.jmo_umhex_destroy.argtypes = [vp]
@@ -636,6 +643,30 @@ class Epzs:
         s.col_mv[0], s.col_mv[1] = self._keep[0].ctypes.data, self._keep[1].ctypes.data
         s.col_ref_id[0], s.col_ref_id[1] = self._keep[2].ctypes.data, self._keep[3].ctypes.data
         lib().jmo_epzs_slice_init(self.h, C.byref(s))
+
+    def search_count(self):
+        """integer searches since the object was created (EPZSBlkCount without its 16-bit wrap)"""
+        return int(_walker_protos().jmo_epzs_search_count(self.h))
+
+    def map_set(self, stamps, blk_count):
+        """EPZSMap ((2R+1, 2R+1) int16 or None = zeros) and EPZSBlkCount of a running encoder"""
+        m = None if stamps is None else np.ascontiguousarray(stamps, dtype=np.int16)
+        _walker_protos().jmo_epzs_map_set(self.h, None if m is None else m.ctypes.data, int(blk_count))
+
+    def ideal_map(self, on=True):
+        """NOT JM: a what-if that answers aliased tests as a map cleared per search would (shows that a test clip's aliases matter)"""
+        _walker_protos().jmo_epzs_ideal_map(self.h, int(on))
+
+    def first_touch(self):
+        """(2R+1, 2R+1) uint32: ordinal of the first search that tested or stamped each map cell since map_set / creation, 0 = none"""
+        side = 2 * self.cfg.search_range + 1
+        out = np.zeros((side, side), np.uint32)
+        _walker_protos().jmo_epzs_first_touch(self.h, out.ctypes.data)
+        return out
+
+    def alias_events(self):
+        """map tests answered "visited" from a stamp 65536 k searches old, or from the initial zero (jmo_epzs.c map_shadow)"""
+        return int(_walker_protos().jmo_epzs_alias_events(self.h))
 
     def close(self):
         if self.h:

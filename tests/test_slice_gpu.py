@@ -95,7 +95,7 @@ def synth_clip(rng, W, H, nframes):
     return load_pkg().slice_host.synth_clip(rng, W, H, nframes)
 
 
-def run_synthetic(pkg, mode, W, H, R, nref, slices=1, nframes=3, seed=5, metric=(0, 2, 2), qp=28, max_mbs=None, t8=0, cavlc=1, wp=None, one_call=False, rdopt=0):
+def run_synthetic(pkg, mode, W, H, R, nref, slices=1, nframes=3, seed=5, metric=(0, 2, 2), qp=28, max_mbs=None, t8=0, cavlc=1, wp=None, one_call=False, rdopt=0, map_log=None, map_init=None, what_if=None, ideal_map=False, first_touch=None):
     """Frames 1.. are coded as P pictures against the previous `nref` SOURCE frames (the search does not care where a reference came from)."""
     rng = np.random.default_rng(seed)
     clip = synth_clip(rng, W, H, nframes + nref - 1)
@@ -106,6 +106,11 @@ def run_synthetic(pkg, mode, W, H, R, nref, slices=1, nframes=3, seed=5, metric=
     ctx = pkg.Context(W, H, yuv_format=0, max_refs=nref, search_range=R)
     ctx.slice_state_reset()
     epzs = oracle.Epzs(W, H, R, nref) if mode == 3 else None
+    if map_init is not None:                             # EPZSMap / EPZSBlkCount of an encoder that is already running
+        ctx.epzs_map_upload(map_init[0], R, map_init[1])
+        epzs.map_set(map_init[0], map_init[1])
+    if ideal_map:                                        # NOT JM: the oracle's what-if with a map cleared per search (with what_if: oracle only, collecting the records)
+        epzs.ideal_map()
     umhex = oracle.Umhex(W, H, R, nref, qp) if mode == 1 else None
     all_mv_state = np.zeros((4, 4, oracle.MAX_REFS, 9, 2), np.int16)
     prev_field = [(np.zeros((H // 4, W // 4, 2), np.int16), np.full((H // 4, W // 4), -1, np.int64))] * 2
@@ -140,6 +145,9 @@ def run_synthetic(pkg, mode, W, H, R, nref, slices=1, nframes=3, seed=5, metric=
             q._sid = sid
             q.slice_id = sid.ctypes.data
             want, _, _ = oracle.lowcplx_p_slice(q, orefs, cur, ref_idx, mvf, mb_first=first, mb_count=count)
+            if what_if is not None:
+                what_if.append(want)
+                continue
             if one_call:                                 # the device searches all slices of the picture in ONE call (slice_mbs) below
                 wants.append(want)
                 continue
@@ -153,6 +161,8 @@ def run_synthetic(pkg, mode, W, H, R, nref, slices=1, nframes=3, seed=5, metric=
             got = ctx.p_slice_search(p)
             passes.append(ctx.slice_passes())
             compare(got, want, nref, "frame %d slice %d" % (f, s))
+            if map_log is not None:                      # EPZS: (aliased map tests of this slice, searches so far) on the device and in the oracle
+                map_log.append((ctx.epzs_map_info(), (epzs.alias_events() - sum(m[1][0] for m in map_log), epzs.search_count())))
         if one_call:
             p = slice_params(pkg, mode, R, nref, lam3, ref_cost1, W, mb_first=0, mb_count=nmb, metric=metric, qp_n=qp, t8=t8, cavlc=cavlc, rdopt=rdopt)
             p.slice_mbs = per
@@ -161,12 +171,15 @@ def run_synthetic(pkg, mode, W, H, R, nref, slices=1, nframes=3, seed=5, metric=
             got = ctx.p_slice_search(p)
             passes.append(ctx.slice_passes())
             compare(got, np.concatenate(wants), nref, "frame %d, %d slices in one call" % (f, slices))
-        gref, gmv = ctx.slice_field()
-        assert np.array_equal(gref, ref_idx) and np.array_equal(gmv, mvf), "frame %d: final field" % f
+        if what_if is None:
+            gref, gmv = ctx.slice_field()
+            assert np.array_equal(gref, ref_idx) and np.array_equal(gmv, mvf), "frame %d: final field" % f
         # what EPZS will read of this picture when it is the co-located one: its vectors and, as reference ids, the POCs of what they point to
         ids = np.where(ref_idx >= 0, np.array(pocs, np.int64)[np.clip(ref_idx, 0, None)], -1)
         prev_field = [(mvf.copy(), ids), prev_field[0]]
     if epzs:
+        if first_touch is not None:
+            first_touch.append(epzs.first_touch())
         epzs.close()
     if umhex:
         umhex.close()
@@ -191,6 +204,40 @@ def run_synthetic(pkg, mode, W, H, R, nref, slices=1, nframes=3, seed=5, metric=
 ])
 def test_synthetic_clip_matches_the_oracle(pkg, mode, W, H, R, nref, slices):
     run_synthetic(pkg, mode, W, H, R, nref, slices=slices)
+
+
+@pytest.mark.gpu
+def test_epzs_visited_map_aliases(pkg):
+    """EPZSMap is never cleared and EPZSBlkCount has 16 bits (me_epzs.c:49,1550,1598,1757,1840): a map test also reads "visited" from the stamp
+    a search 65536 k calls earlier left. 720x576 = 1620 macroblocks x 41 searches x 2 references = 132840 searches per picture, so the counter
+    wraps twice a picture; on this clip (picked with tools/find_epzs_alias.py) the oracle's shadow map counts such tests in the fifth P
+    picture. The device must report the same number of them, slice by slice, the same search count -- and the same searches."""
+    log = []
+    run_synthetic(pkg, 3, 720, 576, 32, 2, nframes=6, seed=5, map_log=log)
+    assert len(log) == 5
+    for dev, orc in log:
+        assert dev == orc, "device (aliased tests, searches) %s, oracle %s" % (dev, orc)
+    assert sum(orc[0] for _, orc in log) > 0, "the clip no longer produces an aliased map test: pick another (tools/find_epzs_alias.py)"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,H,R,nref,slices", [(352, 288, 16, 2, 1), (320, 192, 32, 3, 3)])
+def test_epzs_map_of_a_running_encoder(pkg, W, H, R, nref, slices):
+    """The same mechanism under load: the search starts from the map and the counter of an encoder in mid-stream (jmhip_epzs_map_upload). The
+    map is the worst one: every cell carries the stamp of the search that, with a map cleared per search, would be the first to test it (taken
+    from a what-if run of the oracle) -- so the first test of most cells is answered from the old stamp, in most macroblocks, and that changes
+    what the searches find. The counter also wraps within the first picture."""
+    start = 65000
+    probe, ideal = [], []
+    run_synthetic(pkg, 3, W, H, R, nref, slices=slices, map_init=(None, start), what_if=ideal, ideal_map=True, first_touch=probe)
+    first = probe[0]
+    stamps = np.where(first > 0, first & 0xffff, start).astype(np.uint16).view(np.int16)
+    log, jm = [], []
+    run_synthetic(pkg, 3, W, H, R, nref, slices=slices, map_init=(stamps, start), map_log=log)
+    assert all((dev[0], dev[1] & 0xffff) == (orc[0], orc[1] & 0xffff) for dev, orc in log), log
+    assert sum(orc[0] for _, orc in log) > 100, log
+    run_synthetic(pkg, 3, W, H, R, nref, slices=slices, map_init=(stamps, start), what_if=jm)
+    assert any(a.tobytes() != b.tobytes() for a, b in zip(ideal, jm)), "the aliased tests of this clip change nothing: the test does not show the mechanism"
 
 
 @pytest.mark.gpu
