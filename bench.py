@@ -179,7 +179,8 @@ def jm_end_to_end(frames, config3=False, rdopt1=False):
     """The reference encoder itself, same 1080p clip (frames 0-1: I + P), FullSearch +-32, low-complexity decision with intra off in the P
     picture (RDOptimization 0, DisableIntraInInter 1 -- the configuration whose whole P-slice search + inter decision is ONE device call):
     the unmodified JM (oracle/_ref/jm_plain) against JM bound to libjmhip.so at slice level (oracle/_ref/jm_hip, integration/jm_shim.c,
-    mask 0x1801 = sub-pel planes + slice binding + loop filter on the device, everything else JM's own code). Wall-clock of whole encodes."""
+    mask 0x5801 = sub-pel planes + slice binding + the slice's frame stage (4:2:0, 4x4 transform: JM's prediction and dct_4x4 / dct_chroma calls
+    answered from the device's records) + loop filter on the device, everything else JM's own code). Wall-clock of whole encodes."""
     import re
     import subprocess
     import tempfile
@@ -203,7 +204,7 @@ def jm_end_to_end(frames, config3=False, rdopt1=False):
             f.write(cfg)
         digests = []
         for exe, key in zip(exes, ("jm_plain", "jm_hip")):
-            env = dict(os.environ, JMHIP_SHIM="3801" if rdopt1 else "1801", JMHIP_SHIM_STATS="1")
+            env = dict(os.environ, JMHIP_SHIM="3801" if rdopt1 else "5801", JMHIP_SHIM_STATS="1")
             t0 = time.perf_counter()
             try:
                 r = subprocess.run([exe, "-d", "min.cfg"], cwd=d, env=env, capture_output=True, text=True, timeout=400)
@@ -228,6 +229,11 @@ def jm_end_to_end(frames, config3=False, rdopt1=False):
                 # wall time the shim spent inside its coarse device-side hooks, whole encode (transfers and layout conversion included)
                 out["jm_hip_hooks"] = {k.strip(): {"calls": int(n), "ms": float(v), "last_call_ms": float(l)} for k, n, v, l in
                                        re.findall(r"^\s*(\S[^\n]*?)\s+device\s+(\d+)\s+forwarded\s+\d+\s+([\d.]+) ms inside the hook \(last call ([\d.]+) ms\)", r.stderr, re.M)}
+                for sym, key2 in (("dct_4x4 (slice records)", "dct_4x4_calls"), ("dct_chroma (slice records)", "dct_chroma_calls"), ("LumaPrediction (slice)", "luma_prediction_calls"),
+                                  ("ChromaPrediction4x4 (slice)", "chroma_prediction_calls")):
+                    mm = re.search(r"^\s*%s\s+device\s+(\d+)\s+forwarded\s+(\d+)" % re.escape(sym), r.stderr, re.M)
+                    if mm:
+                        out[key2 + "_served_from_slice_records"] = int(mm.group(1)); out[key2 + "_left_to_jm_in_bound_slices"] = int(mm.group(2))
                 ms = re.search(r"slice binding: (\d+) slices, (\d+) kernel passes", r.stderr)
                 if ms:
                     out["jm_hip_slice_sweeps"] = int(ms.group(2))
@@ -241,7 +247,7 @@ def jm_end_to_end(frames, config3=False, rdopt1=False):
             with open(os.path.join(d, "min4.cfg"), "w") as f:
                 f.write(cfg.replace("FramesToBeEncoded = 2", "FramesToBeEncoded = 4"))
             try:
-                r = subprocess.run([exes[1], "-d", "min4.cfg"], cwd=d, env=dict(os.environ, JMHIP_SHIM="1801", JMHIP_SHIM_STATS="1"),
+                r = subprocess.run([exes[1], "-d", "min4.cfg"], cwd=d, env=dict(os.environ, JMHIP_SHIM="5801", JMHIP_SHIM_STATS="1"),
                                    capture_output=True, text=True, timeout=200)
                 pf = re.findall(r"^000\d\(P\)\s+\d+\s+\d+\s+[\d.]+\s+[\d.]+\s+[\d.]+\s+(\d+)\s+(\d+)", r.stdout, re.M)
                 mh = re.search(r"P slices \(one device call each\)\s+device\s+\d+\s+forwarded\s+\d+\s+[\d.]+ ms inside the hook \(last call ([\d.]+) ms\)", r.stderr)
@@ -254,8 +260,8 @@ def jm_end_to_end(frames, config3=False, rdopt1=False):
                              "(speculative slice binding: a BlockMotionSearch call is answered from the device's record when JM's predictor equals the recorded one, "
                              "else JM's own search runs)")
             return out
-        out["config"] = ("1920x1080 I+P, EPZS +-32, Hadamard SAD at every level, Transform8x8Mode 1, CABAC, 1 reference, RDOptimization 0, DisableIntraInInter 1; jm_hip: JMHIP_SHIM=0x1801"
-                         if config3 else "1920x1080 I+P, FullSearch +-32, 1 reference, RDOptimization 0, DisableIntraInInter 1, CAVLC; jm_hip: JMHIP_SHIM=0x1801")
+        out["config"] = ("1920x1080 I+P, EPZS +-32, Hadamard SAD at every level, Transform8x8Mode 1, CABAC, 1 reference, RDOptimization 0, DisableIntraInInter 1; jm_hip: JMHIP_SHIM=0x5801 (the 8x8 transform keeps the frame stage in JM)"
+                         if config3 else "1920x1080 I+P, FullSearch +-32, 1 reference, RDOptimization 0, DisableIntraInInter 1, CAVLC; jm_hip: JMHIP_SHIM=0x5801 (slice search + frame stage bound at slice level)")
     return out
 
 

@@ -333,6 +333,7 @@ extern "C" int jmhip_residual_frame_q(jmhip_ctx *c, const jmhip_mb_mode *modes, 
   const uint8_t *const *tab = reinterpret_cast<const uint8_t *const *>(c->ref_ptrs_dev);
   F.ref_sub = tab + 32; F.ref_cb = tab + 64; F.ref_cr = tab + 96;
   F.rec_y = c->rec_y; F.rec_u = c->rec_u; F.rec_v = c->rec_v;
+  F.pred_y = c->keep_pred ? c->pred_y : nullptr; F.pred_u = c->keep_pred ? c->pred_u : nullptr; F.pred_v = c->keep_pred ? c->pred_v : nullptr;
   F.fly = chroma_fly ? 1 : 0; F.mul_x = c->cg.mul_x; F.mul_y = c->cg.mul_y; F.pad_cx = c->cg.pad_x; F.pad_cy = c->cg.pad_y;
   for (int k = 0; k < 8; k++) { F.ref_u[k] = k < (int)c->refs.size() ? c->refs[k].u : nullptr; F.ref_v[k] = k < (int)c->refs.size() ? c->refs[k].v : nullptr; }
   F.blk_ref = c->fr_from_slices ? (const int8_t *)c->fr_blk_ref : nullptr;
@@ -358,10 +359,10 @@ extern "C" int jmhip_residual_frame_q(jmhip_ctx *c, const jmhip_mb_mode *modes, 
     rc = jm_launch_frame_fused(c, &F, c->me_jobs_dev, c->me_res_dev, modes_in_dev, modes_out_dev, c->fr_quant, c->fr_rec, coded_dev, n);
     jm_stage_end(c, JMHIP_STAGE_MC);                  // (the TQ stage has no launch of its own here: its time reads 0)
     if (rc) return rc;
-    c->fr_n = n; c->rec_valid = true; c->fr_fused = true;
+    c->fr_n = n; c->rec_valid = true; c->fr_fused = true; c->pred_valid = c->keep_pred;
     return JMHIP_OK;
   }
-  c->fr_fused = false;
+  c->fr_fused = false; c->pred_valid = false;
   jm_stage_begin(c, JMHIP_STAGE_MC);
   mc_kernel<<<jm_xcd_grid(n), 64, 0, c->stream>>>(F, (const jmhip_me_mb *)c->me_jobs_dev, (const jmhip_me_result *)c->me_res_dev, modes_in_dev, modes_out_dev,
                                                   (jmhip_tq_job *)c->fr_jobs_y, (jmhip_tq_job *)c->fr_jobs_c, n);
@@ -426,6 +427,50 @@ extern "C" int jmhip_residual_download(jmhip_ctx *c, jmhip_tq_result *luma, jmhi
       for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) { o.recon[y][x] = R.recon_c[uv][y][x]; if (c->fr_quant_host[1].adaptive_rounding) o.fadjust[y][x] = R.fadj_c[uv][y][x]; }
       o.ret = R.ret[uv]; o.cbp_blk = R.cbp_blk[uv]; o.cbp_clear = R.cbp_clear[uv];
     }
+  }
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_residual_records_download(jmhip_ctx *c, jmhip_mb_residual *records, int n)
+{
+  if (!c || !records) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_residual_records_download: NULL") : JMHIP_ERR_ARG;
+  if (n <= 0 || n > c->fr_n) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_residual_records_download: more macroblocks requested than processed");
+  if (!c->fr_fused) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_residual_records_download: the last frame stage did not take the fused 4:2:0 kernel (use jmhip_residual_download)");
+  JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
+  JM_HIP_CHECK(c, hipMemcpyAsync(records, c->fr_rec, sizeof(jmhip_mb_residual) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  JM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_frame_keep_prediction(jmhip_ctx *c, int on)
+{
+  if (!c) return JMHIP_ERR_ARG;
+  JM_HIP_CHECK(c, hipSetDevice(c->cfg.device));
+  if (on && !c->pred_y) {
+    bool ok = hipMalloc((void **)&c->pred_y, (size_t)c->W * c->H) == hipSuccess;
+    if (ok && c->Wc) ok = hipMalloc((void **)&c->pred_u, (size_t)c->Wc * c->Hc) == hipSuccess && hipMalloc((void **)&c->pred_v, (size_t)c->Wc * c->Hc) == hipSuccess;
+    if (!ok) {
+      if (c->pred_y) (void)hipFree(c->pred_y);
+      if (c->pred_u) (void)hipFree(c->pred_u);
+      if (c->pred_v) (void)hipFree(c->pred_v);
+      c->pred_y = c->pred_u = c->pred_v = nullptr;
+      return jm_fail(c, JMHIP_ERR_NOMEM, "prediction picture");
+    }
+  }
+  c->keep_pred = on != 0;
+  if (!on) c->pred_valid = false;
+  return JMHIP_OK;
+}
+
+extern "C" int jmhip_pred_download(jmhip_ctx *c, void *Y, void *U, void *V, int pel_bytes)
+{
+  if (!c) return JMHIP_ERR_ARG;
+  if (!c->pred_y || !c->pred_valid) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_pred_download: no prediction picture (jmhip_frame_keep_prediction before a fused 4:2:0 jmhip_residual_frame)");
+  int rc = Y ? jm_download_planes(c, c->pred_y, (size_t)c->W * c->H, Y, pel_bytes) : JMHIP_OK;
+  if (rc) return rc;
+  if (c->Wc && U && V) {
+    if ((rc = jm_download_planes(c, c->pred_u, (size_t)c->Wc * c->Hc, U, pel_bytes))) return rc;
+    if ((rc = jm_download_planes(c, c->pred_v, (size_t)c->Wc * c->Hc, V, pel_bytes))) return rc;
   }
   return JMHIP_OK;
 }

@@ -10,6 +10,7 @@ struct FrameDev {
   const uint8_t *cur_y, *cur_u, *cur_v;
   const uint8_t *const *ref_sub, *const *ref_cb, *const *ref_cr;
   uint8_t *rec_y, *rec_u, *rec_v;
+  uint8_t *pred_y, *pred_u, *pred_v;     // the prediction picture (img->mpr of every macroblock), or NULL: jmhip_frame_keep_prediction (fused 4:2:0 stage)
   // chroma prediction without the eighth-pel planes: the sample a plane WOULD hold, computed from the integer chroma picture
   // (reference slots 0..7; see mc_kernel)
   int fly, mul_x, mul_y, pad_cx, pad_cy;
@@ -93,28 +94,10 @@ __device__ __forceinline__ uint32_t luma_row4(const FrameDev &F, int slot, int x
 
 }  // namespace
 
-// Device-resident result record of one macroblock from the fused 4:2:0 frame stage (tq.hip frame_fused_kernel). jmhip_residual_download
-// expands it into the ABI's jmhip_tq_result structs (include/jmhip.h): the same fields the separate TQ kernels write, 2.4 KB instead of 17 KB.
-struct JmMbRes {
-  int16_t lev[24][16];           // (level) lists in scan order: luma blocks 0..15 (JM order b8*4+b4), Cb 16..19, Cr 20..23 (AC)
-  uint8_t run[24][16];
-  uint8_t cnt[24];               // entries of each list; the ABI's 0 terminator follows them
-  int16_t dc_lev[2][4];          // chroma DC lists
-  uint8_t dc_run[2][4];
-  uint8_t dc_cnt[2];
-  uint8_t ac_zeroed[2];          // _CHROMA_COEFF_COST_ thresholding hit: the AC levels of the component read 0, the runs stay (block.c:1384-1410)
-  uint8_t pad0[4];
-  int32_t coeff_cost[16];        // luma, per 4x4 block
-  int32_t ret[2];                // dct_chroma's cr_cbp per component
-  uint16_t nonzero;              // luma: bit blk = dct_4x4's return value
-  uint16_t pad1[3];
-  int64_t cbp_blk[2], cbp_clear[2];
-  int16_t fadj_y[16][16];        // adaptive rounding only
-  int16_t fadj_c[2][8][8];
-  uint8_t recon_y[16][16];       // the transform path's reconstruction (before the coefficient-cost decision picks it or the prediction)
-  uint8_t recon_c[2][8][8];
-  uint8_t pad2[8];
-};
+// Device-resident result record of one macroblock from the fused 4:2:0 frame stage (tq.hip frame_fused_kernel): the ABI's jmhip_mb_residual
+// (include/jmhip.h), which jmhip_residual_records_download hands out as it is and jmhip_residual_download expands into jmhip_tq_result structs --
+// the same fields the separate TQ kernels write, 2.4 KB instead of 17 KB.
+typedef jmhip_mb_residual JmMbRes;
 static_assert(sizeof(JmMbRes) % 16 == 0, "records are copied out of LDS as 16-byte pieces");
 
 int jm_launch_frame_fused(jmhip_ctx *c, const void *frame_dev, const void *mbs, const void *me, const void *modes_in, void *modes_out,

@@ -38,6 +38,7 @@ extern "C" int jmhip_sizeof(int which)
   case 19: return (int)sizeof(jmhip_frame_wp);
   case 20: return (int)sizeof(jmhip_mb_bipred);
   case 21: return (int)sizeof(jmhip_frame_bw);
+  case 22: return (int)sizeof(jmhip_mb_residual);
   default: return -1;
   }
 }
@@ -125,7 +126,7 @@ extern "C" void jmhip_ctx_destroy(jmhip_ctx *c)
   (void)hipFree(c->fr_bi); (void)hipFree(c->fr_rec); (void)hipFree(c->fr_blk_ref); (void)hipFree(c->fr_jobs_y); (void)hipFree(c->fr_jobs_c); (void)hipFree(c->fr_res_y); (void)hipFree(c->fr_res_c);
   jm_slice_state_free(c);
   jm_xslice_free(c);
-  (void)hipFree(c->dbk_dev); (void)hipFree(c->dbr_dev); (void)hipFree(c->fr_quant); (void)hipFree(c->fr_modes); (void)hipFree(c->rec_y); (void)hipFree(c->rec_u); (void)hipFree(c->rec_v);
+  (void)hipFree(c->dbk_dev); (void)hipFree(c->dbr_dev); (void)hipFree(c->fr_quant); (void)hipFree(c->fr_modes); (void)hipFree(c->rec_y); (void)hipFree(c->pred_y); (void)hipFree(c->pred_u); (void)hipFree(c->pred_v); (void)hipFree(c->rec_u); (void)hipFree(c->rec_v);
   for (auto &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto e : c->evt_pool) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -65,6 +65,8 @@ struct jmhip_ctx {
   jmhip_frame_wp fr_wp{};                             // explicit weighted prediction of the frame stage (enable = 0: off)
   jmhip_quant fr_quant_host[4];
   uint8_t *rec_y = nullptr, *rec_u = nullptr, *rec_v = nullptr;
+  uint8_t *pred_y = nullptr, *pred_u = nullptr, *pred_v = nullptr;   // jmhip_frame_keep_prediction: the prediction picture of the last fused frame stage
+  bool keep_pred = false, pred_valid = false;
   bool rec_valid = false;                             // the recon planes hold a reconstruction (cleared by jmhip_recon_to_ref's plane swap)
   bool rec_has_pic = false;                           // recon planes loaded by jmhip_recon_upload
   void *dbk_dev = nullptr; size_t dbk_cap = 0;        // deblocking: macroblock / block / edge arrays

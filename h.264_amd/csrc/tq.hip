@@ -849,6 +849,10 @@ __global__ __launch_bounds__(128) void frame_fused_kernel(FrameDev F, const jmhi
 #pragma unroll
       for (int j = 0; j < 4; j++)
         *reinterpret_cast<uint32_t *>(F.rec_y + (size_t)(mby * 16 + by + j) * F.W + mbx * 16 + bx) = keep ? rec[j] : prd[j];
+      if (F.pred_y) {                                  // img->mpr, kept for a host that answers JM's LumaPrediction from it (jmhip_frame_keep_prediction)
+#pragma unroll
+        for (int j = 0; j < 4; j++) *reinterpret_cast<uint32_t *>(F.pred_y + (size_t)(mby * 16 + by + j) * F.W + mbx * 16 + bx) = prd[j];
+      }
     }
   }
   if (wv == 1) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }   // the chroma tiles are this wave's own
@@ -961,6 +965,12 @@ __global__ __launch_bounds__(128) void frame_fused_kernel(FrameDev F, const jmhi
       for (int k = 0; k < 4; k++) w |= (uint32_t)clip1(q.max_val, rsr(m[j][k], DQ_BITS) + pr[j][k]) << (8 * k);
       *reinterpret_cast<uint32_t *>(&R.recon_c[uv][by + j][bx]) = w;
       if (live) *reinterpret_cast<uint32_t *>((uv ? F.rec_v : F.rec_u) + (size_t)(mby * 8 + by + j) * F.Wc + mbx * 8 + bx) = w;
+      if (live && F.pred_u) {
+        uint32_t pw = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) pw |= (uint32_t)pr[j][k] << (8 * k);
+        *reinterpret_cast<uint32_t *>((uv ? F.pred_v : F.pred_u) + (size_t)(mby * 8 + by + j) * F.Wc + mbx * 8 + bx) = pw;
+      }
     }
     if (b4 == 0) { R.ret[uv] = cr_cbp; R.cbp_blk[uv] = cbp & ~cbp_clear; R.cbp_clear[uv] = cbp_clear; }
   }

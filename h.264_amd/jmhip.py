@@ -131,6 +131,10 @@ QUANT_DTYPE = np.dtype([("qp", "<i4"), ("adaptive_rounding", "<i4"), ("adapt_rnd
                         ("levelscale", "<i4", (64,)), ("invlevelscale", "<i4", (64,)), ("leveloffset", "<i4", (64,))], align=True)
 TQ_JOB_DTYPE = np.dtype([("src", "u1", (16, 16)), ("pred", "u1", (16, 16)), ("quant", "<i4"), ("quant_dc", "<i4"),
                          ("uv", "<i4"), ("cr_cbp_in", "<i4"), ("intra16_unused", "<i4")], align=True)
+MB_RESIDUAL_DTYPE = np.dtype([("lev", "<i2", (24, 16)), ("run", "u1", (24, 16)), ("cnt", "u1", (24,)), ("dc_lev", "<i2", (2, 4)), ("dc_run", "u1", (2, 4)),
+                              ("dc_cnt", "u1", (2,)), ("ac_zeroed", "u1", (2,)), ("pad0", "u1", (4,)), ("coeff_cost", "<i4", (16,)), ("ret", "<i4", (2,)),
+                              ("nonzero", "<u2"), ("pad1", "<u2", (3,)), ("cbp_blk", "<i8", (2,)), ("cbp_clear", "<i8", (2,)), ("fadj_y", "<i2", (16, 16)),
+                              ("fadj_c", "<i2", (2, 8, 8)), ("recon_y", "u1", (16, 16)), ("recon_c", "u1", (2, 8, 8)), ("pad2", "u1", (8,))])      # jmhip_mb_residual
 TQ_RESULT_DTYPE = np.dtype([("levels", "<i4", (16, 17)), ("runs", "<i4", (16, 17)), ("levels8", "<i4", (4, 65)), ("runs8", "<i4", (4, 65)),
                             ("dc_levels", "<i4", (17,)), ("dc_runs", "<i4", (17,)), ("recon", "u1", (16, 16)), ("fadjust", "<i4", (16, 16)),
                             ("coeff_cost", "<i4", (16,)), ("nonzero", "<i4", (16,)), ("ret", "<i4"), ("cbp_blk", "<i8"), ("cbp_clear", "<i8")],
@@ -188,6 +192,9 @@ def load_library():
     lib.jmhip_residual_download.argtypes = [vp, vp, vp, vp, vp, vp, ip]
     lib.jmhip_recon_to_ref.argtypes = [vp, ip]
     lib.jmhip_recon_download.argtypes = [vp, vp, vp, vp, ip]
+    lib.jmhip_residual_records_download.argtypes = [vp, vp, ip]
+    lib.jmhip_frame_keep_prediction.argtypes = [vp, ip]
+    lib.jmhip_pred_download.argtypes = [vp, vp, vp, vp, ip]
     lib.jmhip_recon_copy_band.argtypes = [vp, vp, vp, vp, ip, ip]
     lib.jmhip_sizeof.argtypes = [ip]
     lib.jmhip_cur_bind.argtypes = [vp, vp, vp, vp]
@@ -227,7 +234,7 @@ def load_library():
         if lib.jmhip_sizeof(which) != dt.itemsize:
             raise JmhipError("binding layout mismatch for struct %d: C %d vs numpy %d" % (which, lib.jmhip_sizeof(which), dt.itemsize))
     if lib.jmhip_sizeof(6) != C.sizeof(MeParams) or lib.jmhip_sizeof(7) != C.sizeof(Config) or lib.jmhip_sizeof(12) != C.sizeof(BipredParams) or \
-            lib.jmhip_sizeof(16) != C.sizeof(DeblockParams) or lib.jmhip_sizeof(17) != C.sizeof(SliceParams) or lib.jmhip_sizeof(19) != C.sizeof(FrameWp) or lib.jmhip_sizeof(20) != MB_BIPRED_DTYPE.itemsize or lib.jmhip_sizeof(21) != C.sizeof(FrameBw):
+            lib.jmhip_sizeof(16) != C.sizeof(DeblockParams) or lib.jmhip_sizeof(17) != C.sizeof(SliceParams) or lib.jmhip_sizeof(19) != C.sizeof(FrameWp) or lib.jmhip_sizeof(20) != MB_BIPRED_DTYPE.itemsize or lib.jmhip_sizeof(22) != MB_RESIDUAL_DTYPE.itemsize or lib.jmhip_sizeof(21) != C.sizeof(FrameBw):
         raise JmhipError("binding layout mismatch for jmhip_me_params / jmhip_config")
     _lib = lib
     return lib
@@ -559,6 +566,23 @@ class Context:
 
     def recon_copy_band(self, y_ptr, u_ptr, v_ptr, mb_row0, mb_rows):
         self._chk(self.lib.jmhip_recon_copy_band(self.h, y_ptr, u_ptr, v_ptr, mb_row0, mb_rows), "jmhip_recon_copy_band")
+
+    def residual_records(self, n):
+        """The dense per-macroblock records (jmhip_mb_residual) of the last fused 4:2:0 residual_frame."""
+        rec = np.zeros(n, MB_RESIDUAL_DTYPE)
+        self._chk(self.lib.jmhip_residual_records_download(self.h, _ptr(rec), n), "jmhip_residual_records_download")
+        return rec
+
+    def frame_keep_prediction(self, on=True):
+        self._chk(self.lib.jmhip_frame_keep_prediction(self.h, int(on)), "jmhip_frame_keep_prediction")
+
+    def pred_download(self):
+        """The prediction picture (img->mpr of every macroblock) of the last fused 4:2:0 residual_frame."""
+        Y = np.zeros((self.H, self.W), np.uint8)
+        U = np.zeros((self.Hc, self.Wc), np.uint8) if self.Wc else None
+        V = np.zeros((self.Hc, self.Wc), np.uint8) if self.Wc else None
+        self._chk(self.lib.jmhip_pred_download(self.h, _ptr(Y), _ptr(U), _ptr(V), 1), "jmhip_pred_download")
+        return Y, U, V
 
     def recon_download(self):
         Y = np.zeros((self.H, self.W), np.uint8)

@@ -541,6 +541,36 @@ int jmhip_residual_frame_q(jmhip_ctx *ctx, const jmhip_mb_mode *modes, const jmh
  * thresholding of src/macroblock.c:1236-1258, :1386-1392 and the chroma cr_cbp. Any output pointer may be NULL. */
 int jmhip_residual_download(jmhip_ctx *ctx, jmhip_tq_result *luma, jmhip_tq_result *chroma, jmhip_mb_mode *modes_out,
                             int32_t *cbp, int64_t *cbp_blk, int n);
+/* The dense per-macroblock record of the fused 4:2:0 frame stage (4x4 transform): what JM's dct_4x4 x16 (src/block.c:843) and dct_chroma x2
+ * (:1051) leave behind for one macroblock. jmhip_residual_records_download copies the records of the last jmhip_residual_frame as they are
+ * (2.4 KB each; jmhip_residual_download expands them into three 5.8 KB jmhip_tq_result) -- the form a slice-level binding answers JM's
+ * dct_4x4 / dct_chroma calls from. JMHIP_ERR_UNSUPPORTED when the last frame stage took the separate kernels (4:2:2, 4:0:0, 8x8 transform). */
+typedef struct jmhip_mb_residual {
+  int16_t lev[24][16];           /* (level) lists in scan order: luma blocks 0..15 (JM order b8*4+b4), Cb 16..19, Cr 20..23 (AC) */
+  uint8_t run[24][16];
+  uint8_t cnt[24];               /* entries of each list; JM's 0 terminator follows them */
+  int16_t dc_lev[2][4];          /* chroma DC lists */
+  uint8_t dc_run[2][4];
+  uint8_t dc_cnt[2];
+  uint8_t ac_zeroed[2];          /* _CHROMA_COEFF_COST_ thresholding hit: the AC levels of the component read 0, the runs stay (block.c:1384-1410) */
+  uint8_t pad0[4];
+  int32_t coeff_cost[16];        /* luma, per 4x4 block: what dct_4x4 adds to *coeff_cost */
+  int32_t ret[2];                /* dct_chroma's return value (cr_cbp) per component */
+  uint16_t nonzero;              /* luma: bit blk = dct_4x4's return value */
+  uint16_t pad1[3];
+  int64_t cbp_blk[2], cbp_clear[2];   /* dct_chroma: currMB->cbp_blk = (cbp_blk & ~cbp_clear) | cbp_blk */
+  int16_t fadj_y[16][16];        /* adaptive rounding only: img->fadjust4x4 / fadjust4x4Cr */
+  int16_t fadj_c[2][8][8];
+  uint8_t recon_y[16][16];       /* the transform path's reconstruction, as dct_4x4 writes it (before the caller's coefficient-cost decision) */
+  uint8_t recon_c[2][8][8];
+  uint8_t pad2[8];
+} jmhip_mb_residual;
+int jmhip_residual_records_download(jmhip_ctx *ctx, jmhip_mb_residual *records, int n);
+/* Keep the prediction picture -- img->mpr of every macroblock of jmhip_residual_frame, luma and chroma (src/macroblock.c:836, :1593) -- beside
+ * the recon picture (fused 4:2:0 stage only), and copy it to the host (pel_bytes 1 or 2): a binding that answers JM's LumaPrediction /
+ * ChromaPrediction4x4 from the device reads it, and checks its dct inputs against it. */
+int jmhip_frame_keep_prediction(jmhip_ctx *ctx, int on);
+int jmhip_pred_download(jmhip_ctx *ctx, void *Y, void *U, void *V, int pel_bytes);
 /* Make the recon picture the integer-pel picture of reference slot `ref`, e.g. for the next frame. Nothing is copied: the
  * slot's planes and the recon planes TRADE PLACES. Consequences: (1) device pointers handed out earlier by
  * jmhip_ref_device_planes / jmhip_ref_planes_peek for this slot are stale -- ask again; (2) the recon picture is INVALID
@@ -601,7 +631,8 @@ int jmhip_ref_unpack_bands(jmhip_ctx *ctx, int ref, const void *chunks_device, i
 /* sizeof() of the ABI structs, for language bindings to verify their layout: 0 jmhip_me_mb, 1 jmhip_me_result,
  * 2 jmhip_quant, 3 jmhip_tq_job, 4 jmhip_tq_result, 5 jmhip_dist_job, 6 jmhip_me_params, 7 jmhip_config,
  * 8 jmhip_mb_mode, 9 jmhip_surface_job, 10 jmhip_bipred_job, 11 jmhip_bipred_result, 12 jmhip_bipred_params, 13 jmhip_predcost_job,
- * 14 jmhip_deblock_mb, 15 jmhip_deblock_blk, 16 jmhip_deblock_params. */
+ * 14 jmhip_deblock_mb, 15 jmhip_deblock_blk, 16 jmhip_deblock_params, 17 jmhip_slice_params, 18 jmhip_mb_inter, 19 jmhip_frame_wp,
+ * 20 jmhip_mb_bipred, 21 jmhip_frame_bw, 22 jmhip_mb_residual. */
 int jmhip_sizeof(int which);
 
 /* Flat (no scaling matrix) tables: CalculateQuantParam / CalculateQuant8Param (src/q_matrix.c:451,590) and

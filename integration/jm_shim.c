@@ -21,6 +21,12 @@
  *        candidates in P pictures; search modes -1, 0, 2, whose result is a pure function of the predictor): the device's low-complexity
  *        decision is only a guess of JM's; a call is answered from the record when JM's predictor equals the recorded one and runs JM's
  *        own search otherwise (counted as forwarded), so the bitstream is JM's whatever the guess was worth.
+ * 0x4000 (with 0x1000, exact form, 4:2:0, 4x4 transform) the FRAME STAGE at slice level: right after the slice search the device also predicts,
+ *        transforms, quantises and reconstructs every macroblock of the slice from its own decision (jmhip_slice_to_frame_band ->
+ *        jmhip_residual_frame), and JM's LumaPrediction / ChromaPrediction4x4 / dct_4x4 / dct_chroma calls of the slice are answered from the
+ *        prediction picture and the per-macroblock records -- a prediction call after checking that JM asks for the block the device decided
+ *        (mode, reference, vectors), a dct call after checking that JM's img->mpr / img->m7 are the prediction and residual the device used
+ *        (anything else is a fatal error).
  *
  * The proof of the drop-in claim is tests/test_jm_shim.py: the bitstream and the reconstruction this encoder
  * writes are byte-identical to the unmodified encoder's.
@@ -51,17 +57,19 @@ extern void SetMotionVectorPredictor(short pmv[2], char **refPic, short ***tmp_m
 extern const int LEVELMVLIMIT[17][6];
 extern int *mvbits;                       /* src/mv-search.c:59 */
 
-enum { S_LUMA, S_CHROMA, S_FULL, S_SUB, S_FAST, S_D4, S_D8, S_D16, S_DCR, S_WALK, S_SAD, S_SATD, S_BIFULL, S_BISUB, S_TDEC, S_SKIPC, S_BIDC, S_DEBLOCK, S_SLICE, S_BMS, S_COUNT };
+enum { S_LUMA, S_CHROMA, S_FULL, S_SUB, S_FAST, S_D4, S_D8, S_D16, S_DCR, S_WALK, S_SAD, S_SATD, S_BIFULL, S_BISUB, S_TDEC, S_SKIPC, S_BIDC, S_DEBLOCK, S_SLICE, S_BMS,
+       S_FRAME, S_D4R, S_DCRR, S_LPRED, S_CPRED, S_COUNT };
 static const char *s_names[S_COUNT] = { "getSubImagesLuma", "getSubImagesChroma", "FullPelBlockMotionSearch",
   "SubPelBlockMotionSearch", "FastFullPelBlockMotionSearch", "dct_4x4", "dct_8x8", "dct_16x16", "dct_chroma",
   "EPZS_UMHex_integer_walks", "computeSAD", "computeSATD", "FullPelBlockMotionBiPred", "SubPelBlockSearchBiPred",
   "TransformDecision", "GetSkipCostMB", "BIDPartitionCost", "DeblockFrame",
-  "P slices (one device call each)", "BlockMotionSearch" };
+  "P slices (one device call each)", "BlockMotionSearch",
+  "frame stage of P slices", "dct_4x4 (slice records)", "dct_chroma (slice records)", "LumaPrediction (slice)", "ChromaPrediction4x4 (slice)" };
 static long n_dev[S_COUNT], n_fwd[S_COUNT];
 static double t_dev[S_COUNT], t_last[S_COUNT];             /* JMHIP_SHIM_STATS: wall seconds inside the coarse device-side hooks (planes, slice search, loop filter) */
 static int stats_on;
 static double now_s(void) { struct timespec ts; if (!stats_on) return 0.0; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
-static unsigned shim_mask = 0x1fff;
+static unsigned shim_mask = 0x5fff;
 static int verify;            /* JMHIP_SHIM_VERIFY=1: run JM's own search beside the device's and report differences */
 static jmhip_ctx *g;
 static int g_w, g_h;
@@ -819,10 +827,14 @@ static void put_list(int *lev_dst, int *run_dst, const int32_t *lev, const int32
   for (k = 0; k < max; k++) { lev_dst[k] = lev[k]; run_dst[k] = run[k]; if (!lev[k]) break; }
 }
 
+static int fr_dct4(Macroblock *currMB, int block_x, int block_y, int *coeff_cost, int *ret);
+static int fr_dctc(Macroblock *currMB, int uv, int cr_cbp, int *ret);
+
 int dct_4x4(Macroblock *currMB, ColorPlane pl, int block_x, int block_y, int *coeff_cost, int intra)
 {
   static int (*orig)(Macroblock *, ColorPlane, int, int, int *, int);
   static jmhip_tq_job job; static jmhip_tq_result res; static jmhip_quant q;
+  { int r; if (pl == 0 && !intra && fr_dct4(currMB, block_x, block_y, coeff_cost, &r)) return r; }
   int ok = (shim_mask & 0x10) && ctx_ready() && !(currMB->qp_scaled[pl] == 0 && img->lossless_qpprime_flag == 1) &&
            img->type != SP_SLICE;
   if (ok) ok = fill_tiles(&job, img->m7[pl], img->mpr[pl], block_x, block_y, 4, 4);
@@ -926,6 +938,7 @@ int dct_chroma(Macroblock *currMB, int uv, int cr_cbp)
 {
   static int (*orig)(Macroblock *, int, int);
   static jmhip_tq_job job; static jmhip_tq_result res; static jmhip_quant q[2];
+  { int r; if (fr_dctc(currMB, uv, cr_cbp, &r)) return r; }
   int ok = (shim_mask & 0x40) && ctx_ready() && img->yuv_format != YUV444 && img->yuv_format != YUV400 &&
            !((currMB->qp + img->bitdepth_luma_qp_scale) == 0 && img->lossless_qpprime_flag == 1) && img->type != SP_SLICE;
   if (ok) ok = fill_tiles(&job, img->m7[uv + 1], img->mpr[uv + 1], 0, 0, img->mb_cr_size_x, img->mb_cr_size_y);
@@ -983,6 +996,207 @@ static struct {
   int started;                /* device state reset done */
   long passes, slices;
 } sl;
+
+
+/* ------------------------------------------------------------------ 0x4000 the frame stage at slice level (exact form of the slice binding) */
+
+static struct {
+  int active;                 /* records and prediction picture below belong to macroblocks [mb_first, mb_first + mb_count) of picture `serial` */
+  unsigned long serial;
+  int mb_first, mb_count;
+  jmhip_mb_residual *rec; int cap;
+  imgpel *pred[3]; int pred_ready;
+  /* JM also predicts and transforms blocks the decision then discards (the P8x8 candidate of every macroblock, src/mode_decision.c:874): a dct call
+     is answered from the record only when the prediction it works on was -- per macroblock, the luma 4x4 blocks / chroma 4x4 blocks whose LAST
+     prediction call asked for the decided block and was answered from the prediction picture */
+  int ok_mb; unsigned long ok_serial; unsigned ok_luma, ok_chroma[2];
+} fr;
+
+static void fr_ok_mb(void)
+{
+  if (fr.ok_mb != img->current_mb_nr || fr.ok_serial != pic_serial) { fr.ok_mb = img->current_mb_nr; fr.ok_serial = pic_serial; fr.ok_luma = 0; fr.ok_chroma[0] = fr.ok_chroma[1] = 0; }
+}
+static unsigned fr_luma_bits(int block_x, int block_y, int bsx, int bsy)
+{
+  unsigned m = 0; int bx, by;
+  for (by = block_y >> 2; by < (block_y + bsy) >> 2; by++) for (bx = block_x >> 2; bx < (block_x + bsx) >> 2; bx++) m |= 1u << (by * 4 + bx);
+  return m;
+}
+
+static const jmhip_mb_residual *fr_rec_cur(void)
+{
+  if (!fr.active || fr.serial != pic_serial || img->type != P_SLICE) return NULL;
+  if (img->current_mb_nr < fr.mb_first || img->current_mb_nr >= fr.mb_first + fr.mb_count) return NULL;
+  return &fr.rec[img->current_mb_nr - fr.mb_first];
+}
+
+static void fr_diverged(const char *what, int x, int y)
+{
+  fprintf(stderr, "jm_shim: frame binding diverged at mb %d, %s block (%d,%d): JM's prediction / residual is not what the device coded\n", img->current_mb_nr, what, x, y);
+  exit(95);
+}
+
+/* right after the slice search: prediction, residual, transform, quantisation and reconstruction of the slice's macroblocks on the device */
+static void fr_run(const jmhip_slice_params *p, int first, int count)
+{
+  static jmhip_quant q[3];
+  jmhip_quant qv;
+  jmhip_frame_wp wp;
+  Macroblock *mb = &img->mb_data[first];
+  const int qp = mb->qp_scaled[0], qc0 = mb->qpc[0] + img->bitdepth_chroma_qp_scale, qc1 = mb->qpc[1] + img->bitdepth_chroma_qp_scale;
+  const double t0 = now_s();
+  int r, c;
+  fr.active = 0;
+  if (!(shim_mask & 0x4000) || sl.spec || img->yuv_format != YUV420 || input->Transform8x8Mode || img->type != P_SLICE || img->NoResidueDirect ||
+      (qp == 0 && img->lossless_qpprime_flag == 1) || mb->is_field_mode) return;
+  for (r = 0; r < p->num_refs; r++) if (p->ref_slot[r] >= 8 && !slots[p->ref_slot[r]].has_chroma) return;      /* chroma samples are computed from reference slots 0..7 only */
+  /* the inter quantisers of the slice (no rate control, no macroblock-level dquant: one qp); Cb and Cr must share theirs */
+  fill_quant(&q[0], qp, LevelScale4x4Comp[0][0][qp_rem_matrix[qp]], InvLevelScale4x4Comp[0][0][qp_rem_matrix[qp]], ptLevelOffset4x4[0][qp], 4, mb, AdaptRndWeight, img->max_imgpel_value);
+  fill_quant(&q[1], qc0, LevelScale4x4Comp[1][0][qp_rem_matrix[qc0]], InvLevelScale4x4Comp[1][0][qp_rem_matrix[qc0]], LevelOffset4x4Comp[1][0][qc0], 4, mb, AdaptRndCrWeight, img->max_imgpel_value_comp[1]);
+  fill_quant(&qv, qc1, LevelScale4x4Comp[2][0][qp_rem_matrix[qc1]], InvLevelScale4x4Comp[2][0][qp_rem_matrix[qc1]], LevelOffset4x4Comp[2][0][qc1], 4, mb, AdaptRndCrWeight, img->max_imgpel_value_comp[2]);
+  if (memcmp(&q[1], &qv, sizeof(qv))) return;
+  q[2] = q[1];
+  memset(&wp, 0, sizeof(wp));
+  if (active_pps->weighted_pred_flag) {
+    wp.enable = 1; wp.luma_round = wp_luma_round; wp.luma_denom = luma_log_weight_denom; wp.chroma_round = wp_chroma_round; wp.chroma_denom = chroma_log_weight_denom;
+    for (r = 0; r < p->num_refs; r++) for (c = 0; c < 3; c++) { wp.weight[p->ref_slot[r]][c] = (int16_t)wp_weight[0][r][c]; wp.offset[p->ref_slot[r]][c] = (int16_t)wp_offset[0][r][c]; }
+  }
+  OK(jmhip_frame_wp_set(g, &wp));
+  OK(jmhip_frame_keep_prediction(g, 1));
+  OK(jmhip_slice_to_frame_band(g, p->ref_slot, p->num_refs, first, count));
+  OK(jmhip_residual_frame(g, NULL, q));
+  if (fr.cap < count) { free(fr.rec); fr.rec = malloc(sizeof(jmhip_mb_residual) * (size_t)count); fr.cap = count; }
+  if (!fr.pred_ready) {
+    fr.pred[0] = malloc(sizeof(imgpel) * (size_t)g_w * g_h); fr.pred[1] = malloc(sizeof(imgpel) * (size_t)(g_w / 2) * (g_h / 2)); fr.pred[2] = malloc(sizeof(imgpel) * (size_t)(g_w / 2) * (g_h / 2));
+    fr.pred_ready = 1;
+  }
+  if (!fr.rec || !fr.pred[0] || !fr.pred[1] || !fr.pred[2]) { fprintf(stderr, "jm_shim: out of memory\n"); exit(96); }
+  OK(jmhip_residual_records_download(g, fr.rec, count));
+  OK(jmhip_pred_download(g, fr.pred[0], fr.pred[1], fr.pred[2], (int)sizeof(imgpel)));
+  fr.active = 1; fr.serial = pic_serial; fr.mb_first = first; fr.mb_count = count;
+  n_dev[S_FRAME]++; t_last[S_FRAME] = now_s() - t0; t_dev[S_FRAME] += t_last[S_FRAME];
+}
+
+/* does JM ask for the prediction the device formed for the luma 4x4 blocks [bx0, bx1) x [by0, by1) of the current macroblock? */
+static int fr_asks_decided(int bx0, int by0, int bx1, int by1, int p_dir, int l0_mode, short l0_ref)
+{
+  const jmhip_mb_inter *d = &sl.rec[img->current_mb_nr - sl.mb_first];
+  int bx, by;
+  if (p_dir != 0 || l0_ref < 0 || l0_ref >= JMHIP_SLICE_REFS || l0_mode < 1 || l0_mode > 7) return 0;
+  for (by = by0; by < by1; by++) for (bx = bx0; bx < bx1; bx++) {
+    const int b8 = 2 * (by >> 1) + (bx >> 1), mode = d->best_mode == 8 ? d->b8mode[b8] : d->best_mode;
+    const short *v = img->all_mv[by][bx][LIST_0][l0_ref][l0_mode];
+    if (l0_mode != mode || l0_ref != d->b8ref[b8] || v[0] != d->final_mv[by * 4 + bx][0] || v[1] != d->final_mv[by * 4 + bx][1]) {
+      static int told;
+      if (getenv("JMHIP_SHIM_DEBUG") && told++ < 12)
+        fprintf(stderr, "jm_shim debug: mb %d block (%d,%d): JM asks mode %d ref %d mv (%d,%d), device decided best_mode %d b8mode %d ref %d mv (%d,%d)\n", img->current_mb_nr, bx, by, l0_mode, l0_ref,
+                v[0], v[1], d->best_mode, d->b8mode[b8], d->b8ref[b8], d->final_mv[by * 4 + bx][0], d->final_mv[by * 4 + bx][1]);
+      return 0;
+    }
+  }
+  return 1;
+}
+
+void LumaPrediction(Macroblock *currMB, int block_x, int block_y, int block_size_x, int block_size_y, int p_dir, int l0_mode, int l1_mode, short l0_ref_idx, short l1_ref_idx)
+{
+  static void (*orig)(Macroblock *, int, int, int, int, int, int, int, short, short);
+  if (fr_rec_cur()) { fr_ok_mb(); fr.ok_luma &= ~fr_luma_bits(block_x, block_y, block_size_x, block_size_y); }
+  if (fr_rec_cur() && sl.active && fr_asks_decided(block_x >> 2, block_y >> 2, (block_x + block_size_x) >> 2, (block_y + block_size_y) >> 2, p_dir, l0_mode, l0_ref_idx)) {
+    int j;
+    fr.ok_luma |= fr_luma_bits(block_x, block_y, block_size_x, block_size_y);
+    for (j = block_y; j < block_y + block_size_y; j++)
+      memcpy(&img->mpr[0][j][block_x], fr.pred[0] + (size_t)(img->pix_y + j) * g_w + img->pix_x + block_x, sizeof(imgpel) * (size_t)block_size_x);
+    width_pad = listX[LIST_0][l0_ref_idx]->size_x_pad; height_pad = listX[LIST_0][l0_ref_idx]->size_y_pad;      /* OneComponentLumaPrediction, macroblock.c:817-818 */
+    n_dev[S_LPRED]++;
+    return;
+  }
+  if (!orig) orig = next_sym("LumaPrediction");
+  if (fr_rec_cur()) n_fwd[S_LPRED]++;
+  orig(currMB, block_x, block_y, block_size_x, block_size_y, p_dir, l0_mode, l1_mode, l0_ref_idx, l1_ref_idx);
+}
+
+void ChromaPrediction4x4(Macroblock *currMB, int uv, int block_x, int block_y, int p_dir, int l0_mode, int l1_mode, short l0_ref_idx, short l1_ref_idx)
+{
+  static void (*orig)(Macroblock *, int, int, int, int, int, int, short, short);
+  if (fr_rec_cur()) { fr_ok_mb(); fr.ok_chroma[uv] &= ~(1u << ((block_y >> 2) * 2 + (block_x >> 2))); }
+  /* 4:2:0: the chroma 4x4 block at (block_x, block_y) is predicted with the vectors of the luma 8x8 block at twice that position */
+  if (fr_rec_cur() && sl.active && fr_asks_decided(block_x >> 1, block_y >> 1, (block_x >> 1) + 2, (block_y >> 1) + 2, p_dir, l0_mode, l0_ref_idx)) {
+    int j;
+    fr.ok_chroma[uv] |= 1u << ((block_y >> 2) * 2 + (block_x >> 2));
+    for (j = block_y; j < block_y + 4; j++)
+      memcpy(&img->mpr[uv + 1][j][block_x], fr.pred[uv + 1] + (size_t)(img->pix_c_y + j) * (g_w / 2) + img->pix_c_x + block_x, sizeof(imgpel) * 4);
+    n_dev[S_CPRED]++;
+    return;
+  }
+  if (!orig) orig = next_sym("ChromaPrediction4x4");
+  if (fr_rec_cur()) n_fwd[S_CPRED]++;
+  orig(currMB, uv, block_x, block_y, p_dir, l0_mode, l1_mode, l0_ref_idx, l1_ref_idx);
+}
+
+/* dct_4x4 (src/block.c:843) of an inter luma block, from the macroblock's record */
+static int fr_dct4(Macroblock *currMB, int block_x, int block_y, int *coeff_cost, int *ret)
+{
+  const jmhip_mb_residual *r = fr_rec_cur();
+  if (!r || IS_INTRA(currMB) || currMB->luma_transform_size_8x8_flag) return 0;
+  fr_ok_mb();
+  if (!(fr.ok_luma & (1u << ((block_y >> 2) * 4 + (block_x >> 2))))) { n_fwd[S_D4R]++; return 0; }      /* a candidate the decision discards: JM's prediction, so JM's transform */
+  {
+    const int pos_x = block_x >> 2, pos_y = block_y >> 2, b8 = 2 * (pos_y >> 1) + (pos_x >> 1), b4 = 2 * (pos_y & 1) + (pos_x & 1), blk = b8 * 4 + b4;
+    const int n = r->cnt[blk];
+    int *lev = img->cofAC[b8][b4][0], *run = img->cofAC[b8][b4][1];
+    int **fa = img->AdaptiveRounding ? img->fadjust4x4[0] : NULL;
+    imgpel **img_enc = enc_picture->p_curr_img;
+    int j, i, k;
+    for (j = block_y; j < block_y + 4; j++) for (i = block_x; i < block_x + 4; i++) {
+      const int pr = fr.pred[0][(size_t)(img->pix_y + j) * g_w + img->pix_x + i];
+      if (img->mpr[0][j][i] != pr || img->m7[0][j][i] != pCurImg[img->opix_y + j][img->opix_x + i] - pr) fr_diverged("luma", block_x, block_y);
+    }
+    for (k = 0; k < n; k++) { lev[k] = r->lev[blk][k]; run[k] = r->run[blk][k]; }
+    lev[n] = 0;
+    *coeff_cost += r->coeff_cost[blk];
+    for (j = block_y; j < block_y + 4; j++) for (i = block_x; i < block_x + 4; i++) {
+      img_enc[img->pix_y + j][img->pix_x + i] = r->recon_y[j][i];
+      if (fa) fa[j][i] = r->fadj_y[j][i];
+    }
+    n_dev[S_D4R]++;
+    *ret = (r->nonzero >> blk) & 1;
+    return 1;
+  }
+}
+
+/* dct_chroma (src/block.c:1051) of an inter macroblock's component, 4:2:0, from the record */
+static int fr_dctc(Macroblock *currMB, int uv, int cr_cbp, int *ret)
+{
+  const jmhip_mb_residual *r = fr_rec_cur();
+  if (!r || IS_INTRA(currMB)) return 0;
+  fr_ok_mb();
+  if (fr.ok_chroma[uv] != 15u) { n_fwd[S_DCRR]++; return 0; }
+  {
+    int **fa = img->AdaptiveRounding ? img->fadjust4x4Cr[0][uv] : NULL;
+    const int wc = g_w / 2;
+    int j, i, k, b, n = r->dc_cnt[uv];
+    for (j = 0; j < 8; j++) for (i = 0; i < 8; i++) {
+      const int pr = fr.pred[uv + 1][(size_t)(img->pix_c_y + j) * wc + img->pix_c_x + i];
+      if (img->mpr[uv + 1][j][i] != pr || img->m7[uv + 1][j][i] != imgUV_org[uv][img->opix_c_y + j][img->opix_c_x + i] - pr) fr_diverged(uv ? "Cr" : "Cb", i, j);
+    }
+    for (k = 0; k < n; k++) { img->cofDC[uv + 1][0][k] = r->dc_lev[uv][k]; img->cofDC[uv + 1][1][k] = r->dc_run[uv][k]; }
+    img->cofDC[uv + 1][0][n] = 0;
+    for (b = 0; b < 4; b++) {
+      int *lev = img->cofAC[4 + uv][b][0], *run = img->cofAC[4 + uv][b][1];
+      n = r->ac_zeroed[uv] ? 0 : r->cnt[16 + 4 * uv + b];              /* _CHROMA_COEFF_COST_ (:1384-1410): every AC level of the component reads 0 */
+      for (k = 0; k < n; k++) { lev[k] = r->lev[16 + 4 * uv + b][k]; run[k] = r->run[16 + 4 * uv + b][k]; }
+      lev[n] = 0;
+    }
+    currMB->cbp_blk = (currMB->cbp_blk & ~r->cbp_clear[uv]) | r->cbp_blk[uv];
+    for (j = 0; j < 8; j++) for (i = 0; i < 8; i++) {
+      enc_picture->imgUV[uv][img->pix_c_y + j][img->pix_c_x + i] = r->recon_c[uv][j][i];
+      if (fa && ((j | i) & 3)) fa[j][i] = r->fadj_c[uv][j][i];          /* AC positions only, block.c:1321-1380 */
+    }
+    n_dev[S_DCRR]++;
+    *ret = cr_cbp > r->ret[uv] ? cr_cbp : r->ret[uv];
+    return 1;
+  }
+}
 
 static int slice_mode_covered(void)
 {
@@ -1071,6 +1285,7 @@ static void slice_run(int *lambda_factor)
   sl.slices++;
   sl.active = 1; sl.serial = pic_serial; sl.slice_nr = img->current_slice_nr; sl.mb_first = first; sl.mb_count = count;
   n_dev[S_SLICE]++; t_last[S_SLICE] = now_s() - t0; t_dev[S_SLICE] += t_last[S_SLICE];
+  fr_run(&p, first, count);
 }
 
 static long sl_slices(void) { return sl.slices; }

@@ -51,9 +51,17 @@ def test_residual_frame(pkg, fmt, qp, given_modes, chroma_planes):
         modes = np.zeros(len(mbs), dtype=pkg.MB_MODE_DTYPE)
         modes["mode"] = rng.choice([1, 2, 3, 8], len(mbs))
         modes["b8mode"] = rng.integers(4, 8, (len(mbs), 4))
+    if fmt == 1:
+        ctx.frame_keep_prediction()
     ctx.residual_frame(quants, modes)
     got = ctx.residual_download(len(mbs))
     recon = ctx.recon_download()
+    records, pred = (ctx.residual_records(len(mbs)), ctx.pred_download()) if fmt == 1 else (None, None)
+    if fmt != 1:                                        # the dense records and the prediction picture are the fused 4:2:0 stage's
+        with pytest.raises(pkg.JmhipError):
+            ctx.residual_records(len(mbs))
+        with pytest.raises(pkg.JmhipError):
+            ctx.pred_download()
     ctx.close()
 
     want_modes = modes if given_modes else oracle.pick_modes(me["cost"])
@@ -71,6 +79,27 @@ def test_residual_frame(pkg, fmt, qp, given_modes, chroma_planes):
     assert np.array_equal(got["cbp_blk"], want["cbp_blk"])
     for g, wv, name in zip(recon, want["recon"], "YUV"):
         assert np.array_equal(g, wv), "recon %s" % name
+    if records is not None:
+        # jmhip_residual_records_download: the same results as dense jmhip_mb_residual records (what a slice-level binding answers JM's dct_4x4 /
+        # dct_chroma from), and jmhip_pred_download: img->mpr of every macroblock
+        for i, mb in enumerate(mbs):
+            r, x, y = records[i], 16 * int(mb["mb_x"]), 16 * int(mb["mb_y"])
+            for b in range(16):
+                n = int(r["cnt"][b])
+                assert np.array_equal(r["lev"][b, :n], want["luma"]["levels"][i, b, :n]) and np.array_equal(r["run"][b, :n], want["luma"]["runs"][i, b, :n]) and want["luma"]["levels"][i, b, n] == 0
+                assert ((int(r["nonzero"]) >> b) & 1) == int(want["luma"]["nonzero"][i, b]) and int(r["coeff_cost"][b]) == int(want["luma"]["coeff_cost"][i, b])
+            assert np.array_equal(r["recon_y"], want["luma"]["recon"][i]) and np.array_equal(r["fadj_y"], want["luma"]["fadjust"][i])
+            for uv in range(2):
+                wc = {k: v[2 * i + uv] for k, v in want["chroma"].items()}
+                for b in range(4):
+                    n = int(r["cnt"][16 + 4 * uv + b])
+                    assert np.array_equal(np.where(r["ac_zeroed"][uv], 0, r["lev"][16 + 4 * uv + b, :n]), wc["levels"][b, :n]) and np.array_equal(r["run"][16 + 4 * uv + b, :n], wc["runs"][b, :n])
+                n = int(r["dc_cnt"][uv])
+                assert np.array_equal(r["dc_lev"][uv, :n], wc["dc_levels"][:n]) and np.array_equal(r["dc_run"][uv, :n], wc["dc_runs"][:n]) and wc["dc_levels"][n] == 0
+                assert int(r["ret"][uv]) == int(wc["ret"]) and int(r["cbp_blk"][uv]) == int(wc["cbp_blk"]) and int(r["cbp_clear"][uv]) == int(wc["cbp_clear"])
+                assert np.array_equal(r["recon_c"][uv], wc["recon"][:8, :8])
+                assert np.array_equal(pred[1 + uv][y // 2:y // 2 + 8, x // 2:x // 2 + 8], want["jobs_c"][2 * i + uv]["pred"][:8, :8]), "chroma prediction of macroblock %d" % i
+            assert np.array_equal(pred[0][y:y + 16, x:x + 16], want["jobs_y"][i]["pred"]), "luma prediction of macroblock %d" % i
     # the thresholds must actually be exercised somewhere across the parametrisation
     assert got["cbp"].max() > 0 or qp >= 40
 

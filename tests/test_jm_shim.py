@@ -286,13 +286,28 @@ def test_jm_slice_level_binding_is_byte_identical(tmp_path, name):
     for sym in ("FullPelBlockMotionSearch", "FastFullPelBlockMotionSearch", "SubPelBlockMotionSearch", "EPZS_UMHex_integer_walks", "computeSAD", "computeSATD"):
         mm = re.search(r"^\s*%s\s+device\s+(\d+)\s+forwarded\s+(\d+)" % sym, stats, re.M)
         assert mm and int(mm.group(1)) == 0 and int(mm.group(2)) == 0, (sym, mm and mm.groups())
+    # 4:2:0 with the 4x4 transform: the frame stage is bound at slice level too (mask 0x4000) -- every prediction and every dct_4x4 / dct_chroma of
+    # the P pictures is answered from the device's prediction picture and per-macroblock records, none is computed by JM
+    served = {k: tuple(int(v) for v in re.search(r"^\s*%s\s+device\s+(\d+)\s+forwarded\s+(\d+)" % re.escape(k), stats, re.M).groups())
+              for k in ("frame stage of P slices", "dct_4x4 (slice records)", "dct_chroma (slice records)", "LumaPrediction (slice)", "ChromaPrediction4x4 (slice)")}
+    mbs = (nframes - 1) * 99
+    if SLICE_CASES[name]["yuv"] == 1 and SLICE_CASES[name]["t8x8"] == 0:
+        assert served["frame stage of P slices"][0] == nframes - 1, served
+        # (JM also predicts and transforms the P8x8 candidate of every macroblock, src/mode_decision.c:874, which the decision mostly discards: those
+        # calls -- the `forwarded` counts -- work on JM's own prediction and stay JM's)
+        assert served["dct_4x4 (slice records)"][0] >= 16 * mbs and served["dct_chroma (slice records)"] == (2 * mbs, 0), served
+        assert served["LumaPrediction (slice)"][0] >= 16 * mbs and served["ChromaPrediction4x4 (slice)"] == (8 * mbs, 0), served
+    else:
+        assert served["frame stage of P slices"][0] == 0 and served["dct_4x4 (slice records)"][0] == 0, served
 
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not HAVE, reason="oracle/_ref/jm_hip did not travel")
 def test_jm_1080p_full_search_slice_binding_is_byte_identical_and_faster(tmp_path):
     """BASELINE config 2 through the real encoder: 1920x1080, FullSearch +-32, I + P, low-complexity decision. The P picture's whole motion
-    search + inter decision is one device call (mask 0x1801: sub-pel planes, slice binding, loop filter; everything else stays JM's)."""
+    search + inter decision is one device call, and so is its frame stage -- prediction, residual, transform, quantisation, reconstruction -- whose
+    results answer JM's LumaPrediction / ChromaPrediction4x4 / dct_4x4 / dct_chroma calls (mask 0x5801: sub-pel planes, slice binding with the
+    frame stage, loop filter; everything else stays JM's)."""
     import time
     CASES["slice_full_1080p"] = dict(search=-1, profile=66, cabac=0, t8x8=0, bframes=0, refs=1, rdopt=0, adrnd=1, yuv=1, noi=1)
     prepare(tmp_path, "slice_full_1080p", w=1920, h=1080, frames=2, R=32)
@@ -300,12 +315,15 @@ def test_jm_1080p_full_search_slice_binding_is_byte_identical_and_faster(tmp_pat
     want = run("jm_plain", tmp_path)
     t_plain = time.perf_counter() - t0
     t0 = time.perf_counter()
-    got = run("jm_hip", tmp_path, {"JMHIP_SHIM_STATS": "1", "JMHIP_SHIM": "1801"})
+    got = run("jm_hip", tmp_path, {"JMHIP_SHIM_STATS": "1", "JMHIP_SHIM": "5801"})
     t_hip = time.perf_counter() - t0
     stats = got[2]
     assert got[0] == want[0] and got[1] == want[1], "1080p encode differs\n" + stats
     m = re.search(r"^\s*BlockMotionSearch\s+device\s+(\d+)\s+forwarded\s+(\d+)", stats, re.M)
     assert int(m.group(1)) == 8160 * 41 and int(m.group(2)) == 0, m.groups()
+    d4 = re.search(r"^\s*dct_4x4 \(slice records\)\s+device\s+(\d+)\s+forwarded\s+(\d+)", stats, re.M)
+    dc = re.search(r"^\s*dct_chroma \(slice records\)\s+device\s+(\d+)\s+forwarded\s+(\d+)", stats, re.M)
+    assert int(d4.group(1)) >= 8160 * 16 and (int(dc.group(1)), int(dc.group(2))) == (8160 * 2, 0), (d4.groups(), dc.groups())
     print("1080p I+P, FullSearch +-32: jm_plain %.1f s, jm_hip %.1f s; %s of %s BlockMotionSearch calls answered from the slice record (hit rate 100%%)" % (
         t_plain, t_hip, m.group(1), m.group(1)))
     assert t_hip < t_plain
