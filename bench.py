@@ -702,6 +702,19 @@ def main():
             e2e = jm_end_to_end(frames, rdopt1=True)
             if e2e is not None:
                 out["jm_end_to_end_rdopt1_speculative"] = e2e
+            # for information: the same step in its JM-EXACT form (`--exact`: the slice search with JM's own predictors and decision instead of one
+            # synthetic predictor per macroblock, then the frame stage from that decision), in a process of its own
+            try:
+                import subprocess
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--exact", "--steps", "8", "--warmup", "3", "--cpu-mbs", "0"], capture_output=True, text=True, timeout=300)
+                ex = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+                out["jm_exact_pipeline"] = {"macroblocks_per_s": ex["value"], "ms_per_step": ex["ms_per_step"], "slice_search_ms": ex["roofline"]["slice_search_ms"],
+                                            "sweeps_last_steps": ex["roofline"]["sweeps_last_steps"], "ref_checksum": ex.get("ref_checksum"),
+                                            "note": "bench.py --exact: jmhip_p_slice_search (FullSearch +-32 round every partition's own predictor, sub-pel, skip shortcut, low-complexity "
+                                                    "decision, relaxation sweeps) -> jmhip_slice_to_frame_band -> jmhip_residual_frame -> next reference; what the metric's workload "
+                                                    "costs when JM's raster-order dependencies are kept"}
+            except Exception as e:
+                sys.stderr.write("jm_exact_pipeline: %s\n" % e)
         if args.exact:
             out["metric_note"] = ("--exact: the JM-EXACT form of the step -- jmhip_p_slice_search per slice (predictors, FullSearch +-32 per partition round its own "
                                   "predictor, sub-pel, skip shortcut, low-complexity decision; relaxation sweeps to JM's fixpoint), jmhip_slice_to_frame_band, "

@@ -151,7 +151,8 @@ __device__ __forceinline__ int imin3(int a, int b, int c) { return min(a, min(b,
 // Three functions rather than one: a function that touches no callee-saved VGPR (v40 and up) has no save / restore frame, and the SAD path --
 // half of a macroblock's ~200 evaluation calls -- needs a dozen registers, the 8x8 Hadamard path over a hundred.
 #define EVAL_ARGS const uint8_t *planes, int umv, int wp, int wpw, int wpo, int bx, int by, int bsx, int bsy, int n
-__device__ __attribute__((noinline)) void eval_sad(EVAL_ARGS)
+// SSE: computeSSE(WP) (me_distortion.c:1042/1107) -- the same samples, squared differences
+template <bool SSE> __device__ __forceinline__ void eval_abs(EVAL_ARGS)
 {
   const int lane = threadIdx.x;
   const size_t psz = (size_t)D.Wp * D.Hp;
@@ -184,7 +185,13 @@ __device__ __attribute__((noinline)) void eval_sad(EVAL_ARGS)
         if (base + u * cpb >= n) break;
         uint32_t r = rr[u];
         if (wp) r = wp_apply4(r, wpw, wpo, D.p.wp_round, D.p.wp_denom);
-        int v = k < n ? (int)__builtin_amdgcn_sad_u8(r, curv, 0u) : 0;
+        int v = 0;
+        if (k < n) {
+          if (SSE) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const int df = (int)((r >> (8 * q)) & 255u) - (int)((curv >> (8 * q)) & 255u); v += df * df; }
+          } else v = (int)__builtin_amdgcn_sad_u8(r, curv, 0u);
+        }
         for (int o = 1; o < seg; o <<= 1) v += __shfl_xor(v, o);
         if (k < n && d == 0) L.dist[k] = v;
       }
@@ -195,6 +202,9 @@ __device__ __attribute__((noinline)) void eval_sad(EVAL_ARGS)
 #endif
 }
 
+
+__device__ __attribute__((noinline)) void eval_sad(EVAL_ARGS) { eval_abs<false>(planes, umv, wp, wpw, wpo, bx, by, bsx, bsy, n); }
+__device__ __attribute__((noinline)) void eval_sse(EVAL_ARGS) { eval_abs<true>(planes, umv, wp, wpw, wpo, bx, by, bsx, bsy, n); }
 
 __device__ __attribute__((noinline)) void eval_satd4(EVAL_ARGS)
 {
@@ -325,6 +335,7 @@ __device__ __attribute__((noinline)) void eval_satd8(EVAL_ARGS)
 __device__ __forceinline__ void eval_dist(const uint8_t *planes, int metric, int t8, int umv, int wp, int wpw, int wpo, int bx, int by, int bsx, int bsy, int n)
 {
   if (metric == 0) eval_sad(planes, umv, wp, wpw, wpo, bx, by, bsx, bsy, n);
+  else if (metric == 1) eval_sse(planes, umv, wp, wpw, wpo, bx, by, bsx, bsy, n);
   else if (!t8) eval_satd4(planes, umv, wp, wpw, wpo, bx, by, bsx, bsy, n);
   else eval_satd8(planes, umv, wp, wpw, wpo, bx, by, bsx, bsy, n);
 }
@@ -968,12 +979,15 @@ __device__ int epzs_sub_level(int half, int start, int lam, int metric, int umv,
 {
   const int8_t (*pts)[2] = half ? c_sp_hp : c_sp_qp;
   const int p4x = padq(B.pic_x, 0), p4y = padq(B.pic_y, 0);
+  // every point the level can ask for -- the cross 0..4 and whichever of 5..9 the two best of the cross select (:2433-2520) -- goes through ONE
+  // evaluation: which of them JM looks at, and in what order, is replayed on the results (a point JM skips only saves it work: a distortion
+  // that is cut short is never accepted)
   int n = 0;
-  for (int pos = start; pos < 5; pos++) { L.cx[n] = p4x + *mvx + pts[pos][0]; L.cy[n] = p4y + *mvy + pts[pos][1]; n++; }
+  for (int pos = start; pos < 10; pos++) { L.cx[n] = p4x + *mvx + pts[pos][0]; L.cy[n] = p4y + *mvy + pts[pos][1]; n++; }
   eval_dist(B.planes, metric, B.t8, umv, B.wp, B.wpw, B.wpo, B.mb_x, B.mb_y, B.bsx, B.bsy, n);
   int best = 0, second_pos = 0, second = INT_MAX;
-  for (int pos = start, k = 0; pos < 5; pos++, k++) {
-    const int mcost = mvc(lam, *mvx + pts[pos][0], *mvy + pts[pos][1]) + L.dist[k];
+  for (int pos = start; pos < 5; pos++) {
+    const int mcost = mvc(lam, *mvx + pts[pos][0], *mvy + pts[pos][1]) + L.dist[pos - start];
     if (mcost < *min_mcost) { second = *min_mcost; second_pos = best; *min_mcost = mcost; best = pos; }
     else if (mcost < second) { second = mcost; second_pos = pos; }
   }
@@ -985,13 +999,10 @@ __device__ int epzs_sub_level(int half, int start, int lam, int metric, int umv,
     switch (best + second_pos) { case 0: if (half) { sp = 5; ep = 5; } break; case 1: sp = 8; ep = 10; break; case 2: sp = 5; ep = 7; break; case 5: sp = 6; ep = 8; break; case 7: sp = 7; ep = 9; break; default: break; }
   }
   if (best != 0 || (iabs(B.pmx - *mvx) + iabs(B.pmy - *mvy))) {
-    n = 0;
-    for (int pos = sp; pos < ep; pos++) { L.cx[n] = p4x + *mvx + pts[pos][0]; L.cy[n] = p4y + *mvy + pts[pos][1]; n++; }
-    if (n) eval_dist(B.planes, metric, B.t8, umv, B.wp, B.wpw, B.wpo, B.mb_x, B.mb_y, B.bsx, B.bsy, n);
-    for (int pos = sp, k = 0; pos < ep; pos++, k++) {
+    for (int pos = sp; pos < ep; pos++) {
       int mcost = mvc(lam, *mvx + pts[pos][0], *mvy + pts[pos][1]);
       if (mcost >= *min_mcost) continue;
-      mcost += L.dist[k];
+      mcost += L.dist[pos - start];
       if (mcost < *min_mcost) { *min_mcost = mcost; best = pos; }
     }
   }
@@ -1611,11 +1622,11 @@ template <int SM> __device__ int block_motion_search(int mbx, int mby, int ref, 
       L.cx[0] = padq(mbx * 16, smx); L.cy[0] = padq(mby * 16, smy);
       eval_dist(pl0, 2, P.transform8x8_mode ? 1 : 0, 1, P.wp_pred, P.wp_weight[0], P.wp_offset[0], 0, 0, 16, 16, 1);
       cost = L.dist[0];
-    } else {                                                                   // SAD: LumaPrediction clamps per 4x4 block
+    } else {                                                                   // SAD / SSE: LumaPrediction clamps per 4x4 block
       cost = 0;
       for (int b = 0; b < 16; b++) {
         L.cx[0] = padq(mbx * 16 + (b & 3) * 4, smx); L.cy[0] = padq(mby * 16 + (b >> 2) * 4, smy);
-        eval_dist(pl0, 0, 0, 1, P.wp_pred, P.wp_weight[0], P.wp_offset[0], (b & 3) * 4, (b >> 2) * 4, 4, 4, 1);
+        eval_dist(pl0, P.md_metric, 0, 1, P.wp_pred, P.wp_weight[0], P.wp_offset[0], (b & 3) * 4, (b >> 2) * 4, 4, 4, 1);
         cost += L.dist[0];
       }
     }
@@ -2120,10 +2131,10 @@ template <int SM> __global__ __launch_bounds__(64, 2) void p_slice_relax_kernel(
     }
     if (SM == JMHIP_SEARCH_EPZS && active && lane == 0) D.ep_alias_flag[addr] &= 1;
     if (!active) { if (lane == 0) D.chg_next[addr - first] = 0; continue; }
-    all_mv_from_carry(addr == first ? carry_slice_in : D.carry_mb + (size_t)(addr - 1) * WR * CARRY * 2);
 #ifdef JMHIP_WAVE_PROF
     const unsigned long long mb_t0 = __builtin_amdgcn_s_memtime();
 #endif
+    all_mv_from_carry(addr == first ? carry_slice_in : D.carry_mb + (size_t)(addr - 1) * WR * CARRY * 2);
     mb_stage(mbx, mby);
     if (lane < WR) {
       const int live = D.memo_on && !D.first_sweep;
@@ -2131,10 +2142,20 @@ template <int SM> __global__ __launch_bounds__(64, 2) void p_slice_relax_kernel(
       if (lane == 0) L.memo_live = live;
     }
     __syncthreads();
+#ifdef JMHIP_WAVE_PROF
+    const unsigned long long mb_t1 = __builtin_amdgcn_s_memtime();
+#endif
     macroblock_low<SM>(mbx, mby, D.out + addr);
+#ifdef JMHIP_WAVE_PROF
+    const unsigned long long mb_t2 = __builtin_amdgcn_s_memtime();
+#endif
     const int changed = mb_commit(mbx, mby);
 #ifdef JMHIP_WAVE_PROF
-    if (lane == 0) { atomicAdd(&g_wave_prof[8], __builtin_amdgcn_s_memtime() - mb_t0); atomicAdd(&g_wave_prof[9], 1ull); }
+    if (lane == 0) {
+      const unsigned long long mb_t3 = __builtin_amdgcn_s_memtime();
+      atomicAdd(&g_wave_prof[8], mb_t3 - mb_t0); atomicAdd(&g_wave_prof[9], 1ull);
+      atomicAdd(&g_wave_prof[13], mb_t1 - mb_t0); atomicAdd(&g_wave_prof[14], mb_t2 - mb_t1); atomicAdd(&g_wave_prof[15], mb_t3 - mb_t2);
+    }
 #endif
     if (D.memo_on && lane < WR) D.memo[(size_t)addr * WR + lane] = L.memo_new[lane];
     if (lane == 0) { D.chg_next[addr - first] = (uint8_t)changed; if (changed) atomicAdd(D.n_changed, 1); }
@@ -2398,12 +2419,12 @@ extern "C" int jmhip_p_slice_search(jmhip_ctx *c, const jmhip_slice_params *prm,
   if (!prm->valid[1]) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_p_slice_search: the 16x16 mode must be enabled");
   if (!c->has_cur) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_p_slice_search: current picture not uploaded");
   for (int k = 0; k < 3; k++) {
-    if (prm->metric[k] != 0 && prm->metric[k] != 2) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_p_slice_search: ME metrics are SAD (0) or SATD (2)");
+    if (prm->metric[k] < 0 || prm->metric[k] > 2) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_p_slice_search: ME metrics are SAD (0), SSE (1) or SATD (2)");
     if (prm->lambda_mf[k] < 0 || prm->lambda_mf[k] >= (1 << 24)) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_p_slice_search: lambda factor out of range");
   }
   if ((prm->search_mode == JMHIP_SEARCH_FULL || prm->search_mode == JMHIP_SEARCH_FASTFULL) && prm->metric[0] != 0)
     return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_p_slice_search: the exhaustive searches take the SAD metric at full-pel positions");
-  if (prm->md_metric != 0 && prm->md_metric != 2) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_p_slice_search: mode-decision metric SAD or SATD");
+  if (prm->md_metric < 0 || prm->md_metric > 2) return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_p_slice_search: mode-decision metric SAD (0), SSE (1) or SATD (2)");
   if (prm->slice_mbs < 0) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_p_slice_search: slice_mbs");
   if (prm->rdopt && (prm->search_mode == JMHIP_SEARCH_EPZS || prm->search_mode == JMHIP_SEARCH_UMHEX))
     return jm_fail(c, JMHIP_ERR_UNSUPPORTED, "jmhip_p_slice_search: rdopt != 0 (call records for the high-complexity modes) with search modes -1, 0, 2");
@@ -2621,6 +2642,7 @@ extern "C" int jmhip_p_slice_search(jmhip_ctx *c, const jmhip_slice_params *prm,
     (void)hipStreamSynchronize(c->stream);
     (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wave_prof), sizeof(h));
     const double nmb = h[9] ? (double)h[9] : 1.0;
+    fprintf(stderr, "WAVE PROF stage %.0f decide %.0f commit %.0f | ", h[13] / nmb, h[14] / nmb, h[15] / nmb);
     fprintf(stderr, "WAVE PROF cycles per macroblock (%.0f MBs): total %.0f | predictor %.0f integer %.0f subpel %.0f skip %.0f | epzs: lists %.0f scan+eval %.0f refine %.0f | eval_dist: %.0f cycles in %.1f calls, %.1f candidates\n", nmb, h[8] / nmb,
             h[0] / nmb, h[1] / nmb, h[2] / nmb, h[3] / nmb, h[4] / nmb, h[5] / nmb, h[6] / nmb, h[10] / nmb, h[11] / nmb, h[12] / nmb);
     unsigned long long z[16] = {0};

@@ -20,7 +20,8 @@ class JmhipError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(HERE, "libjmhip.so")
+    # JMHIP_LIBRARY: a development aid -- another build of the SAME library (an instrumented or experimental variant under build_var/)
+    return os.environ.get("JMHIP_LIBRARY") or os.path.join(HERE, "libjmhip.so")
 
 
 def build_library(verbose=False):

@@ -8,7 +8,7 @@ QP_N = 28
 
 
 def slice_params(mode, R, nref, lambda_mf, ref_cost1, W, mb_first=0, mb_count=None, H=None, metric=(0, 2, 2), qp_n=QP_N, full_search=2,
-                 t8=0, t8_qp=None, cavlc=1, rdopt=0):
+                 t8=0, t8_qp=None, cavlc=1, rdopt=0, md_metric=2):
     """SearchMode `mode`, range R, `nref` list-0 references in slots 0..nref-1, every inter mode enabled, JM's default EPZS / UMHexagonS settings
     (jmhip_epzs_setup / jmhip_umhex_setup); t8: Transform8x8Mode with the flat inter 8x8 luma quantiser at t8_qp (jmhip_flat_quant)."""
     lib = jmhip.load_library()
@@ -19,7 +19,7 @@ def slice_params(mode, R, nref, lambda_mf, ref_cost1, W, mb_first=0, mb_count=No
     for m in range(1, 8):
         p.valid[m] = 1
     p.lambda_mf[0], p.lambda_mf[1], p.lambda_mf[2] = lambda_mf
-    p.ref_cost1, p.md_metric = ref_cost1, 2
+    p.ref_cost1, p.md_metric = ref_cost1, md_metric
     p.metric[0], p.metric[1], p.metric[2] = metric
     p.level_mv_min, p.level_mv_max = -511, 511
     p.rdopt = rdopt

@@ -1216,11 +1216,14 @@ static int slice_mode_covered(void)
             (input->Transform8x8Mode == 0 || input->InterSearch[0][4]) &&
             (input->SearchMode == -1 || input->SearchMode == 0 || input->SearchMode == 1 || input->SearchMode == 2 || input->SearchMode == 3) &&
             !(input->SearchMode <= 0 && input->MEErrorMetric[F_PEL] != ERROR_SAD) && !input->EPZSSubPelGrid &&
-            input->search_range <= 33 && input->num_ref_frames <= JMHIP_SLICE_REFS && (input->slice_mode == 0 || input->slice_mode == 1) &&
+            /* ranges up to 33; up to 40 where the exhaustive searches' sweeps over the frame kernels cover the configuration (me_xslice.hip) */
+            (input->search_range <= 33 || (input->search_range <= 40 && input->SearchMode <= 0 && input->full_search == 2 && !input->Transform8x8Mode &&
+                                           input->MEErrorMetric[H_PEL] == ERROR_SATD && input->MEErrorMetric[Q_PEL] == ERROR_SATD)) &&
+            input->num_ref_frames <= JMHIP_SLICE_REFS && (input->slice_mode == 0 || input->slice_mode == 1) &&
             input->num_slice_groups_minus1 == 0 && !input->sp_periodicity && !input->BiPredMotionEstimation && input->InterSearch[0][1] &&
             !input->RestrictRef && !input->CtxAdptLagrangeMult && !input->RCEnable;
-    for (m = 0; m < 3; m++) if (input->MEErrorMetric[m] != ERROR_SAD && input->MEErrorMetric[m] != ERROR_SATD) sl.on = 0;
-    if (input->ModeDecisionMetric != ERROR_SAD && input->ModeDecisionMetric != ERROR_SATD) sl.on = 0;
+    for (m = 0; m < 3; m++) if (input->MEErrorMetric[m] != ERROR_SAD && input->MEErrorMetric[m] != ERROR_SSE && input->MEErrorMetric[m] != ERROR_SATD) sl.on = 0;
+    if (input->ModeDecisionMetric != ERROR_SAD && input->ModeDecisionMetric != ERROR_SSE && input->ModeDecisionMetric != ERROR_SATD) sl.on = 0;
   }
   return sl.on;
 }

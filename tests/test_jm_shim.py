@@ -51,7 +51,7 @@ RDOptimization = {rdopt}
 MEDistortionFPel = {fpel}
 MEDistortionHPel = {hpel}
 MEDistortionQPel = {qpel}
-MDDistortion = 2
+MDDistortion = {mdm}
 ChromaMCBuffer = 1
 ChromaMEEnable = {cme}
 ChromaMEWeight = {cmw}
@@ -167,6 +167,7 @@ def prepare(tmp_path, name, w=176, h=144, frames=3, R=16, qp=28):
     v.setdefault("hpel", 2)
     v.setdefault("qpel", 2)
     v.setdefault("cme", 0)
+    v.setdefault("mdm", 2)
     v.setdefault("cmw", 1)
     v.setdefault("bipred", 0)
     v.setdefault("wbp", 0)
@@ -258,6 +259,11 @@ SLICE_CASES = {
     # NumberReferenceFrames = 5, as in every cfg the reference ships (bin/encoder_baseline.cfg:53): seven pictures, so that list 0 grows to five entries
     "slice_fastfull_5ref": dict(search=0, profile=66, cabac=0, t8x8=0, bframes=0, refs=5, rdopt=0, adrnd=1, yuv=1, noi=1, frames=7),
     "slice_epzs_5ref": dict(search=3, profile=77, cabac=1, t8x8=0, bframes=0, refs=5, rdopt=0, adrnd=0, yuv=1, noi=1, frames=7),
+    # SSE (MEDistortion* / ModeDecisionMetric 1) in the slice path: the walkers at every level, the exhaustive searches at sub-pel positions, the decision costs
+    "slice_epzs_sse": dict(search=3, profile=77, cabac=1, t8x8=0, bframes=0, refs=2, rdopt=0, adrnd=0, yuv=1, noi=1, fpel=1, hpel=1, qpel=1, mdm=1),
+    "slice_umhex_sse_hpel": dict(search=1, profile=66, cabac=0, t8x8=0, bframes=0, refs=2, rdopt=0, adrnd=1, yuv=1, noi=1, fpel=0, hpel=1, qpel=2),
+    "slice_full_sse_subpel_t8": dict(search=-1, profile=100, cabac=1, t8x8=1, bframes=0, refs=1, rdopt=0, adrnd=0, yuv=1, noi=1, fpel=0, hpel=1, qpel=1, mdm=1, qp=32),
+    "slice_full_range40": dict(search=-1, profile=66, cabac=0, t8x8=0, bframes=0, refs=2, rdopt=0, adrnd=1, yuv=1, noi=1, R=40),      # the widest range of the sweeps over the frame kernels
     "slice_umhex_5ref_t8": dict(search=1, profile=100, cabac=1, t8x8=1, bframes=0, refs=5, rdopt=0, adrnd=0, yuv=1, noi=1, frames=7, qp=32),
 }
 CASES.update(SLICE_CASES)
@@ -268,7 +274,7 @@ CASES.update(SLICE_CASES)
 @pytest.mark.parametrize("name", list(SLICE_CASES))
 def test_jm_slice_level_binding_is_byte_identical(tmp_path, name):
     nframes = SLICE_CASES[name].get("frames", 4)
-    prepare(tmp_path, name, frames=nframes)
+    prepare(tmp_path, name, frames=nframes, R=SLICE_CASES[name].get("R", 16))
     want = run("jm_plain", tmp_path)
     got = run("jm_hip", tmp_path, {"JMHIP_SHIM_STATS": "1"})
     stats = got[2]

@@ -95,7 +95,7 @@ def synth_clip(rng, W, H, nframes):
     return load_pkg().slice_host.synth_clip(rng, W, H, nframes)
 
 
-def run_synthetic(pkg, mode, W, H, R, nref, slices=1, nframes=3, seed=5, metric=(0, 2, 2), qp=28, max_mbs=None, t8=0, cavlc=1, wp=None, one_call=False, rdopt=0, map_log=None, map_init=None, what_if=None, ideal_map=False, first_touch=None):
+def run_synthetic(pkg, mode, W, H, R, nref, slices=1, nframes=3, seed=5, metric=(0, 2, 2), qp=28, max_mbs=None, t8=0, cavlc=1, wp=None, one_call=False, rdopt=0, map_log=None, map_init=None, what_if=None, ideal_map=False, first_touch=None, md_metric=2):
     """Frames 1.. are coded as P pictures against the previous `nref` SOURCE frames (the search does not care where a reference came from)."""
     rng = np.random.default_rng(seed)
     clip = synth_clip(rng, W, H, nframes + nref - 1)
@@ -135,7 +135,7 @@ def run_synthetic(pkg, mode, W, H, R, nref, slices=1, nframes=3, seed=5, metric=
         for s in range(slices):
             first, count = s * per, min(per, nmb - s * per)
             q = oracle.lowcplx_params(mode, R, nref, lam3, ref_cost1, W, H, epzs=epzs, umhex=umhex, all_mv_state=all_mv_state, metric=metric,
-                                      transform8x8_mode=t8, qp=qp, cavlc=cavlc, rdopt=rdopt)
+                                      transform8x8_mode=t8, qp=qp, cavlc=cavlc, rdopt=rdopt, md_metric=md_metric)
             if wp:                                       # explicit weighted prediction, used in the search too (UseWeightedReferenceME): (denominator, [(weight, offset)] per reference)
                 q.wp_pred, q.me.apply_weights = 1, 1
                 q.me.luma_log_weight_denom, q.me.wp_luma_round = wp[0], (1 << (wp[0] - 1)) if wp[0] else 0
@@ -151,7 +151,7 @@ def run_synthetic(pkg, mode, W, H, R, nref, slices=1, nframes=3, seed=5, metric=
             if one_call:                                 # the device searches all slices of the picture in ONE call (slice_mbs) below
                 wants.append(want)
                 continue
-            p = slice_params(pkg, mode, R, nref, lam3, ref_cost1, W, mb_first=first, mb_count=count, metric=metric, qp_n=qp, t8=t8, cavlc=cavlc, rdopt=rdopt)
+            p = slice_params(pkg, mode, R, nref, lam3, ref_cost1, W, mb_first=first, mb_count=count, metric=metric, qp_n=qp, t8=t8, cavlc=cavlc, rdopt=rdopt, md_metric=md_metric)
             if mode == 3:
                 lib.jmhip_epzs_scales(p, 2 * f, (C.c_int * nref)(*pocs), nref)
             if wp:
@@ -164,7 +164,7 @@ def run_synthetic(pkg, mode, W, H, R, nref, slices=1, nframes=3, seed=5, metric=
             if map_log is not None:                      # EPZS: (aliased map tests of this slice, searches so far) on the device and in the oracle
                 map_log.append((ctx.epzs_map_info(), (epzs.alias_events() - sum(m[1][0] for m in map_log), epzs.search_count())))
         if one_call:
-            p = slice_params(pkg, mode, R, nref, lam3, ref_cost1, W, mb_first=0, mb_count=nmb, metric=metric, qp_n=qp, t8=t8, cavlc=cavlc, rdopt=rdopt)
+            p = slice_params(pkg, mode, R, nref, lam3, ref_cost1, W, mb_first=0, mb_count=nmb, metric=metric, qp_n=qp, t8=t8, cavlc=cavlc, rdopt=rdopt, md_metric=md_metric)
             p.slice_mbs = per
             if mode == 3:
                 lib.jmhip_epzs_scales(p, 2 * f, (C.c_int * nref)(*pocs), nref)
@@ -204,6 +204,20 @@ def run_synthetic(pkg, mode, W, H, R, nref, slices=1, nframes=3, seed=5, metric=
 ])
 def test_synthetic_clip_matches_the_oracle(pkg, mode, W, H, R, nref, slices):
     run_synthetic(pkg, mode, W, H, R, nref, slices=slices)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,metric,md,t8", [
+    (3, (1, 1, 1), 1, 0),           # EPZS: SSE at every level and in the decision costs
+    (1, (1, 1, 1), 1, 0),           # UMHexagonS (its thresholds are then fed squared errors, as in JM)
+    (2, (0, 1, 2), 0, 0),           # simplified UMHexagonS: SAD integer, SSE half-pel, Hadamard SAD quarter-pel
+    (-1, (0, 1, 1), 1, 1),          # FullSearch: SAD at integer positions (the only metric the exhaustive modes take there), SSE refinement, SSE transform decision
+    (0, (0, 2, 1), 1, 0),           # FastFull
+])
+def test_sse_metric_in_the_slice_search(pkg, mode, metric, md, t8):
+    """computeSSE (me_distortion.c:1042) through the computeUniPred dispatch of mv-search.c:400-424 and as ModeDecisionMetric (distortion4x4 of the skip
+    cost, TransformDecision): the walkers at every level, the exhaustive searches' refinements, the decision costs."""
+    run_synthetic(pkg, mode, 176, 144, 16, 2, metric=metric, md_metric=md, t8=t8, qp=30)
 
 
 @pytest.mark.gpu
