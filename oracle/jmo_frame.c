@@ -117,19 +117,19 @@ long long jmo_hotpath_mbs(const jmo_me_params *p, const jmo_ref *ref, const jmo_
 
 /* ------------------------------------------------------------------ low-complexity mode-decision costs */
 
-/* distortion4x4 / distortion8x8, me_distortion.c:76 / :110 (ModeDecisionMetric: 0 SAD, 2 SATD; SSE not restated) */
+/* distortion4x4 / distortion8x8, me_distortion.c:76 / :110 (ModeDecisionMetric: 0 SAD, 1 SSE through img->quad[] = the squares, 2 SATD) */
 static int dist4(const int *d, int metric)
 {
   int k, s = 0;
   if (metric == JMO_ERR_SATD) return jmo_hadamard_sad4x4(d);
-  for (k = 0; k < 16; k++) s += d[k] < 0 ? -d[k] : d[k];
+  for (k = 0; k < 16; k++) s += metric == JMO_ERR_SSE ? d[k] * d[k] : (d[k] < 0 ? -d[k] : d[k]);
   return s;
 }
 static int dist8(const int *d, int metric)
 {
   int k, s = 0;
   if (metric == JMO_ERR_SATD) return jmo_hadamard_sad8x8(d);
-  for (k = 0; k < 64; k++) s += d[k] < 0 ? -d[k] : d[k];
+  for (k = 0; k < 64; k++) s += metric == JMO_ERR_SSE ? d[k] * d[k] : (d[k] < 0 ? -d[k] : d[k]);
   return s;
 }
 

@@ -37,6 +37,11 @@ RUNS = {
                                             "-p", "AdaptiveRounding=0"],
     "field_umhex_t8_cabac_r16_2ref": COMMON + ["-p", "SearchMode=1", "-p", "NumberReferenceFrames=2", "-p", "Transform8x8Mode=1", "-p", "ProfileIDC=100",
                                                "-p", "AdaptiveRounding=0", "-p", "QPPSlice=32", "-p", "SymbolMode=1"],
+    # SSE (computeSSE, me_distortion.c:1042) in the refinements and as the mode-decision metric, with both transform sizes; EPZS with SSE at every level
+    "field_full_sse_t8_r16_1ref": COMMON + ["-p", "SearchMode=-1", "-p", "NumberReferenceFrames=1", "-p", "Transform8x8Mode=1", "-p", "ProfileIDC=100",
+                                            "-p", "AdaptiveRounding=0", "-p", "QPPSlice=32", "-p", "MEDistortionHPel=1", "-p", "MEDistortionQPel=1", "-p", "MDDistortion=1"],
+    "field_epzs_sse_r16_2ref": COMMON + ["-p", "SearchMode=3", "-p", "NumberReferenceFrames=2", "-p", "MEDistortionFPel=1", "-p", "MEDistortionHPel=1",
+                                         "-p", "MEDistortionQPel=1", "-p", "MDDistortion=1"],
     "field_fastfull_t8_r16_2ref": COMMON + ["-p", "SearchMode=0", "-p", "NumberReferenceFrames=2", "-p", "Transform8x8Mode=1", "-p", "ProfileIDC=100",
                                             "-p", "AdaptiveRounding=0", "-p", "QPPSlice=40"],
 }

@@ -14,7 +14,9 @@ CASES = {"field_full_r16_1ref": -1, "field_fastfull_r16_2ref": 0, "field_epzs_r1
          # Transform8x8Mode 1 / 2 (tests/golden/make_golden_field.py): (search mode, Transform8x8Mode, CAVLC)
          "field_epzs_t8_r16_2ref": (3, 1, 1), "field_full_t8only_r16_1ref": (-1, 2, 1), "field_umhex_t8_cabac_r16_2ref": (1, 1, 0),
          "field_fastfull_t8_r16_2ref": (0, 1, 1),
-         "field_umhexsmp_r16_2ref": 2, "field_umhexsmp_t8_q34_r16_2ref": (2, 1, 1, (2, 2, 2))}
+         "field_umhexsmp_r16_2ref": 2, "field_umhexsmp_t8_q34_r16_2ref": (2, 1, 1, (2, 2, 2)),
+         # SSE: (search mode, Transform8x8Mode, CAVLC, ME metrics, mode-decision metric)
+         "field_full_sse_t8_r16_1ref": (-1, 1, 1, (0, 1, 1), 1), "field_epzs_sse_r16_2ref": (3, 0, 1, (1, 1, 1), 1)}
 QP_N = 28          # QPPSlice of bin/encoder_baseline.cfg (UMHEX thresholds, me_umhex.c:110)
 
 
@@ -26,11 +28,13 @@ def part_index(bt, bx, by):
 
 def replay(name, mode, on_frame=None, epzs_hook=None):
     t8, cavlc = 0, 1
-    metric = (0, 2, 2)
+    metric, md_metric = (0, 2, 2), 2
     if isinstance(mode, tuple):
         mode, t8, cavlc = mode[:3]
         if len(mode_full := CASES[name]) > 3:
             metric = mode_full[3]
+        if len(mode_full) > 4:
+            md_metric = mode_full[4]
     """Runs every P picture of a fixture through the oracle driver (state carried across pictures like JM's) and yields per picture
     (fixture arrays, driver records, final ref_idx, final mv)."""
     z = np.load(os.path.join(GOLD, name + ".npz"))
@@ -55,7 +59,7 @@ def replay(name, mode, on_frame=None, epzs_hook=None):
                             num_ref_idx_l0_active=int(head[11]))
         q = oracle.lowcplx_params(mode, R, nref, [int(v) for v in head[6:9]], int(head[9]), W, H, epzs=epzs, umhex=umhex,
                                   frame_ctr_b=int(head[5]), img_number=int(head[4]), all_mv_state=all_mv_state,
-                                  transform8x8_mode=t8, qp=int(head[2]), cavlc=cavlc, metric=metric)
+                                  transform8x8_mode=t8, qp=int(head[2]), cavlc=cavlc, metric=metric, md_metric=md_metric)
         rec, ref_idx, mv = oracle.lowcplx_p_slice(q, refs, z["f%d_cur" % k])
         out.append((dict(calls=z["f%d_calls" % k], mb=z["f%d_mb" % k], field=z["f%d_field" % k], nref=nref), rec, ref_idx, mv))
     if epzs:

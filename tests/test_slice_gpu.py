@@ -41,6 +41,7 @@ def test_fixture_pictures_match_the_real_jm(pkg, name):
     case = CASES[name] if isinstance(CASES[name], tuple) else (CASES[name], 0, 1)
     mode, t8, cavlc = case[:3]
     metric = case[3] if len(case) > 3 else (0, 2, 2)
+    md_metric = case[4] if len(case) > 4 else 2
     z = np.load(os.path.join(GOLD, name + ".npz"))
     n = int(z["n_frames"])
     W, H = int(z["f0_head"][0]), int(z["f0_head"][1])
@@ -57,7 +58,7 @@ def test_fixture_pictures_match_the_real_jm(pkg, name):
             ctx.ref_upload(r, z["f%d_refs" % k][r])
             ctx.interp_luma(r)
         ctx.cur_upload(z["f%d_cur" % k])
-        p = slice_params(pkg, mode, R, nref, [int(v) for v in head[6:9]], int(head[9]), W, H=H, t8=t8, cavlc=cavlc, metric=metric,
+        p = slice_params(pkg, mode, R, nref, [int(v) for v in head[6:9]], int(head[9]), W, H=H, t8=t8, cavlc=cavlc, metric=metric, md_metric=md_metric,
                          **(dict(qp_n=int(head[2])) if t8 else {}))
         if mode == 3:
             ids = (refinfo[:, 1].astype(np.int64) & 0xffffffff) | (refinfo[:, 2].astype(np.int64) << 32)
