@@ -179,7 +179,7 @@ def jm_end_to_end(frames, config3=False, rdopt1=False):
     """The reference encoder itself, same 1080p clip (frames 0-1: I + P), FullSearch +-32, low-complexity decision with intra off in the P
     picture (RDOptimization 0, DisableIntraInInter 1 -- the configuration whose whole P-slice search + inter decision is ONE device call):
     the unmodified JM (oracle/_ref/jm_plain) against JM bound to libjmhip.so at slice level (oracle/_ref/jm_hip, integration/jm_shim.c,
-    mask 0x5801 = sub-pel planes + slice binding + the slice's frame stage (4:2:0, 4x4 transform: JM's prediction and dct_4x4 / dct_chroma calls
+    mask 0xd801 = sub-pel planes (fetched into JM's rows only when a forwarded call is about to read them) + slice binding + the slice's frame stage (4:2:0, 4x4 transform: JM's prediction and dct_4x4 / dct_chroma calls
     answered from the device's records) + loop filter on the device, everything else JM's own code). Wall-clock of whole encodes."""
     import re
     import subprocess
@@ -204,7 +204,7 @@ def jm_end_to_end(frames, config3=False, rdopt1=False):
             f.write(cfg)
         digests = []
         for exe, key in zip(exes, ("jm_plain", "jm_hip")):
-            env = dict(os.environ, JMHIP_SHIM="3801" if rdopt1 else "5801", JMHIP_SHIM_STATS="1")
+            env = dict(os.environ, JMHIP_SHIM="b801" if rdopt1 else "d801", JMHIP_SHIM_STATS="1")
             t0 = time.perf_counter()
             try:
                 r = subprocess.run([exe, "-d", "min.cfg"], cwd=d, env=env, capture_output=True, text=True, timeout=400)
@@ -247,7 +247,7 @@ def jm_end_to_end(frames, config3=False, rdopt1=False):
             with open(os.path.join(d, "min4.cfg"), "w") as f:
                 f.write(cfg.replace("FramesToBeEncoded = 2", "FramesToBeEncoded = 4"))
             try:
-                r = subprocess.run([exes[1], "-d", "min4.cfg"], cwd=d, env=dict(os.environ, JMHIP_SHIM="5801", JMHIP_SHIM_STATS="1"),
+                r = subprocess.run([exes[1], "-d", "min4.cfg"], cwd=d, env=dict(os.environ, JMHIP_SHIM="d801", JMHIP_SHIM_STATS="1"),
                                    capture_output=True, text=True, timeout=200)
                 pf = re.findall(r"^000\d\(P\)\s+\d+\s+\d+\s+[\d.]+\s+[\d.]+\s+[\d.]+\s+(\d+)\s+(\d+)", r.stdout, re.M)
                 mh = re.search(r"P slices \(one device call each\)\s+device\s+\d+\s+forwarded\s+\d+\s+[\d.]+ ms inside the hook \(last call ([\d.]+) ms\)", r.stderr)
@@ -256,12 +256,12 @@ def jm_end_to_end(frames, config3=False, rdopt1=False):
             except Exception:
                 pass
         if rdopt1:
-            out["config"] = ("1920x1080 I+P, FullSearch +-32, 1 reference, RDOptimization 1, intra candidates in the P picture, CAVLC; jm_hip: JMHIP_SHIM=0x3801 "
+            out["config"] = ("1920x1080 I+P, FullSearch +-32, 1 reference, RDOptimization 1, intra candidates in the P picture, CAVLC; jm_hip: JMHIP_SHIM=0xb801 "
                              "(speculative slice binding: a BlockMotionSearch call is answered from the device's record when JM's predictor equals the recorded one, "
                              "else JM's own search runs)")
             return out
-        out["config"] = ("1920x1080 I+P, EPZS +-32, Hadamard SAD at every level, Transform8x8Mode 1, CABAC, 1 reference, RDOptimization 0, DisableIntraInInter 1; jm_hip: JMHIP_SHIM=0x5801 (the 8x8 transform keeps the frame stage in JM)"
-                         if config3 else "1920x1080 I+P, FullSearch +-32, 1 reference, RDOptimization 0, DisableIntraInInter 1, CAVLC; jm_hip: JMHIP_SHIM=0x5801 (slice search + frame stage bound at slice level)")
+        out["config"] = ("1920x1080 I+P, EPZS +-32, Hadamard SAD at every level, Transform8x8Mode 1, CABAC, 1 reference, RDOptimization 0, DisableIntraInInter 1; jm_hip: JMHIP_SHIM=0xd801 (the 8x8 transform keeps the frame stage in JM)"
+                         if config3 else "1920x1080 I+P, FullSearch +-32, 1 reference, RDOptimization 0, DisableIntraInInter 1, CAVLC; jm_hip: JMHIP_SHIM=0xd801 (slice search + frame stage bound at slice level, sub-pel planes left on the device)")
     return out
 
 

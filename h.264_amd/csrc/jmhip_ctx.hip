@@ -403,6 +403,7 @@ static int download_planes_rows(jmhip_ctx *c, const uint8_t *src, int planes, in
     c->pin_evt.push_back(e);
   }
   for (int p = 0; p < planes; p++) {
+    if (!out_rows[(size_t)p * rows]) continue;                       // a plane whose first row pointer is NULL is not wanted
     JM_HIP_CHECK(c, hipMemcpyAsync(c->pin_host + p * plane, src + p * plane, plane, hipMemcpyDeviceToHost, c->stream));
     JM_HIP_CHECK(c, hipEventRecord(c->pin_evt[p], c->stream));
   }
@@ -414,6 +415,7 @@ static int download_planes_rows(jmhip_ctx *c, const uint8_t *src, int planes, in
   auto work = [&](int t) {
     if (t && hipSetDevice(c->cfg.device) != hipSuccess) { failed = 1; return; }
     for (int p = t; p < planes; p += T) {
+      if (!out_rows[(size_t)p * rows]) continue;
       if (hipEventSynchronize(c->pin_evt[p]) != hipSuccess) { failed = 1; return; }
       for (int j = 0; j < rows; j++) {
         const uint8_t *__restrict__ s = c->pin_host + p * plane + (size_t)j * width;

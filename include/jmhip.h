@@ -112,7 +112,8 @@ int jmhip_ref_download_chroma(jmhip_ctx *ctx, int ref, int uv, void *out, int pe
  * JM binding calls after jmhip_interp_luma / _chroma, because JM's own motion compensation (LumaPrediction, src/macroblock.c:836) reads
  * the planes on the host: packed bytes cross the link into a page-locked staging buffer plane by plane, and the arrived planes are
  * widened into the caller's rows while the rest are still in flight (by four host threads; JMHIP_HOST_THREADS=n sets another count, 1 = the
- * calling thread alone). */
+ * calling thread alone). A plane whose FIRST row pointer is NULL is skipped -- a binding that answers JM's prediction from the device only fetches
+ * the planes a forwarded call is about to read. */
 int jmhip_ref_download_luma_rows(jmhip_ctx *ctx, int ref, void *const *rows, int pel_bytes);
 int jmhip_ref_download_chroma_rows(jmhip_ctx *ctx, int ref, int uv, void *const *rows, int pel_bytes);
 

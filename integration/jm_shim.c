@@ -27,6 +27,11 @@
  *        prediction picture and the per-macroblock records -- a prediction call after checking that JM asks for the block the device decided
  *        (mode, reference, vectors), a dct call after checking that JM's img->mpr / img->m7 are the prediction and residual the device used
  *        (anything else is a fatal error).
+ * 0x8000 the sub-pel planes stay on the device until JM is about to read them: getSubImagesLuma / getSubImagesChroma still upload the finished picture
+ *        and build the planes, but only the integer plane (which JM's weighted-prediction estimation reads) crosses back at once; the other planes
+ *        of a picture are fetched into JM's rows the first time a call is FORWARDED to JM code that reads reference planes (JM's own
+ *        BlockMotionSearch, LumaPrediction / LumaPredictionBi / ChromaPrediction / ChromaPrediction4x4) -- in pictures the slice binding serves
+ *        completely, never.
  *
  * The proof of the drop-in claim is tests/test_jm_shim.py: the bitstream and the reconstruction this encoder
  * writes are byte-identical to the unmodified encoder's.
@@ -58,18 +63,18 @@ extern const int LEVELMVLIMIT[17][6];
 extern int *mvbits;                       /* src/mv-search.c:59 */
 
 enum { S_LUMA, S_CHROMA, S_FULL, S_SUB, S_FAST, S_D4, S_D8, S_D16, S_DCR, S_WALK, S_SAD, S_SATD, S_BIFULL, S_BISUB, S_TDEC, S_SKIPC, S_BIDC, S_DEBLOCK, S_SLICE, S_BMS,
-       S_FRAME, S_D4R, S_DCRR, S_LPRED, S_CPRED, S_COUNT };
+       S_FRAME, S_D4R, S_DCRR, S_LPRED, S_CPRED, S_LAZY, S_COUNT };
 static const char *s_names[S_COUNT] = { "getSubImagesLuma", "getSubImagesChroma", "FullPelBlockMotionSearch",
   "SubPelBlockMotionSearch", "FastFullPelBlockMotionSearch", "dct_4x4", "dct_8x8", "dct_16x16", "dct_chroma",
   "EPZS_UMHex_integer_walks", "computeSAD", "computeSATD", "FullPelBlockMotionBiPred", "SubPelBlockSearchBiPred",
   "TransformDecision", "GetSkipCostMB", "BIDPartitionCost", "DeblockFrame",
   "P slices (one device call each)", "BlockMotionSearch",
-  "frame stage of P slices", "dct_4x4 (slice records)", "dct_chroma (slice records)", "LumaPrediction (slice)", "ChromaPrediction4x4 (slice)" };
+  "frame stage of P slices", "dct_4x4 (slice records)", "dct_chroma (slice records)", "LumaPrediction (slice)", "ChromaPrediction4x4 (slice)", "sub-pel planes fetched on demand" };
 static long n_dev[S_COUNT], n_fwd[S_COUNT];
 static double t_dev[S_COUNT], t_last[S_COUNT];             /* JMHIP_SHIM_STATS: wall seconds inside the coarse device-side hooks (planes, slice search, loop filter) */
 static int stats_on;
 static double now_s(void) { struct timespec ts; if (!stats_on) return 0.0; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
-static unsigned shim_mask = 0x5fff;
+static unsigned shim_mask = 0xdfff;
 static int verify;            /* JMHIP_SHIM_VERIFY=1: run JM's own search beside the device's and report differences */
 static jmhip_ctx *g;
 static int g_w, g_h;
@@ -115,7 +120,7 @@ int main(int argc, char **argv)
 /* ------------------------------------------------------------------ context, reference slots, current picture */
 
 #define MAX_SLOTS 16
-static struct { StorablePicture *pic; unsigned long stamp; int has_chroma; } slots[MAX_SLOTS];
+static struct { StorablePicture *pic; unsigned long stamp; int has_chroma; int host_luma, host_chroma; } slots[MAX_SLOTS];   /* host_*: JM's rows hold the sub-pel planes */
 static unsigned long slot_clock;
 
 /* The context is created on first use for the sequence's FRAME size; 8-bit only. Field pictures and other sizes
@@ -155,9 +160,12 @@ static int slot_assign(StorablePicture *s)
 {
   int i = slot_find(s), k;
   if (i < 0) for (i = 0, k = 1; k < MAX_SLOTS; k++) if (slots[k].stamp < slots[i].stamp) i = k;   /* least recently built */
-  slots[i].pic = s; slots[i].stamp = ++slot_clock; slots[i].has_chroma = 0;
+  slots[i].pic = s; slots[i].stamp = ++slot_clock; slots[i].has_chroma = 0; slots[i].host_luma = slots[i].host_chroma = 0;
   return i;
 }
+
+/* mask 0x8000, not for 4:4:4 (its chroma planes are read through the luma paths of the per-plane code as well) */
+static int lazy_planes(void) { return (shim_mask & 0x8000) && img->yuv_format != YUV444; }
 
 static unsigned long pic_serial;          /* bumped whenever a new source picture goes to the device */
 
@@ -208,9 +216,11 @@ void getSubImagesLuma(StorablePicture *s)
     OK(jmhip_ref_upload(g, slot, s->imgY[0], img->yuv_format != YUV400 ? s->imgUV[0][0] : NULL,
                         img->yuv_format != YUV400 ? s->imgUV[1][0] : NULL, (int)sizeof(imgpel), s->size_x, s->size_x_cr, 0));
     OK(jmhip_interp_luma(g, slot));
-    /* JM's own MC reads imgY_sub on the host: every plane straight into JM's rows */
-    for (p = 0; p < 16; p++) for (j = 0; j < Hp; j++) rows[(size_t)p * Hp + j] = s->p_curr_img_sub[p >> 2][p & 3][j];
+    /* JM's own MC reads imgY_sub on the host: every plane straight into JM's rows -- or (mask 0x8000) only the integer plane now (the weight
+       estimation of src/weighted_prediction.c reads p_curr_img_sub[0][0]) and the rest when a forwarded call is about to read them (host_planes) */
+    for (p = 0; p < 16; p++) for (j = 0; j < Hp; j++) rows[(size_t)p * Hp + j] = (p == 0 || !lazy_planes()) ? s->p_curr_img_sub[p >> 2][p & 3][j] : NULL;
     OK(jmhip_ref_download_luma_rows(g, slot, rows, (int)sizeof(imgpel)));
+    slots[slot].host_luma = !lazy_planes();
     n_dev[S_LUMA]++; t_last[S_LUMA] = now_s() - t0; t_dev[S_LUMA] += t_last[S_LUMA];
   }
 }
@@ -232,13 +242,68 @@ void getSubImagesChroma(StorablePicture *s)
     const double t0 = now_s();
     if (rows_n < need) { free(rows); rows = malloc(need * sizeof(*rows)); rows_n = need; }
     OK(jmhip_interp_chroma(g, slot));
-    for (uv = 0; uv < 2; uv++) {
-      for (p = 0; p < sub_x * sub_y; p++) for (j = 0; j < Hcp; j++) rows[(size_t)p * Hcp + j] = s->imgUV_sub[uv][p / sub_x][p % sub_x][j];
-      OK(jmhip_ref_download_chroma_rows(g, slot, uv, rows, (int)sizeof(imgpel)));
+    slots[slot].has_chroma = 1; slots[slot].host_chroma = 0;
+    if (!lazy_planes()) {
+      for (uv = 0; uv < 2; uv++) {
+        for (p = 0; p < sub_x * sub_y; p++) for (j = 0; j < Hcp; j++) rows[(size_t)p * Hcp + j] = s->imgUV_sub[uv][p / sub_x][p % sub_x][j];
+        OK(jmhip_ref_download_chroma_rows(g, slot, uv, rows, (int)sizeof(imgpel)));
+      }
+      slots[slot].host_chroma = 1;
     }
-    slots[slot].has_chroma = 1;
     n_dev[S_CHROMA]++; t_last[S_CHROMA] = now_s() - t0; t_dev[S_CHROMA] += t_last[S_CHROMA];
   }
+}
+
+/* mask 0x8000: JM code that reads reference planes is about to run -- make JM's rows of every reference picture in the lists hold them */
+static void host_planes(StorablePicture *s)
+{
+  static void **rows; static size_t rows_n;
+  const int i = g ? slot_find(s) : -1;
+  int p, j, uv;
+  if (i < 0 || (slots[i].host_luma && (slots[i].host_chroma || !slots[i].has_chroma))) return;
+  {
+    const int Hp = s->size_y_padded, sub_x = img->yuv_format == YUV444 ? 4 : 8, sub_y = img->yuv_format == YUV420 ? 8 : 4;
+    const int Hcp = s->size_y_cr + 2 * img_pad_size_uv_y;
+    size_t need = (size_t)16 * Hp;
+    const double t0 = now_s();
+    if ((size_t)sub_x * sub_y * Hcp > need) need = (size_t)sub_x * sub_y * Hcp;
+    if (rows_n < need) { free(rows); rows = malloc(need * sizeof(*rows)); rows_n = need; }
+    if (!slots[i].host_luma) {
+      for (p = 0; p < 16; p++) for (j = 0; j < Hp; j++) rows[(size_t)p * Hp + j] = p ? s->p_curr_img_sub[p >> 2][p & 3][j] : NULL;     /* plane 0 went at once */
+      OK(jmhip_ref_download_luma_rows(g, i, rows, (int)sizeof(imgpel)));
+      slots[i].host_luma = 1;
+    }
+    if (slots[i].has_chroma && !slots[i].host_chroma) {
+      for (uv = 0; uv < 2; uv++) {
+        for (p = 0; p < sub_x * sub_y; p++) for (j = 0; j < Hcp; j++) rows[(size_t)p * Hcp + j] = s->imgUV_sub[uv][p / sub_x][p % sub_x][j];
+        OK(jmhip_ref_download_chroma_rows(g, i, uv, rows, (int)sizeof(imgpel)));
+      }
+      slots[i].host_chroma = 1;
+    }
+    n_dev[S_LAZY]++; t_last[S_LAZY] = now_s() - t0; t_dev[S_LAZY] += t_last[S_LAZY];
+  }
+}
+static void host_planes_lists(void)
+{
+  int l, j;
+  if (!lazy_planes() || !g) return;
+  for (l = 0; l < 6; l++) for (j = 0; j < listXsize[l]; j++) if (listX[l][j]) host_planes(listX[l][j]);
+}
+
+/* LumaPredictionBi (src/macroblock.c:948) and ChromaPrediction (:1712) read reference planes and are never answered from the device: forwarded, planes first */
+void LumaPredictionBi(Macroblock *currMB, int block_x, int block_y, int block_size_x, int block_size_y, int l0_mode, int l1_mode, short l0_ref_idx, short l1_ref_idx, int list)
+{
+  static void (*orig)(Macroblock *, int, int, int, int, int, int, short, short, int);
+  if (!orig) orig = next_sym("LumaPredictionBi");
+  host_planes_lists();
+  orig(currMB, block_x, block_y, block_size_x, block_size_y, l0_mode, l1_mode, l0_ref_idx, l1_ref_idx, list);
+}
+void ChromaPrediction(Macroblock *currMB, int uv, int block_x, int block_y, int block_size_x, int block_size_y, int p_dir, int l0_mode, int l1_mode, short l0_ref_idx, short l1_ref_idx)
+{
+  static void (*orig)(Macroblock *, int, int, int, int, int, int, int, int, short, short);
+  if (!orig) orig = next_sym("ChromaPrediction");
+  host_planes_lists();
+  orig(currMB, uv, block_x, block_y, block_size_x, block_size_y, p_dir, l0_mode, l1_mode, l0_ref_idx, l1_ref_idx);
 }
 
 /* ------------------------------------------------------------------ motion search */
@@ -1112,6 +1177,7 @@ void LumaPrediction(Macroblock *currMB, int block_x, int block_y, int block_size
   }
   if (!orig) orig = next_sym("LumaPrediction");
   if (fr_rec_cur()) n_fwd[S_LPRED]++;
+  host_planes_lists();
   orig(currMB, block_x, block_y, block_size_x, block_size_y, p_dir, l0_mode, l1_mode, l0_ref_idx, l1_ref_idx);
 }
 
@@ -1130,6 +1196,7 @@ void ChromaPrediction4x4(Macroblock *currMB, int uv, int block_x, int block_y, i
   }
   if (!orig) orig = next_sym("ChromaPrediction4x4");
   if (fr_rec_cur()) n_fwd[S_CPRED]++;
+  host_planes_lists();
   orig(currMB, uv, block_x, block_y, p_dir, l0_mode, l1_mode, l0_ref_idx, l1_ref_idx);
 }
 
@@ -1301,6 +1368,7 @@ int BlockMotionSearch(short ref, int list, int mb_x, int mb_y, int blocktype, in
                 listXsize[LIST_0] <= JMHIP_SLICE_REFS;
   if (!covered) {
     if (!orig) orig = next_sym("BlockMotionSearch");
+    host_planes_lists();
     n_fwd[S_BMS]++;
     return orig(ref, list, mb_x, mb_y, blocktype, search_range, lambda_factor);
   }
@@ -1344,6 +1412,7 @@ int BlockMotionSearch(short ref, int list, int mb_x, int mb_y, int blocktype, in
       if (!hit) {
         sp_dirty[ref] = 1;
         if (!orig) orig = next_sym("BlockMotionSearch");
+    host_planes_lists();
         n_fwd[S_BMS]++;
         return orig(ref, list, mb_x, mb_y, blocktype, search_range, lambda_factor);
       }
@@ -1366,6 +1435,7 @@ int BlockMotionSearch(short ref, int list, int mb_x, int mb_y, int blocktype, in
       short ax = img->all_mv[by][bx][list][ref][blocktype][0], ay = img->all_mv[by][bx][list][ref][blocktype][1];
       int c;
       if (!orig) orig = next_sym("BlockMotionSearch");
+    host_planes_lists();
       c = orig(ref, list, mb_x, mb_y, blocktype, search_range, lambda_factor);
       if (c != rcost || img->all_mv[by][bx][list][ref][blocktype][0] != ax || img->all_mv[by][bx][list][ref][blocktype][1] != ay)
         fprintf(stderr, "jm_shim VERIFY BlockMotionSearch mb %d ref %d bt %d (%d,%d): jm=(%d,%d,%d) dev=(%d,%d,%d)\n", img->current_mb_nr, ref, blocktype, bx, by,

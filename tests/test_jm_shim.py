@@ -312,8 +312,8 @@ def test_jm_slice_level_binding_is_byte_identical(tmp_path, name):
 def test_jm_1080p_full_search_slice_binding_is_byte_identical_and_faster(tmp_path):
     """BASELINE config 2 through the real encoder: 1920x1080, FullSearch +-32, I + P, low-complexity decision. The P picture's whole motion
     search + inter decision is one device call, and so is its frame stage -- prediction, residual, transform, quantisation, reconstruction -- whose
-    results answer JM's LumaPrediction / ChromaPrediction4x4 / dct_4x4 / dct_chroma calls (mask 0x5801: sub-pel planes, slice binding with the
-    frame stage, loop filter; everything else stays JM's)."""
+    results answer JM's LumaPrediction / ChromaPrediction4x4 / dct_4x4 / dct_chroma calls (mask 0xd801: sub-pel planes built on the device and left there,
+    slice binding with the frame stage, loop filter; everything else stays JM's)."""
     import time
     CASES["slice_full_1080p"] = dict(search=-1, profile=66, cabac=0, t8x8=0, bframes=0, refs=1, rdopt=0, adrnd=1, yuv=1, noi=1)
     prepare(tmp_path, "slice_full_1080p", w=1920, h=1080, frames=2, R=32)
@@ -321,7 +321,7 @@ def test_jm_1080p_full_search_slice_binding_is_byte_identical_and_faster(tmp_pat
     want = run("jm_plain", tmp_path)
     t_plain = time.perf_counter() - t0
     t0 = time.perf_counter()
-    got = run("jm_hip", tmp_path, {"JMHIP_SHIM_STATS": "1", "JMHIP_SHIM": "5801"})
+    got = run("jm_hip", tmp_path, {"JMHIP_SHIM_STATS": "1", "JMHIP_SHIM": "d801"})
     t_hip = time.perf_counter() - t0
     stats = got[2]
     assert got[0] == want[0] and got[1] == want[1], "1080p encode differs\n" + stats
