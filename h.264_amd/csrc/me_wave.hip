@@ -1786,7 +1786,7 @@ template <int SM> __device__ void macroblock_low(int mbx, int mby, jmhip_mb_inte
   const int8_t psz[8][2] = {{4, 4}, {4, 4}, {4, 2}, {2, 4}, {2, 2}, {2, 1}, {1, 2}, {1, 1}};
   const int bx0 = mbx * 4, by0 = mby * 4;
   int best_mode = 1, min_cost = INT_MAX;
-  int l0ref[5][4] = {{0}}, b8m[4] = {0, 0, 0, 0};
+  int l0ref[5][4] = {{0}}, b8m[4] = {0, 0, 0, 0}, p8m[4] = {0, 0, 0, 0}, p8r[4] = {0, 0, 0, 0};
   const int T8 = P.transform8x8_mode;
   int t8_flag = 0, best_tflag = 0, cbp8ts = -1, tr8_cost = INT_MAX, tr4_cost = INT_MAX;
   int ref8ts[4] = {0, 0, 0, 0};
@@ -1881,6 +1881,7 @@ template <int SM> __device__ void macroblock_low(int mbx, int mby, jmhip_mb_inte
       __syncthreads();
     }
     tr4_cost = cost8x8;
+    for (int k = 0; k < 4; k++) { p8m[k] = b8m[k]; p8r[k] = l0ref[4][k]; }      // the P8x8 candidate, before a winning 8x8-transform pass rewrites it below
     }
     if (tr4_cost < min_cost || tr8_cost < min_cost) {    // md_low.c:281-326
       best_mode = 8;
@@ -1927,7 +1928,7 @@ template <int SM> __device__ void macroblock_low(int mbx, int mby, jmhip_mb_inte
   }
   if (threadIdx.x == 0) {
     out->best_mode = best_mode; out->min_cost = min_cost; out->transform8x8_flag = t8_flag; out->cbp8ts = cbp8ts;
-    for (int k = 0; k < 4; k++) { out->b8mode[k] = best_mode == 8 ? b8m[k] : best_mode; out->b8ref[k] = l0ref[best_mode == 8 ? 4 : best_mode][k]; }
+    for (int k = 0; k < 4; k++) { out->b8mode[k] = best_mode == 8 ? b8m[k] : best_mode; out->b8ref[k] = l0ref[best_mode == 8 ? 4 : best_mode][k]; out->p8mode[k] = p8m[k]; out->p8ref[k] = p8r[k]; }
     out->skip_mv[0] = L.all_mv[0][0][0][0]; out->skip_mv[1] = L.all_mv[0][0][0][1];
   }
   __syncthreads();
@@ -2726,19 +2727,22 @@ namespace {
 // one of the reference its 8x8 block settled on), the decided mode, the reference slot per 8x8 block
 struct SlotMap { int s[WR]; };
 __global__ void slice_to_frame_kernel(const jmhip_mb_inter *__restrict__ rec, int first, int n, int mbw, SlotMap sm,
-                                      jmhip_me_mb *__restrict__ jobs, jmhip_me_result *__restrict__ res, jmhip_mb_mode *__restrict__ modes, int8_t *__restrict__ blk_ref)
+                                      jmhip_me_mb *__restrict__ jobs, jmhip_me_result *__restrict__ res, jmhip_mb_mode *__restrict__ modes, int8_t *__restrict__ blk_ref, int candidates)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const jmhip_mb_inter &r = rec[first + i];              // job i of the frame stage = macroblock first + i of the picture
   const int *slots = sm.s;
+  // the decided mode, or (candidates) the P8x8 candidate of submacroblock_mode_decision: its sub-modes and references per 8x8 block
+  const bool p8 = candidates && r.p8mode[0] >= 4;
+  const int32_t *bref = p8 ? r.p8ref : r.b8ref;
   jmhip_me_mb &j = jobs[i];
-  j.mb_x = (int16_t)((first + i) % mbw); j.mb_y = (int16_t)((first + i) / mbw); j.ref = (int16_t)slots[r.b8ref[0]]; j.ref_is_0 = (int16_t)(r.b8ref[0] == 0);
+  j.mb_x = (int16_t)((first + i) % mbw); j.mb_y = (int16_t)((first + i) / mbw); j.ref = (int16_t)slots[bref[0]]; j.ref_is_0 = (int16_t)(bref[0] == 0);
   jmhip_me_result &o = res[i];
   for (int p = 0; p < JMHIP_NPART; p++) {
     const PartInfo q = c_part[p];
-    const int ref = r.b8ref[2 * (q.y4 >> 1) + (q.x4 >> 1)];
-    if (r.best_mode == 8 && r.transform8x8_flag && p >= 5 && p < 9) {        // a P8x8 macroblock with the 8x8 transform keeps the vectors of its 8x8-transform pass
+    const int ref = bref[2 * (q.y4 >> 1) + (q.x4 >> 1)];
+    if (!p8 && r.best_mode == 8 && r.transform8x8_flag && p >= 5 && p < 9) {        // a P8x8 macroblock with the 8x8 transform keeps the vectors of its 8x8-transform pass
       const int k = p - 5;
       j.pred_mv[p][0] = r.pred8ts[ref][k][0]; j.pred_mv[p][1] = r.pred8ts[ref][k][1];
       o.mv[p][0] = r.mv8ts[ref][k][0]; o.mv[p][1] = r.mv8ts[ref][k][1]; o.cost[p] = r.cost8ts[ref][k];
@@ -2750,11 +2754,11 @@ __global__ void slice_to_frame_kernel(const jmhip_mb_inter *__restrict__ rec, in
     o.mv_int[p][0] = r.mv_int[ref][p][0]; o.mv_int[p][1] = r.mv_int[ref][p][1]; o.cost_int[p] = r.cost_int[ref][p];
   }
   jmhip_mb_mode m;
-  m.mode = (int8_t)r.best_mode;
+  m.mode = (int8_t)(p8 ? 8 : r.best_mode);
   // (P skip is not a mode of the rdopt = 0 decision: md_low.c:655 turns a 16x16 macroblock into a skip AFTER residual coding, when cbp == 0,
   // ref_idx == 0 and the vector equals skip_mv -- the caller has all three)
-  for (int k = 0; k < 4; k++) { m.b8mode[k] = (int8_t)(r.best_mode == 8 ? r.b8mode[k] : 4); blk_ref[(size_t)i * 4 + k] = (int8_t)slots[r.b8ref[k]]; }
-  m.pad[0] = (int8_t)(r.transform8x8_flag ? 1 : 0);      // luma_transform_size_8x8_flag as the decision left it (the residual coder's transform)
+  for (int k = 0; k < 4; k++) { m.b8mode[k] = (int8_t)(p8 ? r.p8mode[k] : (r.best_mode == 8 ? r.b8mode[k] : 4)); blk_ref[(size_t)i * 4 + k] = (int8_t)slots[bref[k]]; }
+  m.pad[0] = (int8_t)(!p8 && r.transform8x8_flag ? 1 : 0);      // luma_transform_size_8x8_flag as the decision left it (the residual coder's transform)
   m.pad[1] = m.pad[2] = 0;
   modes[i] = m;
 }
@@ -2766,7 +2770,10 @@ extern "C" int jmhip_slice_to_frame(jmhip_ctx *c, const int32_t *ref_slot, int n
   return jmhip_slice_to_frame_band(c, ref_slot, num_refs, 0, c->mbw * c->mbh);
 }
 
-extern "C" int jmhip_slice_to_frame_band(jmhip_ctx *c, const int32_t *ref_slot, int num_refs, int mb_first, int mb_count)
+static int slice_to_frame(jmhip_ctx *c, const int32_t *ref_slot, int num_refs, int mb_first, int mb_count, int candidates);
+extern "C" int jmhip_slice_to_frame_band(jmhip_ctx *c, const int32_t *ref_slot, int num_refs, int mb_first, int mb_count) { return slice_to_frame(c, ref_slot, num_refs, mb_first, mb_count, 0); }
+extern "C" int jmhip_slice_to_frame_candidates(jmhip_ctx *c, const int32_t *ref_slot, int num_refs, int mb_first, int mb_count) { return slice_to_frame(c, ref_slot, num_refs, mb_first, mb_count, 1); }
+static int slice_to_frame(jmhip_ctx *c, const int32_t *ref_slot, int num_refs, int mb_first, int mb_count, int candidates)
 {
   if (!c || !ref_slot || num_refs < 1 || num_refs > JMHIP_SLICE_REFS) return c ? jm_fail(c, JMHIP_ERR_ARG, "jmhip_slice_to_frame: arguments") : JMHIP_ERR_ARG;
   if (!c->slice_state) return jm_fail(c, JMHIP_ERR_ARG, "jmhip_slice_to_frame: no slice has been searched");
@@ -2794,12 +2801,12 @@ extern "C" int jmhip_slice_to_frame_band(jmhip_ctx *c, const int32_t *ref_slot, 
     }
   }
   slice_to_frame_kernel<<<(n + 127) / 128, 128, 0, c->stream>>>(s->out, mb_first, n, c->mbw, sm, (jmhip_me_mb *)c->me_jobs_dev,
-                                                                (jmhip_me_result *)c->me_res_dev, (jmhip_mb_mode *)c->fr_modes + n, (int8_t *)c->fr_blk_ref);
+                                                                (jmhip_me_result *)c->me_res_dev, (jmhip_mb_mode *)c->fr_modes + n, (int8_t *)c->fr_blk_ref, candidates);
   JM_HIP_CHECK(c, hipGetLastError());
   // the search-stage arrays now hold this picture; a resident re-run of jmhip_me_frame on them is meaningless and is refused (geometry check)
   c->me_n = n; c->me_ref_mask = mask; c->me_last_mode = 0x7fffffff; c->me_fast_idx.clear(); c->me_gen_idx.clear();
   c->fr_from_slices = true;
-  c->fr_slices_t8 = s->t8_any;
+  c->fr_slices_t8 = s->t8_any && !candidates;      // (the candidates are coded with the 4x4 transform: the P8x8 pass of the 4x4 transform)
   return JMHIP_OK;
 }
 

@@ -697,6 +697,7 @@ __global__ __launch_bounds__(CHAIN ? 256 : 64) void x_sim_kernel(XDev D)
     jmhip_mb_inter &o = D.out[addr];
     o.best_mode = best_mode; o.min_cost = min_cost;
     for (int k = 0; k < 4; k++) { o.b8mode[k] = best_mode == 8 ? (int)((b8 >> (3 * k)) & 7u) : best_mode; o.b8ref[k] = l0_get(best_mode == 8 ? 4 : best_mode, k); }
+    for (int k = 0; k < 4; k++) { o.p8mode[k] = (int)((b8 >> (3 * k)) & 7u); o.p8ref[k] = o.p8mode[k] ? l0_get(4, k) : 0; }      // the P8x8 candidate, whatever mode wins
     o.skip_mv[0] = (int16_t)skx; o.skip_mv[1] = (int16_t)sky;
     o.transform8x8_flag = 0; o.cbp8ts = -1;
   }

@@ -112,7 +112,7 @@ MB_INTER_DTYPE = np.dtype([("best_mode", "<i4"), ("min_cost", "<i4"), ("b8mode",
                            ("cost_int", "<i4", (SLICE_REFS, NPART)), ("cost", "<i4", (SLICE_REFS, NPART)),
                            ("pred8ts", "<i2", (SLICE_REFS, 4, 2)), ("mv_int8ts", "<i2", (SLICE_REFS, 4, 2)), ("mv8ts", "<i2", (SLICE_REFS, 4, 2)),
                            ("cost_int8ts", "<i4", (SLICE_REFS, 4)), ("cost8ts", "<i4", (SLICE_REFS, 4)),
-                           ("transform8x8_flag", "<i4"), ("cbp8ts", "<i4")], align=True)
+                           ("transform8x8_flag", "<i4"), ("cbp8ts", "<i4"), ("p8mode", "<i4", (4,)), ("p8ref", "<i4", (4,))], align=True)
 
 PREDCOST_JOB_DTYPE = np.dtype([("mb_x", "<i2"), ("mb_y", "<i2"), ("blocks", "<u2"), ("weighted", "<i2"), ("wp_round", "<i2"), ("wp_denom", "<i2"),
                                ("mv", "<i2", (16, 2)), ("mv1", "<i2", (16, 2)), ("ref", "i1", (16,)), ("ref1", "i1", (16,)), ("bi", "i1", (16,)),
@@ -227,6 +227,7 @@ def load_library():
     lib.jmhip_epzs_map_upload.argtypes = [vp, vp, ip, ip]
     lib.jmhip_slice_to_frame.argtypes = [vp, vp, ip]
     lib.jmhip_slice_to_frame_band.argtypes = [vp, vp, ip, ip, ip]
+    lib.jmhip_slice_to_frame_candidates.argtypes = [vp, vp, ip, ip, ip]
     lib.jmhip_frame_wp_set.argtypes = [vp, vp]
     lib.jmhip_frame_bipred_set.argtypes = [vp, vp, ip, vp]
     for which, dt in ((0, ME_MB_DTYPE), (1, ME_RESULT_DTYPE), (2, QUANT_DTYPE), (3, TQ_JOB_DTYPE), (4, TQ_RESULT_DTYPE),
@@ -436,6 +437,11 @@ class Context:
         """The same for macroblocks [mb_first, mb_first + mb_count) alone (a rank's slice): job i of residual_frame is macroblock mb_first + i."""
         a = np.ascontiguousarray(ref_slot, dtype=np.int32)
         self._chk(self.lib.jmhip_slice_to_frame_band(self.h, _ptr(a), len(a), mb_first, mb_count), "jmhip_slice_to_frame_band")
+
+    def slice_to_frame_candidates(self, ref_slot, mb_first, mb_count):
+        """The same for macroblocks [mb_first, mb_first + mb_count) alone (a rank's slice): job i of residual_frame is macroblock mb_first + i."""
+        a = np.ascontiguousarray(ref_slot, dtype=np.int32)
+        self._chk(self.lib.jmhip_slice_to_frame_candidates(self.h, _ptr(a), len(a), mb_first, mb_count), "jmhip_slice_to_frame_candidates")
 
     def frame_wp_set(self, wp=None):
         """wp: None (off) or dict(luma_round, luma_denom, chroma_round, chroma_denom, weight[(slot, comp)], offset[(slot, comp)] as (16,3) arrays)."""

@@ -372,6 +372,10 @@ typedef struct jmhip_mb_inter {
   int16_t pred8ts[JMHIP_SLICE_REFS][4][2], mv_int8ts[JMHIP_SLICE_REFS][4][2], mv8ts[JMHIP_SLICE_REFS][4][2];
   int32_t cost_int8ts[JMHIP_SLICE_REFS][4], cost8ts[JMHIP_SLICE_REFS][4];
   int32_t transform8x8_flag, cbp8ts;
+  /* the P8x8 CANDIDATE as submacroblock_mode_decision (src/mode_decision.c:531) leaves it, whatever mode wins: sub-mode (4..7; 0 when the 8x8 modes
+   * are disabled) and list-0 reference of each 8x8 block. JM predicts and transforms it per 8x8 block before the decision (:874) -- a slice-level
+   * binding that also answers those calls codes it with jmhip_slice_to_frame_candidates. */
+  int32_t p8mode[4], p8ref[4];
 } jmhip_mb_inter;
 
 /* Host helpers that fill the search-mode blocks of jmhip_slice_params exactly as JM's initialisation does. */
@@ -416,6 +420,10 @@ int jmhip_slice_to_frame(jmhip_ctx *ctx, const int32_t *ref_slot, int num_refs);
  * src/slice.c:214 with SliceMode 1) hands ITS slice to the frame stage: job i of jmhip_residual_frame is macroblock mb_first + i, the
  * reconstruction covers those macroblocks' rows (jmhip_recon_pack_band). The range must have been searched in the current picture. */
 int jmhip_slice_to_frame_band(jmhip_ctx *ctx, const int32_t *ref_slot, int num_refs, int mb_first, int mb_count);
+/* The same hand-over with every macroblock in its P8x8 CANDIDATE form (jmhip_mb_inter.p8mode / p8ref, the vectors of those sub-modes) instead of the
+ * decided mode: jmhip_residual_frame then yields what LumaResidualCoding8x8 computes for the candidate inside submacroblock_mode_decision
+ * (src/mode_decision.c:874). The reconstruction of that pass is not a picture: call it BEFORE the hand-over of the decision. */
+int jmhip_slice_to_frame_candidates(jmhip_ctx *ctx, const int32_t *ref_slot, int num_refs, int mb_first, int mb_count);
 
 /* ------------------------------------------------------------------ low-complexity (rdopt off) mode-decision costs */
 

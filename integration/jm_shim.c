@@ -1071,15 +1071,18 @@ static struct {
   int mb_first, mb_count;
   jmhip_mb_residual *rec; int cap;
   imgpel *pred[3]; int pred_ready;
+  /* ... and the same for the P8x8 CANDIDATE of every macroblock, which JM predicts and transforms per 8x8 block inside submacroblock_mode_decision
+     (src/mode_decision.c:874) before it decides: luma only (jmhip_slice_to_frame_candidates) */
+  jmhip_mb_residual *rec2; int cap2; imgpel *pred2; int have2;
   /* JM also predicts and transforms blocks the decision then discards (the P8x8 candidate of every macroblock, src/mode_decision.c:874): a dct call
      is answered from the record only when the prediction it works on was -- per macroblock, the luma 4x4 blocks / chroma 4x4 blocks whose LAST
      prediction call asked for the decided block and was answered from the prediction picture */
-  int ok_mb; unsigned long ok_serial; unsigned ok_luma, ok_chroma[2];
+  int ok_mb; unsigned long ok_serial; unsigned ok_luma, ok_luma2, ok_chroma[2];      /* ok_luma2: ... was answered from the candidate's prediction picture */
 } fr;
 
 static void fr_ok_mb(void)
 {
-  if (fr.ok_mb != img->current_mb_nr || fr.ok_serial != pic_serial) { fr.ok_mb = img->current_mb_nr; fr.ok_serial = pic_serial; fr.ok_luma = 0; fr.ok_chroma[0] = fr.ok_chroma[1] = 0; }
+  if (fr.ok_mb != img->current_mb_nr || fr.ok_serial != pic_serial) { fr.ok_mb = img->current_mb_nr; fr.ok_serial = pic_serial; fr.ok_luma = fr.ok_luma2 = 0; fr.ok_chroma[0] = fr.ok_chroma[1] = 0; }
 }
 static unsigned fr_luma_bits(int block_x, int block_y, int bsx, int bsy)
 {
@@ -1128,6 +1131,18 @@ static void fr_run(const jmhip_slice_params *p, int first, int count)
   }
   OK(jmhip_frame_wp_set(g, &wp));
   OK(jmhip_frame_keep_prediction(g, 1));
+  fr.have2 = 0;
+  if (input->InterSearch[0][4] || input->InterSearch[0][5] || input->InterSearch[0][6] || input->InterSearch[0][7]) {
+    /* first the P8x8 candidates (their reconstruction is not a picture: the decision's pass below overwrites it) */
+    OK(jmhip_slice_to_frame_candidates(g, p->ref_slot, p->num_refs, first, count));
+    OK(jmhip_residual_frame(g, NULL, q));
+    if (fr.cap2 < count) { free(fr.rec2); fr.rec2 = malloc(sizeof(jmhip_mb_residual) * (size_t)count); fr.cap2 = count; }
+    if (!fr.pred2) fr.pred2 = malloc(sizeof(imgpel) * (size_t)g_w * g_h);
+    if (!fr.rec2 || !fr.pred2) { fprintf(stderr, "jm_shim: out of memory\n"); exit(96); }
+    OK(jmhip_residual_records_download(g, fr.rec2, count));
+    OK(jmhip_pred_download(g, fr.pred2, NULL, NULL, (int)sizeof(imgpel)));
+    fr.have2 = 1;
+  }
   OK(jmhip_slice_to_frame_band(g, p->ref_slot, p->num_refs, first, count));
   OK(jmhip_residual_frame(g, NULL, q));
   if (fr.cap < count) { free(fr.rec); fr.rec = malloc(sizeof(jmhip_mb_residual) * (size_t)count); fr.cap = count; }
@@ -1162,16 +1177,41 @@ static int fr_asks_decided(int bx0, int by0, int bx1, int by1, int p_dir, int l0
   return 1;
 }
 
+/* ... or for the P8x8 candidate's prediction of them (sub-mode and reference of the 8x8 block, the vectors the slice search found for that sub-mode)? */
+static int fr_asks_candidate(int bx0, int by0, int bx1, int by1, int p_dir, int l0_mode, short l0_ref)
+{
+  const jmhip_mb_inter *d = &sl.rec[img->current_mb_nr - sl.mb_first];
+  int bx, by;
+  if (!fr.have2 || p_dir != 0 || l0_ref < 0 || l0_ref >= JMHIP_SLICE_REFS || l0_mode < 4 || l0_mode > 7) return 0;
+  for (by = by0; by < by1; by++) for (bx = bx0; bx < bx1; bx++) {
+    const int b8 = 2 * (by >> 1) + (bx >> 1);
+    const int ox = (l0_mode == 4 || l0_mode == 5) ? (bx & ~1) : bx, oy = (l0_mode == 4 || l0_mode == 6) ? (by & ~1) : by;      /* origin of the sub-partition that covers the block */
+    const int pi = partition_of(l0_mode, ox << 2, oy << 2);
+    const short *v = img->all_mv[by][bx][LIST_0][l0_ref][l0_mode];
+    if (l0_mode != d->p8mode[b8] || l0_ref != d->p8ref[b8] || pi < 0 || v[0] != d->mv[l0_ref][pi][0] || v[1] != d->mv[l0_ref][pi][1]) return 0;
+  }
+  return 1;
+}
+
 void LumaPrediction(Macroblock *currMB, int block_x, int block_y, int block_size_x, int block_size_y, int p_dir, int l0_mode, int l1_mode, short l0_ref_idx, short l1_ref_idx)
 {
   static void (*orig)(Macroblock *, int, int, int, int, int, int, int, short, short);
-  if (fr_rec_cur()) { fr_ok_mb(); fr.ok_luma &= ~fr_luma_bits(block_x, block_y, block_size_x, block_size_y); }
+  if (fr_rec_cur()) { fr_ok_mb(); fr.ok_luma &= ~fr_luma_bits(block_x, block_y, block_size_x, block_size_y); fr.ok_luma2 &= ~fr_luma_bits(block_x, block_y, block_size_x, block_size_y); }
   if (fr_rec_cur() && sl.active && fr_asks_decided(block_x >> 2, block_y >> 2, (block_x + block_size_x) >> 2, (block_y + block_size_y) >> 2, p_dir, l0_mode, l0_ref_idx)) {
     int j;
     fr.ok_luma |= fr_luma_bits(block_x, block_y, block_size_x, block_size_y);
     for (j = block_y; j < block_y + block_size_y; j++)
       memcpy(&img->mpr[0][j][block_x], fr.pred[0] + (size_t)(img->pix_y + j) * g_w + img->pix_x + block_x, sizeof(imgpel) * (size_t)block_size_x);
     width_pad = listX[LIST_0][l0_ref_idx]->size_x_pad; height_pad = listX[LIST_0][l0_ref_idx]->size_y_pad;      /* OneComponentLumaPrediction, macroblock.c:817-818 */
+    n_dev[S_LPRED]++;
+    return;
+  }
+  if (fr_rec_cur() && sl.active && fr_asks_candidate(block_x >> 2, block_y >> 2, (block_x + block_size_x) >> 2, (block_y + block_size_y) >> 2, p_dir, l0_mode, l0_ref_idx)) {
+    int j;
+    fr.ok_luma2 |= fr_luma_bits(block_x, block_y, block_size_x, block_size_y);
+    for (j = block_y; j < block_y + block_size_y; j++)
+      memcpy(&img->mpr[0][j][block_x], fr.pred2 + (size_t)(img->pix_y + j) * g_w + img->pix_x + block_x, sizeof(imgpel) * (size_t)block_size_x);
+    width_pad = listX[LIST_0][l0_ref_idx]->size_x_pad; height_pad = listX[LIST_0][l0_ref_idx]->size_y_pad;
     n_dev[S_LPRED]++;
     return;
   }
@@ -1204,9 +1244,15 @@ void ChromaPrediction4x4(Macroblock *currMB, int uv, int block_x, int block_y, i
 static int fr_dct4(Macroblock *currMB, int block_x, int block_y, int *coeff_cost, int *ret)
 {
   const jmhip_mb_residual *r = fr_rec_cur();
+  const imgpel *pred0 = fr.pred[0];
   if (!r || IS_INTRA(currMB) || currMB->luma_transform_size_8x8_flag) return 0;
   fr_ok_mb();
-  if (!(fr.ok_luma & (1u << ((block_y >> 2) * 4 + (block_x >> 2))))) { n_fwd[S_D4R]++; return 0; }      /* a candidate the decision discards: JM's prediction, so JM's transform */
+  {
+    const unsigned bit = 1u << ((block_y >> 2) * 4 + (block_x >> 2));
+    if (fr.ok_luma & bit) ;                                                      /* the decided block */
+    else if (fr.ok_luma2 & bit) { r = &fr.rec2[img->current_mb_nr - fr.mb_first]; pred0 = fr.pred2; }      /* the P8x8 candidate's block */
+    else { n_fwd[S_D4R]++; return 0; }                                           /* JM's own prediction, so JM's transform */
+  }
   {
     const int pos_x = block_x >> 2, pos_y = block_y >> 2, b8 = 2 * (pos_y >> 1) + (pos_x >> 1), b4 = 2 * (pos_y & 1) + (pos_x & 1), blk = b8 * 4 + b4;
     const int n = r->cnt[blk];
@@ -1215,7 +1261,7 @@ static int fr_dct4(Macroblock *currMB, int block_x, int block_y, int *coeff_cost
     imgpel **img_enc = enc_picture->p_curr_img;
     int j, i, k;
     for (j = block_y; j < block_y + 4; j++) for (i = block_x; i < block_x + 4; i++) {
-      const int pr = fr.pred[0][(size_t)(img->pix_y + j) * g_w + img->pix_x + i];
+      const int pr = pred0[(size_t)(img->pix_y + j) * g_w + img->pix_x + i];
       if (img->mpr[0][j][i] != pr || img->m7[0][j][i] != pCurImg[img->opix_y + j][img->opix_x + i] - pr) fr_diverged("luma", block_x, block_y);
     }
     for (k = 0; k < n; k++) { lev[k] = r->lev[blk][k]; run[k] = r->run[blk][k]; }

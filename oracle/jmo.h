@@ -335,6 +335,7 @@ typedef struct {
   short pred8ts[JMO_LC_REFS][4][2], mv_int8ts[JMO_LC_REFS][4][2], mv8ts[JMO_LC_REFS][4][2];
   int cost_int8ts[JMO_LC_REFS][4], cost8ts[JMO_LC_REFS][4];
   int transform8x8_flag, cbp8ts;
+  int p8mode[4], p8ref[4];             /* the P8x8 candidate of submacroblock_mode_decision (mode_decision.c:531), whatever mode wins: sub-mode and reference per 8x8 block */
 } jmo_mb_inter;
 
 void jmo_lowcplx_p_slice(const jmo_lowcplx_params *q, const jmo_ref *refs, const jmo_pel *cur, int cur_stride,

@@ -368,7 +368,8 @@ static void macroblock_low(lc_ctx *c)
   static const int part_size[8][2] = {{4, 4}, {4, 4}, {4, 2}, {2, 4}, {2, 2}, {2, 1}, {1, 2}, {1, 1}};
   const jmo_lowcplx_params *q = c->q;
   int mode, block, best_mode = 1, min_cost = JMO_INT_MAX, cost, i, j, k, r;
-  int best8x8l0ref[5][4], best8x8mode[4] = {0, 0, 0, 0};            /* [1..3] and [4] = P8x8 */
+  int best8x8l0ref[5][4], best8x8mode[4] = {0, 0, 0, 0};
+  int p8cand_mode[4] = {0, 0, 0, 0}, p8cand_ref[4] = {0, 0, 0, 0};            /* [1..3] and [4] = P8x8 */
   const int T8 = q->transform8x8_mode;
   int t8_flag = 0, best_transform_flag = 0, cbp8ts = -1;
   int ref8ts[4] = {0, 0, 0, 0}; short mv8ts[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};       /* StoreNewMotionVectorsBlock8x8 of the 8x8-transform pass */
@@ -471,6 +472,7 @@ static void macroblock_low(lc_ctx *c)
       }
     }
     tr4_cost = cost8x8;
+    for (k = 0; k < 4; k++) { p8cand_mode[k] = best8x8mode[k]; p8cand_ref[k] = best8x8l0ref[4][k]; }      /* the candidate, before a winning 8x8-transform pass rewrites it below */
     }
     if (tr4_cost < min_cost || tr8_cost < min_cost) {         /* md_low.c:281-326 */
       best_mode = 8;
@@ -526,6 +528,7 @@ static void macroblock_low(lc_ctx *c)
   for (k = 0; k < 4; k++) {
     c->out->b8mode[k] = best_mode == 8 ? best8x8mode[k] : best_mode;
     c->out->b8ref[k] = best8x8l0ref[best_mode == 8 ? 4 : best_mode][k];
+    c->out->p8mode[k] = p8cand_mode[k]; c->out->p8ref[k] = p8cand_ref[k];
   }
   for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) {
     const int k8 = 2 * (j >> 1) + (i >> 1), ref = c->out->b8ref[k8], m8 = c->out->b8mode[k8];

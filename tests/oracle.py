@@ -586,7 +586,7 @@ MB_INTER_DTYPE = np.dtype([("best_mode", "<i4"), ("min_cost", "<i4"), ("b8mode",
                            ("cost_int", "<i4", (LC_REFS, 41)), ("cost", "<i4", (LC_REFS, 41)),
                            ("pred8ts", "<i2", (LC_REFS, 4, 2)), ("mv_int8ts", "<i2", (LC_REFS, 4, 2)), ("mv8ts", "<i2", (LC_REFS, 4, 2)),
                            ("cost_int8ts", "<i4", (LC_REFS, 4)), ("cost8ts", "<i4", (LC_REFS, 4)),
-                           ("transform8x8_flag", "<i4"), ("cbp8ts", "<i4")], align=True)
+                           ("transform8x8_flag", "<i4"), ("cbp8ts", "<i4"), ("p8mode", "<i4", (4,)), ("p8ref", "<i4", (4,))], align=True)
 
 # JM's shipped defaults (bin/encoder_*.cfg: EPZSPattern 2, Dual 3, Fixed 2, Temporal 1, SpatialMem 1, thresholds 0/1/2, sub-pel 2; UMHexDSR 1, UMHexScale 3)
 EPZS_DEFAULTS = dict(pattern=2, dual=3, fixed=2, temporal=1, spatial_mem=1, min_scale=0, med_scale=1, max_scale=2, subpel_scale=2)

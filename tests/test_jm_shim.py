@@ -299,10 +299,13 @@ def test_jm_slice_level_binding_is_byte_identical(tmp_path, name):
     mbs = (nframes - 1) * 99
     if SLICE_CASES[name]["yuv"] == 1 and SLICE_CASES[name]["t8x8"] == 0:
         assert served["frame stage of P slices"][0] == nframes - 1, served
-        # (JM also predicts and transforms the P8x8 candidate of every macroblock, src/mode_decision.c:874, which the decision mostly discards: those
-        # calls -- the `forwarded` counts -- work on JM's own prediction and stay JM's)
-        assert served["dct_4x4 (slice records)"][0] >= 16 * mbs and served["dct_chroma (slice records)"] == (2 * mbs, 0), served
-        assert served["LumaPrediction (slice)"][0] >= 16 * mbs and served["ChromaPrediction4x4 (slice)"] == (8 * mbs, 0), served
+        # -- JM predicts and transforms every macroblock twice: its P8x8 candidate inside submacroblock_mode_decision (src/mode_decision.c:874), then the
+        # decided mode; both passes are answered (the candidate from a second frame-stage pass, jmhip_slice_to_frame_candidates)
+        # (JM leaves the candidate pass out for some macroblocks, so the luma counts lie between one and two passes; nothing is left to JM)
+        assert 16 * mbs <= served["dct_4x4 (slice records)"][0] <= 32 * mbs and served["dct_4x4 (slice records)"][1] == 0 and served["dct_chroma (slice records)"] == (2 * mbs, 0), served
+        assert served["LumaPrediction (slice)"] == served["dct_4x4 (slice records)"] and served["ChromaPrediction4x4 (slice)"] == (8 * mbs, 0), served
+        lazy = re.search(r"^\s*sub-pel planes fetched on demand\s+device\s+(\d+)", stats, re.M)
+        assert int(lazy.group(1)) == 0, "the bound P pictures needed no sub-pel plane on the host\n" + stats
     else:
         assert served["frame stage of P slices"][0] == 0 and served["dct_4x4 (slice records)"][0] == 0, served
 
@@ -329,7 +332,7 @@ def test_jm_1080p_full_search_slice_binding_is_byte_identical_and_faster(tmp_pat
     assert int(m.group(1)) == 8160 * 41 and int(m.group(2)) == 0, m.groups()
     d4 = re.search(r"^\s*dct_4x4 \(slice records\)\s+device\s+(\d+)\s+forwarded\s+(\d+)", stats, re.M)
     dc = re.search(r"^\s*dct_chroma \(slice records\)\s+device\s+(\d+)\s+forwarded\s+(\d+)", stats, re.M)
-    assert int(d4.group(1)) >= 8160 * 16 and (int(dc.group(1)), int(dc.group(2))) == (8160 * 2, 0), (d4.groups(), dc.groups())
+    assert 8160 * 16 <= int(d4.group(1)) <= 8160 * 32 and int(d4.group(2)) == 0 and (int(dc.group(1)), int(dc.group(2))) == (8160 * 2, 0), (d4.groups(), dc.groups())
     print("1080p I+P, FullSearch +-32: jm_plain %.1f s, jm_hip %.1f s; %s of %s BlockMotionSearch calls answered from the slice record (hit rate 100%%)" % (
         t_plain, t_hip, m.group(1), m.group(1)))
     assert t_hip < t_plain

@@ -24,7 +24,7 @@ def compare(got, want, nref, what):
         if not np.array_equal(got[f][:, :nref], want[f][:, :nref]):
             i = int(np.argwhere(np.any((got[f][:, :nref] != want[f][:, :nref]).reshape(len(got), -1), axis=1))[0][0])
             raise AssertionError("%s: %s differs at macroblock %d: device %s oracle %s" % (what, f, i, got[f][i, :nref].tolist(), want[f][i, :nref].tolist()))
-    for f in ("best_mode", "min_cost", "b8mode", "b8ref", "final_mv", "skip_mv", "transform8x8_flag", "cbp8ts"):
+    for f in ("best_mode", "min_cost", "b8mode", "b8ref", "final_mv", "skip_mv", "transform8x8_flag", "cbp8ts", "p8mode", "p8ref"):
         if not np.array_equal(got[f], want[f]):
             i = int(np.argwhere(np.any((got[f] != want[f]).reshape(len(got), -1), axis=1))[0][0])
             raise AssertionError("%s: %s differs at macroblock %d: device %s oracle %s" % (what, f, i, got[f][i].tolist(), want[f][i].tolist()))
