@@ -42,7 +42,7 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 # 1024 SIMDs. (Until the min3 pairing was built the model charged one v_min_u32 per partition: 266 ns.)
 VALU_NS_PER_WAVE_CANDIDATE = 64 * 1.89 + 25 * 1.04 + 40 * 1.04 + 20.5 * 1.89
 N_SIMD = 1024
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_final_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_final_summary.json")
 
 
 def pmc_traffic(kernel, n_units):
@@ -50,7 +50,8 @@ def pmc_traffic(kernel, n_units):
     WRITE_SIZE in separate runs, KB units). Only meaningful for the full-frame single-GPU launch it was recorded on."""
     try:
         with open(PMC_SUMMARY) as f:
-            k = json.load(f)[kernel]
+            d = json.load(f)
+            k = d.get(kernel) or d[kernel + "<false>"]        # (the kernel is a template since round 3: <false> = the frame form, <true> = device-resident item lists)
         if n_units != MBW * MBH:
             return None
         return int((k["FETCH_SIZE_KB_raw_per_launch"] + k["WRITE_SIZE_KB_raw_per_launch"]) * 1024)

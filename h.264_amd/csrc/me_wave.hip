@@ -83,6 +83,9 @@ struct Lds {
   int surf_c[2 * WR][5];                       // per surface slot (0: the macroblock's, 1: a partition's own) and reference: centre (pels), half side, valid, block rows
   // the macroblock's view of the picture-level state: staged once by mb_stage, used and updated in LDS, handed on by mb_commit.
   // Grid [y + 1][x + 1] of the 4x4 blocks x = -1..4, y = -1..3: the macroblock's own sixteen and the ring its predictors read (A, B, C, D)
+  // the inter decision's running state (macroblock_low): in LDS, not in registers or private arrays -- the decision loop is wrapped round the whole search
+  // code, where register-resident state was both expensive (live across 6 k instructions) and, with dynamic indices, scratch
+  struct Dec { int best_mode, min_cost, t8_flag, best_tflag, cbp8ts, tr8_cost, tr4_cost, cost, cost8x8, mc8; int l0ref[5][4], b8m[4], p8m[4], p8r[4], ref8ts[4]; short mv8ts[4][2]; } dec;
   int mbx, mby;
   int pass8ts;                                 // inside the 8x8-transform P8x8 pass (Transform8x8Mode): the call records go to the *8ts arrays
   int memo_live, ff_same[WR];                  // this evaluation may reuse call records (WaveDev.memo); FastFull: the reference's window centre is the recorded one
@@ -1655,7 +1658,7 @@ __device__ __forceinline__ void field_set(int by, int bx, int ref, int mvx, int 
 }
 
 // PartitionMotionSearch, mv-search.c:1378
-template <int SM> __device__ void partition_motion_search(int mbx, int mby, int bt, int block8, jmhip_mb_inter *out)
+template <int SM> __device__ __forceinline__ void partition_motion_search(int mbx, int mby, int bt, int block8, jmhip_mb_inter *out)
 {
   const int8_t bx0[5][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 2, 0, 0}, {0, 2, 0, 2}};
   const int8_t by0[5][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 2, 0, 0}, {0, 0, 0, 0}, {0, 0, 2, 2}};
@@ -1785,12 +1788,14 @@ template <int SM> __device__ void macroblock_low(int mbx, int mby, jmhip_mb_inte
   const jmhip_slice_params &P = D.p;
   const int8_t psz[8][2] = {{4, 4}, {4, 4}, {4, 2}, {2, 4}, {2, 2}, {2, 1}, {1, 2}, {1, 1}};
   const int bx0 = mbx * 4, by0 = mby * 4;
-  int best_mode = 1, min_cost = INT_MAX;
-  int l0ref[5][4] = {{0}}, b8m[4] = {0, 0, 0, 0}, p8m[4] = {0, 0, 0, 0}, p8r[4] = {0, 0, 0, 0};
+  // (every lane executes the same control flow and writes the same values: one wave, LDS operations in order)
+  int &best_mode = L.dec.best_mode, &min_cost = L.dec.min_cost, &t8_flag = L.dec.t8_flag, &best_tflag = L.dec.best_tflag, &cbp8ts = L.dec.cbp8ts, &tr8_cost = L.dec.tr8_cost, &tr4_cost = L.dec.tr4_cost;
+  int (&l0ref)[5][4] = L.dec.l0ref; int (&b8m)[4] = L.dec.b8m; int (&p8m)[4] = L.dec.p8m; int (&p8r)[4] = L.dec.p8r; int (&ref8ts)[4] = L.dec.ref8ts; short (&mv8ts)[4][2] = L.dec.mv8ts;
   const int T8 = P.transform8x8_mode;
-  int t8_flag = 0, best_tflag = 0, cbp8ts = -1, tr8_cost = INT_MAX, tr4_cost = INT_MAX;
-  int ref8ts[4] = {0, 0, 0, 0};
-  short mv8ts[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+  __syncthreads();
+  best_mode = 1; min_cost = INT_MAX; t8_flag = 0; best_tflag = 0; cbp8ts = -1; tr8_cost = INT_MAX; tr4_cost = INT_MAX;
+  for (int k = 0; k < 20; k++) (&l0ref[0][0])[k] = 0;
+  for (int k = 0; k < 4; k++) { b8m[k] = 0; p8m[k] = 0; p8r[k] = 0; ref8ts[k] = 0; mv8ts[k][0] = 0; mv8ts[k][1] = 0; }
   if (threadIdx.x == 0) L.pass8ts = 0;
   for (int e = threadIdx.x; e < WR * 4; e += 64) {                             // the 8x8-transform pass's call records: zero unless that pass runs
     const int r = e >> 2, k = e & 3;
@@ -1804,13 +1809,33 @@ template <int SM> __device__ void macroblock_low(int mbx, int mby, jmhip_mb_inte
       out->cost_int[r][k] = out->cost[r][k] = 0;
     }
   for (int r = 0; r < 2 * WR; r++) L.surf_c[r][3] = 0;
-  for (int mode = 1; mode < 4; mode++) {
-    if (!P.valid[mode]) continue;
-    int cost = 0;
-    for (int block = 0; block < (mode == 1 ? 1 : 2); block++) {
-      int best_ref = 0;
+  // The 25 partition searches of the inter decision -- modes 1..3 (their blocks), the four 8x8 blocks of the 8x8-transform P8x8 pass, then per 8x8
+  // block its sub-modes 4..7 -- as ONE loop with ONE call of partition_motion_search, so that the search code is inlined exactly once: as a function
+  // called from three loops it saved and restored ~127 callee-saved VGPRs through scratch on every call (21-25 calls per macroblock: 1.5 GB fetched and
+  // 2.1 GB written per sweep at 1080p, profiles/r03_p_slice_sq_counters.txt), which is where a third of a macroblock's time went.
+  const bool any8 = P.valid[4] || P.valid[5] || P.valid[6] || P.valid[7];
+  int &cost = L.dec.cost, &cost8x8 = L.dec.cost8x8, &mc8 = L.dec.mc8;
+  cost = 0; cost8x8 = 0; mc8 = INT_MAX;
+  for (int it = 0; it < 25; it++) {
+    const int phase = it < 5 ? 0 : it < 9 ? 1 : 2;                  // 0: modes 1..3, 1: the 8x8-transform P8x8 pass, 2: the 4x4-transform P8x8 pass
+    const int mode = phase == 0 ? (it == 0 ? 1 : it < 3 ? 2 : 3) : phase == 1 ? 4 : 4 + ((it - 9) & 3);
+    const int block = phase == 0 ? (it == 0 ? 0 : (it - 1) & 1) : phase == 1 ? it - 5 : (it - 9) >> 2;
+    const bool run = phase == 0 ? P.valid[mode] != 0 : phase == 1 ? (any8 && T8 != 0) : (any8 && T8 != 2 && P.valid[mode] != 0);
+    if (phase == 0 && block == 0) cost = 0;
+    if (phase == 1 && block == 0 && run) {                          // the 8x8 partition with the 8x8 transform: sub-mode 4 only (mode_decision.c:556)
+      tr8_cost = 0;
+      __syncthreads();
+      if (threadIdx.x == 0) L.pass8ts = 1;
+      __syncthreads();
+    }
+    if (phase == 2 && mode == 4) mc8 = INT_MAX;
+    int best_ref = 0, c = 0;
+    if (run) {
       partition_motion_search<SM>(mbx, mby, mode, block, out);
-      cost += list0_cost(mode, block, &best_ref);
+      c = list0_cost(mode, block, &best_ref);
+    }
+    if (phase == 0 && run) {
+      cost += c;
       if (mode == 1) {
         for (int b = 0; b < 16; b++) field_set(by0 + (b >> 2), bx0 + (b & 3), best_ref, L.all_mv[b][best_ref][1][0], L.all_mv[b][best_ref][1][1]);
         for (int k = 0; k < 4; k++) l0ref[1][k] = best_ref;
@@ -1820,69 +1845,60 @@ template <int SM> __device__ void macroblock_low(int mbx, int mby, jmhip_mb_inte
         for (int j = 0; j < psz[mode][1]; j++) for (int i = 0; i < psz[mode][0]; i++)
           field_set(by0 + j, bx0 + i, best_ref, L.all_mv[j * 4 + i][best_ref][mode][0], L.all_mv[j * 4 + i][best_ref][mode][1]);
       __syncthreads();
-    }
-    if (T8) {
-      // SetModesAndRefframeForBlocks (md_low.c:186, rdopt.c:1470-1500) writes the mode's best references into the picture array -- a side effect only
-      // Transform8x8Mode has -- and TransformDecision predicts with them
-      for (int b = 0; b < 16; b++) FREF(by0 + (b >> 2), bx0 + (b & 3)) = (int8_t)l0ref[mode][2 * (b >> 3) + ((b & 3) >> 1)];
-      __syncthreads();
-      if (T8 == 2) t8_flag = 1;
-      else if (P.md_metric != 2) t8_flag = 0;            // SAD: cost8x8 == cost4x4, the cost stays
-      else {
-        int c4 = 0, c8 = 0;
-        for (int k8 = 0; k8 < 4; k8++) {
-          const int b = (k8 >> 1) * 8 + (k8 & 1) * 2, r = l0ref[mode][k8];
-          c4 += pred_block_cost(mbx, mby, 8 * (k8 & 1), 8 * (k8 >> 1), 8, r, L.all_mv[b][r][mode][0], L.all_mv[b][r][mode][1], 0);
-          c8 += pred_block_cost(mbx, mby, 8 * (k8 & 1), 8 * (k8 >> 1), 8, r, L.all_mv[b][r][mode][0], L.all_mv[b][r][mode][1], 1);
+      if (mode == 1 || block == 1) {                                // the mode's last block
+        if (T8) {
+          // SetModesAndRefframeForBlocks (md_low.c:186, rdopt.c:1470-1500) writes the mode's best references into the picture array -- a side effect only
+          // Transform8x8Mode has -- and TransformDecision predicts with them
+          for (int b = 0; b < 16; b++) FREF(by0 + (b >> 2), bx0 + (b & 3)) = (int8_t)l0ref[mode][2 * (b >> 3) + ((b & 3) >> 1)];
+          __syncthreads();
+          if (T8 == 2) t8_flag = 1;
+          else if (P.md_metric != 2) t8_flag = 0;            // SAD / SSE: cost8x8 == cost4x4, the cost stays
+          else {
+            int c4 = 0, c8 = 0;
+            for (int k8 = 0; k8 < 4; k8++) {
+              const int b = (k8 >> 1) * 8 + (k8 & 1) * 2, r = l0ref[mode][k8];
+              c4 += pred_block_cost(mbx, mby, 8 * (k8 & 1), 8 * (k8 >> 1), 8, r, L.all_mv[b][r][mode][0], L.all_mv[b][r][mode][1], 0);
+              c8 += pred_block_cost(mbx, mby, 8 * (k8 & 1), 8 * (k8 >> 1), 8, r, L.all_mv[b][r][mode][0], L.all_mv[b][r][mode][1], 1);
+            }
+            if (c8 < c4) t8_flag = 1; else { cost = cost - c8 + c4; t8_flag = 0; }
+          }
         }
-        if (c8 < c4) t8_flag = 1; else { cost = cost - c8 + c4; t8_flag = 0; }
+        if (cost < min_cost) { best_mode = mode; min_cost = cost; best_tflag = t8_flag; }
       }
     }
-    if (cost < min_cost) { best_mode = mode; min_cost = cost; best_tflag = t8_flag; }
-  }
-  if (P.valid[4] || P.valid[5] || P.valid[6] || P.valid[7]) {
-    int cost8x8 = 0;
-    if (T8) {                                            // the 8x8 partition with the 8x8 transform: sub-mode 4 only (mode_decision.c:556)
-      tr8_cost = 0;
+    if (phase == 1 && run) {
+      const int j0 = block & 2, i0 = (block & 1) * 2;
+      if (c != INT_MAX) c += ((P.lambda_mf[2] * (P.num_refs <= 1 ? 0 : refbits(0))) >> 16) - 1;
+      tr8_cost += c;
+      ref8ts[block] = best_ref; mv8ts[block][0] = L.all_mv[j0 * 4 + i0][best_ref][4][0]; mv8ts[block][1] = L.all_mv[j0 * 4 + i0][best_ref][4][1];
+      for (int j = j0; j < j0 + 2; j++) for (int i = i0; i < i0 + 2; i++) field_set(by0 + j, bx0 + i, best_ref, mv8ts[block][0], mv8ts[block][1]);
       __syncthreads();
-      if (threadIdx.x == 0) L.pass8ts = 1;
-      __syncthreads();
-      for (int block = 0; block < 4; block++) {
-        const int j0 = block & 2, i0 = (block & 1) * 2;
-        int best_ref = 0;
-        partition_motion_search<SM>(mbx, mby, 4, block, out);
-        int cost = list0_cost(4, block, &best_ref);
-        if (cost != INT_MAX) cost += ((P.lambda_mf[2] * (P.num_refs <= 1 ? 0 : refbits(0))) >> 16) - 1;
-        tr8_cost += cost;
-        ref8ts[block] = best_ref; mv8ts[block][0] = L.all_mv[j0 * 4 + i0][best_ref][4][0]; mv8ts[block][1] = L.all_mv[j0 * 4 + i0][best_ref][4][1];
-        for (int j = j0; j < j0 + 2; j++) for (int i = i0; i < i0 + 2; i++) field_set(by0 + j, bx0 + i, best_ref, mv8ts[block][0], mv8ts[block][1]);
+      if (block == 3) {
+        if (threadIdx.x == 0) L.pass8ts = 0;
         __syncthreads();
       }
-      if (threadIdx.x == 0) L.pass8ts = 0;
-      __syncthreads();
     }
-    if (T8 != 2) {
-    for (int block = 0; block < 4; block++) {
-      int mc8 = INT_MAX;
+    if (phase == 2 && any8 && T8 != 2) {
       const int j0 = block & 2, i0 = (block & 1) * 2;
-      for (int mode = 4; mode < 8; mode++) {
-        if (!P.valid[mode]) continue;
-        int best_ref = 0;
-        partition_motion_search<SM>(mbx, mby, mode, block, out);
-        int cost = list0_cost(mode, block, &best_ref);
+      if (run) {
         for (int j = 0; j < 2; j++) for (int i = 0; i < 2; i++) FREF(by0 + j0 + j, bx0 + i0 + i) = (int8_t)best_ref;
         __syncthreads();
-        if (cost != INT_MAX) cost += ((P.lambda_mf[2] * (P.num_refs <= 1 ? 0 : refbits(mode - 4))) >> 16) - 1;
-        if (cost < mc8) { mc8 = cost; b8m[block] = mode; l0ref[4][block] = best_ref; }
+        if (c != INT_MAX) c += ((P.lambda_mf[2] * (P.num_refs <= 1 ? 0 : refbits(mode - 4))) >> 16) - 1;
+        if (c < mc8) { mc8 = c; b8m[block] = mode; l0ref[4][block] = best_ref; }
       }
-      cost8x8 += mc8;
-      for (int j = j0; j < j0 + 2; j++) for (int i = i0; i < i0 + 2; i++)
-        field_set(by0 + j, bx0 + i, l0ref[4][block], L.all_mv[j * 4 + i][l0ref[4][block]][b8m[block]][0], L.all_mv[j * 4 + i][l0ref[4][block]][b8m[block]][1]);
-      __syncthreads();
+      if (mode == 7) {                                              // the 8x8 block is decided (mode_decision.c:531, :965)
+        cost8x8 += mc8;
+        for (int j = j0; j < j0 + 2; j++) for (int i = i0; i < i0 + 2; i++)
+          field_set(by0 + j, bx0 + i, l0ref[4][block], L.all_mv[j * 4 + i][l0ref[4][block]][b8m[block]][0], L.all_mv[j * 4 + i][l0ref[4][block]][b8m[block]][1]);
+        __syncthreads();
+        if (block == 3) {
+          tr4_cost = cost8x8;
+          for (int k = 0; k < 4; k++) { p8m[k] = b8m[k]; p8r[k] = l0ref[4][k]; }      // the P8x8 candidate, before a winning 8x8-transform pass rewrites it below
+        }
+      }
     }
-    tr4_cost = cost8x8;
-    for (int k = 0; k < 4; k++) { p8m[k] = b8m[k]; p8r[k] = l0ref[4][k]; }      // the P8x8 candidate, before a winning 8x8-transform pass rewrites it below
-    }
+  }
+  if (any8) {
     if (tr4_cost < min_cost || tr8_cost < min_cost) {    // md_low.c:281-326
       best_mode = 8;
       if (T8 == 2) { min_cost = tr8_cost; t8_flag = 1; }
