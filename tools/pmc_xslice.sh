@@ -12,7 +12,10 @@ root=$PWD
 out=$root/gpurun_out/$tag
 mkdir -p $out
 cd /tmp
-for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES"; do
+sets=("FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES")
+# third argument "icache": the instruction-cache view instead (a 14 k-instruction decision function on one wave per macroblock)
+if [ "$3" = "icache" ]; then sets=("SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE" "SQ_IFETCH SQ_IFETCH_LEVEL SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES" "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA"); fi
+for set in "${sets[@]}"; do
   n=$(echo $set | tr ' ' '_' | cut -c1-40)
   timeout -k 10 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/$n -- python3 $root/tools/time_slice.py --modes=$modes --frames $frames --clip bench > $out/$n.log 2>&1 || echo "failed: $set"
 done
