@@ -348,9 +348,12 @@ def upsampled_chroma(rng, Y):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode,weighted,planes,t8", [(3, False, True, 0), (3, True, False, 0), (-1, True, True, 0), (1, False, False, 0),
-                                                     (3, False, False, 1), (-1, True, True, 1), (0, False, True, 2)])
-def test_slice_search_feeds_the_frame_stage(pkg, mode, weighted, planes, t8):
+@pytest.mark.parametrize("mode,weighted,planes,t8,candidates", [(3, False, True, 0, 0), (3, True, False, 0, 0), (-1, True, True, 0, 0), (1, False, False, 0, 0),
+                                                                (3, False, False, 1, 0), (-1, True, True, 1, 0), (0, False, True, 2, 0),
+                                                                # jmhip_slice_to_frame_candidates: every macroblock in its P8x8 candidate form (what JM codes inside
+                                                                # submacroblock_mode_decision before it decides, src/mode_decision.c:874), whatever mode won
+                                                                (-1, False, False, 0, 1), (3, True, True, 0, 1), (0, False, False, 0, 1)])
+def test_slice_search_feeds_the_frame_stage(pkg, mode, weighted, planes, t8, candidates):
     """The searched picture goes to jmhip_residual_frame without leaving the device (jmhip_slice_to_frame): every 8x8 block predicts from the
     reference ITS decision chose (LumaPrediction's l0_ref_idx), optionally with explicit weighted prediction; reconstruction, cbp and cbp_blk of
     every macroblock against the oracle's LumaResidualCoding / ChromaResidualCoding restatement fed with the same records."""
@@ -393,7 +396,12 @@ def test_slice_search_feeds_the_frame_stage(pkg, mode, weighted, planes, t8):
         wp["weight"][0], wp["offset"][0] = (30, 17, 15), (2, -1, 0)
         wp["weight"][1], wp["offset"][1] = (34, 16, 14), (-3, 1, 2)
     ctx.frame_wp_set(wp)
-    ctx.slice_to_frame(slot_of)
+    if candidates:
+        assert (rec["best_mode"] != 8).any() and (rec["p8mode"] >= 4).all()
+        ctx.frame_keep_prediction()
+        ctx.slice_to_frame_candidates(slot_of, 0, nmb)
+    else:
+        ctx.slice_to_frame(slot_of)
     ar = 0 if t8 else 1                                    # Transform8x8Mode 1 in the slice search: no adaptive rounding
     quants = [pkg.flat_quant(28 + d, 342, adaptive_rounding=ar, adapt_rnd_weight=4, cavlc=1) for d in (0, 0, 3)]
     if t8:
@@ -402,6 +410,7 @@ def test_slice_search_feeds_the_frame_stage(pkg, mode, weighted, planes, t8):
     ctx.residual_frame(quants, None)
     got = ctx.residual_download(nmb)
     recon = ctx.recon_download()
+    records, pred = (ctx.residual_records(nmb), ctx.pred_download()) if candidates else (None, None)
     ctx.frame_wp_set(None)
     ctx.close()
 
@@ -412,15 +421,17 @@ def test_slice_search_feeds_the_frame_stage(pkg, mode, weighted, planes, t8):
     parts = pkg.partition_table()
     for i in range(nmb):
         mbs[i]["mb_x"], mbs[i]["mb_y"] = i % (W // 16), i // (W // 16)
-        modes[i]["mode"] = rec[i]["best_mode"]
-        modes[i]["b8mode"] = rec[i]["b8mode"] if rec[i]["best_mode"] == 8 else 4
-        modes[i]["pad"][0] = rec[i]["transform8x8_flag"]
-        blk_ref[i] = [slot_of[int(r)] for r in rec[i]["b8ref"]]
+        cand = candidates
+        modes[i]["mode"] = 8 if cand else rec[i]["best_mode"]
+        modes[i]["b8mode"] = rec[i]["p8mode"] if cand else (rec[i]["b8mode"] if rec[i]["best_mode"] == 8 else 4)
+        modes[i]["pad"][0] = 0 if cand else rec[i]["transform8x8_flag"]
+        refs8 = rec[i]["p8ref"] if cand else rec[i]["b8ref"]
+        blk_ref[i] = [slot_of[int(r)] for r in refs8]
         for pi in range(41):
             x4, y4 = parts[pi][1], parts[pi][2]
-            rr = int(rec[i]["b8ref"][2 * (y4 >> 1) + (x4 >> 1)])
+            rr = int(refs8[2 * (y4 >> 1) + (x4 >> 1)])
             mv[i, pi] = rec[i]["mv"][rr, pi]
-            if rec[i]["best_mode"] == 8 and rec[i]["transform8x8_flag"] and 5 <= pi < 9:       # the 8x8-transform pass's vectors
+            if not cand and rec[i]["best_mode"] == 8 and rec[i]["transform8x8_flag"] and 5 <= pi < 9:       # the 8x8-transform pass's vectors
                 mv[i, pi] = rec[i]["mv8ts"][rr, pi - 5]
     assert np.array_equal(got["modes"]["mode"], modes["mode"]) and np.array_equal(got["modes"]["b8mode"], modes["b8mode"])
     if t8:
@@ -433,6 +444,14 @@ def test_slice_search_feeds_the_frame_stage(pkg, mode, weighted, planes, t8):
     for k in range(3):
         assert np.array_equal(recon[k], want["recon"][k]), "plane %d" % k
     assert (got["cbp"] != 0).any()
+    if candidates:                                         # what the JM binding answers the candidate pass from: the prediction picture and the dense records
+        for i in range(nmb):
+            x, y = 16 * (i % (W // 16)), 16 * (i // (W // 16))
+            assert np.array_equal(pred[0][y:y + 16, x:x + 16], want["jobs_y"][i]["pred"]), "candidate prediction of macroblock %d" % i
+            assert np.array_equal(records[i]["recon_y"], want["luma"]["recon"][i]) and np.array_equal(records[i]["coeff_cost"], want["luma"]["coeff_cost"][i])
+            for b in range(16):
+                n = int(records[i]["cnt"][b])
+                assert np.array_equal(records[i]["lev"][b, :n], want["luma"]["levels"][i, b, :n]) and want["luma"]["levels"][i, b, n] == 0
 
 
 @pytest.mark.gpu
