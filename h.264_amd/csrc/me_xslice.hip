@@ -805,6 +805,8 @@ struct XState {
   uint8_t *pending = nullptr, *chg[2] = {nullptr, nullptr};
   int *items = nullptr, *sub_list = nullptr, *skip_list = nullptr, *cnt = nullptr;
   MeDev *medev = nullptr;                        // the frame kernels' parameter block in device memory (their list form re-reads it per item)
+  // the sweeps' flag words arrive in page-locked host memory one sweep behind the launches (no host wait between sweeps): two ints per sweep, an event each
+  int *h_flags = nullptr; hipEvent_t evt[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int nmb = 0, refs = 0;
 };
 
@@ -814,6 +816,8 @@ void x_release(XState *x)
 {
   void *bufs[] = {x->jobs, x->res, x->valid_rec, x->need_rec, x->skip, x->pending, x->chg[0], x->chg[1], x->items, x->sub_list, x->skip_list, x->cnt, x->medev};
   for (void *b : bufs) if (b) (void)hipFree(b);
+  if (x->h_flags) (void)hipHostFree(x->h_flags);
+  for (hipEvent_t e : x->evt) if (e) (void)hipEventDestroy(e);
   delete x;
 }
 
@@ -857,6 +861,8 @@ int jm_xslice_run(jmhip_ctx *c, const jmhip_slice_params *prm, int8_t *ref_idx, 
               hipMalloc((void **)&x->skip_list, sizeof(int) * (size_t)JM_SHARDS * x_cap(nmb)) == hipSuccess &&
               hipMalloc((void **)&x->cnt, sizeof(int) * (size_t)X_CNT_SWEEP * (X_MAX_SWEEPS + 1)) == hipSuccess &&
               hipMalloc((void **)&x->medev, sizeof(MeDev)) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&x->h_flags, sizeof(int) * 2 * (X_MAX_SWEEPS + 1), hipHostMallocDefault) == hipSuccess;
+    for (int k = 0; ok && k < 8; k++) ok = hipEventCreateWithFlags(&x->evt[k], hipEventDisableTiming) == hipSuccess;
     if (!ok) { x_release(x); return jm_fail(c, JMHIP_ERR_NOMEM, "record arrays of the exhaustive slice search"); }
     JM_HIP_CHECK(c, hipMemsetAsync(x->jobs, 0, sizeof(jmhip_me_mb) * nj, c->stream));
     JM_HIP_CHECK(c, hipMemsetAsync(x->res, 0, sizeof(jmhip_me_result) * nj, c->stream));
@@ -944,7 +950,19 @@ int jm_xslice_run(jmhip_ctx *c, const jmhip_slice_params *prm, int8_t *ref_idx, 
       if (!chain && !prm->rdopt) x_skip_kernel<<<wide ? std::max(1, prm->mb_count / 4) : 256, 64, 0, c->stream>>>(D);
     }
     JM_HIP_CHECK(c, hipGetLastError());
-    if (trace || (chain ? ((sweep - chain_from) % check_every) == 0 : (sweep >= 2 && (sweep & 1) == 0))) {      // (the first sweeps always ask for records: nothing to learn from their flags)
+    if (!trace) {
+      // The sweep's two flag words (anything changed, anything needed) follow it into page-locked host memory; the host looks at the PREVIOUS sweep's
+      // while this one runs, so the device never waits for the host between sweeps. A settled sweep is therefore followed by one sweep that finds nothing
+      // to do (its lists are empty, no macroblock is due): ~30 us of empty launches instead of a host round trip per sweep.
+      JM_HIP_CHECK(c, hipMemcpyAsync(x->h_flags + 2 * sweep, cnt + X_CNT_FLAGS, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      JM_HIP_CHECK(c, hipEventRecord(x->evt[sweep & 7], c->stream));
+      if (sweep >= 1) {
+        JM_HIP_CHECK(c, hipEventSynchronize(x->evt[(sweep - 1) & 7]));
+        if (x->h_flags[2 * (sweep - 1)] == 0 && x->h_flags[2 * (sweep - 1) + 1] == 0) { quiet = 1; break; }      // settled one sweep ago: `sweep` sweeps did the work
+      }
+      continue;
+    }
+    {
       int h[8];
       JM_HIP_CHECK(c, hipMemcpyAsync(h, cnt + X_CNT_FLAGS, sizeof(h), hipMemcpyDeviceToHost, c->stream));
       JM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
