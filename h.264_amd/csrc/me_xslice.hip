@@ -62,6 +62,7 @@ struct XDev {
   int *cnt;                                      // this sweep's counters: three shard-counter blocks (items, refinements, skip costs), then flags / statistics
   int debug;                                     // JMHIP_X_DEBUG (timing experiments only, results are WRONG): 1 no refinement loads, 2 no integer scan, 4 no window staging
   int stats;                                     // count simulated / changed / needing macroblocks exactly (JMHIP_SLICE_TRACE); else flags only
+  int chain_budget;                              // CHAIN, FullSearch: records a macroblock searches in place per sweep; what it misses beyond that goes to the work lists
 };
 
 // static description of partition p for the replay: block type, rectangle in 4x4 units, the ring cells of its neighbours A, B, C, D
@@ -527,6 +528,7 @@ __global__ __launch_bounds__(CHAIN ? 256 : 64) void x_sim_kernel(XDev D)
 #pragma unroll
   for (int r = 0; r < NR; r++) ctr16[r] = 0u;
   unsigned lists = 0u;                                                      // CHAIN: references whose missing records go to the work lists
+  int budget = D.chain_budget;                                              // CHAIN: in-place searches left (a macroblock that misses everything would hold its sweep for 41 searches)
   unsigned long long inplace[NR];                                           // CHAIN: records computed in place (to write back)
 #pragma unroll
   for (int r = 0; r < NR; r++) inplace[r] = 0ull;
@@ -553,9 +555,10 @@ __global__ __launch_bounds__(CHAIN ? 256 : 64) void x_sim_kernel(XDev D)
         int cost; uint32_t m;
         // CHAIN searches a missing record in place -- except FastFullSearch records of a reference whose window moved: all 41 are void then, and one
         // walk of the frame kernel (work lists, as in sweep 0) is cheaper than 41 scans
-        const bool in_place = CHAIN && !(FFS && ((lists >> r) & 1u));
+        const bool in_place = CHAIN && !(FFS && ((lists >> r) & 1u)) && budget > 0;
         if (FFS && CHAIN && p == 0 && !ok && v == 0ull) lists |= 1u << r;
         if (!ok && in_place && !(FFS && ((lists >> r) & 1u))) {
+          budget--;
           const uint32_t ctr = FFS ? sel32(ctr16, r) : x_centre(D, mv_x(pk), mv_y(pk));
           cost = search_partition(r, p, g, mv_x(pk), mv_y(pk), mv_x(ctr), mv_y(ctr), &m);
           v |= 1ull << p;
@@ -928,11 +931,17 @@ int jm_xslice_run(jmhip_ctx *c, const jmhip_slice_params *prm, int8_t *ref_idx, 
   // FullSearch: five list sweeps, then the replay searches in place (measured on 1080p pictures: the tail of single macroblocks' chains is what the
   // list sweeps are slow at). FastFullSearch stays with the lists: its records die in whole references (the window moves) and its in-place
   // sweeps were slower than the list sweeps they replaced.
+  // ... up to `chain_budget` records per macroblock and sweep: a macroblock that misses all 41 would hold its sweep for 41 serial searches (0.5 ms) while
+  // the rest of the GPU idles; beyond the budget it asks through the work lists like an early sweep does, so the list kernels run in every sweep
+  // (measured, 1080p bench clip: one reference 8.7 / 6.4 / 13.8 ms per picture without a budget, 8.1 / 6.1 / 15.6 with 10, 9.4 / 7.8 / 20.4 with 3 -- more, cheaper sweeps, no gain; two
+  // references 17.1 / 18.5 ms without, 11.8 / 12.0 with 10, 10.3 / 10.5 with 3: a macroblock's chain is twice as long there)
+  const int chain_budget = getenv("JMHIP_X_CHAIN_BUDGET") ? std::max(1, atoi(getenv("JMHIP_X_CHAIN_BUDGET"))) : (nr == 1 ? JMHIP_NPART : 4);
   const int chain_from = getenv("JMHIP_X_CHAIN_FROM") ? atoi(getenv("JMHIP_X_CHAIN_FROM")) : (ffs ? (1 << 30) : 5);
   for (; sweep < cap; sweep++) {
     int *cnt = x->cnt + (size_t)X_CNT_SWEEP * sweep;
     D.cnt = cnt; D.stats = trace; D.debug = getenv("JMHIP_X_DEBUG") ? atoi(getenv("JMHIP_X_DEBUG")) : 0;
     D.first_sweep = sweep == 0; D.chg_prev = x->chg[sweep & 1]; D.chg_next = x->chg[(sweep + 1) & 1];
+    D.chain_budget = chain_budget;
     // The first sweeps ask for nearly every record of nearly every macroblock: the frame kernels compute them at their full rate over work lists.
     // Once few macroblocks still ask (chain_from), the replay computes what it misses in place and a sweep resolves a macroblock's whole chain;
     // what it still sends to the lists (FastFullSearch windows that moved) is a trickle: small grids.
@@ -943,7 +952,7 @@ int jm_xslice_run(jmhip_ctx *c, const jmhip_slice_params *prm, int8_t *ref_idx, 
       int big = jm_xcd_grid(std::min(nr * prm->mb_count * 2, 65536)), small = 1024;
       if (const char *e = getenv("JMHIP_X_GRID")) big = small = std::max(8, atoi(e) & ~7);        // experiments: few workgroups, many trips each
       const bool wide = !chain && sweep < 3;
-      if (!chain || ffs) {
+      {
         jm_launch_me_pair_list(c, P, x->medev, plds, x->jobs, x->items, x->res, cnt, D.cap_items, wide ? big : small);
         jm_launch_me_sub_list(c, P, x->jobs, x->res, x->sub_list, x->need_rec, cnt + X_CNT_LIST, D.cap_sub, wide ? std::min(big, jm_xcd_grid(nr * prm->mb_count)) : small);
       }
